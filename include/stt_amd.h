@@ -1,0 +1,99 @@
+/* include/stt_amd.h -- C-ABI additions of the MI355X engine next to coqui-stt.h.
+ *
+ * coqui-stt.h is batch-1 and host-buffer only (one utterance per call, like the reference).  A GPU
+ * wants many utterances per launch, device-resident audio and stage-level entry points for parity
+ * tests.  Everything here is additive: a binding that only knows coqui-stt.h keeps working.
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Which reference interface each entry point stands in for:
+ *   STTX_SpeechToTextBatch*      evaluate_export.py:25-80 (one Model.stt() per utterance in worker processes);
+ *                                semantically == calling STT_SpeechToText (stt.cc:655-662) on every element
+ *   STTX_ComputeMfcc             ModelState::compute_mfcc (modelstate.h:36-42, tflitemodelstate.cc:407-436),
+ *                                applied to every window of an utterance with stt.cc's framing
+ *   STTX_AcousticProbs           the feedAudioContent -> infer chain (stt.cc:105-334) for a batch, probs only
+ *   STTX_InferChunk              ModelState::infer (modelstate.h:44-54, tflitemodelstate.cc:369-405)
+ *   STTX_Decoder*                DecoderState::{init,next,decode} (ctc_beam_search_decoder.h:14-87) and
+ *                                ctc_beam_search_decoder_batch (ctc_beam_search_decoder.cpp:608-652)
+ */
+#ifndef STT_AMD_H
+#define STT_AMD_H
+
+#include "coqui-stt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STTX_EXPORT __attribute__((visibility("default")))
+
+/* Selects the HIP device used by models created afterwards in this process (one process per GPU). */
+STTX_EXPORT int STTX_SetDevice(int aDevice);
+/* Number of visible HIP devices, or a negative STT error if the runtime is unusable. */
+STTX_EXPORT int STTX_GetDeviceCount(void);
+
+/* ---- batch recognition ---------------------------------------------------------------------- */
+/* aBuffers[i] holds aBufferSizes[i] 16-bit mono samples (host memory).  Returns aBatch malloc'd strings
+ * (array freed with STTX_FreeStrings) or NULL on error. */
+STTX_EXPORT char** STTX_SpeechToTextBatch(ModelState* aCtx, const short* const* aBuffers, const unsigned int* aBufferSizes,
+                                         unsigned int aBatch);
+STTX_EXPORT Metadata** STTX_SpeechToTextBatchWithMetadata(ModelState* aCtx, const short* const* aBuffers,
+                                                         const unsigned int* aBufferSizes, unsigned int aBatch,
+                                                         unsigned int aNumResults);
+/* Audio already resident in HBM: aDeviceAudio is a device pointer to [aBatch][aStride] int16 (row i holds
+ * aBufferSizes[i] valid samples).  This is the entry point bench.py times. */
+STTX_EXPORT char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride,
+                                               const unsigned int* aBufferSizes, unsigned int aBatch);
+STTX_EXPORT void STTX_FreeStrings(char** aStrings, unsigned int aCount);
+STTX_EXPORT void STTX_FreeMetadataArray(Metadata** aMetadata, unsigned int aCount);
+
+/* Per-stage GPU time of the last batch call, measured with HIP events on the engine's own stream.
+ * aMs receives up to aCap floats: [0] features, [1] dense layers 1-3 + x-projection, [2] LSTM recurrence,
+ * [3] layers 5-6 + softmax, [4] decoder next, [5] decoder decode + D2H, [6] LSTM launches, [7] timesteps. */
+STTX_EXPORT int STTX_SetProfiling(ModelState* aCtx, int aEnable);
+STTX_EXPORT int STTX_GetStageTimes(ModelState* aCtx, float* aMs, int aCap);
+/* Decoder counters accumulated over the last batch call: steps, candidates, lm queries, lm memory probes. */
+STTX_EXPORT int STTX_GetDecoderStats(ModelState* aCtx, unsigned long long* aOut4);
+
+/* ---- stage-level entry points (host buffers in and out) --------------------------------------- */
+/* aOut: [aCapFrames][n_input] floats; *aNumFrames = frames produced for aNumSamples samples. */
+STTX_EXPORT int STTX_ComputeMfcc(ModelState* aCtx, const short* aBuffer, unsigned int aNumSamples, float* aOut,
+                                unsigned int aCapFrames, unsigned int* aNumFrames);
+/* aProbs: [aBatch][aMaxFrames][n_classes] floats; aNumFrames[i] = frames of utterance i. */
+STTX_EXPORT int STTX_AcousticProbs(ModelState* aCtx, const short* const* aBuffers, const unsigned int* aBufferSizes,
+                                  unsigned int aBatch, float* aProbs, unsigned int aMaxFrames, unsigned int* aNumFrames);
+/* One infer() call: aMfcc [aNumFrames][n_input*(2*n_context+1)], state vectors [n_hidden]; aProbs [aNumFrames][n_classes]. */
+STTX_EXPORT int STTX_InferChunk(ModelState* aCtx, const float* aMfcc, unsigned int aNumFrames, const float* aStateC,
+                               const float* aStateH, float* aProbs, float* aNewStateC, float* aNewStateH);
+STTX_EXPORT int STTX_GetGeometry(const ModelState* aCtx, int* aOut10);
+
+/* ---- decoder on caller-supplied emissions ----------------------------------------------------- */
+typedef struct STTX_Decoder STTX_Decoder;
+/* aNumStreams independent DecoderStates sharing the model's alphabet, scorer and hot words (captured now). */
+STTX_EXPORT int STTX_DecoderCreate(ModelState* aCtx, unsigned int aNumStreams, unsigned int aBeamWidth, double aCutoffProb,
+                                  unsigned int aCutoffTopN, STTX_Decoder** retval);
+/* aProbs: [aNumStreams][aStride][n_classes] floats; stream i consumes its first aNumFrames[i] rows. */
+STTX_EXPORT int STTX_DecoderNext(STTX_Decoder* aDec, const float* aProbs, unsigned int aStride, const unsigned int* aNumFrames);
+/* Writes for stream i, result r: tokens/timesteps [i][r][aMaxLen], lens [i][r], confidences [i][r]; aNumResultsOut[i]. */
+STTX_EXPORT int STTX_DecoderDecode(const STTX_Decoder* aDec, unsigned int aNumResults, unsigned int aMaxLen,
+                                  unsigned int* aTokens, unsigned int* aTimesteps, int* aLens, double* aConfidences,
+                                  int* aNumResultsOut);
+/* Raw beam of one stream after the last next(): up to aCap entries of (score, log_prob_b_prev, log_prob_nb_prev, character). */
+STTX_EXPORT int STTX_DecoderBeam(const STTX_Decoder* aDec, unsigned int aStream, float* aScore, float* aPb, float* aPnb,
+                                int* aChar, unsigned int aCap);
+STTX_EXPORT int STTX_DecoderStats(const STTX_Decoder* aDec, unsigned long long* aOut4);
+STTX_EXPORT void STTX_DecoderFree(STTX_Decoder* aDec);
+
+/* ---- kernel-level test hooks ------------------------------------------------------------------ */
+/* y = epi(x[M][K] . w[K][N] + bias): runs the MFMA dense kernel (f16 operands, f32 accumulate).  aEpilogue 0 = clipped
+ * ReLU (y rounded to f16, returned as f32), 1 = bias only (f32). */
+STTX_EXPORT int STTX_TestDense(int aM, int aN, int aK, const float* aX, const float* aW, const float* aBias, float aClip,
+                              int aEpilogue, float* aY);
+/* Device expf/logf/log_sum_exp of sttmath.h over arrays (aOp 0 = expf, 1 = logf, 2 = log_sum_exp(a, b)). */
+STTX_EXPORT int STTX_TestMath(int aOp, const float* aA, const float* aB, float* aOut, unsigned int aCount);
+/* Host-side packing of the recurrent matrix (no GPU needed): aKernel [2H][4H] f32 -> aOut [4H*H] f16 bits. */
+STTX_EXPORT int STTX_PackLstmRecurrent(const float* aKernel, int aHidden, unsigned short* aOut);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STT_AMD_H */

@@ -27,6 +27,7 @@ def lib():
         sig = {
             "port_murmur64a": (C.c_uint64, [C.c_char_p, C.c_size_t, C.c_uint64]),
             "port_scorer_load": (vp, [vp, C.c_size_t, C.POINTER(ci)]),
+            "port_kenlm_load": (vp, [vp, C.c_size_t, C.POINTER(ci)]),
             "port_scorer_free": (None, [vp]),
             "port_scorer_order": (ci, [vp]),
             "port_scorer_utf8": (ci, [vp]),
@@ -88,7 +89,7 @@ def utf8_alphabet():
 
 
 class Scorer:
-    def __init__(self, path=None, data=None):
+    def __init__(self, path=None, data=None, lm_only=False):
         if data is None:
             with open(path, "rb") as f:
                 data = f.read()
@@ -96,10 +97,11 @@ class Scorer:
         self._buf = np.zeros((len(data) + 16 + 7) // 8 + 1, dtype=np.uint64)
         self._buf.view(np.uint8)[:len(data)] = np.frombuffer(data, dtype=np.uint8)
         err = C.c_int(0)
-        self.h = lib().port_scorer_load(self._buf.ctypes.data, len(data), C.byref(err))
+        self.h = (lib().port_kenlm_load if lm_only else lib().port_scorer_load)(self._buf.ctypes.data, len(data), C.byref(err))
         self.err = err.value
         if not self.h:
             raise RuntimeError("port_scorer_load failed: 0x%x" % self.err)
+        self.lm_only = lm_only
         self.utf8 = bool(lib().port_scorer_utf8(self.h))
         self.order = lib().port_scorer_order(self.h)
         self.model_type = lib().port_scorer_model_type(self.h)

@@ -14,7 +14,8 @@
  *
  * Documented deviations (all concern orders the reference itself leaves to libstdc++):
  *  - ties of (score, character) in std::partial_sort / std::nth_element
- *    (ctc_beam_search_decoder.cpp:138,264,305) are broken by `origin` (see step()).
+ *    (ctc_beam_search_decoder.cpp:138,264,305) are broken by `origin`: live prefixes (by beam
+ *    index) before prefixes created this step (by parent beam index); see step().
  *  - std::sort ties between equal class probabilities (ctc_beam_search_decoder.cpp:338)
  *    are broken by class index.
  *  - KenLM probing-hash models (model types 0/1) are not supported, trie types 2-5 are.
@@ -148,7 +149,7 @@ void port_scorer_free(PortScorer* s) { free(s); }
 
 /* Parses [KenLM trie binary]['TRIE' header][ConstFst].  Error codes mirror
  * scorer.cpp:108-222 (STT_ERR_SCORER_*), coqui-stt.h:92-124. */
-PortScorer* port_scorer_load(const uint8_t* buf, size_t len, int* err) {
+static PortScorer* scorer_load_impl(const uint8_t* buf, size_t len, int lm_only, int* err) {
   static const char kMagic[] = "mmap lm http://kheafield.com/code format version 5\n";
   int e = 0;
   PortScorer* s = (PortScorer*)calloc(1, sizeof(PortScorer));
@@ -227,6 +228,7 @@ PortScorer* port_scorer_load(const uint8_t* buf, size_t len, int* err) {
   s->eos_index = port_kenlm_index(s, "</s>", 4);
   s->bos_backoff = rdf32(s->unigram + 16 * (uint64_t)s->bos_index + 4); /* lm/model.cc:115-124 */
   /* ---- package trailer, scorer.cpp:177-222 */
+  if (lm_only) { if (err) *err = 0; return s; } /* bare KenLM binary (model_test.cc known answers) */
   if (len <= s->lm_end) { e = 0x2007; goto fail; }
   {
     const uint8_t* p = buf + s->lm_end;
@@ -266,6 +268,8 @@ fail:
   return NULL;
 }
 
+PortScorer* port_scorer_load(const uint8_t* buf, size_t len, int* err) { return scorer_load_impl(buf, len, 0, err); }
+PortScorer* port_kenlm_load(const uint8_t* buf, size_t len, int* err) { return scorer_load_impl(buf, len, 1, err); }
 int port_scorer_order(const PortScorer* s) { return s->order; }
 int port_scorer_utf8(const PortScorer* s) { return s->utf8; }
 double port_scorer_alpha(const PortScorer* s) { return s->alpha; }
@@ -698,7 +702,7 @@ static void step(PortDecoder* d, const double* prob) {
         slot = n + m++;
         b_cur[slot] = NEG_INF; nb_cur[slot] = NEG_INF; pend[slot] = 0;
         c_parent[slot] = i; c_ch[slot] = c; c_fst[slot] = child_fst; c_key[slot] = ck;
-        c_origin[slot] = (uint32_t)(beam + k * beam + i);
+        c_origin[slot] = (uint32_t)(beam + i); /* unique among equal (score, character): one child per (parent, character) */
         HT_PUT(ck, slot);
         d->stat_candidates++;
       }

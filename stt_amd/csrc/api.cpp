@@ -1,0 +1,636 @@
+// stt_amd/csrc/api.cpp -- the exported C ABI: coqui-stt.h (29 functions) + stt_amd.h (STTX_*).
+//
+// Function-by-function replacement of native_client/stt.cc:336-737, native_client/modelstate.cc:32-76 and
+// native_client/stt_errors.cc:4-19.  All recognition work is enqueued on the GPU; an unusable GPU runtime or a
+// missing kernel image surfaces as an error code / NULL, never as a silent CPU path.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "../../include/stt_amd.h"
+#include "engine.h"
+
+namespace {
+int g_device = 0;
+const char* kVersion = "1.4.0";  // training/coqui_stt_training/VERSION of the reference this ABI mirrors
+
+struct Prof {
+  bool on = false;
+  hipEvent_t ev[8] = {};
+  float ms[8] = {};
+  unsigned long long dec_stats[4] = {};
+};
+std::unordered_map<ModelState*, Prof> g_prof;
+
+Prof& prof_of(ModelState* m) { return g_prof[m]; }
+void mark(ModelState* m, int i) {
+  Prof& p = prof_of(m);
+  if (!p.on) return;
+  if (!p.ev[i]) HIP_CHECK(hipEventCreate(&p.ev[i]));
+  HIP_CHECK(hipEventRecord(p.ev[i], m->stream));
+}
+
+template <class F> int guarded(F&& f, int fail_code) {
+  try { return f(); }
+  catch (const std::exception& e) { std::cerr << "stt_amd: " << e.what() << std::endl; return fail_code; }
+}
+
+// ModelState::decode_metadata, modelstate.cc:39-76
+Metadata* make_metadata(const ModelState* m, const std::vector<Output>& out) {
+  const unsigned num_returned = (unsigned)out.size();
+  CandidateTranscript* transcripts = (CandidateTranscript*)malloc(sizeof(CandidateTranscript) * std::max(1u, num_returned));
+  for (unsigned i = 0; i < num_returned; ++i) {
+    const size_t nt = out[i].tokens.size();
+    TokenMetadata* tokens = (TokenMetadata*)malloc(sizeof(TokenMetadata) * std::max<size_t>(1, nt));
+    for (size_t j = 0; j < nt; ++j) {
+      const unsigned ts = j < out[i].timesteps.size() ? out[i].timesteps[j] : 0;
+      TokenMetadata token{strdup(m->alphabet_.DecodeSingle(out[i].tokens[j]).c_str()), ts,
+                          ts * ((float)m->g.win_step / m->g.sample_rate)};
+      memcpy(&tokens[j], &token, sizeof(TokenMetadata));
+    }
+    CandidateTranscript tr{tokens, (unsigned)nt, out[i].confidence};
+    memcpy(&transcripts[i], &tr, sizeof(CandidateTranscript));
+  }
+  Metadata* ret = (Metadata*)malloc(sizeof(Metadata));
+  Metadata md{transcripts, num_returned, NULL};
+  memcpy(ret, &md, sizeof(Metadata));
+  return ret;
+}
+
+// stt.cc:136-175: attach the emissions of the last processed batch
+Metadata* with_emissions(const StreamingState* s, Metadata* m) {
+  const size_t alphabet_size = s->model_->alphabet_.GetSize();
+  const int num_timesteps = (int)(s->probs_.size() / (alphabet_size + 1));
+  AcousticModelEmissions* em = (AcousticModelEmissions*)malloc(sizeof(AcousticModelEmissions));
+  em->num_symbols = (int)alphabet_size;
+  em->num_timesteps = num_timesteps;
+  em->symbols = (const char**)malloc(sizeof(char*) * (alphabet_size + 1));
+  for (size_t i = 0; i < alphabet_size; ++i) em->symbols[i] = strdup(s->model_->alphabet_.DecodeSingle((unsigned)i).c_str());
+  em->symbols[alphabet_size] = strdup("\t");
+  double* probs = (double*)malloc(sizeof(double) * std::max<size_t>(1, (alphabet_size + 1) * num_timesteps));
+  memcpy(probs, s->probs_.data(), sizeof(double) * (alphabet_size + 1) * num_timesteps);
+  em->emissions = probs;
+  Metadata* ret = (Metadata*)malloc(sizeof(Metadata));
+  Metadata md{m->transcripts, m->num_transcripts, em};
+  memcpy(ret, &md, sizeof(Metadata));
+  free(m);
+  return ret;
+}
+
+char* decode_string(const StreamingState* s) {  // ModelState::decode, modelstate.cc:32-37
+  std::vector<Output> out = s->decode(1);
+  if (out.empty()) return strdup("");
+  return strdup(s->model_->alphabet_.Decode(out[0].tokens.data(), (int)out[0].tokens.size()).c_str());
+}
+Metadata* decode_metadata(const StreamingState* s, unsigned n) {
+  Metadata* m = make_metadata(s->model_, s->decode(n));
+  return s->keep_emissions_ ? with_emissions(s, m) : m;
+}
+
+int create_stream(ModelState* aCtx, StreamingState** retval, bool keep_emissions) {  // stt.cc:519-593
+  *retval = nullptr;
+  return guarded([&]() {
+    std::unique_ptr<StreamingState> ctx(new StreamingState());
+    ctx->model_ = aCtx;
+    ctx->scorer_ = aCtx->scorer_;
+    ctx->hot_words_ = aCtx->hot_words_;
+    ctx->beam_width_ = aCtx->beam_width_;
+    ctx->keep_emissions_ = keep_emissions;
+    HIP_CHECK(hipSetDevice(aCtx->device));
+    ctx->pushZeroFrames(aCtx->g.n_context);                         // stt.cc:533
+    ctx->d_c.reserve((size_t)aCtx->g.n_hidden * 4); ctx->d_h.reserve((size_t)aCtx->g.n_hidden * 4);
+    HIP_CHECK(hipMemsetAsync(ctx->d_c.p, 0, (size_t)aCtx->g.n_hidden * 4, aCtx->stream));  // stt.cc:535-536
+    HIP_CHECK(hipMemsetAsync(ctx->d_h.p, 0, (size_t)aCtx->g.n_hidden * 4, aCtx->stream));
+    aCtx->decoder_create(ctx->dec, 1, (int)aCtx->beam_width_, 64, ctx->scorer_);  // cutoff_top_n = 40, cutoff_prob = 1.0 fixed (stt.cc:539-540)
+    *retval = ctx.release();
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_CREATE_STREAM);
+}
+
+// ---- batch path: every utterance goes through exactly the arithmetic of STT_SpeechToText ---------------------
+std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio, unsigned stride, const unsigned* sizes, unsigned B, unsigned num_results) {
+  std::vector<std::vector<Output>> all;
+  HIP_CHECK(hipSetDevice(m->device));
+  Prof& pr = prof_of(m);
+  if (pr.on) { for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; }
+  for (unsigned g0 = 0; g0 < B; g0 += 64) {
+    const int Bg = (int)std::min(64u, B - g0);
+    std::vector<int> hn(Bg), nfr;
+    int t_max = 1;
+    for (int b = 0; b < Bg; ++b) { hn[b] = (int)sizes[g0 + b]; t_max = std::max(t_max, n_frames_for(m->g, hn[b])); }
+    mark(m, 0);
+    m->run_mfcc(d_audio + (size_t)g0 * stride, hn.data(), Bg, (int)stride, t_max, nfr);
+    mark(m, 1);
+    m->run_acoustic(m->ws_feats.as<float>(), m->ws_nframes.as<int>(), Bg, t_max, nullptr, nullptr, false);
+    mark(m, 4);
+    DecoderBatch db;
+    m->decoder_create(db, Bg, (int)m->beam_width_, t_max, m->scorer_);
+    std::vector<int> zeros(Bg, 0);
+    m->ws_fbegin.upload(zeros.data(), Bg * 4, m->stream);
+    m->ws_fcount.upload(nfr.data(), Bg * 4, m->stream);
+    DecParams p{};
+    p.C = m->g.n_classes; p.blank = p.C - 1; p.beam = db.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = t_max;
+    DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
+    launch_ctc_next(p, ds, m->dev_alphabet, db.table.as<DecStream>(), Bg, m->ws_probs.as<float>(), m->ws_fbegin.as<int>(), m->ws_fcount.as<int>(), m->stream);
+    mark(m, 5);
+    auto outs = decode_streams(*m, db, m->scorer_, m->hot_words_, num_results, 4096);
+    mark(m, 6);
+    if (pr.on) {
+      HIP_CHECK(hipStreamSynchronize(m->stream));
+      float t;
+      HIP_CHECK(hipEventElapsedTime(&t, pr.ev[0], pr.ev[1])); pr.ms[0] += t;
+      HIP_CHECK(hipEventElapsedTime(&t, pr.ev[1], pr.ev[2])); pr.ms[1] += t;
+      HIP_CHECK(hipEventElapsedTime(&t, pr.ev[2], pr.ev[3])); pr.ms[2] += t;
+      HIP_CHECK(hipEventElapsedTime(&t, pr.ev[3], pr.ev[4])); pr.ms[3] += t;
+      HIP_CHECK(hipEventElapsedTime(&t, pr.ev[4], pr.ev[5])); pr.ms[4] += t;
+      HIP_CHECK(hipEventElapsedTime(&t, pr.ev[5], pr.ev[6])); pr.ms[5] += t;
+      pr.ms[6] += (float)t_max; pr.ms[7] += (float)t_max * Bg;
+      std::vector<DecStream> tb(Bg);
+      HIP_CHECK(hipMemcpy(tb.data(), db.table.p, sizeof(DecStream) * Bg, hipMemcpyDeviceToHost));
+      for (auto& S : tb) for (int k = 0; k < 4; ++k) pr.dec_stats[k] += S.stat[k];
+    }
+    for (auto& o : outs) all.push_back(std::move(o));
+  }
+  return all;
+}
+}  // namespace
+
+void launch_test_math(int op, const float* a, const float* b, float* out, unsigned n, hipStream_t st);  // ctc.hip
+
+// hooks used by engine.cpp for the profiling marks inside run_acoustic_rows
+void stt_prof_mark(ModelState* m, int i) { mark(m, i); }
+
+extern "C" {
+
+// ================================================================ coqui-stt.h
+int STT_CreateModelFromBuffer(const char* aModelBuffer, unsigned int aBufferSize, ModelState** retval) {
+  *retval = nullptr;
+  // stt.cc:344-345 prints two version lines on stderr; CI scripts grep for them (ci_scripts/asserts.sh:284-321)
+  std::cerr << "TensorFlow: none (MI355X HIP engine, gfx950)" << std::endl;
+  std::cerr << " Coqui STT: " << kVersion << "-mi355x" << std::endl;
+  if (!aModelBuffer || !aBufferSize) {
+    std::cerr << "No model specified, cannot continue." << std::endl;
+    return STT_ERR_NO_MODEL;
+  }
+  return guarded([&]() {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      std::cerr << "stt_amd: no HIP device available; this engine has no CPU path." << std::endl;
+      return (int)STT_ERR_FAIL_INIT_SESS;
+    }
+    std::unique_ptr<ModelState> model(new ModelState());
+    model->device = g_device;
+    int err = model->InitFromBuffer(aModelBuffer, aBufferSize);
+    if (err != STT_ERR_OK) return err;
+    *retval = model.release();
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_CREATE_MODEL);
+}
+
+int STT_CreateModel(const char* aModelPath, ModelState** retval) {
+  *retval = nullptr;
+  if (!aModelPath || !strlen(aModelPath)) {
+    std::cerr << "TensorFlow: none (MI355X HIP engine, gfx950)" << std::endl;
+    std::cerr << " Coqui STT: " << kVersion << "-mi355x" << std::endl;
+    std::cerr << "No model specified, cannot continue." << std::endl;
+    return STT_ERR_NO_MODEL;
+  }
+  std::ifstream in(aModelPath, std::ios::binary | std::ios::ate);
+  if (!in) {
+    std::cerr << "TensorFlow: none (MI355X HIP engine, gfx950)" << std::endl;
+    std::cerr << " Coqui STT: " << kVersion << "-mi355x" << std::endl;
+    return STT_ERR_FAIL_INIT_MMAP;
+  }
+  const std::streamsize sz = in.tellg();
+  in.seekg(0);
+  std::vector<char> data((size_t)std::max<std::streamsize>(sz, 0));
+  if (sz > 0) in.read(data.data(), sz);
+  return STT_CreateModelFromBuffer(data.data(), (unsigned)data.size(), retval);
+}
+
+unsigned int STT_GetModelBeamWidth(const ModelState* aCtx) { return aCtx->beam_width_; }
+int STT_SetModelBeamWidth(ModelState* aCtx, unsigned int aBeamWidth) { aCtx->beam_width_ = aBeamWidth; return 0; }
+int STT_GetModelSampleRate(const ModelState* aCtx) { return aCtx->g.sample_rate; }
+void STT_FreeModel(ModelState* ctx) {
+  if (!ctx) return;
+  auto it = g_prof.find(ctx);
+  if (it != g_prof.end()) { for (auto e : it->second.ev) if (e) (void)hipEventDestroy(e); g_prof.erase(it); }
+  delete ctx;
+}
+
+static int enable_scorer(ModelState* aCtx, const char* data, size_t len, const char* path) {  // stt.cc:414-449
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(aCtx->device));
+    auto sc = std::make_shared<ScorerDev>();
+    const int err = path ? sc->LoadFile(path, aCtx->alphabet_) : sc->LoadBuffer(data, len, aCtx->alphabet_);
+    if (err != STT_ERR_OK) return (int)STT_ERR_INVALID_SCORER;
+    aCtx->scorer_ = sc;
+    return (int)STT_ERR_OK;
+  }, STT_ERR_INVALID_SCORER);
+}
+int STT_EnableExternalScorer(ModelState* aCtx, const char* aScorerPath) { return enable_scorer(aCtx, nullptr, 0, aScorerPath); }
+int STT_EnableExternalScorerFromBuffer(ModelState* aCtx, const char* aScorerBuffer, unsigned int aBufferSize) {
+  return enable_scorer(aCtx, aScorerBuffer, aBufferSize, nullptr);
+}
+int STT_AddHotWord(ModelState* aCtx, const char* word, float boost) {  // stt.cc:451-466
+  if (!aCtx->scorer_) return STT_ERR_SCORER_NOT_ENABLED;
+  const size_t before = aCtx->hot_words_.size();
+  aCtx->hot_words_.insert(std::pair<std::string, float>(word, boost));
+  return aCtx->hot_words_.size() == before ? STT_ERR_FAIL_INSERT_HOTWORD : STT_ERR_OK;
+}
+int STT_EraseHotWord(ModelState* aCtx, const char* word) {  // stt.cc:468-483
+  if (!aCtx->scorer_) return STT_ERR_SCORER_NOT_ENABLED;
+  const size_t before = aCtx->hot_words_.size();
+  aCtx->hot_words_.erase(word);
+  return aCtx->hot_words_.size() == before ? STT_ERR_FAIL_ERASE_HOTWORD : STT_ERR_OK;
+}
+int STT_ClearHotWords(ModelState* aCtx) {  // stt.cc:485-497
+  if (!aCtx->scorer_) return STT_ERR_SCORER_NOT_ENABLED;
+  aCtx->hot_words_.clear();
+  return STT_ERR_OK;
+}
+int STT_DisableExternalScorer(ModelState* aCtx) {  // stt.cc:499-506
+  if (!aCtx->scorer_) return STT_ERR_SCORER_NOT_ENABLED;
+  aCtx->scorer_.reset();
+  return STT_ERR_OK;
+}
+int STT_SetScorerAlphaBeta(ModelState* aCtx, float aAlpha, float aBeta) {  // stt.cc:508-517
+  if (!aCtx->scorer_) return STT_ERR_SCORER_NOT_ENABLED;
+  aCtx->scorer_->reset_params(aAlpha, aBeta);
+  return STT_ERR_OK;
+}
+
+int STT_CreateStream(ModelState* aCtx, StreamingState** retval) { return create_stream(aCtx, retval, false); }
+
+void STT_FeedAudioContent(StreamingState* aSctx, const short* aBuffer, unsigned int aBufferSize) {
+  guarded([&]() { HIP_CHECK(hipSetDevice(aSctx->model_->device)); aSctx->feedAudioContent(aBuffer, aBufferSize); return 0; }, 0);
+}
+char* STT_IntermediateDecode(const StreamingState* aSctx) {
+  char* r = nullptr;
+  guarded([&]() { r = decode_string(aSctx); return 0; }, 0);
+  return r;
+}
+Metadata* STT_IntermediateDecodeWithMetadata(const StreamingState* aSctx, unsigned int aNumResults) {
+  Metadata* r = nullptr;
+  guarded([&]() { r = decode_metadata(aSctx, aNumResults); return 0; }, 0);
+  return r;
+}
+char* STT_IntermediateDecodeFlushBuffers(StreamingState* aSctx) {
+  char* r = nullptr;
+  guarded([&]() { aSctx->flushBuffers(false); r = decode_string(aSctx); return 0; }, 0);
+  return r;
+}
+Metadata* STT_IntermediateDecodeWithMetadataFlushBuffers(StreamingState* aSctx, unsigned int aNumResults) {
+  Metadata* r = nullptr;
+  guarded([&]() { aSctx->flushBuffers(false); r = decode_metadata(aSctx, aNumResults); return 0; }, 0);
+  return r;
+}
+void STT_FreeStream(StreamingState* aSctx) { delete aSctx; }
+char* STT_FinishStream(StreamingState* aSctx) {
+  char* r = nullptr;
+  guarded([&]() { aSctx->flushBuffers(true); r = decode_string(aSctx); return 0; }, 0);
+  STT_FreeStream(aSctx);
+  return r;
+}
+Metadata* STT_FinishStreamWithMetadata(StreamingState* aSctx, unsigned int aNumResults) {
+  Metadata* r = nullptr;
+  guarded([&]() { aSctx->flushBuffers(true); r = decode_metadata(aSctx, aNumResults); return 0; }, 0);
+  STT_FreeStream(aSctx);
+  return r;
+}
+
+// One-shot calls are "create stream, feed everything, finish" in the reference (stt.cc:641-688); the result only
+// depends on the whole utterance, so they run as a batch of one through the time-parallel path (same kernels, same
+// per-row arithmetic as the chunked streaming path).
+char* STT_SpeechToText(ModelState* aCtx, const short* aBuffer, unsigned int aBufferSize) {
+  char** r = STTX_SpeechToTextBatch(aCtx, &aBuffer, &aBufferSize, 1);
+  if (!r) return nullptr;
+  char* s = r[0];
+  free(r);
+  return s;
+}
+Metadata* STT_SpeechToTextWithMetadata(ModelState* aCtx, const short* aBuffer, unsigned int aBufferSize, unsigned int aNumResults) {
+  Metadata** r = STTX_SpeechToTextBatchWithMetadata(aCtx, &aBuffer, &aBufferSize, 1, aNumResults);
+  if (!r) return nullptr;
+  Metadata* m = r[0];
+  free(r);
+  return m;
+}
+Metadata* STT_SpeechToTextWithEmissions(ModelState* aCtx, const short* aBuffer, unsigned int aBufferSize, unsigned int aNumResults) {
+  StreamingState* ctx;  // stt.cc:674-688: needs the stream's last batch of emissions -> streaming path
+  if (create_stream(aCtx, &ctx, true) != STT_ERR_OK) return nullptr;
+  STT_FeedAudioContent(ctx, aBuffer, aBufferSize);
+  return STT_FinishStreamWithMetadata(ctx, aNumResults);
+}
+
+void STT_FreeMetadata(Metadata* m) {  // stt.cc:696-726
+  if (!m) return;
+  for (unsigned i = 0; i < m->num_transcripts; ++i) {
+    for (unsigned j = 0; j < m->transcripts[i].num_tokens; ++j) free((void*)m->transcripts[i].tokens[j].text);
+    free((void*)m->transcripts[i].tokens);
+  }
+  free((void*)m->transcripts);
+  if (m->emissions) {
+    if (m->emissions->symbols) {
+      for (int i = 0; i < m->emissions->num_symbols + 1; i++) free((void*)m->emissions->symbols[i]);
+      free((void*)m->emissions->symbols);
+    }
+    if (m->emissions->emissions) free((void*)m->emissions->emissions);
+    free((void*)m->emissions);
+  }
+  free(m);
+}
+void STT_FreeString(char* str) { free(str); }
+char* STT_Version() { return strdup(kVersion); }
+char* STT_ErrorCodeToErrorMessage(int aErrorCode) {
+#define RETURN_MESSAGE(NAME, VALUE, DESC) case NAME: return strdup(DESC);
+  switch (aErrorCode) {
+    STT_FOR_EACH_ERROR(RETURN_MESSAGE)
+    default: return strdup("Unknown error, please make sure you are using the correct native binary.");
+  }
+#undef RETURN_MESSAGE
+}
+
+// ================================================================ stt_amd.h
+int STTX_SetDevice(int aDevice) { g_device = aDevice; return hipSetDevice(aDevice) == hipSuccess ? STT_ERR_OK : STT_ERR_FAIL_INIT_SESS; }
+int STTX_GetDeviceCount(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : -STT_ERR_FAIL_INIT_SESS; }
+
+char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride, const unsigned int* aBufferSizes, unsigned int aBatch) {
+  char** res = nullptr;
+  guarded([&]() {
+    auto outs = batch_run(aCtx, aDeviceAudio, aStride, aBufferSizes, aBatch, 1);
+    res = (char**)malloc(sizeof(char*) * std::max(1u, aBatch));
+    for (unsigned i = 0; i < aBatch; ++i)
+      res[i] = outs[i].empty() ? strdup("") : strdup(aCtx->alphabet_.Decode(outs[i][0].tokens.data(), (int)outs[i][0].tokens.size()).c_str());
+    return 0;
+  }, 0);
+  return res;
+}
+
+static void upload_batch_audio(ModelState* m, const short* const* bufs, const unsigned* sizes, unsigned B, unsigned& stride) {
+  stride = 1;
+  for (unsigned i = 0; i < B; ++i) stride = std::max(stride, sizes[i]);
+  stride = (stride + 7) & ~7u;
+  HIP_CHECK(hipSetDevice(m->device));
+  m->ws_audio.reserve((size_t)B * stride * 2);
+  HIP_CHECK(hipMemsetAsync(m->ws_audio.p, 0, (size_t)B * stride * 2, m->stream));
+  for (unsigned i = 0; i < B; ++i)
+    if (sizes[i]) HIP_CHECK(hipMemcpyAsync(m->ws_audio.as<int16_t>() + (size_t)i * stride, bufs[i], (size_t)sizes[i] * 2, hipMemcpyHostToDevice, m->stream));
+  HIP_CHECK(hipStreamSynchronize(m->stream));
+}
+
+char** STTX_SpeechToTextBatch(ModelState* aCtx, const short* const* aBuffers, const unsigned int* aBufferSizes, unsigned int aBatch) {
+  char** res = nullptr;
+  guarded([&]() {
+    unsigned stride;
+    upload_batch_audio(aCtx, aBuffers, aBufferSizes, aBatch, stride);
+    res = STTX_SpeechToTextBatchDevice(aCtx, aCtx->ws_audio.as<short>(), stride, aBufferSizes, aBatch);
+    return 0;
+  }, 0);
+  return res;
+}
+Metadata** STTX_SpeechToTextBatchWithMetadata(ModelState* aCtx, const short* const* aBuffers, const unsigned int* aBufferSizes, unsigned int aBatch, unsigned int aNumResults) {
+  Metadata** res = nullptr;
+  guarded([&]() {
+    unsigned stride;
+    upload_batch_audio(aCtx, aBuffers, aBufferSizes, aBatch, stride);
+    auto outs = batch_run(aCtx, aCtx->ws_audio.as<int16_t>(), stride, aBufferSizes, aBatch, aNumResults);
+    res = (Metadata**)malloc(sizeof(Metadata*) * std::max(1u, aBatch));
+    for (unsigned i = 0; i < aBatch; ++i) res[i] = make_metadata(aCtx, outs[i]);
+    return 0;
+  }, 0);
+  return res;
+}
+void STTX_FreeStrings(char** aStrings, unsigned int aCount) {
+  if (!aStrings) return;
+  for (unsigned i = 0; i < aCount; ++i) free(aStrings[i]);
+  free(aStrings);
+}
+void STTX_FreeMetadataArray(Metadata** aMetadata, unsigned int aCount) {
+  if (!aMetadata) return;
+  for (unsigned i = 0; i < aCount; ++i) STT_FreeMetadata(aMetadata[i]);
+  free(aMetadata);
+}
+int STTX_SetProfiling(ModelState* aCtx, int aEnable) { prof_of(aCtx).on = aEnable != 0; return STT_ERR_OK; }
+int STTX_GetStageTimes(ModelState* aCtx, float* aMs, int aCap) {
+  Prof& p = prof_of(aCtx);
+  for (int i = 0; i < aCap && i < 8; ++i) aMs[i] = p.ms[i];
+  return STT_ERR_OK;
+}
+int STTX_GetDecoderStats(ModelState* aCtx, unsigned long long* aOut4) {
+  Prof& p = prof_of(aCtx);
+  for (int i = 0; i < 4; ++i) aOut4[i] = p.dec_stats[i];
+  return STT_ERR_OK;
+}
+
+int STTX_GetGeometry(const ModelState* aCtx, int* o) {
+  const Geometry& g = aCtx->g;
+  o[0] = g.n_input; o[1] = g.n_context; o[2] = g.n_hidden; o[3] = g.n_classes; o[4] = g.n_steps;
+  o[5] = g.sample_rate; o[6] = g.win_len; o[7] = g.win_step; o[8] = g.beam_width; o[9] = (int)aCtx->alphabet_.GetSpaceLabel();
+  return STT_ERR_OK;
+}
+
+int STTX_ComputeMfcc(ModelState* m, const short* aBuffer, unsigned int aNumSamples, float* aOut, unsigned int aCapFrames, unsigned int* aNumFrames) {
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(m->device));
+    const int n = (int)aNumSamples;
+    const int T = n_frames_for(m->g, n);
+    *aNumFrames = (unsigned)T;
+    if ((unsigned)T > aCapFrames) return (int)STT_ERR_INVALID_SHAPE;
+    const short* bufs[1] = {aBuffer};
+    unsigned stride;
+    upload_batch_audio(m, bufs, &aNumSamples, 1, stride);
+    std::vector<int> nfr;
+    m->run_mfcc(m->ws_audio.as<int16_t>(), &n, 1, (int)stride, T, nfr);
+    HIP_CHECK(hipMemcpyAsync(aOut, m->ws_feats.p, (size_t)T * m->g.n_input * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
+
+int STTX_AcousticProbs(ModelState* m, const short* const* aBuffers, const unsigned int* aBufferSizes, unsigned int aBatch, float* aProbs,
+                       unsigned int aMaxFrames, unsigned int* aNumFrames) {
+  return guarded([&]() {
+    if (aBatch > 64) return (int)STT_ERR_INVALID_SHAPE;
+    unsigned stride;
+    upload_batch_audio(m, aBuffers, aBufferSizes, aBatch, stride);
+    std::vector<int> hn(aBatch), nfr;
+    int t_max = 1;
+    for (unsigned b = 0; b < aBatch; ++b) { hn[b] = (int)aBufferSizes[b]; t_max = std::max(t_max, n_frames_for(m->g, hn[b])); }
+    if ((unsigned)t_max > aMaxFrames) return (int)STT_ERR_INVALID_SHAPE;
+    m->run_mfcc(m->ws_audio.as<int16_t>(), hn.data(), (int)aBatch, (int)stride, t_max, nfr);
+    m->run_acoustic(m->ws_feats.as<float>(), m->ws_nframes.as<int>(), (int)aBatch, t_max, nullptr, nullptr, false);
+    const int C = m->g.n_classes;
+    for (unsigned b = 0; b < aBatch; ++b) {
+      aNumFrames[b] = (unsigned)nfr[b];
+      HIP_CHECK(hipMemcpyAsync(aProbs + (size_t)b * aMaxFrames * C, m->ws_probs.as<float>() + (size_t)b * t_max * C, (size_t)nfr[b] * C * 4,
+                               hipMemcpyDeviceToHost, m->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
+
+int STTX_InferChunk(ModelState* m, const float* aMfcc, unsigned int aNumFrames, const float* aStateC, const float* aStateH, float* aProbs,
+                    float* aNewStateC, float* aNewStateH) {
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(m->device));
+    const Geometry& g = m->g;
+    const int T = (int)aNumFrames, kw = g.n_in1(), kp = g.k1_pad(), H = g.n_hidden, C = g.n_classes;
+    std::vector<_Float16> x1((size_t)T * kp, (_Float16)0.0f);
+    for (int t = 0; t < T; ++t)
+      for (int k = 0; k < kw; ++k) x1[(size_t)t * kp + k] = (_Float16)aMfcc[(size_t)t * kw + k];
+    m->ws_x1.upload(x1.data(), x1.size() * 2, m->stream);
+    DevBuf c, h;
+    c.upload(aStateC, (size_t)H * 4, m->stream); h.upload(aStateH, (size_t)H * 4, m->stream);
+    m->ws_probs.reserve((size_t)T * C * 4);
+    m->run_acoustic_rows(m->ws_x1.as<_Float16>(), 1, T, c.as<float>(), h.as<float>(), true, m->ws_probs.as<float>(), T);
+    HIP_CHECK(hipMemcpyAsync(aProbs, m->ws_probs.p, (size_t)T * C * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipMemcpyAsync(aNewStateC, c.p, (size_t)H * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipMemcpyAsync(aNewStateH, h.p, (size_t)H * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
+
+// ---- decoder on caller-supplied emissions
+struct STTX_Decoder {
+  ModelState* m;
+  std::shared_ptr<ScorerDev> scorer;
+  std::map<std::string, float> hot;
+  DecoderBatch db;
+  DecParams p;
+  DevBuf probs, fbegin, fcount, hh, hb;
+};
+int STTX_DecoderCreate(ModelState* m, unsigned int aNumStreams, unsigned int aBeamWidth, double aCutoffProb, unsigned int aCutoffTopN, STTX_Decoder** retval) {
+  *retval = nullptr;
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(m->device));
+    std::unique_ptr<STTX_Decoder> d(new STTX_Decoder());
+    d->m = m; d->scorer = m->scorer_; d->hot = m->hot_words_;
+    m->decoder_create(d->db, (int)aNumStreams, (int)aBeamWidth, 64, d->scorer);
+    d->p = DecParams{};
+    d->p.C = m->g.n_classes; d->p.blank = d->p.C - 1; d->p.beam = (int)aBeamWidth; d->p.cutoff_top_n = (int)aCutoffTopN; d->p.cutoff_prob = aCutoffProb;
+    *retval = d.release();
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_CREATE_STREAM);
+}
+int STTX_DecoderNext(STTX_Decoder* d, const float* aProbs, unsigned int aStride, const unsigned int* aNumFrames) {
+  return guarded([&]() {
+    ModelState* m = d->m;
+    HIP_CHECK(hipSetDevice(m->device));
+    const int n = d->db.n_streams;
+    std::vector<int> more(n), zeros(n, 0);
+    for (int i = 0; i < n; ++i) more[i] = (int)aNumFrames[i];
+    m->decoder_reserve(d->db, more);
+    d->probs.upload(aProbs, (size_t)n * aStride * d->p.C * 4, m->stream);
+    d->fbegin.upload(zeros.data(), n * 4, m->stream);
+    d->fcount.upload(more.data(), n * 4, m->stream);
+    d->p.t_max = (int)aStride;
+    DevScorer ds = m->current_scorer(d->scorer, d->hot, d->hh, d->hb);
+    launch_ctc_next(d->p, ds, m->dev_alphabet, d->db.table.as<DecStream>(), n, d->probs.as<float>(), d->fbegin.as<int>(), d->fcount.as<int>(), m->stream);
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    HIP_CHECK(hipGetLastError());
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
+int STTX_DecoderDecode(const STTX_Decoder* d, unsigned int aNumResults, unsigned int aMaxLen, unsigned int* aTokens, unsigned int* aTimesteps, int* aLens,
+                       double* aConfidences, int* aNumResultsOut) {
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(d->m->device));
+    auto outs = decode_streams(*d->m, d->db, d->scorer, d->hot, aNumResults, (int)aMaxLen);
+    for (size_t i = 0; i < outs.size(); ++i) {
+      aNumResultsOut[i] = (int)outs[i].size();
+      for (size_t r = 0; r < outs[i].size(); ++r) {
+        const size_t ob = i * aNumResults + r;
+        aLens[ob] = (int)outs[i][r].tokens.size();
+        aConfidences[ob] = outs[i][r].confidence;
+        for (size_t j = 0; j < outs[i][r].tokens.size(); ++j) {
+          aTokens[ob * aMaxLen + j] = outs[i][r].tokens[j];
+          if (aTimesteps) aTimesteps[ob * aMaxLen + j] = j < outs[i][r].timesteps.size() ? outs[i][r].timesteps[j] : 0;
+        }
+      }
+    }
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
+int STTX_DecoderBeam(const STTX_Decoder* d, unsigned int aStream, float* aScore, float* aPb, float* aPnb, int* aChar, unsigned int aCap) {
+  int n = 0;
+  guarded([&]() {
+    ModelState* m = d->m;
+    DecStream S;
+    HIP_CHECK(hipMemcpy(&S, d->db.table.as<DecStream>() + aStream, sizeof(DecStream), hipMemcpyDeviceToHost));
+    n = std::min<int>(S.n, (int)aCap);
+    HIP_CHECK(hipMemcpy(aScore, S.score, n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(aPb, S.pb, n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(aPnb, S.pnb, n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(aChar, S.ch, n * 4, hipMemcpyDeviceToHost));
+    (void)m;
+    return 0;
+  }, 0);
+  return n;
+}
+int STTX_DecoderStats(const STTX_Decoder* d, unsigned long long* aOut4) {
+  return guarded([&]() {
+    std::vector<DecStream> tb(d->db.n_streams);
+    HIP_CHECK(hipMemcpy(tb.data(), d->db.table.p, sizeof(DecStream) * tb.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) aOut4[k] = 0;
+    for (auto& S : tb) for (int k = 0; k < 4; ++k) aOut4[k] += S.stat[k];
+    aOut4[3] |= 0;  // probes
+    int err = 0;
+    for (auto& S : tb) err |= S.error;
+    return err ? (int)STT_ERR_FAIL_RUN_SESS : (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
+void STTX_DecoderFree(STTX_Decoder* d) { delete d; }
+
+// ---- kernel-level hooks
+int STTX_TestDense(int M, int N, int K, const float* aX, const float* aW, const float* aBias, float aClip, int aEpilogue, float* aY) {
+  return guarded([&]() {
+    if (N % 128 || K % 64) return (int)STT_ERR_INVALID_SHAPE;
+    HIP_CHECK(hipSetDevice(g_device));
+    std::vector<_Float16> x((size_t)M * K), wt((size_t)N * K);
+    for (size_t i = 0; i < x.size(); ++i) x[i] = (_Float16)aX[i];
+    for (int k = 0; k < K; ++k) for (int n = 0; n < N; ++n) wt[(size_t)n * K + k] = (_Float16)aW[(size_t)k * N + n];
+    DevBuf dx, dw, db, dy;
+    dx.upload(x.data(), x.size() * 2); dw.upload(wt.data(), wt.size() * 2); db.upload(aBias, (size_t)N * 4);
+    dy.reserve((size_t)M * N * 4);
+    DenseArgs d{};
+    d.wt = dw.as<_Float16>(); d.x = dx.as<_Float16>(); d.bias = db.as<float>(); d.y = dy.p; d.M = M; d.N = N; d.K = K; d.ldx = K; d.ldy = N; d.relu_clip = aClip;
+    launch_dense(d, aEpilogue == 0 ? DENSE_EPI_RELU_F16 : DENSE_EPI_BIAS_F32, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipGetLastError());
+    if (aEpilogue == 0) {
+      std::vector<_Float16> y((size_t)M * N);
+      HIP_CHECK(hipMemcpy(y.data(), dy.p, y.size() * 2, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < y.size(); ++i) aY[i] = (float)y[i];
+    } else {
+      HIP_CHECK(hipMemcpy(aY, dy.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    }
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
+
+int STTX_TestMath(int aOp, const float* aA, const float* aB, float* aOut, unsigned int aCount) {
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(g_device));
+    DevBuf a, b, o;
+    a.upload(aA, (size_t)aCount * 4);
+    b.upload(aB ? aB : aA, (size_t)aCount * 4);
+    o.reserve((size_t)aCount * 4);
+    launch_test_math(aOp, a.as<float>(), b.as<float>(), o.as<float>(), aCount, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(aOut, o.p, (size_t)aCount * 4, hipMemcpyDeviceToHost));
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
+int STTX_PackLstmRecurrent(const float* aKernel, int aHidden, unsigned short* aOut) {
+  if (aHidden % 128) return STT_ERR_INVALID_SHAPE;
+  pack_lstm_recurrent_host(aKernel, aHidden, reinterpret_cast<_Float16*>(aOut));
+  return STT_ERR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+// stt_amd/csrc/ctc.h -- device-side data model of the CTC prefix beam search (internal header).
+//
+// The reference keeps a heap trie of PathTrie nodes (path_trie.h:44-113) and walks it with one CPU
+// thread per utterance.  Here a stream's search state is a flat struct-of-arrays beam (<= beam_size
+// live prefixes, always kept in prefix_compare order) plus two append-only arenas in HBM:
+//   path arena  {parent, character}        -> token back-tracking and n-gram reconstruction
+//   time arena  {parent, timestep}         -> the TimestepTreeNode tree (path_trie.h:17-37)
+// A prefix's identity is a 64-bit path hash (key); "does this child already exist in the beam"
+// (get_path_trie's child scan, path_trie.cpp:37-50) becomes an LDS hash probe.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define STT_KENLM_MAX_ORDER 6
+#define STT_ROOT_CH 0xFFFFFFFFu
+#define STT_MAX_BEAM 1024
+#define STT_MAX_CLASSES 8192
+
+struct DevBitPacked {
+  const uint8_t* base;
+  uint64_t word_mask, next_mask;
+  const uint64_t* off_begin;  // ArrayBhiksha offsets (null for DontBhiksha)
+  uint32_t off_count;
+  uint8_t word_bits, total_bits, quant_bits, next_bits;
+};
+
+// Everything a kernel needs to score with the .scorer package uploaded to HBM (KenLM trie +
+// dictionary FST + alphabet label bytes).  Passed by value.
+struct DevScorer {
+  int enabled;
+  int order, quant, utf8;
+  double alpha, beta;
+  const uint64_t* vocab;
+  uint64_t vocab_n;
+  const uint8_t* unigram;
+  const float* qprob[STT_KENLM_MAX_ORDER];
+  const float* qbackoff[STT_KENLM_MAX_ORDER];
+  DevBitPacked middle[STT_KENLM_MAX_ORDER - 2];
+  DevBitPacked longest;
+  uint32_t prob_mask, backoff_mask;
+  uint8_t prob_bits, backoff_bits;
+  uint32_t bos_index;
+  float bos_backoff;
+  // dictionary FST, repacked: state s -> arcs [state_pos[s], state_pos[s+1]); arc = {ilabel, nextstate}
+  int fst_start;
+  const uint32_t* fst_state_pos;
+  const uint8_t* fst_final;
+  const uint2* fst_arcs;
+  // hot words (murmur hashes of the words)
+  int n_hot;
+  const uint64_t* hot_hash;
+  const float* hot_boost;
+};
+
+struct DevAlphabet {
+  int n_labels;              // C - 1
+  int space_id;
+  const uint8_t* label_bytes;
+  const int* label_off;      // [n_labels] end offsets
+};
+
+// Per-stream search state; lives in HBM between launches, in LDS during a launch.
+struct DecStream {
+  int n;                // live prefixes
+  int abs_t;            // abs_time_step_
+  int start_expanding;  // ctc_beam_search_decoder.cpp:125-132
+  int error;            // bit0: path arena full, bit1: time arena full, bit2: candidate workspace full
+  uint32_t pa_n, ta_n, pa_cap, ta_cap;
+  // beam arrays [beam_cap]
+  float *score, *pb, *pnb;
+  uint32_t *ch, *node, *ts;
+  int* fst;
+  uint64_t* key;
+  uint2* pa;  // {parent, character}; entry 0 = root
+  uint2* ta;  // {parent, timestep};  entry 0 = timestep_tree_root_
+  // per-step candidate workspace [cand_cap]
+  float* c_logp;
+  uint32_t* c_pi;  // parent beam index | class position << 16 | needs_lm << 31
+  int* c_fst;
+  uint64_t* c_key;
+  uint64_t* sel_keys;  // [beam_cap + cand_cap]
+  uint32_t cand_cap;
+  // statistics (DESIGN.md roofline accounting): steps, candidates, lm queries, lm memory probes
+  unsigned long long stat[4];
+};
+
+struct DecParams {
+  int C, blank, beam, cutoff_top_n;
+  double cutoff_prob;
+  int t_max;  // row stride of probs in frames
+};
+
+struct DecodeOut {
+  uint32_t* tokens;     // [n_streams][num_results][max_len]
+  uint32_t* timesteps;  // same shape
+  int* lens;            // [n_streams][num_results]
+  double* confidence;   // [n_streams][num_results]
+  int* n_results;       // [n_streams]
+  int num_results, max_len;
+};
+
+void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
+                     const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st);
+void launch_ctc_decode(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const DecStream* streams, int n_streams,
+                       const DecodeOut& out, hipStream_t st);
+size_t ctc_next_lds_bytes(int beam, int C);
+void launch_ctc_init(DecStream* streams, int n_streams, int fst_start, hipStream_t st);

@@ -1,0 +1,741 @@
+// stt_amd/csrc/ctc.hip -- CTC prefix beam search with KenLM/FST scorer as gfx950 kernels.
+//
+// Replaces DecoderState::{next,decode} (native_client/ctcdecode/ctc_beam_search_decoder.cpp:112-326),
+// PathTrie (path_trie.cpp:37-209), the Scorer query side (scorer.cpp:272-396) and the KenLM trie
+// lookup (kenlm/lm/model.cc:170-176,285-338; lm/trie.cc:32-99; lm/bhiksha.hh:76-95;
+// lm/quantize.hh:152-209) plus OpenFst's SortedMatcher::Find on the dictionary (matcher.h:347-386).
+//
+// One 1024-thread workgroup per stream walks the timesteps of its chunk; a timestep is
+//   P0  class log-probs (glibc-exact logf), optional class sort/cut-off        get_pruned_emissions :328-358
+//   P1  LDS hash of the live prefixes' path keys
+//   P2  expand: blank / repeat / extend events per live prefix (FST arc scan)   :150-207, path_trie.cpp:37-100
+//   P3  language-model scores of boundary extensions (trie walk in HBM)        :209-243, scorer.cpp:308-396
+//   P4  merge the <=3 events of every live prefix in the reference's visiting order :166-193,245-253
+//   P5  scores (iterate_to_vec), radix-select the top beam_size, bitonic sort   path_trie.cpp:159-190, :263-274
+//   P6  write the new beam, append arena nodes
+// Float arithmetic uses sttmath.h (bit-exact glibc expf/logf), so scores are bit-identical to the
+// reference; ties the reference leaves to libstdc++ are broken by (live-before-new, beam index).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ctc.h"
+#include "sttmath.h"
+
+using sttm::stt_log_sum_exp;
+using sttm::stt_logf;
+
+#define NTHREADS 1024
+#define ABSENT_BITS 0xFFFFFFFFu
+#define OOV_SCORE_D (-1000.0)  // scorer.h:16
+
+// ------------------------------------------------------------------------------------ small helpers
+__device__ __forceinline__ uint64_t ld64u(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ bool is_absent(float x) { return __float_as_uint(x) == ABSENT_BITS; }
+__device__ __forceinline__ float absent() { return __uint_as_float(ABSENT_BITS); }
+
+__device__ __forceinline__ uint64_t child_key(uint64_t parent_key, uint32_t c) {
+  uint64_t x = parent_key + 0x9E3779B97F4A7C15ULL * (uint64_t)(c + 1);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31;
+  return x | 1ULL;  // 0 is the empty marker of the LDS hash
+}
+
+// selection key: ascending key order == (score desc, character asc, live before new, beam index asc)
+__device__ __forceinline__ uint64_t sel_key(float score, uint32_t ch, uint32_t is_new, uint32_t idx) {
+  uint32_t u = __float_as_uint(score);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> uint
+  const uint32_t c16 = ch == STT_ROOT_CH ? 0xFFFFu : (ch & 0xFFFFu);
+  return ((uint64_t)(~u) << 32) | ((uint64_t)c16 << 11) | ((uint64_t)is_new << 10) | (uint64_t)idx;
+}
+
+// ------------------------------------------------------------------------------------ KenLM trie query
+struct KState { uint32_t words[STT_KENLM_MAX_ORDER - 1]; float backoff[STT_KENLM_MAX_ORDER - 1]; int length; };
+struct KNode { uint64_t begin, end; };
+
+__device__ __forceinline__ uint64_t read_int57(const uint8_t* base, uint64_t bit_off, uint64_t mask) {
+  return (ld64u(base + (bit_off >> 3)) >> (bit_off & 7)) & mask;
+}
+__device__ __forceinline__ bool has_extension(float backoff) { return __float_as_uint(backoff) != 0x80000000u; }
+
+__device__ uint32_t vocab_index(const DevScorer& s, uint64_t h, unsigned& probes) {
+  uint64_t lo = 0, hi = s.vocab_n;
+  while (lo < hi) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    const uint64_t v = s.vocab[mid];
+    ++probes;
+    if (v < h) lo = mid + 1; else if (v > h) hi = mid; else return (uint32_t)(mid + 1);
+  }
+  return 0;
+}
+__device__ bool find_bitpacked(const DevBitPacked& bp, uint64_t begin, uint64_t end, uint64_t key, uint64_t& at, unsigned& probes) {
+  while (begin < end) {
+    const uint64_t mid = begin + (end - begin) / 2;
+    const uint64_t v = read_int57(bp.base, mid * bp.total_bits, bp.word_mask);
+    ++probes;
+    if (v < key) begin = mid + 1; else if (v > key) end = mid; else { at = mid; return true; }
+  }
+  return false;
+}
+__device__ void read_next(const DevBitPacked& m, uint64_t bit_offset, uint64_t index, KNode& out, unsigned& probes) {
+  if (!m.off_begin) {
+    out.begin = read_int57(m.base, bit_offset, m.next_mask);
+    out.end = read_int57(m.base, bit_offset + m.total_bits, m.next_mask);
+    probes += 2;
+    return;
+  }
+  uint32_t lo = 0, hi = m.off_count;  // upper_bound(offsets, index) - 1
+  while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; ++probes; if (m.off_begin[mid] <= index) lo = mid + 1; else hi = mid; }
+  const uint32_t bi = lo - 1;
+  uint32_t ei = bi + 1;
+  while (ei < m.off_count && m.off_begin[ei] <= index + 1) { ++ei; ++probes; }
+  --ei;
+  out.begin = ((uint64_t)bi << m.next_bits) | read_int57(m.base, bit_offset, m.next_mask);
+  out.end = ((uint64_t)ei << m.next_bits) | read_int57(m.base, bit_offset + m.total_bits, m.next_mask);
+  probes += 2;
+}
+__device__ bool lookup_middle(const DevScorer& s, int om2, uint32_t word, KNode& node, bool& independent_left, float& prob, float& backoff, unsigned& probes) {
+  const DevBitPacked& m = s.middle[om2];
+  uint64_t at;
+  if (!find_bitpacked(m, node.begin, node.end, word, at, probes)) { independent_left = true; return false; }
+  const uint64_t addr = at * m.total_bits + m.word_bits;
+  read_next(m, addr + m.quant_bits, at, node, probes);
+  independent_left = (node.begin == node.end);
+  if (s.quant) {
+    backoff = s.qbackoff[om2][(ld32u(m.base + (addr >> 3)) >> (addr & 7)) & s.backoff_mask];
+    const uint64_t pa = addr + s.backoff_bits;
+    prob = s.qprob[om2][(ld32u(m.base + (pa >> 3)) >> (pa & 7)) & s.prob_mask];
+  } else {
+    prob = __uint_as_float((uint32_t)(ld64u(m.base + (addr >> 3)) >> (addr & 7)) | 0x80000000u);
+    const uint64_t ba = addr + 31;
+    backoff = __uint_as_float((uint32_t)(ld64u(m.base + (ba >> 3)) >> (ba & 7)));
+  }
+  probes += 2;
+  return true;
+}
+__device__ bool lookup_longest(const DevScorer& s, uint32_t word, const KNode& node, float& prob, unsigned& probes) {
+  const DevBitPacked& l = s.longest;
+  uint64_t at;
+  if (!find_bitpacked(l, node.begin, node.end, word, at, probes)) return false;
+  const uint64_t addr = at * l.total_bits + l.word_bits;
+  if (s.quant) prob = s.qprob[s.order - 2][(ld32u(l.base + (addr >> 3)) >> (addr & 7)) & s.prob_mask];
+  else prob = __uint_as_float((uint32_t)(ld64u(l.base + (addr >> 3)) >> (addr & 7)) | 0x80000000u);
+  ++probes;
+  return true;
+}
+// GenericModel::FullScore (model.cc:170-176) = ScoreExceptBackoff (:285-310) + ResumeScore (:312-338)
+__device__ float kenlm_full_score(const DevScorer& s, const KState& in, uint32_t new_word, KState& out, unsigned& probes) {
+  KNode node;
+  const uint8_t* u = s.unigram + 16 * (uint64_t)new_word;
+  float prob = __uint_as_float(ld32u(u));
+  out.backoff[0] = __uint_as_float(ld32u(u + 4));
+  node.begin = ld64u(u + 8);
+  node.end = ld64u(u + 24);
+  probes += 2;
+  bool independent_left = (node.begin == node.end);
+  int nl = 1;
+  out.length = has_extension(out.backoff[0]) ? 1 : 0;
+  out.words[0] = new_word;
+  if (in.length != 0) {
+    int hi = 0;
+    int om2 = 0;
+    bool at_longest = false;
+    for (;; ++om2, ++hi) {
+      if (hi == in.length) break;
+      if (independent_left) break;
+      if (om2 == s.order - 2) { at_longest = true; break; }
+      float p, b;
+      if (!lookup_middle(s, om2, in.words[hi], node, independent_left, p, b, probes)) break;
+      out.backoff[om2 + 1] = b;
+      prob = p;
+      nl = om2 + 2;
+      if (has_extension(b)) out.length = nl;
+    }
+    if (at_longest) {
+      float p;
+      if (lookup_longest(s, in.words[hi], node, p, probes)) { prob = p; nl = s.order; }
+    }
+    for (int i = 0; i + 1 < out.length; ++i) out.words[i + 1] = in.words[i];
+  }
+  for (int i = nl - 1; i < in.length; ++i) prob = __fadd_rn(prob, in.backoff[i]);
+  return prob;
+}
+
+// MurmurHash64A(seed 0) of the UTF-8 bytes of labels labs[nl-1], ..., labs[0]  (labels were collected backwards)
+__device__ uint64_t hash_labels_reversed(const DevAlphabet& al, const uint32_t* labs, int nl) {
+  const uint64_t m = 0xc6a4a7935bd1e995ULL;
+  const int r = 47;
+  size_t len = 0;
+  for (int i = 0; i < nl; ++i) { const uint32_t c = labs[i]; len += al.label_off[c] - (c ? al.label_off[c - 1] : 0); }
+  uint64_t h = 0 ^ (len * m);
+  uint64_t k = 0;
+  int nb = 0;
+  for (int i = nl - 1; i >= 0; --i) {
+    const uint32_t c = labs[i];
+    const int b0 = c ? al.label_off[c - 1] : 0, b1 = al.label_off[c];
+    for (int b = b0; b < b1; ++b) {
+      k |= (uint64_t)al.label_bytes[b] << (8 * nb);
+      if (++nb == 8) {
+        k *= m; k ^= k >> r; k *= m;
+        h ^= k; h *= m;
+        k = 0; nb = 0;
+      }
+    }
+  }
+  if (nb) { h ^= k; h *= m; }  // the tail switch of MurmurHash64A xors the remaining bytes little-endian, then multiplies
+  h ^= h >> r; h *= m; h ^= h >> r;
+  return h;
+}
+
+#define MAX_UNIT_LABELS 64  // longest word (in labels) the device reconstructs; dictionary words are far shorter
+
+// Scorer::make_ngram (scorer.cpp:370-396) + get_log_cond_prob (:308-344) + hot words (ctc_beam_search_decoder.cpp:224-236).
+// The prefix to score is `first` (a virtual last label, or STT_ROOT_CH for none) on top of path-arena node `node`.
+// Returns (log_cond_prob + hot_boost) * alpha rounded to float, exactly as the reference's `float score`.
+__device__ float lm_score(const DevScorer& s, const DevAlphabet& al, const uint2* pa, uint32_t node, uint32_t first, bool with_hot, unsigned& probes) {
+  uint64_t hashes[STT_KENLM_MAX_ORDER];
+  int n = 0;
+  uint32_t cur = node;
+  uint32_t pending = first;  // virtual top-of-path label
+  uint32_t labs[MAX_UNIT_LABELS];
+  for (int order = 0; order < s.order; ++order) {
+    // current_node == nullptr || character == ROOT
+    uint32_t cur_ch;
+    if (pending != STT_ROOT_CH) cur_ch = pending;
+    else { if (cur == STT_ROOT_CH) break; cur_ch = pa[cur].y; ++probes; }
+    if (cur_ch == STT_ROOT_CH) break;
+    int nl = 0;
+    // walk back to the unit's stop node (space/root in word mode, first byte of the codepoint in utf8 mode)
+    for (;;) {
+      uint32_t c;
+      if (pending != STT_ROOT_CH) c = pending; else { c = pa[cur].y; ++probes; }
+      if (s.utf8) {
+        if (c == STT_ROOT_CH) break;  // stop = root, nothing pushed
+        if (nl < MAX_UNIT_LABELS) labs[nl++] = c;
+        const uint8_t fb = al.label_bytes[c ? al.label_off[c - 1] : 0];
+        const bool boundary = (fb & 0xC0) != 0x80;
+        // move to the parent either way: if boundary, stop = this node and current = stop->parent
+        if (pending != STT_ROOT_CH) pending = STT_ROOT_CH; else cur = pa[cur].x;
+        if (boundary) break;
+      } else {
+        if (c == (uint32_t)al.space_id || c == STT_ROOT_CH) {
+          // stop = this node; current = stop->parent
+          if (pending != STT_ROOT_CH) pending = STT_ROOT_CH; else cur = pa[cur].x;
+          break;
+        }
+        if (nl < MAX_UNIT_LABELS) labs[nl++] = c;
+        if (pending != STT_ROOT_CH) pending = STT_ROOT_CH; else cur = pa[cur].x;
+        if (cur == STT_ROOT_CH) break;  // unreachable for well-formed arenas (root has character ROOT)
+      }
+    }
+    hashes[n++] = hash_labels_reversed(al, labs, nl);
+  }
+  // hashes[] is newest-first; the reference reverses to oldest-first
+  float hot_boost = 0.0f;
+  if (with_hot && s.n_hot) {
+    for (int i = n - 1; i >= 0; --i)
+      for (int j = 0; j < s.n_hot; ++j)
+        if (hashes[i] == s.hot_hash[j]) hot_boost = __fadd_rn(hot_boost, s.hot_boost[j]);
+  }
+  const bool bos = n < s.order;
+  KState a, b;
+  KState* in = &a; KState* out = &b;
+  in->length = 0;
+  if (bos) { in->length = 1; in->words[0] = s.bos_index; in->backoff[0] = s.bos_backoff; }
+  double cond_prob = 0.0;
+  bool oov = false;
+  for (int i = n - 1; i >= 0; --i) {
+    const uint32_t wi = vocab_index(s, hashes[i], probes);
+    if (wi == 0) { oov = true; break; }
+    cond_prob = (double)kenlm_full_score(s, *in, wi, *out, probes);
+    KState* t = in; in = out; out = t;
+  }
+  const double lcp = oov ? OOV_SCORE_D : __ddiv_rn(cond_prob, (double)0.4342944819f);  // / NUM_FLT_LOGE (a float constant)
+  return (float)__dmul_rn(__dadd_rn(lcp, (double)hot_boost), s.alpha);
+}
+
+// Scorer::is_scoring_boundary (scorer.cpp:272-299) for the prefix (`first` on top of `node`) and label `new_label`
+__device__ bool is_scoring_boundary(const DevScorer& s, const DevAlphabet& al, const uint2* pa, uint32_t node, uint32_t first, uint32_t new_label, unsigned& probes) {
+  if (!s.utf8) return (int)new_label == al.space_id;
+  uint32_t cur = node, pending = first;
+  int dist = 0;
+  uint8_t first_byte = 0;
+  bool found = false;
+  for (;;) {
+    uint32_t c;
+    if (pending != STT_ROOT_CH) c = pending; else { if (cur == STT_ROOT_CH) break; c = pa[cur].y; ++probes; }
+    if (c == STT_ROOT_CH) break;  // prefix->character == -1 -> false / walked past the first label
+    const uint8_t fb = al.label_bytes[c ? al.label_off[c - 1] : 0];
+    dist += 1;
+    if ((fb & 0xC0) != 0x80) { first_byte = (uint8_t)((uint8_t)c + 1); found = true; break; }
+    if (pending != STT_ROOT_CH) pending = STT_ROOT_CH; else cur = pa[cur].x;
+  }
+  if (!found) return false;
+  int needed;
+  if ((first_byte >> 3) == 0x1E) needed = 4;
+  else if ((first_byte >> 4) == 0x0E) needed = 3;
+  else if ((first_byte >> 5) == 0x06) needed = 2;
+  else if ((first_byte >> 7) == 0x00) needed = 1;
+  else return false;
+  return dist == needed;
+}
+
+// ------------------------------------------------------------------------------------ LDS layout
+struct Lds {
+  float *score[2], *pb[2], *pnb[2];
+  uint32_t *ch[2], *node[2], *ts[2];
+  int* fst[2];
+  uint64_t* key[2];
+  float *ev_self, *ev_blank, *ev_ext;  // reused as new pnb / new pb / new score in P4
+  uint32_t* ev_exti;                   // parent beam index | needs_lm << 31 ; reused as pending timestep parent
+  uint64_t* ht_key; uint16_t* ht_idx; uint32_t ht_mask;
+  float *pf, *lp; uint16_t *cls, *pos;
+  uint32_t* hist;
+  uint64_t* skey; uint32_t* ssrc;
+  int* sc;  // scalars
+};
+enum { SC_M = 0, SC_CUTLEN, SC_FULL, SC_KEEP, SC_START, SC_DIGIT, SC_NEED, SC_SKIP, SC_LMQ, SC_PROBES, SC_ERR, SC_MINCUT, SC_COUNT = 16 };
+
+__host__ __device__ inline uint32_t pow2_ge(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+__host__ __device__ inline size_t lds_carve(int beam, int C, Lds* l, unsigned char* base) {
+  const uint32_t cap = (uint32_t)((beam + 63) & ~63);
+  const uint32_t sortn = pow2_ge((uint32_t)beam);
+  const uint32_t htn = 2 * pow2_ge(cap);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
+  size_t offs[64]; int k = 0;
+  for (int d = 0; d < 2; ++d) {
+    offs[k++] = take(cap * 8);                                     // key
+    for (int a = 0; a < 7; ++a) offs[k++] = take(cap * 4);         // score pb pnb ch node ts fst
+  }
+  for (int a = 0; a < 4; ++a) offs[k++] = take(cap * 4);           // events
+  offs[k++] = take(htn * 8); offs[k++] = take(htn * 2);            // hash
+  offs[k++] = take((size_t)C * 4); offs[k++] = take((size_t)C * 4); offs[k++] = take((size_t)C * 2); offs[k++] = take((size_t)C * 2);
+  offs[k++] = take(256 * 4);
+  offs[k++] = take(sortn * 8); offs[k++] = take(sortn * 4);
+  offs[k++] = take(SC_COUNT * 4);
+  if (l) {
+    k = 0;
+    for (int d = 0; d < 2; ++d) {
+      l->key[d] = (uint64_t*)(base + offs[k++]);
+      l->score[d] = (float*)(base + offs[k++]); l->pb[d] = (float*)(base + offs[k++]); l->pnb[d] = (float*)(base + offs[k++]);
+      l->ch[d] = (uint32_t*)(base + offs[k++]); l->node[d] = (uint32_t*)(base + offs[k++]); l->ts[d] = (uint32_t*)(base + offs[k++]);
+      l->fst[d] = (int*)(base + offs[k++]);
+    }
+    l->ev_self = (float*)(base + offs[k++]); l->ev_blank = (float*)(base + offs[k++]); l->ev_ext = (float*)(base + offs[k++]);
+    l->ev_exti = (uint32_t*)(base + offs[k++]);
+    l->ht_key = (uint64_t*)(base + offs[k++]); l->ht_idx = (uint16_t*)(base + offs[k++]); l->ht_mask = htn - 1;
+    l->pf = (float*)(base + offs[k++]); l->lp = (float*)(base + offs[k++]); l->cls = (uint16_t*)(base + offs[k++]); l->pos = (uint16_t*)(base + offs[k++]);
+    l->hist = (uint32_t*)(base + offs[k++]);
+    l->skey = (uint64_t*)(base + offs[k++]); l->ssrc = (uint32_t*)(base + offs[k++]);
+    l->sc = (int*)(base + offs[k++]);
+  }
+  return o;
+}
+size_t ctc_next_lds_bytes(int beam, int C) { return lds_carve(beam, C, nullptr, nullptr); }
+
+__device__ __forceinline__ int ht_find(const Lds& L, uint64_t k) {
+  uint32_t h = (uint32_t)(k >> 17) & L.ht_mask;
+  for (;;) {
+    const uint64_t v = L.ht_key[h];
+    if (v == k) return (int)L.ht_idx[h];
+    if (v == 0) return -1;
+    h = (h + 1) & L.ht_mask;
+  }
+}
+
+// in-LDS bitonic sort of (key, src) pairs, ascending by key; n must be a power of two
+__device__ void bitonic_sort(uint64_t* key, uint32_t* src, uint32_t n) {
+  for (uint32_t k = 2; k <= n; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t ixj = i ^ j;
+        if (ixj > i) {
+          const uint64_t a = key[i], b = key[ixj];
+          const bool up = ((i & k) == 0);
+          if ((a > b) == up) { key[i] = b; key[ixj] = a; const uint32_t t = src[i]; src[i] = src[ixj]; src[ixj] = t; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ one timestep
+__device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphabet& al, DecStream& S, const Lds& L, int& cur, int& n,
+                         const float* prob_row) {
+  const int tid = threadIdx.x;
+  const int C = p.C, beam = p.beam;
+  int* sc = L.sc;
+  const float NEG = STT_NEG_INF;
+
+  // ---- P0: emissions
+  for (int c = tid; c < C; c += NTHREADS) L.pf[c] = prob_row[c];
+  if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; }
+  __syncthreads();
+  if (tid == 0) {
+    if ((double)L.pf[p.blank] < 0.999) S.start_expanding = 1;
+    sc[SC_START] = S.start_expanding;
+  }
+  __syncthreads();
+  if (!sc[SC_START]) { if (tid == 0) S.abs_t++; __syncthreads(); return; }
+
+  const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
+  if (sort_classes) {  // std::sort by probability, descending (ties: class index)
+    for (int c = tid; c < C; c += NTHREADS) {
+      const float v = L.pf[c];
+      int rank = 0;
+      for (int o = 0; o < C; ++o) { const float w = L.pf[o]; rank += (w > v) || (w == v && o < c); }
+      L.cls[rank] = (uint16_t)c;
+    }
+  } else {
+    for (int c = tid; c < C; c += NTHREADS) L.cls[c] = (uint16_t)c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int cutoff_len = C;
+    if (sort_classes && p.cutoff_prob < 1.0) {
+      double cum = 0.0; cutoff_len = 0;
+      for (int i = 0; i < C; ++i) { cum = __dadd_rn(cum, (double)L.pf[L.cls[i]]); cutoff_len += 1; if (cum >= p.cutoff_prob || cutoff_len >= p.cutoff_top_n) break; }
+    }
+    sc[SC_CUTLEN] = cutoff_len;
+    float min_cutoff = NEG; int full = 0;
+    if (s.enabled) {  // :136-146 (the beam is kept in prefix_compare order, so no partial_sort is needed)
+      const double mc = __dadd_rn(__dadd_rn((double)L.score[cur][n - 1], log((double)L.pf[p.blank])), -fmax(0.0, s.beta));
+      min_cutoff = (float)mc;
+      full = (n == beam);
+    }
+    sc[SC_FULL] = full;
+    ((float*)sc)[SC_MINCUT] = min_cutoff;
+  }
+  for (int c = tid; c < C; c += NTHREADS) L.pos[c] = 0xFFFF;
+  __syncthreads();
+  const int cutoff_len = sc[SC_CUTLEN];
+  const bool full_beam = sc[SC_FULL] != 0;
+  const float min_cutoff = ((float*)sc)[SC_MINCUT];
+  for (int k = tid; k < cutoff_len; k += NTHREADS) {
+    const int c = L.cls[k];
+    L.pos[c] = (uint16_t)k;
+    L.lp[k] = stt_logf(__fadd_rn(L.pf[c], STT_FLT_MIN));  // log(prob + NUM_FLT_MIN), :355
+  }
+  // ---- P1: hash of live keys, clear events
+  for (uint32_t h = tid; h <= L.ht_mask; h += NTHREADS) L.ht_key[h] = 0;
+  for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
+  __syncthreads();
+  for (int i = tid; i < n; i += NTHREADS) {
+    const uint64_t k = L.key[cur][i];
+    uint32_t h = (uint32_t)(k >> 17) & L.ht_mask;
+    for (;;) {
+      const unsigned long long old = atomicCAS((unsigned long long*)&L.ht_key[h], 0ULL, (unsigned long long)k);
+      if (old == 0ULL) { L.ht_idx[h] = (uint16_t)i; break; }
+      h = (h + 1) & L.ht_mask;
+    }
+  }
+  __syncthreads();
+
+  // ---- P2: expand every live prefix
+  unsigned probes = 0;
+  for (int i = tid; i < n; i += NTHREADS) {
+    const float sci = L.score[cur][i];
+    if (sci == NEG) continue;  // :160-162
+    const uint32_t chi = L.ch[cur][i];
+    const uint64_t keyi = L.key[cur][i];
+    {  // blank, :166-179
+      const int kb = L.pos[p.blank];
+      if (kb != 0xFFFF) { const float lpc = L.lp[kb]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_blank[i] = __fadd_rn(lpc, sci); }
+    }
+    if (chi != STT_ROOT_CH) {  // repeated character, :182-193
+      const int ks = L.pos[chi];
+      if (ks != 0xFFFF) { const float lpc = L.lp[ks]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_self[i] = __fadd_rn(lpc, L.pnb[cur][i]); }
+    }
+    // extensions: with a dictionary only the out-arcs of the prefix's FST state can succeed (path_trie.cpp:54-64)
+    uint32_t a0 = 0, a1 = (uint32_t)(C - 1);
+    if (s.enabled) { const int st = L.fst[cur][i]; a0 = s.fst_state_pos[st]; a1 = s.fst_state_pos[st + 1]; }
+    for (uint32_t a = a0; a < a1; ++a) {
+      uint32_t c; int child_fst = 0;
+      if (s.enabled) {
+        const uint2 arc = s.fst_arcs[a];
+        if (arc.x == 0 || arc.x > (uint32_t)(C - 1)) continue;  // epsilon / label outside the alphabet: never matched
+        c = arc.x - 1;
+        child_fst = s.fst_final[arc.y] ? s.fst_start : (int)arc.y;  // path_trie.cpp:79-87
+      } else {
+        c = a;
+      }
+      if ((int)c == p.blank) continue;
+      const int k = L.pos[c];
+      if (k == 0xFFFF) continue;
+      const float lpc = L.lp[k];
+      if (full_beam && __fadd_rn(lpc, sci) < min_cutoff) continue;  // the `break` of :157-159 (beam is sorted by score)
+      float log_p = NEG;  // :199-207
+      if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
+      else log_p = __fadd_rn(lpc, sci);
+      uint32_t needs_lm = 0;
+      if (s.enabled) needs_lm = s.utf8 ? (is_scoring_boundary(s, al, S.pa, L.node[cur][i], c, c, probes) ? 1u : 0u) : ((int)c == al.space_id ? 1u : 0u);
+      const uint64_t ck = child_key(keyi, c);
+      const int j = ht_find(L, ck);
+      if (j >= 0) {  // the child is a live prefix: one extension event per live prefix per step
+        L.ev_ext[j] = log_p;
+        L.ev_exti[j] = (uint32_t)i | (needs_lm << 31) ;
+      } else {
+        const int slot = atomicAdd(&sc[SC_M], 1);
+        if ((uint32_t)slot < S.cand_cap) {
+          S.c_logp[slot] = log_p;
+          S.c_pi[slot] = (uint32_t)i | ((uint32_t)k << 16) | (needs_lm << 31);
+          S.c_fst[slot] = child_fst;
+          S.c_key[slot] = ck;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  int m = sc[SC_M];
+  if ((uint32_t)m > S.cand_cap) { m = (int)S.cand_cap; if (tid == 0) sc[SC_ERR] |= 4; }
+
+  // ---- P3: language model on scoring boundaries (:209-243)
+  if (s.enabled) {
+    unsigned lmq = 0;
+    for (int x = tid; x < m + n; x += NTHREADS) {
+      uint32_t pi; float lp0;
+      if (x < m) { pi = S.c_pi[x]; lp0 = S.c_logp[x]; }
+      else { const int j = x - m; if (is_absent(L.ev_ext[j])) continue; pi = L.ev_exti[j]; lp0 = L.ev_ext[j]; }
+      if (!(pi >> 31)) continue;
+      const int i = (int)(pi & 0xFFFFu);
+      uint32_t first = STT_ROOT_CH;
+      if (s.utf8) first = (x < m) ? (uint32_t)L.cls[(pi >> 16) & 0x7FFFu] : L.ch[cur][x - m];  // score the *new* prefix
+      const float lms = lm_score(s, al, S.pa, L.node[cur][i], first, true, probes);
+      ++lmq;
+      float lpv = __fadd_rn(lp0, lms);                       // log_p += score;
+      lpv = (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
+      if (x < m) S.c_logp[x] = lpv; else L.ev_ext[x - m] = lpv;
+    }
+    if (lmq) atomicAdd(&sc[SC_LMQ], (int)lmq);
+  }
+  if (probes) atomicAdd(&sc[SC_PROBES], (int)probes);
+  __syncthreads();
+
+  // ---- P4: merge events of live prefixes in the reference's visiting order (class position, then beam index)
+  for (int j = tid; j < n; j += NTHREADS) {
+    const float e_self = L.ev_self[j], e_blank = L.ev_blank[j], e_ext = L.ev_ext[j];
+    const uint32_t ei = L.ev_exti[j] & 0x7FFFFFFFu;
+    float nb = NEG, bb = NEG;
+    uint32_t pend = 0xFFFFFFFEu;  // "no pending update" (previous_timesteps == nullptr)
+    const uint32_t chj = L.ch[cur][j];
+    const int kblank = L.pos[p.blank];
+    const int kself = chj == STT_ROOT_CH ? 0xFFFF : L.pos[chj];
+    const bool blank_first = kblank < kself;
+    if (blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
+    const bool ext_first = (int)ei < j;
+    if (ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = stt_log_sum_exp(nb, e_ext); }
+    if (!is_absent(e_self)) { if (nb < e_self) pend = 0xFFFFFFFEu; nb = stt_log_sum_exp(nb, e_self); }
+    if (!ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = stt_log_sum_exp(nb, e_ext); }
+    if (!blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
+    const float nscore = stt_log_sum_exp(bb, nb);  // iterate_to_vec, path_trie.cpp:170
+    L.ev_blank[j] = bb; L.ev_self[j] = nb; L.ev_ext[j] = nscore; L.ev_exti[j] = pend;
+    S.sel_keys[j] = sel_key(nscore, chj, 0, (uint32_t)j);
+  }
+  for (int x = tid; x < m; x += NTHREADS) {
+    const uint32_t pi = S.c_pi[x];
+    S.sel_keys[n + x] = sel_key(S.c_logp[x], (uint32_t)L.cls[(pi >> 16) & 0x7FFFu], 1, pi & 0xFFFFu);
+  }
+  __syncthreads();
+
+  // ---- P5: keep the best beam_size (nth_element + resize, :263-274), fully sorted
+  const int total = n + m;
+  const int keep = total < beam ? total : beam;
+  const uint32_t sortn = pow2_ge((uint32_t)(keep > 0 ? keep : 1));
+  uint64_t threshold = ~0ULL;
+  if (total > beam) {
+    uint64_t prefix = 0, mask = 0;
+    if (tid == 0) sc[SC_NEED] = keep;
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 56 - 8 * pass;
+      for (int d = tid; d < 256; d += NTHREADS) L.hist[d] = 0;
+      __syncthreads();
+      for (int x = tid; x < total; x += NTHREADS) {
+        const uint64_t k = S.sel_keys[x];
+        if ((k & mask) == prefix) atomicAdd(&L.hist[(k >> shift) & 255], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int need = sc[SC_NEED];
+        uint32_t cum = 0; int d = 0;
+        for (; d < 256; ++d) { if (cum + L.hist[d] >= (uint32_t)need) break; cum += L.hist[d]; }
+        sc[SC_DIGIT] = d; sc[SC_NEED] = need - (int)cum;
+      }
+      __syncthreads();
+      prefix |= (uint64_t)sc[SC_DIGIT] << shift;
+      mask |= 0xFFULL << shift;
+    }
+    threshold = prefix;  // keys are unique, so exactly `keep` keys are <= threshold
+  }
+  if (tid == 0) sc[SC_KEEP] = 0;
+  for (uint32_t x = tid; x < sortn; x += NTHREADS) { L.skey[x] = ~0ULL; L.ssrc[x] = 0; }
+  __syncthreads();
+  for (int x = tid; x < total; x += NTHREADS) {
+    const uint64_t k = S.sel_keys[x];
+    if (k <= threshold) { const int r = atomicAdd(&sc[SC_KEEP], 1); if (r < (int)sortn) { L.skey[r] = k; L.ssrc[r] = (uint32_t)x; } }
+  }
+  __syncthreads();
+  bitonic_sort(L.skey, L.ssrc, sortn);
+
+  // ---- P6: new beam
+  const int nxt = cur ^ 1;
+  for (int r = tid; r < keep; r += NTHREADS) {
+    const uint32_t x = L.ssrc[r];
+    uint32_t ts_new, pend;
+    if ((int)x < n) {
+      L.score[nxt][r] = L.ev_ext[x]; L.pb[nxt][r] = L.ev_blank[x]; L.pnb[nxt][r] = L.ev_self[x];
+      L.ch[nxt][r] = L.ch[cur][x]; L.node[nxt][r] = L.node[cur][x]; L.fst[nxt][r] = L.fst[cur][x]; L.key[nxt][r] = L.key[cur][x];
+      pend = L.ev_exti[x]; ts_new = L.ts[cur][x];
+    } else {
+      const int cx = (int)x - n;
+      const uint32_t pi = S.c_pi[cx];
+      const int i = (int)(pi & 0xFFFFu);
+      const uint32_t c = (uint32_t)L.cls[(pi >> 16) & 0x7FFFu];
+      const float lpv = S.c_logp[cx];
+      L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
+      L.ch[nxt][r] = c; L.fst[nxt][r] = S.c_fst[cx]; L.key[nxt][r] = S.c_key[cx];
+      const uint32_t slot = atomicAdd(&S.pa_n, 1u);
+      if (slot < S.pa_cap) { S.pa[slot] = make_uint2(L.node[cur][i], c); L.node[nxt][r] = slot; }
+      else { L.node[nxt][r] = 0; atomicOr(&sc[SC_ERR], 1); }
+      pend = (NEG < lpv) ? L.ts[cur][i] : 0xFFFFFFFEu;  // :246-251 with log_prob_nb_cur == -inf
+      ts_new = STT_ROOT_CH;                              // timesteps == nullptr
+    }
+    if (pend != 0xFFFFFFFEu) {  // path_trie.cpp:172-184
+      const uint32_t slot = atomicAdd(&S.ta_n, 1u);
+      if (slot < S.ta_cap) { S.ta[slot] = make_uint2(pend, (uint32_t)S.abs_t); ts_new = slot; }
+      else atomicOr(&sc[SC_ERR], 2);
+    }
+    L.ts[nxt][r] = ts_new;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    S.abs_t++;
+    S.stat[0] += 1; S.stat[1] += (unsigned long long)m; S.stat[2] += (unsigned long long)sc[SC_LMQ]; S.stat[3] += (unsigned long long)(unsigned)sc[SC_PROBES];
+  }
+  cur = nxt;
+  n = keep;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScorer s, DevAlphabet al, DecStream* streams,
+                                                            const float* probs, const int* frame_begin, const int* frame_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Lds L;
+  lds_carve(p.beam, p.C, &L, smem);
+  DecStream& S = streams[blockIdx.x];
+  const int nfr = frame_count[blockIdx.x];
+  if (nfr <= 0) return;
+  const int tid = threadIdx.x;
+  int n = S.n;
+  int cur = 0;
+  for (int i = tid; i < n; i += NTHREADS) {
+    L.score[0][i] = S.score[i]; L.pb[0][i] = S.pb[i]; L.pnb[0][i] = S.pnb[i];
+    L.ch[0][i] = S.ch[i]; L.node[0][i] = S.node[i]; L.ts[0][i] = S.ts[i]; L.fst[0][i] = S.fst[i]; L.key[0][i] = S.key[i];
+  }
+  if (tid == 0) L.sc[SC_ERR] = 0;
+  __syncthreads();
+  const float* row = probs + ((size_t)blockIdx.x * p.t_max + frame_begin[blockIdx.x]) * p.C;
+  for (int t = 0; t < nfr; ++t) ctc_step(p, s, al, S, L, cur, n, row + (size_t)t * p.C);
+  for (int i = tid; i < n; i += NTHREADS) {
+    S.score[i] = L.score[cur][i]; S.pb[i] = L.pb[cur][i]; S.pnb[i] = L.pnb[cur][i];
+    S.ch[i] = L.ch[cur][i]; S.node[i] = L.node[cur][i]; S.ts[i] = L.ts[cur][i]; S.fst[i] = L.fst[cur][i]; S.key[i] = L.key[cur][i];
+  }
+  if (tid == 0) { S.n = n; S.error |= L.sc[SC_ERR]; }
+}
+
+// ------------------------------------------------------------------------------------ decode
+// DecoderState::decode (ctc_beam_search_decoder.cpp:278-326): add the LM score of an unfinished last word,
+// rank by prefix_compare_external, back-track tokens and timesteps.  Read-only on the stream.
+__global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevScorer s, DevAlphabet al, const DecStream* streams, DecodeOut out) {
+  __shared__ uint64_t skey[STT_MAX_BEAM];
+  __shared__ uint32_t ssrc[STT_MAX_BEAM];
+  __shared__ float sscore[STT_MAX_BEAM];
+  const DecStream& S = streams[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int n = S.n;
+  const uint32_t sortn = pow2_ge((uint32_t)(n > 0 ? n : 1));
+  unsigned probes = 0;
+  for (uint32_t i = tid; i < sortn; i += NTHREADS) {
+    if ((int)i >= n) { skey[i] = ~0ULL; ssrc[i] = 0; continue; }
+    float sc = S.score[i];
+    if (s.enabled && (int)i < p.beam) {
+      const uint32_t node = S.node[i], chi = S.ch[i];
+      bool do_score;
+      if (s.utf8) {
+        do_score = !is_scoring_boundary(s, al, S.pa, node, STT_ROOT_CH, chi, probes);  // prefix_boundary = prefix
+      } else {
+        const uint32_t par = S.pa[node].x;  // prefix_boundary = prefix->parent (null for the root)
+        do_score = (par != STT_ROOT_CH) && !((int)chi == al.space_id);
+      }
+      if (do_score) {
+        float v = lm_score(s, al, S.pa, node, STT_ROOT_CH, false, probes);  // :293-297, no hot-word boost here
+        v = (float)__dadd_rn((double)v, s.beta);
+        sc = __fadd_rn(sc, v);
+      }
+    }
+    sscore[i] = sc;
+    skey[i] = sel_key(sc, S.ch[i], 0, i);
+    ssrc[i] = i;
+  }
+  __syncthreads();
+  bitonic_sort(skey, ssrc, sortn);
+  const int nret = n < out.num_results ? n : out.num_results;
+  if (tid == 0) out.n_results[blockIdx.x] = nret;
+  for (int r = tid; r < nret; r += NTHREADS) {
+    const uint32_t i = ssrc[r];
+    const size_t ob = ((size_t)blockIdx.x * out.num_results + r);
+    int len = 0;
+    for (uint32_t x = S.node[i]; x != STT_ROOT_CH && S.pa[x].y != STT_ROOT_CH; x = S.pa[x].x) ++len;
+    int tl = 0;
+    for (uint32_t x = S.ts[i]; x != STT_ROOT_CH && x != 0; x = S.ta[x].x) ++tl;
+    const int wl = len < out.max_len ? len : out.max_len;
+    out.lens[ob] = len;
+    out.confidence[ob] = (double)sscore[i];
+    int j = len;
+    for (uint32_t x = S.node[i]; x != STT_ROOT_CH && S.pa[x].y != STT_ROOT_CH; x = S.pa[x].x) { --j; if (j < wl) out.tokens[ob * out.max_len + j] = S.pa[x].y; }
+    j = tl;
+    for (uint32_t x = S.ts[i]; x != STT_ROOT_CH && x != 0; x = S.ta[x].x) { --j; const int jj = j - (tl - len); if (jj >= 0 && jj < wl) out.timesteps[ob * out.max_len + jj] = S.ta[x].y; }
+  }
+}
+
+// root prefix of every stream (DecoderState::init, ctc_beam_search_decoder.cpp:43-56)
+__global__ void ctc_init_kernel(DecStream* streams, int n_streams, int fst_start) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_streams) return;
+  DecStream& S = streams[i];
+  S.score[0] = 0.0f; S.pb[0] = 0.0f; S.pnb[0] = STT_NEG_INF; S.ch[0] = STT_ROOT_CH; S.node[0] = 0; S.ts[0] = 0;
+  S.fst[0] = fst_start; S.key[0] = 0x5151515151515151ULL;
+  S.pa[0] = make_uint2(STT_ROOT_CH, STT_ROOT_CH); S.ta[0] = make_uint2(STT_ROOT_CH, 0);
+  S.n = 1; S.abs_t = 0; S.start_expanding = 0; S.error = 0; S.pa_n = 1; S.ta_n = 1;
+  S.stat[0] = S.stat[1] = S.stat[2] = S.stat[3] = 0;
+}
+void launch_ctc_init(DecStream* streams, int n_streams, int fst_start, hipStream_t st) {
+  hipLaunchKernelGGL(ctc_init_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, st, streams, n_streams, fst_start);
+}
+
+// ------------------------------------------------------------------------------------ launchers
+void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
+                     const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st) {
+  const size_t lds = lds_carve(p.beam, p.C, nullptr, nullptr);
+  static size_t configured = 0;
+  if (lds > configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_next_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = lds;
+  }
+  hipLaunchKernelGGL(ctc_next_kernel, dim3(n_streams), dim3(NTHREADS), lds, st, p, s, al, streams, probs, frame_begin, frame_count);
+}
+void launch_ctc_decode(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const DecStream* streams, int n_streams,
+                       const DecodeOut& out, hipStream_t st) {
+  hipLaunchKernelGGL(ctc_decode_kernel, dim3(n_streams), dim3(NTHREADS), 0, st, p, s, al, streams, out);
+}
+
+// ------------------------------------------------------------------------------------ sttmath.h test hook
+__global__ void test_math_kernel(int op, const float* a, const float* b, float* out, unsigned n) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = op == 0 ? sttm::stt_expf(a[i]) : op == 1 ? sttm::stt_logf(a[i]) : sttm::stt_log_sum_exp(a[i], b[i]);
+}
+void launch_test_math(int op, const float* a, const float* b, float* out, unsigned n, hipStream_t st) {
+  hipLaunchKernelGGL(test_math_kernel, dim3((n + 255) / 256), dim3(256), 0, st, op, a, b, out, n);
+}

@@ -1,0 +1,320 @@
+// stt_amd/csrc/engine.cpp -- pipeline orchestration on one HIP stream: features -> acoustic model -> decoder.
+//
+// Replaces TFLiteModelState::{compute_mfcc,infer} (tflitemodelstate.cc:369-436), ModelState::decode*
+// (modelstate.cc:32-76) and StreamingState (stt.cc:60-334).  Nothing here computes on the CPU: host code
+// only sizes buffers, enqueues kernels and turns token ids into strings.
+#include <algorithm>
+#include <cstring>
+
+#include "../../include/coqui-stt.h"
+#include "engine.h"
+
+uint64_t stt_murmur64a(const void* key, size_t len);
+
+// ------------------------------------------------------------------------------------------- features
+void ModelState::run_mfcc(const int16_t* d_audio, const int* h_nsamples, int B, int n_max, int t_max, std::vector<int>& n_frames) {
+  n_frames.resize(B);
+  for (int b = 0; b < B; ++b) n_frames[b] = n_frames_for(g, h_nsamples[b]);
+  ws_nsamp.reserve(B * 4); ws_nframes.reserve(B * 4);
+  HIP_CHECK(hipMemcpyAsync(ws_nsamp.p, h_nsamples, B * 4, hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipMemcpyAsync(ws_nframes.p, n_frames.data(), B * 4, hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));  // n_frames is a caller-owned vector; keep the copy simple and safe
+  ws_feats.reserve((size_t)B * t_max * g.n_input * 4);
+  MfccArgs a = mfcc_args();
+  a.audio = d_audio; a.n_samples = ws_nsamp.as<int>(); a.n_frames = ws_nframes.as<int>();
+  a.feats = ws_feats.as<float>(); a.n_max = n_max; a.t_max = t_max;
+  launch_mfcc(a, B * t_max, stream);
+}
+
+// ------------------------------------------------------------------------------------------- acoustic model
+// rows: x1 [T*B][k1_pad] f16, row = t*B + b.  B <= 64.
+void ModelState::run_acoustic_rows(const _Float16* d_x1, int B, int T, float* d_c, float* d_h, bool carry_in, float* d_probs_out, int probs_t_max) {
+  const int H = g.n_hidden, M = T * B, C = g.n_classes;
+  const int NT = lstm_nt_for_batch(B);
+  if (NT < 0) throw std::runtime_error("run_acoustic_rows: batch > 64");
+  ws_a.reserve((size_t)M * H * 2); ws_b.reserve((size_t)M * H * 2);
+  ws_xproj.reserve((size_t)M * 4 * H * 4); ws_hall.reserve((size_t)M * H * 2);
+  ws_logits.reserve((size_t)M * g.c_pad() * 4);
+  const size_t hp_bytes = (size_t)(H / 32) * NT * 64 * 16;
+  ws_hp0.reserve(hp_bytes); ws_hp1.reserve(hp_bytes);
+  ws_c.reserve((size_t)B * H * 4);
+  DenseArgs d{};
+  d.relu_clip = g.relu_clip; d.M = M;
+  // layers 1-3 (deepspeech_model.py:204-224)
+  d.wt = w1t.as<_Float16>(); d.x = d_x1; d.bias = b1.as<float>(); d.y = ws_a.p; d.N = H; d.K = g.k1_pad(); d.ldx = g.k1_pad(); d.ldy = H;
+  launch_dense(d, DENSE_EPI_RELU_F16, stream);
+  d.wt = w2t.as<_Float16>(); d.x = ws_a.as<_Float16>(); d.bias = b2.as<float>(); d.y = ws_b.p; d.K = H; d.ldx = H;
+  launch_dense(d, DENSE_EPI_RELU_F16, stream);
+  d.wt = w3t.as<_Float16>(); d.x = ws_b.as<_Float16>(); d.bias = b3.as<float>(); d.y = ws_a.p;
+  launch_dense(d, DENSE_EPI_RELU_F16, stream);
+  // x-projection of all timesteps at once: [M][H] x [H][4H] + lstm bias
+  d.wt = wxt.as<_Float16>(); d.x = ws_a.as<_Float16>(); d.bias = bl.as<float>(); d.y = ws_xproj.p; d.N = 4 * H; d.ldy = 4 * H;
+  launch_dense(d, DENSE_EPI_BIAS_F32, stream);
+  stt_prof_mark(this, 2);
+  // recurrence
+  float* cbuf = d_c ? d_c : ws_c.as<float>();
+  if (!carry_in || !d_c) HIP_CHECK(hipMemsetAsync(cbuf, 0, (size_t)B * H * 4, stream));
+  if (carry_in && d_h) launch_pack_h(d_h, ws_hp0.p, B, H, NT, stream);
+  else HIP_CHECK(hipMemsetAsync(ws_hp0.p, 0, hp_bytes, stream));
+  LstmArgs l{};
+  l.whp = whp.as<_Float16>(); l.xproj = ws_xproj.as<float>(); l.c = cbuf; l.h_all = ws_hall.as<_Float16>();
+  l.n_hidden = H; l.batch = B;
+  for (int t = 0; t < T; ++t) {
+    l.hp_in = (t & 1) ? ws_hp1.as<_Float16>() : ws_hp0.as<_Float16>();
+    l.hp_out = (t & 1) ? ws_hp0.as<_Float16>() : ws_hp1.as<_Float16>();
+    l.t = t;
+    l.h_f32 = (t == T - 1) ? d_h : nullptr;
+    launch_lstm_step(l, NT, stream);
+  }
+  stt_prof_mark(this, 3);
+  // layer 5, layer 6, softmax (deepspeech_model.py:241-252, 357)
+  d.wt = w5t.as<_Float16>(); d.x = ws_hall.as<_Float16>(); d.bias = b5.as<float>(); d.y = ws_b.p; d.N = H; d.K = H; d.ldx = H; d.ldy = H;
+  launch_dense(d, DENSE_EPI_RELU_F16, stream);
+  d.wt = w6t.as<_Float16>(); d.x = ws_b.as<_Float16>(); d.bias = b6.as<float>(); d.y = ws_logits.p; d.N = g.c_pad(); d.ldy = g.c_pad();
+  launch_dense(d, DENSE_EPI_BIAS_F32, stream);
+  SoftmaxArgs s{};
+  s.logits = ws_logits.as<float>(); s.probs = d_probs_out; s.M = M; s.C = C; s.ldl = g.c_pad(); s.batch = B; s.t_max = probs_t_max;
+  launch_softmax(s, stream);
+}
+
+void ModelState::run_acoustic(const float* d_feats, const int* d_nframes, int B, int t_max, float* d_c, float* d_h, bool carry_in) {
+  const int M = t_max * B;
+  ws_x1.reserve((size_t)M * g.k1_pad() * 2);
+  ws_probs.reserve((size_t)B * t_max * g.n_classes * 4);
+  ContextArgs c{};
+  c.feats = d_feats; c.n_frames = d_nframes; c.x1 = ws_x1.as<_Float16>();
+  c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = g.k1_pad();
+  launch_context(c, M, stream);
+  run_acoustic_rows(ws_x1.as<_Float16>(), B, t_max, d_c, d_h, carry_in, ws_probs.as<float>(), t_max);
+}
+
+// ------------------------------------------------------------------------------------------- decoder state
+DevScorer ModelState::current_scorer(std::shared_ptr<ScorerDev> sc, const std::map<std::string, float>& hot, DevBuf& hh, DevBuf& hb) const {
+  DevScorer s{};
+  if (!sc) return s;
+  s = sc->dev;
+  s.n_hot = 0;
+  if (!hot.empty()) {
+    std::vector<uint64_t> hs; std::vector<float> bs;
+    for (const auto& kv : hot) { hs.push_back(stt_murmur64a(kv.first.data(), kv.first.size())); bs.push_back(kv.second); }
+    hh.upload(hs.data(), hs.size() * 8, stream); hb.upload(bs.data(), bs.size() * 4, stream);
+    s.n_hot = (int)hs.size(); s.hot_hash = hh.as<uint64_t>(); s.hot_boost = hb.as<float>();
+  }
+  return s;
+}
+
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Lays out every stream's arrays in one slab and uploads the pointer table.  Arena capacity covers
+// `expected_frames` timesteps (each step appends at most beam path nodes and beam time nodes).
+void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc) {
+  const int C = g.n_classes;
+  if (beam < 1 || beam > STT_MAX_BEAM) throw std::runtime_error("beam width must be in [1, 1024]");
+  db.n_streams = n_streams; db.beam = beam; db.C = C;
+  const uint32_t cap = (uint32_t)((beam + 63) & ~63);
+  const uint32_t cand_cap = (uint32_t)beam * (uint32_t)(C - 1);
+  const uint32_t arena = (uint32_t)(expected_frames + 2) * (uint32_t)beam + 2;
+  const size_t fixed = al256(cap * 8) + 7 * al256(cap * 4) + al256(cand_cap * 4) * 3 + al256(cand_cap * 8) + al256(((size_t)cap + cand_cap) * 8);
+  const size_t per = fixed + 2 * al256((size_t)arena * 8);
+  db.per_stream_fixed = fixed;
+  db.slab.reserve(per * n_streams);
+  db.host.assign(n_streams, DecStream{});
+  db.pa_cap.assign(n_streams, arena); db.ta_cap.assign(n_streams, arena);
+  uint8_t* base = db.slab.as<uint8_t>();
+  for (int i = 0; i < n_streams; ++i) {
+    uint8_t* p = base + per * i;
+    DecStream& S = db.host[i];
+    auto take = [&](size_t bytes) { uint8_t* r = p; p += al256(bytes); return r; };
+    S.key = (uint64_t*)take(cap * 8);
+    S.score = (float*)take(cap * 4); S.pb = (float*)take(cap * 4); S.pnb = (float*)take(cap * 4);
+    S.ch = (uint32_t*)take(cap * 4); S.node = (uint32_t*)take(cap * 4); S.ts = (uint32_t*)take(cap * 4); S.fst = (int*)take(cap * 4);
+    S.c_logp = (float*)take(cand_cap * 4); S.c_pi = (uint32_t*)take(cand_cap * 4); S.c_fst = (int*)take(cand_cap * 4);
+    S.c_key = (uint64_t*)take(cand_cap * 8); S.sel_keys = (uint64_t*)take(((size_t)cap + cand_cap) * 8);
+    S.pa = (uint2*)take((size_t)arena * 8); S.ta = (uint2*)take((size_t)arena * 8);
+    S.cand_cap = cand_cap; S.pa_cap = arena; S.ta_cap = arena;
+  }
+  db.table.upload(db.host.data(), sizeof(DecStream) * n_streams, stream);
+  launch_ctc_init(db.table.as<DecStream>(), n_streams, sc ? sc->dev.fst_start : 0, stream);
+}
+
+// Streaming use: make sure stream i can append `more_frames[i]` further timesteps.  Grows the whole slab
+// (copying the live state) when an arena would overflow; rare (capacity doubles).
+void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_frames) {
+  HIP_CHECK(hipMemcpyAsync(db.host.data(), db.table.p, sizeof(DecStream) * db.n_streams, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  bool grow = false;
+  uint32_t need = 0;
+  for (int i = 0; i < db.n_streams; ++i) {
+    const uint32_t want = std::max(db.host[i].pa_n, db.host[i].ta_n) + (uint32_t)(more_frames[i] + 1) * db.beam + 2;
+    if (want > db.host[i].pa_cap) grow = true;
+    need = std::max(need, want);
+  }
+  if (!grow) return;
+  const uint32_t arena = need * 2;
+  const size_t per = db.per_stream_fixed + 2 * al256((size_t)arena * 8);
+  DevBuf ns;
+  ns.reserve(per * db.n_streams);
+  const size_t old_per = db.per_stream_fixed + 2 * al256((size_t)db.host[0].pa_cap * 8);
+  std::vector<DecStream> nh = db.host;
+  for (int i = 0; i < db.n_streams; ++i) {
+    uint8_t* ob = db.slab.as<uint8_t>() + old_per * i;
+    uint8_t* nb = ns.as<uint8_t>() + per * i;
+    HIP_CHECK(hipMemcpyAsync(nb, ob, db.per_stream_fixed, hipMemcpyDeviceToDevice, stream));
+    const ptrdiff_t delta = nb - ob;
+    DecStream& S = nh[i];
+    auto mv = [&](auto*& ptr) { ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(reinterpret_cast<uint8_t*>(ptr) + delta); };
+    mv(S.key); mv(S.score); mv(S.pb); mv(S.pnb); mv(S.ch); mv(S.node); mv(S.ts); mv(S.fst);
+    mv(S.c_logp); mv(S.c_pi); mv(S.c_fst); mv(S.c_key); mv(S.sel_keys);
+    uint2* npa = reinterpret_cast<uint2*>(nb + db.per_stream_fixed);
+    uint2* nta = reinterpret_cast<uint2*>(nb + db.per_stream_fixed + al256((size_t)arena * 8));
+    HIP_CHECK(hipMemcpyAsync(npa, db.host[i].pa, (size_t)db.host[i].pa_n * 8, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(nta, db.host[i].ta, (size_t)db.host[i].ta_n * 8, hipMemcpyDeviceToDevice, stream));
+    S.pa = npa; S.ta = nta; S.pa_cap = arena; S.ta_cap = arena;
+  }
+  HIP_CHECK(hipStreamSynchronize(stream));
+  std::swap(db.slab.p, ns.p); std::swap(db.slab.cap, ns.cap);
+  db.host = nh;
+  db.table.upload(db.host.data(), sizeof(DecStream) * db.n_streams, stream);
+}
+
+std::vector<std::vector<Output>> decode_streams(const ModelState& mc, const DecoderBatch& db, std::shared_ptr<ScorerDev> sc,
+                                                const std::map<std::string, float>& hot, unsigned num_results, int max_len) {
+  ModelState& m = const_cast<ModelState&>(mc);  // workspaces only
+  const int n = db.n_streams;
+  const int nr = (int)std::max(1u, std::min<unsigned>(num_results, (unsigned)db.beam));
+  m.ws_out_tok.reserve((size_t)n * nr * max_len * 4); m.ws_out_ts.reserve((size_t)n * nr * max_len * 4);
+  m.ws_out_len.reserve((size_t)n * nr * 4); m.ws_out_conf.reserve((size_t)n * nr * 8); m.ws_out_n.reserve((size_t)n * 4);
+  DecodeOut o{};
+  o.tokens = m.ws_out_tok.as<uint32_t>(); o.timesteps = m.ws_out_ts.as<uint32_t>(); o.lens = m.ws_out_len.as<int>();
+  o.confidence = m.ws_out_conf.as<double>(); o.n_results = m.ws_out_n.as<int>(); o.num_results = nr; o.max_len = max_len;
+  DecParams p{};
+  p.C = db.C; p.blank = db.C - 1; p.beam = db.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = 0;
+  DevScorer ds = m.current_scorer(sc, hot, m.ws_hot_hash, m.ws_hot_boost);
+  launch_ctc_decode(p, ds, m.dev_alphabet, db.table.as<DecStream>(), n, o, m.stream);
+  std::vector<uint32_t> tok((size_t)n * nr * max_len), ts((size_t)n * nr * max_len);
+  std::vector<int> lens((size_t)n * nr), nres(n);
+  std::vector<double> conf((size_t)n * nr);
+  HIP_CHECK(hipMemcpyAsync(tok.data(), o.tokens, tok.size() * 4, hipMemcpyDeviceToHost, m.stream));
+  HIP_CHECK(hipMemcpyAsync(ts.data(), o.timesteps, ts.size() * 4, hipMemcpyDeviceToHost, m.stream));
+  HIP_CHECK(hipMemcpyAsync(lens.data(), o.lens, lens.size() * 4, hipMemcpyDeviceToHost, m.stream));
+  HIP_CHECK(hipMemcpyAsync(conf.data(), o.confidence, conf.size() * 8, hipMemcpyDeviceToHost, m.stream));
+  HIP_CHECK(hipMemcpyAsync(nres.data(), o.n_results, nres.size() * 4, hipMemcpyDeviceToHost, m.stream));
+  HIP_CHECK(hipStreamSynchronize(m.stream));
+  std::vector<std::vector<Output>> out(n);
+  for (int i = 0; i < n; ++i) {
+    for (int r = 0; r < nres[i]; ++r) {
+      Output ou;
+      const size_t ob = (size_t)i * nr + r;
+      const int len = std::min(lens[ob], max_len);
+      ou.confidence = conf[ob];
+      ou.tokens.assign(tok.begin() + ob * max_len, tok.begin() + ob * max_len + len);
+      ou.timesteps.assign(ts.begin() + ob * max_len, ts.begin() + ob * max_len + len);
+      out[i].push_back(std::move(ou));
+    }
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------- streaming
+// Equivalent of the three nested buffers of stt.cc:105-334, expressed in counts:
+//   frames_        MFCC frames pushed (starts at n_context zero frames, stt.cc:533)
+//   windows ready  = frames_ - 2*n_context  (a 19-frame window completes with every frame beyond the 18th)
+//   windows_done_  windows already sent through the model in batches of n_steps
+void StreamingState::pushZeroFrames(int n) {
+  ModelState& m = *model_;
+  const int need = frames_ + n;
+  if (need > frames_cap) { frames_cap = std::max(need * 2, 256); d_frames.reserve((size_t)frames_cap * m.g.n_input * 4, true, m.stream); }
+  HIP_CHECK(hipMemsetAsync(d_frames.as<float>() + (size_t)frames_ * m.g.n_input, 0, (size_t)n * m.g.n_input * 4, m.stream));
+  frames_ += n;
+}
+
+// span = int16 samples covering n_new_frames windows starting every win_step (the last one may be short -> zero padded)
+void StreamingState::pushFrames(const int16_t* span, int n_span, int n_new_frames) {
+  ModelState& m = *model_;
+  const int need = frames_ + n_new_frames;
+  if (need > frames_cap) { frames_cap = std::max(need * 2, 256); d_frames.reserve((size_t)frames_cap * m.g.n_input * 4, true, m.stream); }
+  m.ws_audio.reserve((size_t)std::max(n_span, 1) * 2);
+  if (n_span) HIP_CHECK(hipMemcpyAsync(m.ws_audio.p, span, (size_t)n_span * 2, hipMemcpyHostToDevice, m.stream));
+  const int hn[2] = {n_span, n_new_frames};
+  m.ws_nsamp.reserve(4); m.ws_nframes.reserve(4);
+  HIP_CHECK(hipMemcpyAsync(m.ws_nsamp.p, &hn[0], 4, hipMemcpyHostToDevice, m.stream));
+  HIP_CHECK(hipMemcpyAsync(m.ws_nframes.p, &hn[1], 4, hipMemcpyHostToDevice, m.stream));
+  HIP_CHECK(hipStreamSynchronize(m.stream));  // span / hn are host temporaries
+  MfccArgs a = m.mfcc_args();
+  a.audio = m.ws_audio.as<int16_t>(); a.n_samples = m.ws_nsamp.as<int>(); a.n_frames = m.ws_nframes.as<int>();
+  a.feats = d_frames.as<float>() + (size_t)frames_ * m.g.n_input; a.n_max = std::max(n_span, 1); a.t_max = n_new_frames;
+  launch_mfcc(a, n_new_frames, m.stream);
+  frames_ += n_new_frames;
+}
+
+void StreamingState::feedAudioContent(const short* buffer, unsigned int buffer_size) {
+  const Geometry& g = model_->g;
+  // identical to filling audio_buffer_ sample by sample and firing a window whenever it holds win_len samples (stt.cc:105-128)
+  std::vector<int16_t> all(audio_buffer_);
+  all.insert(all.end(), buffer, buffer + buffer_size);
+  const int len = (int)all.size();
+  const int W = len >= g.win_len ? (len - g.win_len) / g.win_step + 1 : 0;
+  if (W > 0) {
+    pushFrames(all.data(), (W - 1) * g.win_step + g.win_len, W);
+    audio_buffer_.assign(all.begin() + (size_t)W * g.win_step, all.end());
+    processReady(false, false);
+  } else {
+    audio_buffer_.swap(all);
+  }
+}
+
+void StreamingState::flushBuffers(bool addZeroMfccVectors) {
+  // stt.cc:236-254: the partial audio window goes through the feature graph as is (zero padded), audio_buffer_ is kept
+  pushFrames(audio_buffer_.data(), (int)audio_buffer_.size(), 1);
+  if (addZeroMfccVectors) pushZeroFrames(model_->g.n_context);
+  processReady(true, addZeroMfccVectors);
+}
+
+// Runs every complete batch of n_steps windows; with flush_partial also the remaining partial batch
+// (zero padded to n_steps through the LSTM exactly like tflitemodelstate.cc:341-355 unless it is the final flush,
+// where the padded steps cannot influence anything that is still observable).
+void StreamingState::processReady(bool flush_partial, bool final_flush) {
+  ModelState& m = *model_;
+  const Geometry& g = m.g;
+  const int H = g.n_hidden, C = g.n_classes, kp = g.k1_pad(), kw = g.n_in1();
+  for (;;) {
+    const int ready = std::max(0, frames_ - 2 * g.n_context) - windows_done_;
+    int take = 0;
+    if (ready >= g.n_steps) take = g.n_steps;
+    else if (flush_partial && ready > 0) take = ready;
+    if (take == 0) break;
+    const int T = (take < g.n_steps && !final_flush) ? g.n_steps : take;  // padded steps perturb the carried state (coqui-stt.h:393-399 of the reference)
+    // windows are contiguous slices of the frame list: window w = frames[w .. w+19) flattened (stt.cc:292-309)
+    m.ws_x1.reserve((size_t)T * kp * 2);
+    HIP_CHECK(hipMemsetAsync(m.ws_x1.p, 0, (size_t)T * kp * 2, m.stream));
+    // raw gather: x1[t][k] = frames_flat[(windows_done_ + t) * n_input + k], k < 494; rows >= take stay zero
+    launch_window_rows(d_frames.as<float>() + (size_t)windows_done_ * g.n_input, m.ws_x1.as<_Float16>(), take, g.n_input, kw, kp, m.stream);
+    d_c.reserve((size_t)H * 4); d_h.reserve((size_t)H * 4);
+    m.ws_probs.reserve((size_t)T * C * 4);
+    m.run_acoustic_rows(m.ws_x1.as<_Float16>(), 1, T, d_c.as<float>(), d_h.as<float>(), state_nonzero, m.ws_probs.as<float>(), T);
+    state_nonzero = true;
+    if (keep_emissions_) {  // stt.cc:326-329: probs_ is *replaced* by the last batch
+      std::vector<float> pr((size_t)take * C);
+      HIP_CHECK(hipMemcpyAsync(pr.data(), m.ws_probs.p, pr.size() * 4, hipMemcpyDeviceToHost, m.stream));
+      HIP_CHECK(hipStreamSynchronize(m.stream));
+      probs_.assign(pr.begin(), pr.end());
+    }
+    // decoder_state_.next(inputs, n_frames, num_classes)
+    m.decoder_reserve(dec, std::vector<int>{take});
+    DecParams p{};
+    p.C = C; p.blank = C - 1; p.beam = dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = T;  // stt.cc:539-540
+    const int fb[2] = {0, take};
+    m.ws_fbegin.reserve(4); m.ws_fcount.reserve(4);
+    HIP_CHECK(hipMemcpyAsync(m.ws_fbegin.p, &fb[0], 4, hipMemcpyHostToDevice, m.stream));
+    HIP_CHECK(hipMemcpyAsync(m.ws_fcount.p, &fb[1], 4, hipMemcpyHostToDevice, m.stream));
+    HIP_CHECK(hipStreamSynchronize(m.stream));
+    DevScorer ds = m.current_scorer(scorer_, hot_words_, hot_hash, hot_boost);
+    launch_ctc_next(p, ds, m.dev_alphabet, dec.table.as<DecStream>(), 1, m.ws_probs.as<float>(), m.ws_fbegin.as<int>(), m.ws_fcount.as<int>(), m.stream);
+    windows_done_ += take;
+  }
+}
+
+std::vector<Output> StreamingState::decode(unsigned num_results) const {
+  auto r = decode_streams(*model_, dec, scorer_, hot_words_, num_results, 4096);
+  return r.empty() ? std::vector<Output>() : r[0];
+}

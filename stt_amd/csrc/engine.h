@@ -1,0 +1,176 @@
+// stt_amd/csrc/engine.h -- host side of the MI355X engine (internal header).
+//
+// Mirrors the reference's layering so each class can be read next to the file it replaces:
+//   Alphabet        native_client/alphabet.{h,cc}
+//   ScorerDev       native_client/ctcdecode/scorer.{h,cpp} (loader + constants; queries run on the GPU)
+//   ModelState      native_client/modelstate.{h,cc} + tflitemodelstate.{h,cc}
+//   StreamingState  native_client/stt.cc:60-334
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "ctc.h"
+#include "kernels.h"
+
+#define HIP_CHECK(expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess)                                                                                 \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " + __FILE__ + ":" + std::to_string(__LINE__)); \
+  } while (0)
+
+// Growable device allocation (never shrinks); the engine keeps its workspaces resident in HBM.
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  void reserve(size_t bytes, bool keep = false, hipStream_t st = nullptr);
+  void upload(const void* src, size_t bytes, hipStream_t st = nullptr);
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---------------------------------------------------------------------------------------------
+class Alphabet {
+ public:
+  int InitFromFile(const char* path);                     // alphabet.cc:42-68
+  int Deserialize(const char* buffer, int buffer_size);   // alphabet.cc:133-169
+  std::string Serialize() const;                          // alphabet.cc:102-131
+  void InitUTF8();                                        // UTF8Alphabet, alphabet.h:80-91
+  size_t GetSize() const { return labels_.size(); }
+  int GetSpaceLabel() const { return space_index_; }
+  const std::string& DecodeSingle(unsigned idx) const { return labels_[idx]; }
+  std::string Decode(const unsigned* idx, int n) const;
+  const std::vector<std::string>& labels() const { return labels_; }
+
+ private:
+  std::vector<std::string> labels_;
+  int space_index_ = -2;
+};
+
+// ---------------------------------------------------------------------------------------------
+// .scorer package resident in HBM: the KenLM trie blob is uploaded verbatim (the device walks the same
+// bit-packed arrays KenLM mmaps), the ConstFst is repacked to {state_pos, final, arcs}.
+class ScorerDev {
+ public:
+  // returns an STT_ERR_* code (scorer.cpp:108-222)
+  int LoadFile(const std::string& path, const Alphabet& alphabet);
+  int LoadBuffer(const char* data, size_t len, const Alphabet& alphabet);
+  void reset_params(float a, float b) { dev.alpha = a; dev.beta = b; }
+  DevScorer dev{};  // alpha/beta live here (read at every launch, like the reference reads Scorer::alpha)
+  bool is_utf8 = false;
+  int order = 0;
+  uint64_t blob_bytes = 0;
+
+ private:
+  int Parse(const uint8_t* buf, size_t len);
+  DevBuf blob_, fst_pos_, fst_final_, fst_arcs_;
+};
+
+// ---------------------------------------------------------------------------------------------
+struct Geometry {
+  int n_input = 26, n_context = 9, n_hidden = 2048, n_classes = 29, n_steps = 16;
+  int sample_rate = 16000, win_len = 512, win_step = 320, beam_width = 500;
+  float relu_clip = 20.0f;
+  int n_in1() const { return n_input * (2 * n_context + 1); }
+  int k1_pad() const { return (n_in1() + 63) / 64 * 64; }
+  int c_pad() const { return (n_classes + 127) / 128 * 128; }
+};
+
+struct StreamingState;
+
+// Decoder states of a batch of streams (device arrays + host mirror of the pointer table).
+struct DecoderBatch {
+  int n_streams = 0, beam = 0, C = 0;
+  std::vector<DecStream> host;  // pointer table as uploaded
+  DevBuf table;                 // DecStream[n_streams]
+  DevBuf slab;                  // all per-stream arrays
+  std::vector<uint32_t> pa_cap, ta_cap;
+  size_t per_stream_fixed = 0;
+};
+
+struct ModelState {
+  Geometry g;
+  Alphabet alphabet_;
+  std::shared_ptr<ScorerDev> scorer_;
+  std::map<std::string, float> hot_words_;  // ordered => deterministic upload order
+  unsigned beam_width_ = 500;
+  hipStream_t stream = nullptr;
+  int device = 0;
+
+  // weights in HBM (f16, transposed / packed; see kernels_am.hip header)
+  DevBuf w1t, w2t, w3t, wxt, whp, w5t, w6t;
+  DevBuf b1, b2, b3, bl, b5, b6;
+  // feature tables
+  DevBuf t_window, t_twiddle, t_melw, t_mel_idx, t_dct;
+  // alphabet on device
+  DevBuf al_bytes, al_off;
+  DevAlphabet dev_alphabet{};
+  // workspaces (grown on demand, reused)
+  DevBuf ws_audio, ws_nsamp, ws_nframes, ws_feats, ws_x1, ws_a, ws_b, ws_xproj, ws_hall, ws_logits, ws_probs;
+  DevBuf ws_c, ws_hp0, ws_hp1, ws_hf32, ws_fbegin, ws_fcount;
+  DevBuf ws_out_tok, ws_out_ts, ws_out_len, ws_out_conf, ws_out_n, ws_hot_hash, ws_hot_boost;
+
+  ~ModelState();
+  int InitFromBuffer(const char* buf, size_t len);  // STT_ERR_* code
+  MfccArgs mfcc_args() const;
+
+  // ---- stages (all asynchronous on `stream`) ----
+  // audio already in ws_audio ([B][n_max] int16) or at d_audio; fills ws_feats [B][t_max][n_input]
+  void run_mfcc(const int16_t* d_audio, const int* h_nsamples, int B, int n_max, int t_max, std::vector<int>& n_frames);
+  // feats (device, [B][t_max][n_input]) -> probs (ws_probs [B][t_max][C]); c/h are [B][H] f32 device (in/out, may be null = zero)
+  void run_acoustic(const float* d_feats, const int* d_nframes, int B, int t_max, float* d_c, float* d_h, bool carry_in);
+  // windows (device f16 [rows][k1_pad], row = t*B+b) -> probs; used by the chunked streaming path and STTX_InferChunk
+  void run_acoustic_rows(const _Float16* d_x1, int B, int T, float* d_c, float* d_h, bool carry_in, float* d_probs_out, int probs_t_max);
+
+  // ---- decoder ----
+  DevScorer current_scorer(std::shared_ptr<ScorerDev> sc, const std::map<std::string, float>& hot, DevBuf& hh, DevBuf& hb) const;
+  void decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc);
+  void decoder_reserve(DecoderBatch& db, const std::vector<int>& more_frames);
+};
+
+struct Output {
+  double confidence;
+  std::vector<unsigned> tokens, timesteps;
+};
+
+// One resumable utterance: the three buffers of stt.cc:60-71 with the frames and LSTM state kept in HBM.
+struct StreamingState {
+  ModelState* model_ = nullptr;
+  std::shared_ptr<ScorerDev> scorer_;         // captured at creation (stt.cc:542-547)
+  std::map<std::string, float> hot_words_;    // copied at creation
+  unsigned beam_width_ = 0;
+  bool keep_emissions_ = false;
+  std::vector<int16_t> audio_buffer_;         // <= win_len samples (kept as int16; scaled on the GPU like stt.cc:113)
+  int frames_ = 0;                            // MFCC frames pushed so far (incl. n_context leading zero frames)
+  int windows_done_ = 0;                      // context windows already run through the model
+  DevBuf d_frames;                            // f32 [frames_cap][n_input]
+  int frames_cap = 0;
+  DevBuf d_c, d_h;                            // LSTM state [H] f32
+  bool state_nonzero = false;
+  DecoderBatch dec;                           // one stream
+  DevBuf hot_hash, hot_boost;
+  std::vector<double> probs_;                 // emissions of the last processed batch (keep_emissions_)
+
+  void feedAudioContent(const short* buffer, unsigned int buffer_size);
+  void flushBuffers(bool addZeroMfccVectors);
+  void pushFrames(const int16_t* d_audio_span_host, int n_samples_span, int n_new_frames);
+  void pushZeroFrames(int n);
+  void processReady(bool flush_partial, bool final_flush);
+  std::vector<Output> decode(unsigned num_results) const;
+};
+
+std::vector<std::vector<Output>> decode_streams(const ModelState& m, const DecoderBatch& db, std::shared_ptr<ScorerDev> sc,
+                                                const std::map<std::string, float>& hot, unsigned num_results, int max_len);
+int n_frames_for(const Geometry& g, int n_samples);
+void stt_prof_mark(ModelState* m, int i);  // HIP-event marks for STTX_GetStageTimes (api.cpp)
+void pack_lstm_recurrent_host(const float* kernel /*[2H][4H]*/, int H, _Float16* out);

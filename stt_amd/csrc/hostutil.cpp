@@ -1,0 +1,100 @@
+// stt_amd/csrc/hostutil.cpp -- device buffers, Alphabet (native_client/alphabet.{h,cc}).
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "engine.h"
+
+void DevBuf::reserve(size_t bytes, bool keep, hipStream_t st) {
+  if (bytes <= cap && p) return;
+  size_t ncap = bytes + bytes / 4 + 256;
+  void* np = nullptr;
+  HIP_CHECK(hipMalloc(&np, ncap));
+  if (p) {
+    if (keep) {
+      HIP_CHECK(hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+    }
+    HIP_CHECK(hipFree(p));
+  }
+  p = np;
+  cap = ncap;
+}
+void DevBuf::upload(const void* src, size_t bytes, hipStream_t st) {
+  reserve(bytes ? bytes : 1);
+  if (bytes) {
+    HIP_CHECK(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));  // src may be a temporary
+  }
+}
+
+// ---- Alphabet --------------------------------------------------------------------------------
+// Text format: one label per line; '#' starts a comment, "\#" is the literal '#'; a line holding a
+// single space is the space label; \n, \r\n and \r all end a line (alphabet.cc:8-68).
+int Alphabet::InitFromFile(const char* path) {
+  std::ifstream in(path, std::ios::in | std::ios::binary);
+  if (!in) return 1;
+  std::stringstream ss;
+  ss << in.rdbuf();
+  const std::string data = ss.str();
+  labels_.clear();
+  space_index_ = -2;
+  size_t i = 0;
+  const size_t n = data.size();
+  while (i < n) {
+    std::string line;
+    while (i < n && data[i] != '\n' && data[i] != '\r') line += data[i++];
+    if (i < n) {  // consume the line ending
+      if (data[i] == '\r' && i + 1 < n && data[i + 1] == '\n') i += 2; else i += 1;
+    }
+    if (line.size() == 2 && line[0] == '\\' && line[1] == '#') line = "#";
+    else if (!line.empty() && line[0] == '#') continue;
+    if (line == " ") space_index_ = (int)labels_.size();
+    if (line.empty()) continue;
+    labels_.push_back(line);
+  }
+  return 0;
+}
+void Alphabet::InitUTF8() {
+  labels_.clear();
+  for (int idx = 0; idx < 255; ++idx) labels_.push_back(std::string(1, (char)(idx + 1)));
+  space_index_ = ' ' - 1;
+}
+// Binary format: u16 count; count x { u16 key; u16 len; bytes[len] } (alphabet.cc:102-169)
+std::string Alphabet::Serialize() const {
+  std::string out;
+  auto put16 = [&](uint16_t v) { out.append(reinterpret_cast<const char*>(&v), 2); };
+  put16((uint16_t)labels_.size());
+  for (size_t i = 0; i < labels_.size(); ++i) {
+    put16((uint16_t)i);
+    put16((uint16_t)labels_[i].size());
+    out.append(labels_[i]);
+  }
+  return out;
+}
+int Alphabet::Deserialize(const char* buffer, int buffer_size) {
+  int offset = 0;
+  if (buffer_size - offset < 2) return 1;
+  uint16_t size;
+  memcpy(&size, buffer + offset, 2); offset += 2;
+  labels_.assign(size, std::string());
+  space_index_ = -2;
+  for (int i = 0; i < size; ++i) {
+    if (buffer_size - offset < 4) return 1;
+    uint16_t label, len;
+    memcpy(&label, buffer + offset, 2); offset += 2;
+    memcpy(&len, buffer + offset, 2); offset += 2;
+    if (buffer_size - offset < len) return 1;
+    std::string val(buffer + offset, len);
+    offset += len;
+    if (label >= size) return 1;
+    if (val == " ") space_index_ = label;
+    labels_[label] = val;
+  }
+  return 0;
+}
+std::string Alphabet::Decode(const unsigned* idx, int n) const {
+  std::string s;
+  for (int i = 0; i < n; ++i) if (idx[i] < labels_.size()) s += labels_[idx[i]];
+  return s;
+}

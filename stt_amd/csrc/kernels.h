@@ -1,0 +1,64 @@
+// stt_amd/csrc/kernels.h -- argument blocks and launchers of the HIP kernels (internal header;
+// the public boundary is include/coqui-stt.h + include/stt_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- features -----------------------------------------------------------------------------------
+struct MfccArgs {
+  const int16_t* audio;    // [B][n_max]
+  const int* n_samples;    // [B]
+  const int* n_frames;     // [B]
+  float* feats;            // [B][t_max][n_coef]
+  int n_max, t_max;
+  int win_len, win_step, n_coef, n_mel;
+  const double* window;    // [win_len]
+  const double2* twiddle;  // [256] (cos, -sin)(2 pi m / 512)
+  const double* mel_w;     // [257]
+  const int *mel_lo_begin, *mel_lo_end, *mel_hi_begin, *mel_hi_end;  // [n_mel] bin ranges
+  const double* dct;       // [n_coef][n_mel]
+};
+struct ContextArgs {
+  const float* feats;   // [B][t_max][n_coef]
+  const int* n_frames;  // [B]
+  _Float16* x1;         // [t_max*B][k_pad], row = t*B + b
+  int batch, t_max, n_coef, n_context, k_pad;
+};
+
+// ---- dense --------------------------------------------------------------------------------------
+enum { DENSE_EPI_RELU_F16 = 0, DENSE_EPI_BIAS_F32 = 1 };
+struct DenseArgs {
+  const _Float16* wt;  // [N][K]
+  const _Float16* x;   // [M][ldx]
+  const float* bias;   // [N]
+  void* y;             // f16 or f32 [M][ldy]
+  int M, N, K, ldx, ldy;
+  float relu_clip;
+};
+
+// ---- LSTM ---------------------------------------------------------------------------------------
+struct LstmArgs {
+  const _Float16* whp;    // packed recurrent weights, see pack_lstm_recurrent()
+  const _Float16* hp_in;  // h_{t-1}, fragment order [H/32][NT][64][8]
+  _Float16* hp_out;       // h_t, same order
+  const float* xproj;     // [t_max*B][4H], row = t*B + b
+  float* c;               // [B][H] cell state, updated in place
+  float* h_f32;           // optional [B][H] copy of h_t in f32 (state hand-back); may be null
+  _Float16* h_all;        // [t_max*B][H]
+  int n_hidden, batch, t;
+};
+
+struct SoftmaxArgs {
+  const float* logits;  // [M][ldl]
+  float* probs;         // [B][t_max][C]
+  int M, C, ldl, batch, t_max;
+};
+
+void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st);
+void launch_context(const ContextArgs& a, int rows, hipStream_t st);
+void launch_dense(const DenseArgs& a, int epi, hipStream_t st);
+int lstm_nt_for_batch(int B);
+void launch_lstm_step(const LstmArgs& a, int NT, hipStream_t st);
+void launch_pack_h(const float* h, void* hp, int B, int H, int NT, hipStream_t st);
+void launch_softmax(const SoftmaxArgs& a, hipStream_t st);
+void launch_window_rows(const float* frames, _Float16* x1, int rows, int n_input, int kw, int kp, hipStream_t st);

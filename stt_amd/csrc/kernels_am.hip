@@ -1,0 +1,410 @@
+// stt_amd/csrc/kernels_am.hip -- acoustic half of the hot path as hand-written gfx950 kernels.
+//
+// Reference rows:  a2/a3 feedAudioContent + compute_mfcc (stt.cc:105-128,
+// tflitemodelstate.cc:407-436; op definition util/feeding.py:51-73), a4 context windows
+// (stt.cc:272-309), a5 infer (tflitemodelstate.cc:369-405; graph deepspeech_model.py:66-89,
+// 144-168, 171-263, 357).
+//
+// Data layout in HBM:
+//   audio      int16 [B][n_max]                      (row b = utterance b, zero tail)
+//   feats      f32   [B][t_max][26]                  MFCC, the `mfccs` tensor of the reference
+//   x1         f16   [t_max*B][512]                  19-frame context rows, time-major (row = t*B+b), K padded 494->512
+//   act        f16   [t_max*B][2048]                 dense activations, time-major
+//   xproj      f32   [t_max*B][8192]                 x.K[:H] + b  (gate order i,j,f,o)
+//   whp        f16   packed per (workgroup, wave, k-step, tile, lane) for the recurrent kernel
+//   hp         f16   [H/32][NT][64][8]               h_{t-1} in MFMA B-fragment order (double buffered)
+//   probs      f32   [B][t_max][C]
+// All dense weights are stored transposed, W^T [N][K] f16, so both MFMA operands are K-contiguous.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// =============================================================================================
+// MFCC: one 256-thread workgroup per 512-sample window.  Hann window, 512-point FFT (Stockham
+// radix-2, LDS ping-pong), |X|^2 -> f32 -> sqrt, 40 triangular mel bands, ln, DCT-II -> 26.
+// Arithmetic is f64 like the TensorFlow ops it restates (oracle/am_ref.py); the explicit
+// __dmul_rn/__dadd_rn keep the accumulation orders of the op (no contraction).
+// =============================================================================================
+__global__ __launch_bounds__(256) void mfcc_kernel(MfccArgs a) {
+  __shared__ double2 buf[2][512];
+  __shared__ double amp[257];
+  __shared__ double lmel[40];
+  const int frame = blockIdx.x;
+  const int b = frame / a.t_max;
+  const int f = frame - b * a.t_max;
+  const int n = a.n_samples[b];
+  const int nf = a.n_frames[b];
+  float* out = a.feats + ((size_t)b * a.t_max + f) * a.n_coef;
+  if (f >= nf) {  // beyond the utterance: defined zeros (never consumed)
+    if (threadIdx.x < a.n_coef) out[threadIdx.x] = 0.0f;
+    return;
+  }
+  const int16_t* au = a.audio + (size_t)b * a.n_max;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 512; i += 256) {
+    const int s = f * a.win_step + i;
+    // stt.cc:113-114: (float)sample * (1.0f / 32768); zero tail = tflitemodelstate.cc:341-355
+    const float x = (s < n && i < a.win_len) ? (float)au[s] * (1.0f / 32768.0f) : 0.0f;
+    const double w = (i < a.win_len) ? a.window[i] : 0.0;
+    buf[0][i] = make_double2(__dmul_rn((double)x, w), 0.0);
+  }
+  __syncthreads();
+  int cur = 0;
+#pragma unroll 1
+  for (int ns = 1; ns < 512; ns <<= 1) {
+    const int j = tid;
+    const int k = j & (ns - 1);
+    const double2 tw = a.twiddle[k * (256 / ns)];  // (cos, -sin)(2 pi m / 512)
+    const double2 u = buf[cur][j];
+    const double2 v = buf[cur][j + 256];
+    const double vr = __dadd_rn(__dmul_rn(v.x, tw.x), -__dmul_rn(v.y, tw.y));
+    const double vi = __dadd_rn(__dmul_rn(v.x, tw.y), __dmul_rn(v.y, tw.x));
+    const int j0 = ((j - k) << 1) + k;
+    buf[cur ^ 1][j0] = make_double2(__dadd_rn(u.x, vr), __dadd_rn(u.y, vi));
+    buf[cur ^ 1][j0 + ns] = make_double2(__dadd_rn(u.x, -vr), __dadd_rn(u.y, -vi));
+    cur ^= 1;
+    __syncthreads();
+  }
+  for (int i = tid; i < 257; i += 256) {
+    const double2 z = buf[cur][i];
+    const float p = (float)__dadd_rn(__dmul_rn(z.x, z.x), __dmul_rn(z.y, z.y));  // spectrogram output is float
+    amp[i] = sqrt((double)p);
+  }
+  __syncthreads();
+  if (tid < a.n_mel) {
+    // bins whose lower band is tid-1 feed this band with (amp - amp*w); bins whose lower band is tid with amp*w
+    double acc = 0.0;
+    for (int i = a.mel_lo_begin[tid]; i < a.mel_lo_end[tid]; ++i) {
+      const double s = amp[i];
+      acc = __dadd_rn(acc, __dadd_rn(s, -__dmul_rn(s, a.mel_w[i])));
+    }
+    for (int i = a.mel_hi_begin[tid]; i < a.mel_hi_end[tid]; ++i) acc = __dadd_rn(acc, __dmul_rn(amp[i], a.mel_w[i]));
+    lmel[tid] = log(acc < 1e-12 ? 1e-12 : acc);
+  }
+  __syncthreads();
+  if (tid < a.n_coef) {
+    double acc = 0.0;
+    const double* row = a.dct + tid * a.n_mel;
+    for (int j = 0; j < a.n_mel; ++j) acc = __dadd_rn(acc, __dmul_rn(row[j], lmel[j]));
+    out[tid] = (float)acc;
+  }
+}
+
+// context rows: x1[t*B+b][k] = feats[b][t - n_context + k/26][k%26] (zero outside [0, T_b)), k < 494; zero pad to 512
+__global__ __launch_bounds__(256) void context_kernel(ContextArgs a) {
+  const int row = blockIdx.x;  // t*B + b
+  const int t = row / a.batch;
+  const int b = row - t * a.batch;
+  const int nf = a.n_frames[b];
+  const int kw = a.n_coef * (2 * a.n_context + 1);
+  for (int k = threadIdx.x; k < a.k_pad; k += blockDim.x) {
+    float v = 0.0f;
+    if (k < kw && t < nf) {
+      const int j = k / a.n_coef;
+      const int c = k - j * a.n_coef;
+      const int ft = t - a.n_context + j;
+      if (ft >= 0 && ft < nf) v = a.feats[((size_t)b * a.t_max + ft) * a.n_coef + c];
+    }
+    a.x1[(size_t)row * a.k_pad + k] = (_Float16)v;
+  }
+}
+
+// =============================================================================================
+// Dense layer: Y[M][N] = epi(X[M][K] . W[K][N] + bias) with W stored transposed WT[N][K].
+// 128x128x64 tile, 4 waves (2 along N x 2 along M), each wave 4x4 tiles of mfma_f32_16x16x32_f16.
+// The MFMA "A" operand is the weight tile (rows = output features), "B" is the activation tile
+// (columns = rows of X), so every lane ends up with 4 *consecutive output features* of one X row
+// and stores them with one 8-byte (f16) or 16-byte (f32) store.
+// =============================================================================================
+#define GT_BM 128
+#define GT_BN 128
+#define GT_BK 64
+#define GT_LDS_STRIDE 72  // halfs per LDS row: 64 + 8 pad => ds_read_b128 of 16 rows is conflict-free
+
+template <int EPI>
+__global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 lw[GT_BN * GT_LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) _Float16 lx[GT_BM * GT_LDS_STRIDE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wn = wave >> 1, wm = wave & 1;
+  // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs; give each XCD a
+  // contiguous band of M-tiles so the activation band it streams stays in that XCD's L2.
+  const int n_tiles_n = a.N / GT_BN;
+  const int n_tiles_m = (a.M + GT_BM - 1) / GT_BM;
+  const int total = n_tiles_n * n_tiles_m;
+  int wg = blockIdx.x;
+  {
+    const int q = total / 8, r = total % 8;
+    const int xcd = wg % 8, idx = wg / 8;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = wg / n_tiles_n;
+  const int tile_n = wg - tile_m * n_tiles_n;
+  const int n0 = tile_n * GT_BN, m0 = tile_m * GT_BM;
+  const int K = a.K;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging: 1024 16-byte chunks per tile, 4 per thread; chunk q -> row q>>3, 8-half column group q&7
+  uint4 rw0, rw1, rw2, rw3, rx0, rx1, rx2, rx3;
+  const _Float16* WT = a.wt;
+  const _Float16* X = a.x;
+  const int srow = tid >> 3, scg = (tid & 7) * 8;  // this thread's chunk: rows srow + 32*i
+  const _Float16* wsrc = WT + (size_t)(n0 + srow) * K + scg;
+  const size_t wstep = (size_t)32 * K;
+  size_t xoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int mr = m0 + srow + 32 * i;
+    mr = mr < a.M ? mr : a.M - 1;
+    xoff[i] = (size_t)mr * a.ldx + scg;
+  }
+#define GLOAD(k0)                                                          \
+  do {                                                                     \
+    rw0 = *reinterpret_cast<const uint4*>(wsrc + (k0));                    \
+    rw1 = *reinterpret_cast<const uint4*>(wsrc + wstep + (k0));            \
+    rw2 = *reinterpret_cast<const uint4*>(wsrc + 2 * wstep + (k0));        \
+    rw3 = *reinterpret_cast<const uint4*>(wsrc + 3 * wstep + (k0));        \
+    rx0 = *reinterpret_cast<const uint4*>(X + xoff[0] + (k0));             \
+    rx1 = *reinterpret_cast<const uint4*>(X + xoff[1] + (k0));             \
+    rx2 = *reinterpret_cast<const uint4*>(X + xoff[2] + (k0));             \
+    rx3 = *reinterpret_cast<const uint4*>(X + xoff[3] + (k0));             \
+  } while (0)
+#define LSTORE()                                                                                  \
+  do {                                                                                            \
+    *reinterpret_cast<uint4*>(lw + (srow + 0) * GT_LDS_STRIDE + scg) = rw0;                        \
+    *reinterpret_cast<uint4*>(lw + (srow + 32) * GT_LDS_STRIDE + scg) = rw1;                       \
+    *reinterpret_cast<uint4*>(lw + (srow + 64) * GT_LDS_STRIDE + scg) = rw2;                       \
+    *reinterpret_cast<uint4*>(lw + (srow + 96) * GT_LDS_STRIDE + scg) = rw3;                       \
+    *reinterpret_cast<uint4*>(lx + (srow + 0) * GT_LDS_STRIDE + scg) = rx0;                        \
+    *reinterpret_cast<uint4*>(lx + (srow + 32) * GT_LDS_STRIDE + scg) = rx1;                       \
+    *reinterpret_cast<uint4*>(lx + (srow + 64) * GT_LDS_STRIDE + scg) = rx2;                       \
+    *reinterpret_cast<uint4*>(lx + (srow + 96) * GT_LDS_STRIDE + scg) = rx3;                       \
+  } while (0)
+  const int nk = K / GT_BK;
+  GLOAD(0);
+  LSTORE();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) GLOAD((kt + 1) * GT_BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 fa[4], fb[4];
+      const int kof = ks * 32 + (lane >> 4) * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *reinterpret_cast<const f16x8*>(lw + (wn * 64 + i * 16 + (lane & 15)) * GT_LDS_STRIDE + kof);
+        fb[i] = *reinterpret_cast<const f16x8*>(lx + (wm * 64 + i * 16 + (lane & 15)) * GT_LDS_STRIDE + kof);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      LSTORE();
+      __syncthreads();
+    }
+  }
+#undef GLOAD
+#undef LSTORE
+  // epilogue: lane holds features n = nb + (lane>>4)*4 + 0..3 of X row m = mb + (lane&15)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+    const float4 bias = *reinterpret_cast<const float4*>(a.bias + n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+      if (m >= a.M) continue;
+      float v0 = acc[i][j][0] + bias.x, v1 = acc[i][j][1] + bias.y, v2 = acc[i][j][2] + bias.z, v3 = acc[i][j][3] + bias.w;
+      if (EPI == DENSE_EPI_RELU_F16) {
+        // deepspeech_model.py:82-86: minimum(relu(x), relu_clip)
+        v0 = fminf(fmaxf(v0, 0.f), a.relu_clip); v1 = fminf(fmaxf(v1, 0.f), a.relu_clip);
+        v2 = fminf(fmaxf(v2, 0.f), a.relu_clip); v3 = fminf(fmaxf(v3, 0.f), a.relu_clip);
+        f16x4 o = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+        *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.y) + (size_t)m * a.ldy + n) = o;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + n) = make_float4(v0, v1, v2, v3);
+      }
+    }
+  }
+}
+
+template __global__ void dense_kernel<DENSE_EPI_RELU_F16>(DenseArgs);
+template __global__ void dense_kernel<DENSE_EPI_BIAS_F32>(DenseArgs);
+
+// =============================================================================================
+// LSTM recurrent step (deepspeech_model.py:144-168, tf LSTMCell semantics, forget_bias = 0):
+//   z = xproj[t] + h_{t-1} . K[H:2H]        gates i, j, f, o
+//   c' = sigmoid(f) * c + sigmoid(i) * tanh(j);   h' = sigmoid(o) * tanh(c')
+// One workgroup owns 8 hidden units (32 gate columns = two 16-row MFMA tiles: [i|j] and [f|o]) for all
+// batch rows; its 4 waves split K = H into quarters and reduce through LDS.  Weights are pre-packed so
+// each wave streams its slice with fully coalesced 1 KiB loads; h is exchanged between steps in
+// B-fragment order (hp), so the 256 KiB h read is coalesced too.  HBM/L2-bound: 33.5 MB of f16
+// recurrent weights per step for H = 2048, shared by all batch rows.
+// =============================================================================================
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  const float e = __expf(-2.0f * fabsf(x));
+  const float t = (1.0f - e) / (1.0f + e);
+  return copysignf(t, x);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[4][2][NT][64][4];
+  __shared__ __attribute__((aligned(16))) _Float16 hout[NT * 16][8];
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+  const int wg = blockIdx.x;
+  const int H = a.n_hidden;
+  const int ksteps = H / 128;  // 32-deep k-steps per wave
+  const uint4* wp = reinterpret_cast<const uint4*>(a.whp) + ((size_t)(wg * 4 + q) * ksteps) * 2 * 64 + lane;
+  const uint4* hp = reinterpret_cast<const uint4*>(a.hp_in) + ((size_t)(q * ksteps) * NT) * 64 + lane;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int s = 0; s < ksteps; ++s) {
+    uint4 w0 = wp[(size_t)(s * 2 + 0) * 64];
+    uint4 w1 = wp[(size_t)(s * 2 + 1) * 64];
+    f16x8 fa0 = *reinterpret_cast<f16x8*>(&w0), fa1 = *reinterpret_cast<f16x8*>(&w1);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      uint4 hv = hp[(size_t)(s * NT + j) * 64];
+      f16x8 fb = *reinterpret_cast<f16x8*>(&hv);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb, acc[1][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&red[q][i][j][lane][0]) = acc[i][j];
+  __syncthreads();
+  // cell update: (unit u in 0..7, batch row b): gate row r = g*8+u lives in tile r>>4, lane group (r&15)>>2, reg r&3
+  const int B = a.batch;
+  for (int p = tid; p < NT * 16 * 8; p += 256) {
+    const int b = p >> 3, u = p & 7;
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int r = g * 8 + u;
+      const int mt = r >> 4, rr = r & 15;
+      const int ln = ((rr >> 2) << 4) + (b & 15);
+      const int nt = b >> 4;
+      z[g] = red[0][mt][nt][ln][rr & 3] + red[1][mt][nt][ln][rr & 3] + red[2][mt][nt][ln][rr & 3] + red[3][mt][nt][ln][rr & 3];
+    }
+    float hval = 0.0f;
+    if (b < B) {
+      const int unit = wg * 8 + u;
+      const float* xp = a.xproj + ((size_t)a.t * B + b) * (4 * H) + unit;
+      const float zi = z[0] + xp[0], zj = z[1] + xp[H], zf = z[2] + xp[2 * H], zo = z[3] + xp[3 * H];
+      float* cptr = a.c + (size_t)b * H + unit;
+      const float cn = sigmoidf_(zf) * (*cptr) + sigmoidf_(zi) * tanhf_(zj);
+      *cptr = cn;
+      hval = sigmoidf_(zo) * tanhf_(cn);
+      if (a.h_f32) a.h_f32[(size_t)b * H + unit] = hval;
+    }
+    hout[b][u] = (_Float16)hval;
+  }
+  __syncthreads();
+  // publish h: one 16-byte chunk per batch row, into next step's fragment-ordered buffer and the time-major h_all
+  for (int b = tid; b < NT * 16; b += 256) {
+    const uint4 v = *reinterpret_cast<const uint4*>(&hout[b][0]);
+    const int k0 = wg * 8;
+    const int ksg = k0 >> 5, grp = (k0 & 31) >> 3;
+    reinterpret_cast<uint4*>(a.hp_out)[((size_t)ksg * NT + (b >> 4)) * 64 + grp * 16 + (b & 15)] = v;
+    if (b < B) *reinterpret_cast<uint4*>(a.h_all + ((size_t)a.t * B + b) * H + k0) = v;
+  }
+}
+template __global__ void lstm_step_kernel<1>(LstmArgs);
+template __global__ void lstm_step_kernel<2>(LstmArgs);
+template __global__ void lstm_step_kernel<4>(LstmArgs);
+
+// h (f32 [B][H]) -> fragment-ordered f16 hp (used once per chunk to seed the recurrence from a carried state)
+__global__ void pack_h_kernel(const float* h, _Float16* hp, int B, int H, int NT) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over NT*16 * H
+  if (idx >= NT * 16 * H) return;
+  const int b = idx / H, k = idx - b * H;
+  const float v = b < B ? h[(size_t)b * H + k] : 0.0f;
+  const int ksg = k >> 5, grp = (k & 31) >> 3, e = k & 7;
+  hp[(((size_t)ksg * NT + (b >> 4)) * 64 + grp * 16 + (b & 15)) * 8 + e] = (_Float16)v;
+}
+
+// streaming path: the frame list already contains the explicit zero context frames, so window t is the
+// contiguous slice frames[t*n_input .. t*n_input + kw) (stt.cc:292-309)
+__global__ void window_rows_kernel(const float* frames, _Float16* x1, int rows, int n_input, int kw, int kp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * kp) return;
+  const int t = idx / kp, k = idx - t * kp;
+  x1[idx] = (_Float16)(k < kw ? frames[(size_t)t * n_input + k] : 0.0f);
+}
+void launch_window_rows(const float* frames, _Float16* x1, int rows, int n_input, int kw, int kp, hipStream_t st) {
+  const int n = rows * kp;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(window_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, frames, x1, rows, n_input, kw, kp);
+}
+
+// softmax over the first C of ldl logits per row (deepspeech_model.py:357); row m = t*B+b -> probs[b][t][:]
+__global__ void softmax_kernel(SoftmaxArgs a) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= a.M) return;
+  const float* l = a.logits + (size_t)m * a.ldl;
+  const int t = m / a.batch, b = m - t * a.batch;
+  float mx = l[0];
+  for (int c = 1; c < a.C; ++c) mx = fmaxf(mx, l[c]);
+  float s = 0.f;
+  for (int c = 0; c < a.C; ++c) s += expf(l[c] - mx);
+  float* o = a.probs + ((size_t)b * a.t_max + t) * a.C;
+  const float inv = 1.0f / s;
+  for (int c = 0; c < a.C; ++c) o[c] = expf(l[c] - mx) * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------
+void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st) {
+  hipLaunchKernelGGL(mfcc_kernel, dim3(n_frames_total), dim3(256), 0, st, a);
+}
+void launch_context(const ContextArgs& a, int rows, hipStream_t st) {
+  hipLaunchKernelGGL(context_kernel, dim3(rows), dim3(256), 0, st, a);
+}
+void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
+  const int tiles = (a.N / GT_BN) * ((a.M + GT_BM - 1) / GT_BM);
+  if (epi == DENSE_EPI_RELU_F16)
+    hipLaunchKernelGGL(dense_kernel<DENSE_EPI_RELU_F16>, dim3(tiles), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(dense_kernel<DENSE_EPI_BIAS_F32>, dim3(tiles), dim3(256), 0, st, a);
+}
+int lstm_nt_for_batch(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : -1; }  // 64 rows per launch (LDS reduce buffer 32 KiB)
+void launch_lstm_step(const LstmArgs& a, int NT, hipStream_t st) {
+  const dim3 grid(a.n_hidden / 8), block(256);
+  switch (NT) {
+    case 1: hipLaunchKernelGGL(lstm_step_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(lstm_step_kernel<2>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(lstm_step_kernel<4>, grid, block, 0, st, a); break;
+  }
+}
+void launch_pack_h(const float* h, void* hp, int B, int H, int NT, hipStream_t st) {
+  const int n = NT * 16 * H;
+  hipLaunchKernelGGL(pack_h_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h, reinterpret_cast<_Float16*>(hp), B, H, NT);
+}
+void launch_softmax(const SoftmaxArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_kernel, dim3((a.M + 255) / 256), dim3(256), 0, st, a);
+}

@@ -1,0 +1,192 @@
+// stt_amd/csrc/model.cpp -- model container reader and weight preparation for HBM.
+//
+// Replaces TFLiteModelState::init (native_client/tflitemodelstate.cc:161-338): instead of building a
+// TFLite interpreter, the weights of the exported graph (training/coqui_stt_training/deepspeech_model.py:
+// 171-263, variable names SURVEY.md A.4) are converted once to the layouts the kernels stream:
+// f16, transposed to [N][K] for the dense layers, fragment-packed for the recurrent matrix.
+//
+// Container ("STTAMDW1", little endian; written by stt_amd/modelfile.py):
+//   char magic[8]; u32 version(=1), n_input, n_context, n_hidden, n_classes, n_steps, sample_rate,
+//   win_len, win_step, beam_width; f32 relu_clip; u32 alphabet_bytes; u32 reserved[2]          (64 bytes)
+//   alphabet blob (Alphabet::Serialize format, alphabet.cc:102-131), zero padded to 8 bytes
+//   f32 tensors, row-major, in this order:
+//     layer_1/weights [n_input*(2*n_context+1)][H], layer_1/bias [H], layer_2/weights [H][H], layer_2/bias,
+//     layer_3/weights [H][H], layer_3/bias, lstm/kernel [2H][4H] (rows x then h; columns i|j|f|o), lstm/bias [4H],
+//     layer_5/weights [H][H], layer_5/bias, layer_6/weights [H][C], layer_6/bias [C]
+// The released .tflite files (hybrid int8) are SURVEY.md 8f rank 1 ("next"); this container carries the
+// same tensors in f32.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/coqui-stt.h"
+#include "engine.h"
+
+namespace {
+struct SttwHeader {
+  char magic[8];
+  uint32_t version, n_input, n_context, n_hidden, n_classes, n_steps, sample_rate, win_len, win_step, beam_width;
+  float relu_clip;
+  uint32_t alphabet_bytes;
+  uint32_t reserved[2];
+};
+static_assert(sizeof(SttwHeader) == 64, "header is 64 bytes");
+
+// W [K][N] f32 -> WT [N_pad][K_pad] f16 (zero padded)
+std::vector<_Float16> transpose_f16(const float* w, int K, int N, int K_pad, int N_pad, int ldw) {
+  std::vector<_Float16> out((size_t)N_pad * K_pad, (_Float16)0.0f);
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) out[(size_t)n * K_pad + k] = (_Float16)w[(size_t)k * ldw + n];
+  return out;
+}
+}  // namespace
+
+int n_frames_for(const Geometry& g, int n_samples) {  // stt.cc:105-128 + flushBuffers :236-254
+  const int full = n_samples >= g.win_len ? (n_samples - g.win_len) / g.win_step + 1 : 0;
+  return full + 1;
+}
+
+// Recurrent half of the LSTM kernel, packed for lstm_step_kernel:
+//   out[((wg*4 + q)*ksteps + s)*2 + mt][lane][e]  with  ksteps = H/128,
+//   row r = mt*16 + (lane&15): gate g = r>>3, unit u = wg*8 + (r&7)  -> column n = g*H + u
+//   k = q*(H/4) + s*32 + (lane>>4)*8 + e                             -> kernel[H + k][n]
+void pack_lstm_recurrent_host(const float* kernel, int H, _Float16* out) {
+  const int ksteps = H / 128;
+  const size_t ld = (size_t)4 * H;
+  for (int wg = 0; wg < H / 8; ++wg)
+    for (int q = 0; q < 4; ++q)
+      for (int s = 0; s < ksteps; ++s)
+        for (int mt = 0; mt < 2; ++mt)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int r = mt * 16 + (lane & 15);
+            const int n = (r >> 3) * H + wg * 8 + (r & 7);
+            const int k0 = q * (H / 4) + s * 32 + (lane >> 4) * 8;
+            _Float16* o = out + ((((size_t)(wg * 4 + q) * ksteps + s) * 2 + mt) * 64 + lane) * 8;
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)kernel[(size_t)(H + k0 + e) * ld + n];
+          }
+}
+
+ModelState::~ModelState() {
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+int ModelState::InitFromBuffer(const char* buf, size_t len) {
+  if (len < sizeof(SttwHeader)) return STT_ERR_FAIL_READ_PROTOBUF;
+  SttwHeader h;
+  memcpy(&h, buf, sizeof(h));
+  if (memcmp(h.magic, "STTAMDW1", 8) != 0) return STT_ERR_FAIL_READ_PROTOBUF;
+  if (h.version != 1) return STT_ERR_MODEL_INCOMPATIBLE;
+  g.n_input = h.n_input; g.n_context = h.n_context; g.n_hidden = h.n_hidden; g.n_classes = h.n_classes; g.n_steps = h.n_steps;
+  g.sample_rate = h.sample_rate; g.win_len = h.win_len; g.win_step = h.win_step; g.beam_width = h.beam_width; g.relu_clip = h.relu_clip;
+  beam_width_ = h.beam_width;
+  const int H = g.n_hidden, C = g.n_classes, K1 = g.n_in1();
+  if (H % 128 != 0 || H < 128 || C < 2 || C > 1024 || g.win_len > 512 || g.n_input > 64 || g.n_steps < 1) return STT_ERR_INVALID_SHAPE;
+  size_t off = sizeof(SttwHeader);
+  if (off + h.alphabet_bytes > len) return STT_ERR_INVALID_ALPHABET;
+  if (alphabet_.Deserialize(buf + off, (int)h.alphabet_bytes) != 0) return STT_ERR_INVALID_ALPHABET;
+  if ((int)alphabet_.GetSize() + 1 != C) return STT_ERR_INVALID_ALPHABET;  // tflitemodelstate.cc:319-329
+  off += (h.alphabet_bytes + 7) & ~(size_t)7;
+  const size_t n_f32 = (size_t)K1 * H + H + 2 * ((size_t)H * H + H) + (size_t)2 * H * 4 * H + 4 * H + (size_t)H * H + H + (size_t)H * C + C;
+  if (off + n_f32 * 4 > len) return STT_ERR_INVALID_SHAPE;
+  const float* f = reinterpret_cast<const float*>(buf + off);
+  const float* l1w = f; f += (size_t)K1 * H; const float* l1b = f; f += H;
+  const float* l2w = f; f += (size_t)H * H; const float* l2b = f; f += H;
+  const float* l3w = f; f += (size_t)H * H; const float* l3b = f; f += H;
+  const float* lk = f; f += (size_t)2 * H * 4 * H; const float* lb = f; f += 4 * H;
+  const float* l5w = f; f += (size_t)H * H; const float* l5b = f; f += H;
+  const float* l6w = f; f += (size_t)H * C; const float* l6b = f; f += C;
+
+  HIP_CHECK(hipSetDevice(device));
+  if (!stream) HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  {
+    auto t = transpose_f16(l1w, K1, H, g.k1_pad(), H, H); w1t.upload(t.data(), t.size() * 2, stream);
+    t = transpose_f16(l2w, H, H, H, H, H); w2t.upload(t.data(), t.size() * 2, stream);
+    t = transpose_f16(l3w, H, H, H, H, H); w3t.upload(t.data(), t.size() * 2, stream);
+    t = transpose_f16(lk, H, 4 * H, H, 4 * H, 4 * H); wxt.upload(t.data(), t.size() * 2, stream);  // x rows of the kernel
+    t = transpose_f16(l5w, H, H, H, H, H); w5t.upload(t.data(), t.size() * 2, stream);
+    t = transpose_f16(l6w, H, C, H, g.c_pad(), C); w6t.upload(t.data(), t.size() * 2, stream);
+    std::vector<_Float16> packed((size_t)H * 4 * H);
+    pack_lstm_recurrent_host(lk, H, packed.data());
+    whp.upload(packed.data(), packed.size() * 2, stream);
+    b1.upload(l1b, H * 4, stream); b2.upload(l2b, H * 4, stream); b3.upload(l3b, H * 4, stream);
+    bl.upload(lb, 4 * H * 4, stream); b5.upload(l5b, H * 4, stream);
+    std::vector<float> b6p(g.c_pad(), 0.0f);
+    memcpy(b6p.data(), l6b, C * 4);
+    b6.upload(b6p.data(), b6p.size() * 4, stream);
+  }
+  // ---- feature tables (oracle/am_ref.py MfccSpec; upstream tensorflow spectrogram.cc / mfcc_mel_filterbank.cc / mfcc_dct.cc)
+  {
+    const int n_mel = 40, n_bins = 257;
+    std::vector<double> window(g.win_len);
+    for (int i = 0; i < g.win_len; ++i) window[i] = 0.5 - 0.5 * cos(2.0 * M_PI * i / g.win_len);
+    std::vector<double2> tw(256);
+    for (int m = 0; m < 256; ++m) tw[m] = make_double2(cos(2.0 * M_PI * m / 512.0), -sin(2.0 * M_PI * m / 512.0));
+    auto mel = [](double fq) { return 1127.0 * log1p(fq / 700.0); };
+    const double lower = 20.0, upper = g.sample_rate / 2.0;
+    const double mel_low = mel(lower), mel_hi = mel(upper), spacing = (mel_hi - mel_low) / (n_mel + 1);
+    std::vector<double> center(n_mel + 1);
+    for (int i = 0; i <= n_mel; ++i) center[i] = mel_low + spacing * (i + 1);
+    const double hz_per_sbin = 0.5 * g.sample_rate / (n_bins - 1);
+    const int start_index = (int)(1.5 + lower / hz_per_sbin), end_index = (int)(upper / hz_per_sbin);
+    std::vector<int> mapper(n_bins, -2);
+    std::vector<double> wts(n_bins, 0.0);
+    int channel = 0;
+    for (int b = 0; b < n_bins; ++b) {
+      const double melf = mel(b * hz_per_sbin);
+      if (b < start_index || b > end_index) { mapper[b] = -2; continue; }
+      while (channel < n_mel && center[channel] < melf) ++channel;
+      mapper[b] = channel - 1;
+    }
+    for (int b = 0; b < n_bins; ++b) {
+      const int ch = mapper[b];
+      if (b < start_index || b > end_index) wts[b] = 0.0;
+      else if (ch >= 0) wts[b] = (center[ch + 1] - mel(b * hz_per_sbin)) / (center[ch + 1] - center[ch]);
+      else wts[b] = (center[0] - mel(b * hz_per_sbin)) / (center[0] - mel_low);
+    }
+    // band c receives (amp - amp*w) from bins mapped to c-1 and amp*w from bins mapped to c; both are contiguous bin ranges
+    std::vector<int> idx(4 * n_mel, 0);
+    for (int c = 0; c < n_mel; ++c) {
+      int lo_b = -1, lo_e = -1, hi_b = -1, hi_e = -1;
+      for (int b = start_index; b <= end_index && b < n_bins; ++b) {
+        if (mapper[b] == c - 1) { if (lo_b < 0) lo_b = b; lo_e = b + 1; }
+        if (mapper[b] == c) { if (hi_b < 0) hi_b = b; hi_e = b + 1; }
+      }
+      idx[c] = lo_b < 0 ? 0 : lo_b; idx[n_mel + c] = lo_b < 0 ? 0 : lo_e;
+      idx[2 * n_mel + c] = hi_b < 0 ? 0 : hi_b; idx[3 * n_mel + c] = hi_b < 0 ? 0 : hi_e;
+    }
+    std::vector<double> dct((size_t)g.n_input * n_mel);
+    const double fnorm = sqrt(2.0 / n_mel), arg = M_PI / n_mel;
+    for (int i = 0; i < g.n_input; ++i)
+      for (int j = 0; j < n_mel; ++j) dct[(size_t)i * n_mel + j] = fnorm * cos(i * arg * (j + 0.5));
+    t_window.upload(window.data(), window.size() * 8, stream);
+    t_twiddle.upload(tw.data(), tw.size() * sizeof(double2), stream);
+    t_melw.upload(wts.data(), wts.size() * 8, stream);
+    t_mel_idx.upload(idx.data(), idx.size() * 4, stream);
+    t_dct.upload(dct.data(), dct.size() * 8, stream);
+  }
+  // ---- alphabet label bytes for on-device word hashing
+  {
+    std::string bytes;
+    std::vector<int> offs;
+    for (const auto& l : alphabet_.labels()) { bytes += l; offs.push_back((int)bytes.size()); }
+    bytes.push_back('\0');
+    al_bytes.upload(bytes.data(), bytes.size(), stream);
+    al_off.upload(offs.data(), offs.size() * 4, stream);
+    dev_alphabet.n_labels = (int)alphabet_.GetSize();
+    dev_alphabet.space_id = alphabet_.GetSpaceLabel();
+    dev_alphabet.label_bytes = al_bytes.as<uint8_t>();
+    dev_alphabet.label_off = al_off.as<int>();
+  }
+  HIP_CHECK(hipStreamSynchronize(stream));
+  return STT_ERR_OK;
+}
+
+MfccArgs ModelState::mfcc_args() const {
+  MfccArgs a{};
+  a.win_len = g.win_len; a.win_step = g.win_step; a.n_coef = g.n_input; a.n_mel = 40;
+  a.window = t_window.as<double>(); a.twiddle = t_twiddle.as<double2>(); a.mel_w = t_melw.as<double>();
+  const int* idx = t_mel_idx.as<int>();
+  a.mel_lo_begin = idx; a.mel_lo_end = idx + 40; a.mel_hi_begin = idx + 80; a.mel_hi_end = idx + 120;
+  a.dct = t_dct.as<double>();
+  return a;
+}

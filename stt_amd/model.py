@@ -1,0 +1,330 @@
+"""stt_amd/model.py -- Python host-side mirror of the reference's `stt` package API.
+
+Same class and method names, argument meaning and error behaviour as native_client/python/__init__.py:26-430
+(Model, Stream, Metadata wrappers), implemented over the C-ABI of include/coqui-stt.h; the `*Batch`,
+stage-level and decoder helpers wrap include/stt_amd.h.  No compute happens in Python.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import native
+
+
+def _audio(a):
+    a = np.ascontiguousarray(a, dtype=np.int16)
+    return a, a.ctypes.data, a.shape[0]
+
+
+def _metadata_to_py(mp, free=True):
+    """Metadata* -> list of dicts (confidence, tokens[(text, timestep, start_time)]) (+ emissions)."""
+    if not mp:
+        return None
+    m = mp.contents
+    out = []
+    for i in range(m.num_transcripts):
+        tr = m.transcripts[i]
+        toks = [(tr.tokens[j].text.decode("utf-8", "replace"), tr.tokens[j].timestep, tr.tokens[j].start_time)
+                for j in range(tr.num_tokens)]
+        out.append({"confidence": tr.confidence, "tokens": toks, "text": "".join(t[0] for t in toks)})
+    res = {"transcripts": out}
+    if m.emissions:
+        e = m.emissions.contents
+        n = e.num_timesteps * (e.num_symbols + 1)
+        res["emissions"] = np.ctypeslib.as_array(e.emissions, shape=(n,)).reshape(e.num_timesteps, e.num_symbols + 1).copy()
+        res["symbols"] = [e.symbols[i].decode("utf-8", "replace") for i in range(e.num_symbols + 1)]
+    if free:
+        native.lib().STT_FreeMetadata(mp)
+    return res
+
+
+class Model(object):
+    """native_client/python/__init__.py:26-221"""
+
+    def __init__(self, model_path=None, model_bytes=None):
+        L = native.lib()
+        self._impl = None
+        h = C.c_void_p()
+        if model_bytes is not None:
+            self._buf = C.create_string_buffer(model_bytes, len(model_bytes))  # caller keeps the buffer alive (client.cc:491)
+            status = L.STT_CreateModelFromBuffer(C.cast(self._buf, C.c_void_p), len(model_bytes), C.byref(h))
+        else:
+            status = L.STT_CreateModel(str(model_path).encode(), C.byref(h))
+        if status != 0:
+            raise RuntimeError("CreateModel failed with '{}' (0x{:X})".format(native.error_message(status), status))
+        self._impl = h
+
+    def __del__(self):
+        if getattr(self, "_impl", None):
+            native.lib().STT_FreeModel(self._impl)
+            self._impl = None
+
+    def beamWidth(self):
+        return native.lib().STT_GetModelBeamWidth(self._impl)
+
+    def setBeamWidth(self, beam_width):
+        return native.lib().STT_SetModelBeamWidth(self._impl, beam_width)
+
+    def sampleRate(self):
+        return native.lib().STT_GetModelSampleRate(self._impl)
+
+    def enableExternalScorer(self, scorer_path=None, scorer_bytes=None):
+        if scorer_bytes is not None:
+            buf = C.create_string_buffer(scorer_bytes, len(scorer_bytes))
+            status = native.lib().STT_EnableExternalScorerFromBuffer(self._impl, C.cast(buf, C.c_void_p), len(scorer_bytes))
+        else:
+            status = native.lib().STT_EnableExternalScorer(self._impl, str(scorer_path).encode())
+        if status != 0:
+            raise RuntimeError("EnableExternalScorer failed with '{}' (0x{:X})".format(native.error_message(status), status))
+
+    def disableExternalScorer(self):
+        return native.lib().STT_DisableExternalScorer(self._impl)
+
+    def addHotWord(self, word, boost):
+        status = native.lib().STT_AddHotWord(self._impl, word.encode(), boost)
+        if status != 0:
+            raise RuntimeError("AddHotWord failed with '{}' (0x{:X})".format(native.error_message(status), status))
+
+    def eraseHotWord(self, word):
+        status = native.lib().STT_EraseHotWord(self._impl, word.encode())
+        if status != 0:
+            raise RuntimeError("EraseHotWord failed with '{}' (0x{:X})".format(native.error_message(status), status))
+
+    def clearHotWords(self):
+        status = native.lib().STT_ClearHotWords(self._impl)
+        if status != 0:
+            raise RuntimeError("ClearHotWords failed with '{}' (0x{:X})".format(native.error_message(status), status))
+
+    def setScorerAlphaBeta(self, alpha, beta):
+        return native.lib().STT_SetScorerAlphaBeta(self._impl, alpha, beta)
+
+    def stt(self, audio_buffer):
+        a, p, n = _audio(audio_buffer)
+        s = native.take_string(native.lib().STT_SpeechToText(self._impl, p, n))
+        if s is None:
+            raise RuntimeError("STT_SpeechToText failed")
+        return s.decode("utf-8", "replace")
+
+    def sttWithMetadata(self, audio_buffer, num_results=1):
+        a, p, n = _audio(audio_buffer)
+        return _metadata_to_py(native.lib().STT_SpeechToTextWithMetadata(self._impl, p, n, num_results))
+
+    def sttWithEmissions(self, audio_buffer, num_results=1):
+        a, p, n = _audio(audio_buffer)
+        return _metadata_to_py(native.lib().STT_SpeechToTextWithEmissions(self._impl, p, n, num_results))
+
+    def createStream(self):
+        h = C.c_void_p()
+        status = native.lib().STT_CreateStream(self._impl, C.byref(h))
+        if status != 0:
+            raise RuntimeError("CreateStream failed with '{}' (0x{:X})".format(native.error_message(status), status))
+        return Stream(h, self)
+
+    # ---- stt_amd.h ----------------------------------------------------------------------------
+    def geometry(self):
+        g = (C.c_int * 10)()
+        native.lib().STTX_GetGeometry(self._impl, g)
+        keys = ["n_input", "n_context", "n_hidden", "n_classes", "n_steps", "sample_rate", "win_len", "win_step", "beam_width", "space"]
+        return dict(zip(keys, list(g)))
+
+    def sttBatch(self, audio_buffers):
+        arrs = [np.ascontiguousarray(a, dtype=np.int16) for a in audio_buffers]
+        B = len(arrs)
+        ptrs = (C.c_void_p * B)(*[a.ctypes.data for a in arrs])
+        sizes = (C.c_uint * B)(*[a.shape[0] for a in arrs])
+        r = native.lib().STTX_SpeechToTextBatch(self._impl, ptrs, sizes, B)
+        if not r:
+            raise RuntimeError("STTX_SpeechToTextBatch failed")
+        out = [C.string_at(r[i]).decode("utf-8", "replace") for i in range(B)]
+        native.lib().STTX_FreeStrings(r, B)
+        return out
+
+    def sttBatchWithMetadata(self, audio_buffers, num_results=1):
+        arrs = [np.ascontiguousarray(a, dtype=np.int16) for a in audio_buffers]
+        B = len(arrs)
+        ptrs = (C.c_void_p * B)(*[a.ctypes.data for a in arrs])
+        sizes = (C.c_uint * B)(*[a.shape[0] for a in arrs])
+        r = native.lib().STTX_SpeechToTextBatchWithMetadata(self._impl, ptrs, sizes, B, num_results)
+        if not r:
+            raise RuntimeError("STTX_SpeechToTextBatchWithMetadata failed")
+        out = [_metadata_to_py(r[i], free=False) for i in range(B)]
+        native.lib().STTX_FreeMetadataArray(r, B)
+        return out
+
+    def sttBatchDevice(self, device_ptr, stride, sizes):
+        """device_ptr: integer address of int16 [B][stride] already in HBM (e.g. torch tensor .data_ptr())."""
+        B = len(sizes)
+        sz = (C.c_uint * B)(*[int(s) for s in sizes])
+        r = native.lib().STTX_SpeechToTextBatchDevice(self._impl, C.c_void_p(device_ptr), stride, sz, B)
+        if not r:
+            raise RuntimeError("STTX_SpeechToTextBatchDevice failed")
+        out = [C.string_at(r[i]).decode("utf-8", "replace") for i in range(B)]
+        native.lib().STTX_FreeStrings(r, B)
+        return out
+
+    def setProfiling(self, on):
+        native.lib().STTX_SetProfiling(self._impl, int(on))
+
+    def stageTimes(self):
+        ms = (C.c_float * 8)()
+        native.lib().STTX_GetStageTimes(self._impl, ms, 8)
+        keys = ["features_ms", "dense_in_ms", "lstm_ms", "dense_out_ms", "decoder_next_ms", "decoder_decode_ms", "lstm_launches", "timesteps"]
+        return dict(zip(keys, list(ms)))
+
+    def decoderStats(self):
+        st = (C.c_ulonglong * 4)()
+        native.lib().STTX_GetDecoderStats(self._impl, st)
+        return dict(steps=st[0], candidates=st[1], lm_queries=st[2], lm_probes=st[3])
+
+    def computeMfcc(self, audio_buffer):
+        a, p, n = _audio(audio_buffer)
+        g = self.geometry()
+        cap = n // g["win_step"] + 4
+        out = np.zeros((cap, g["n_input"]), dtype=np.float32)
+        nf = C.c_uint(0)
+        status = native.lib().STTX_ComputeMfcc(self._impl, p, n, out.ctypes.data, cap, C.byref(nf))
+        if status != 0:
+            raise RuntimeError("STTX_ComputeMfcc failed 0x%X" % status)
+        return out[:nf.value].copy()
+
+    def acousticProbs(self, audio_buffers):
+        arrs = [np.ascontiguousarray(a, dtype=np.int16) for a in audio_buffers]
+        B = len(arrs)
+        g = self.geometry()
+        tmax = max(a.shape[0] for a in arrs) // g["win_step"] + 4
+        probs = np.zeros((B, tmax, g["n_classes"]), dtype=np.float32)
+        nfr = (C.c_uint * B)()
+        ptrs = (C.c_void_p * B)(*[a.ctypes.data for a in arrs])
+        sizes = (C.c_uint * B)(*[a.shape[0] for a in arrs])
+        status = native.lib().STTX_AcousticProbs(self._impl, ptrs, sizes, B, probs.ctypes.data, tmax, nfr)
+        if status != 0:
+            raise RuntimeError("STTX_AcousticProbs failed 0x%X" % status)
+        return [probs[b, :nfr[b]].copy() for b in range(B)]
+
+    def inferChunk(self, windows, state_c, state_h):
+        g = self.geometry()
+        w = np.ascontiguousarray(windows, dtype=np.float32)
+        T = w.shape[0]
+        c = np.ascontiguousarray(state_c, dtype=np.float32); h = np.ascontiguousarray(state_h, dtype=np.float32)
+        probs = np.zeros((T, g["n_classes"]), dtype=np.float32)
+        nc = np.zeros_like(c); nh = np.zeros_like(h)
+        status = native.lib().STTX_InferChunk(self._impl, w.ctypes.data, T, c.ctypes.data, h.ctypes.data, probs.ctypes.data,
+                                              nc.ctypes.data, nh.ctypes.data)
+        if status != 0:
+            raise RuntimeError("STTX_InferChunk failed 0x%X" % status)
+        return probs, nc, nh
+
+    def createDecoder(self, n_streams=1, beam_width=None, cutoff_prob=1.0, cutoff_top_n=40):
+        return Decoder(self, n_streams, beam_width or self.beamWidth(), cutoff_prob, cutoff_top_n)
+
+
+class Stream(object):
+    """native_client/python/__init__.py:223-384"""
+
+    def __init__(self, native_stream, model):
+        self._impl = native_stream
+        self._model = model  # keep the model alive
+
+    def __del__(self):
+        if getattr(self, "_impl", None):
+            self.freeStream()
+
+    def _check(self):
+        if not self._impl:
+            raise RuntimeError("Stream object is not valid. Trying to use it after finishStream or freeStream?")
+
+    def feedAudioContent(self, audio_buffer):
+        self._check()
+        a, p, n = _audio(audio_buffer)
+        native.lib().STT_FeedAudioContent(self._impl, p, n)
+
+    def intermediateDecode(self):
+        self._check()
+        return native.take_string(native.lib().STT_IntermediateDecode(self._impl)).decode("utf-8", "replace")
+
+    def intermediateDecodeWithMetadata(self, num_results=1):
+        self._check()
+        return _metadata_to_py(native.lib().STT_IntermediateDecodeWithMetadata(self._impl, num_results))
+
+    def intermediateDecodeFlushBuffers(self):
+        self._check()
+        return native.take_string(native.lib().STT_IntermediateDecodeFlushBuffers(self._impl)).decode("utf-8", "replace")
+
+    def intermediateDecodeWithMetadataFlushBuffers(self, num_results=1):
+        self._check()
+        return _metadata_to_py(native.lib().STT_IntermediateDecodeWithMetadataFlushBuffers(self._impl, num_results))
+
+    def finishStream(self):
+        self._check()
+        s = native.take_string(native.lib().STT_FinishStream(self._impl))
+        self._impl = None
+        return s.decode("utf-8", "replace")
+
+    def finishStreamWithMetadata(self, num_results=1):
+        self._check()
+        m = _metadata_to_py(native.lib().STT_FinishStreamWithMetadata(self._impl, num_results))
+        self._impl = None
+        return m
+
+    def freeStream(self):
+        self._check()
+        native.lib().STT_FreeStream(self._impl)
+        self._impl = None
+
+
+class Decoder(object):
+    """DecoderState (ctc_beam_search_decoder.h:14-87) for n independent streams, running on the GPU."""
+
+    def __init__(self, model, n_streams, beam_width, cutoff_prob, cutoff_top_n):
+        h = C.c_void_p()
+        status = native.lib().STTX_DecoderCreate(model._impl, n_streams, beam_width, cutoff_prob, cutoff_top_n, C.byref(h))
+        if status != 0:
+            raise RuntimeError("STTX_DecoderCreate failed 0x%X" % status)
+        self._impl, self._model, self.n, self.beam = h, model, n_streams, beam_width
+        self.C = model.geometry()["n_classes"]
+
+    def next(self, probs, n_frames=None):
+        """probs: float32 [n_streams, T, C] (or [T, C] for one stream)."""
+        p = np.ascontiguousarray(probs, dtype=np.float32)
+        if p.ndim == 2:
+            p = p[None]
+        assert p.shape[0] == self.n and p.shape[2] == self.C
+        nf = (C.c_uint * self.n)(*([p.shape[1]] * self.n if n_frames is None else [int(x) for x in n_frames]))
+        status = native.lib().STTX_DecoderNext(self._impl, p.ctypes.data, p.shape[1], nf)
+        if status != 0:
+            raise RuntimeError("STTX_DecoderNext failed 0x%X" % status)
+
+    def decode(self, num_results=1, max_len=2048):
+        tok = np.zeros((self.n, num_results, max_len), dtype=np.uint32)
+        ts = np.zeros((self.n, num_results, max_len), dtype=np.uint32)
+        lens = np.zeros((self.n, num_results), dtype=np.int32)
+        conf = np.zeros((self.n, num_results), dtype=np.float64)
+        nres = np.zeros(self.n, dtype=np.int32)
+        status = native.lib().STTX_DecoderDecode(self._impl, num_results, max_len, tok.ctypes.data, ts.ctypes.data,
+                                                 lens.ctypes.data, conf.ctypes.data, nres.ctypes.data)
+        if status != 0:
+            raise RuntimeError("STTX_DecoderDecode failed 0x%X" % status)
+        return [[(conf[i, r], tok[i, r, :lens[i, r]].copy(), ts[i, r, :lens[i, r]].copy()) for r in range(nres[i])]
+                for i in range(self.n)]
+
+    def raw_beam(self, stream=0):
+        cap = self.beam + 8
+        sc = np.zeros(cap, np.float32); pb = np.zeros(cap, np.float32); pnb = np.zeros(cap, np.float32); ch = np.zeros(cap, np.int32)
+        n = native.lib().STTX_DecoderBeam(self._impl, stream, sc.ctypes.data, pb.ctypes.data, pnb.ctypes.data, ch.ctypes.data, cap)
+        return sc[:n], pb[:n], pnb[:n], ch[:n]
+
+    def stats(self):
+        st = (C.c_ulonglong * 4)()
+        status = native.lib().STTX_DecoderStats(self._impl, st)
+        return dict(steps=st[0], candidates=st[1], lm_queries=st[2], lm_probes=st[3], error=status)
+
+    def close(self):
+        if self._impl:
+            native.lib().STTX_DecoderFree(self._impl)
+            self._impl = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

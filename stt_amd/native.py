@@ -1,0 +1,135 @@
+"""stt_amd/native.py -- ctypes binding of stt_amd/lib/libstt.so (the C-ABI of include/coqui-stt.h + stt_amd.h).
+
+This is the stub a maintainer of the reference's Python package would write instead of the SWIG module
+(native_client/python/impl.i): every function is declared with the exact C signature.  There is no Python
+or CPU implementation behind it -- if the shared library is missing, importing raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstt.so")
+
+
+class TokenMetadata(C.Structure):
+    _fields_ = [("text", C.c_char_p), ("timestep", C.c_uint), ("start_time", C.c_float)]
+
+
+class CandidateTranscript(C.Structure):
+    _fields_ = [("tokens", C.POINTER(TokenMetadata)), ("num_tokens", C.c_uint), ("confidence", C.c_double)]
+
+
+class AcousticModelEmissions(C.Structure):
+    _fields_ = [("num_symbols", C.c_int), ("symbols", C.POINTER(C.c_char_p)), ("num_timesteps", C.c_int),
+                ("emissions", C.POINTER(C.c_double))]
+
+
+class Metadata(C.Structure):
+    _fields_ = [("transcripts", C.POINTER(CandidateTranscript)), ("num_transcripts", C.c_uint),
+                ("emissions", C.POINTER(AcousticModelEmissions))]
+
+
+COQUI_STT_H = [
+    "STT_CreateModel", "STT_CreateModelFromBuffer", "STT_GetModelBeamWidth", "STT_SetModelBeamWidth",
+    "STT_GetModelSampleRate", "STT_FreeModel", "STT_EnableExternalScorer", "STT_EnableExternalScorerFromBuffer",
+    "STT_AddHotWord", "STT_EraseHotWord", "STT_ClearHotWords", "STT_DisableExternalScorer", "STT_SetScorerAlphaBeta",
+    "STT_SpeechToText", "STT_SpeechToTextWithMetadata", "STT_SpeechToTextWithEmissions", "STT_CreateStream",
+    "STT_FeedAudioContent", "STT_IntermediateDecode", "STT_IntermediateDecodeWithMetadata",
+    "STT_IntermediateDecodeFlushBuffers", "STT_IntermediateDecodeWithMetadataFlushBuffers", "STT_FinishStream",
+    "STT_FinishStreamWithMetadata", "STT_FreeStream", "STT_FreeMetadata", "STT_FreeString", "STT_Version",
+    "STT_ErrorCodeToErrorMessage",
+]
+STT_AMD_H = [
+    "STTX_SetDevice", "STTX_GetDeviceCount", "STTX_SpeechToTextBatch", "STTX_SpeechToTextBatchWithMetadata",
+    "STTX_SpeechToTextBatchDevice", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
+    "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
+    "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
+    "STTX_DecoderStats", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libstt.so; raises if it has not been built (python -m stt_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("stt_amd: %s is missing -- build it with `python -m stt_amd.build`; "
+                           "there is no fallback implementation." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cu, cf, cd, cs = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_double, C.c_char_p
+    pp = C.POINTER
+    sig = {
+        "STT_CreateModel": (ci, [cs, pp(vp)]),
+        "STT_CreateModelFromBuffer": (ci, [vp, cu, pp(vp)]),
+        "STT_GetModelBeamWidth": (cu, [vp]),
+        "STT_SetModelBeamWidth": (ci, [vp, cu]),
+        "STT_GetModelSampleRate": (ci, [vp]),
+        "STT_FreeModel": (None, [vp]),
+        "STT_EnableExternalScorer": (ci, [vp, cs]),
+        "STT_EnableExternalScorerFromBuffer": (ci, [vp, vp, cu]),
+        "STT_AddHotWord": (ci, [vp, cs, cf]),
+        "STT_EraseHotWord": (ci, [vp, cs]),
+        "STT_ClearHotWords": (ci, [vp]),
+        "STT_DisableExternalScorer": (ci, [vp]),
+        "STT_SetScorerAlphaBeta": (ci, [vp, cf, cf]),
+        "STT_SpeechToText": (vp, [vp, vp, cu]),
+        "STT_SpeechToTextWithMetadata": (pp(Metadata), [vp, vp, cu, cu]),
+        "STT_SpeechToTextWithEmissions": (pp(Metadata), [vp, vp, cu, cu]),
+        "STT_CreateStream": (ci, [vp, pp(vp)]),
+        "STT_FeedAudioContent": (None, [vp, vp, cu]),
+        "STT_IntermediateDecode": (vp, [vp]),
+        "STT_IntermediateDecodeWithMetadata": (pp(Metadata), [vp, cu]),
+        "STT_IntermediateDecodeFlushBuffers": (vp, [vp]),
+        "STT_IntermediateDecodeWithMetadataFlushBuffers": (pp(Metadata), [vp, cu]),
+        "STT_FinishStream": (vp, [vp]),
+        "STT_FinishStreamWithMetadata": (pp(Metadata), [vp, cu]),
+        "STT_FreeStream": (None, [vp]),
+        "STT_FreeMetadata": (None, [pp(Metadata)]),
+        "STT_FreeString": (None, [vp]),
+        "STT_Version": (vp, []),
+        "STT_ErrorCodeToErrorMessage": (vp, [ci]),
+        "STTX_SetDevice": (ci, [ci]),
+        "STTX_GetDeviceCount": (ci, []),
+        "STTX_SpeechToTextBatch": (pp(vp), [vp, pp(vp), pp(cu), cu]),
+        "STTX_SpeechToTextBatchWithMetadata": (pp(pp(Metadata)), [vp, pp(vp), pp(cu), cu, cu]),
+        "STTX_SpeechToTextBatchDevice": (pp(vp), [vp, vp, cu, pp(cu), cu]),
+        "STTX_FreeStrings": (None, [pp(vp), cu]),
+        "STTX_FreeMetadataArray": (None, [pp(pp(Metadata)), cu]),
+        "STTX_SetProfiling": (ci, [vp, ci]),
+        "STTX_GetStageTimes": (ci, [vp, pp(cf), ci]),
+        "STTX_GetDecoderStats": (ci, [vp, pp(C.c_ulonglong)]),
+        "STTX_ComputeMfcc": (ci, [vp, vp, cu, vp, cu, pp(cu)]),
+        "STTX_AcousticProbs": (ci, [vp, pp(vp), pp(cu), cu, vp, cu, pp(cu)]),
+        "STTX_InferChunk": (ci, [vp, vp, cu, vp, vp, vp, vp, vp]),
+        "STTX_GetGeometry": (ci, [vp, pp(ci)]),
+        "STTX_DecoderCreate": (ci, [vp, cu, cu, cd, cu, pp(vp)]),
+        "STTX_DecoderNext": (ci, [vp, vp, cu, pp(cu)]),
+        "STTX_DecoderDecode": (ci, [vp, cu, cu, vp, vp, vp, vp, vp]),
+        "STTX_DecoderBeam": (ci, [vp, cu, vp, vp, vp, vp, cu]),
+        "STTX_DecoderStats": (ci, [vp, pp(C.c_ulonglong)]),
+        "STTX_DecoderFree": (None, [vp]),
+        "STTX_TestDense": (ci, [ci, ci, ci, vp, vp, vp, cf, ci, vp]),
+        "STTX_TestMath": (ci, [ci, vp, vp, vp, cu]),
+        "STTX_PackLstmRecurrent": (ci, [vp, ci, vp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+def take_string(ptr):
+    """char* returned by the library -> bytes, released with STT_FreeString."""
+    if not ptr:
+        return None
+    s = C.string_at(ptr)
+    lib().STT_FreeString(ptr)
+    return s
+
+
+def error_message(code):
+    return take_string(lib().STT_ErrorCodeToErrorMessage(code)).decode()

@@ -1,0 +1,142 @@
+"""The HIP CTC beam-search decoder against the oracle: bit-exact scores, identical tokens and timesteps."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import canon, case_emissions, dump, golden_results
+from stt_amd import modelfile, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(tmp, labels, beam, name):
+    from stt_amd import Model
+    C = len(labels) + 1
+    w = synth.synth_weights(3, n_hidden=128, n_classes=C)
+    path = str(tmp / (name + ".sttw"))
+    modelfile.write_model(path, w, labels, beam_width=beam)
+    return Model(path)
+
+
+@pytest.fixture(scope="module")
+def models(tmp_path_factory, port, fix):
+    tmp = tmp_path_factory.mktemp("dec")
+    word = _mk(tmp, synth.ENGLISH_LABELS, 500, "word")
+    word_lm = _mk(tmp, synth.ENGLISH_LABELS, 500, "word_lm")
+    word_lm.enableExternalScorer(os.path.join(fix, "pruned_lm.scorer"))
+    ulabels, _ = port.utf8_alphabet()
+    byte = _mk(tmp, ulabels, 500, "bytes")
+    byte_lm = _mk(tmp, ulabels, 500, "bytes_lm")
+    byte_lm.enableExternalScorer(os.path.join(fix, "pruned_lm.bytes.scorer"))
+    return {("word", False): word, ("word", True): word_lm, ("bytes", False): byte, ("bytes", True): byte_lm}
+
+
+def _gpu_decode(models, case, probs):
+    m = models[(case["mode"], case["lm"])]
+    m.clearHotWords() if case["lm"] else None
+    for wd, boost in (case.get("hot") or {}).items():
+        m.addHotWord(wd, boost)
+    d = m.createDecoder(1, case["beam"], case.get("cutoff_prob", 1.0), case.get("cutoff_top_n", 40))
+    if case.get("chunk"):
+        for i in range(0, len(probs), case["chunk"]):
+            d.next(probs[i:i + case["chunk"]])
+    else:
+        d.next(probs)
+    res = d.decode(min(case["beam"], 50))[0]
+    st = d.stats()
+    if case["lm"]:
+        m.clearHotWords()
+    return res, st, d
+
+
+def test_decoder_matches_reference_goldens(models, decoder_cases):
+    cases, gold = decoder_cases
+    bad = []
+    for case in cases:
+        res, st, _ = _gpu_decode(models, case, case_emissions(case))
+        want = golden_results(gold, case["name"])
+        ok = canon(res) == sorted(want)
+        print(case["name"], "OK" if ok else "MISMATCH", st)
+        if not ok:
+            bad.append(case["name"])
+            dump("dec_gold_" + case["name"], got_conf=np.array([r[0] for r in res]), want_conf=np.array([r[0] for r in want]),
+                 got_len=np.array([len(r[1]) for r in res]), want_len=np.array([len(r[1]) for r in want]))
+        assert st["error"] == 0, (case["name"], st)
+    assert not bad, bad
+
+
+def test_decoder_whole_beam_vs_port(models, port, english, fix):
+    """Fresh seeds; the complete beam (every prefix's score / blank / non-blank log-probs and last character) bit for bit."""
+    labels, space = english
+    P = port.Scorer(os.path.join(fix, "pruned_lm.scorer"))
+    vocab = open(os.path.join(fix, "vocab.pruned.txt")).read().split()
+    rng = np.random.RandomState(4242)
+    for it in range(6):
+        sent = " ".join(rng.choice(vocab, size=rng.randint(2, 8)))
+        lab = [0 if ch == " " else (27 if ch == "'" else ord(ch) - ord("a") + 1) for ch in sent]
+        T = 30 + 5 * len(lab)
+        noise = [0.02, 0.1, 0.3, 1.0, 0.05, 0.5][it]
+        p = synth.peaky_emissions(lab, T, 29, 28, seed=900 + it, noise=noise)
+        for beam, lm in [(1, False), (37, True), (500, True), (500, False), (1024, True)]:
+            dp = port.Decoder(labels, space, beam, P if lm else None)
+            dp.next(p)
+            d = models[("word", lm)].createDecoder(1, beam)
+            d.next(p)
+            gs, gb, gnb, gch = d.raw_beam(0)
+            ps, pb, pnb, pch, _ = dp.raw_beam()
+            tag = "it%d beam%d lm%d" % (it, beam, lm)
+            if not (len(gs) == len(ps) and np.array_equal(gs.view(np.uint32), ps.view(np.uint32))):
+                dump("beam_mismatch_%d_%d_%d" % (it, beam, lm), gs=gs, ps=ps, gch=gch, pch=pch, gb=gb, pb=pb, gnb=gnb, pnb=pnb)
+            assert len(gs) == len(ps), tag
+            assert np.array_equal(gs.view(np.uint32), ps.view(np.uint32)), tag
+            assert np.array_equal(gb.view(np.uint32), pb.view(np.uint32)) and np.array_equal(gnb.view(np.uint32), pnb.view(np.uint32)), tag
+            assert np.array_equal(gch, pch), tag
+            n = min(beam, 30)
+            assert canon(d.decode(n)[0]) == canon(dp.decode(n)), tag
+            assert d.stats()["error"] == 0
+
+
+def test_decoder_random_softmax_and_edge_cases(models, port, english, fix):
+    labels, space = english
+    P = port.Scorer(os.path.join(fix, "pruned_lm.scorer"))
+    rng = np.random.RandomState(5)
+    logits = rng.randn(90, 29) * 0.7
+    p = np.exp(logits); p = (p / p.sum(1, keepdims=True)).astype(np.float32)   # near-uniform: worst case for the beam
+    for beam, lm in [(64, False), (200, True)]:
+        dp = port.Decoder(labels, space, beam, P if lm else None); dp.next(p)
+        d = models[("word", lm)].createDecoder(1, beam); d.next(p)
+        assert canon(d.decode(beam)[0]) == canon(dp.decode(beam)), (beam, lm)
+    # nothing fed / only blanks (start_expanding never set, ctc_beam_search_decoder.cpp:125-132) / single frame
+    for frames in (None, np.tile(np.eye(29, dtype=np.float32)[28], (7, 1)), p[:1]):
+        dp = port.Decoder(labels, space, 16, P); d = models[("word", True)].createDecoder(1, 16)
+        if frames is not None:
+            dp.next(frames); d.next(frames)
+        assert canon(d.decode(4)[0]) == canon(dp.decode(4))
+
+
+def test_decoder_streams_are_independent_and_chunking_is_exact(models, port, english, fix):
+    """A batch of streams decoded together == each decoded alone; feeding 16-frame chunks == feeding all at once."""
+    labels, space = english
+    vocab = open(os.path.join(fix, "vocab.pruned.txt")).read().split()
+    rng = np.random.RandomState(77)
+    probs, nfr = [], []
+    for i in range(5):
+        sent = " ".join(rng.choice(vocab, size=rng.randint(2, 6)))
+        lab = [0 if ch == " " else (27 if ch == "'" else ord(ch) - ord("a") + 1) for ch in sent]
+        probs.append(synth.peaky_emissions(lab, 30 + 5 * len(lab), 29, 28, seed=i, noise=0.2)); nfr.append(len(probs[-1]))
+    tmax = max(nfr)
+    batch = np.zeros((5, tmax, 29), np.float32)
+    for i, p in enumerate(probs):
+        batch[i, :len(p)] = p
+    m = models[("word", True)]
+    d = m.createDecoder(5, 100)
+    d.next(batch, nfr)
+    together = d.decode(10)
+    for i, p in enumerate(probs):
+        d1 = m.createDecoder(1, 100); d1.next(p)
+        d2 = m.createDecoder(1, 100)
+        for k in range(0, len(p), 16):
+            d2.next(p[k:k + 16])
+        a, b, c = canon(together[i]), canon(d1.decode(10)[0]), canon(d2.decode(10)[0])
+        assert a == b == c, i

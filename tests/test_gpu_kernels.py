@@ -1,0 +1,122 @@
+"""Parity of the individual HIP kernels against the oracle, through the C-ABI (needs a MI355X).
+
+Tolerances (stated here, per the north star's "within a stated logit tolerance"):
+  * decoder float helpers: bit exact.
+  * MFCC: |gpu - oracle| <= 2e-4 absolute per coefficient (both sides f64 internally, f32 out; coefficients are O(1..50)).
+  * dense MFMA kernel: f16 operands, f32 accumulate; against an f64 product of the same f16-rounded operands:
+    <= 1e-3 * (1 + |y|) (accumulation order only), output rounding to f16 allowed for the ReLU epilogue.
+  * acoustic model (f16 weights/activations, f32 state) vs the f64 oracle fed the same f16-rounded weights/activations:
+    softmax probabilities within 3e-3 absolute; vs the unrounded f64 oracle within 2e-2 absolute.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import dump
+from oracle import am_ref
+from stt_amd import modelfile, native, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small_model(tmp_path_factory):
+    from stt_amd import Model
+    w = synth.synth_weights(7, n_hidden=256)
+    path = str(tmp_path_factory.mktemp("m") / "small.sttw")
+    modelfile.write_model(path, w, synth.ENGLISH_LABELS, beam_width=100)
+    return Model(path), w
+
+
+def test_device_math_bit_exact(port):
+    L, P = native.lib(), port.lib()
+    rng = np.random.default_rng(1)
+    a = np.concatenate([-np.abs(rng.standard_normal(300000) * 25), rng.uniform(-110, 90, 300000),
+                        [0.0, -87.5, -88.0, -103.9, -104.5, float.fromhex("-0x1.f8cbb2p+5"), float.fromhex("0x1.04845ep+5")]]).astype(np.float32)
+    got = np.zeros_like(a); want = np.zeros_like(a)
+    assert L.STTX_TestMath(0, a.ctypes.data, None, got.ctypes.data, len(a)) == 0
+    P.port_expf_array(a.ctypes.data, want.ctypes.data, len(a))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "expf"
+    b = np.concatenate([rng.uniform(1, 2, 300000), rng.uniform(0, 1, 300000) + 1.17549435e-38, [1.17549435e-38, 1.0, 2.0]]).astype(np.float32)
+    got = np.zeros_like(b); want = np.zeros_like(b)
+    assert L.STTX_TestMath(1, b.ctypes.data, None, got.ctypes.data, len(b)) == 0
+    P.port_logf_array(b.ctypes.data, want.ctypes.data, len(b))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "logf"
+    # log_sum_exp incl. the -FLT_MAX sentinel
+    x = (-np.abs(rng.standard_normal(200000)) * 40).astype(np.float32); y = (-np.abs(rng.standard_normal(200000)) * 40).astype(np.float32)
+    x[:100] = -3.4028234663852886e38; y[50:150] = -3.4028234663852886e38
+    got = np.zeros_like(x)
+    assert L.STTX_TestMath(2, x.ctypes.data, y.ctypes.data, got.ctypes.data, len(x)) == 0
+    ex = np.zeros_like(x); ey = np.zeros_like(x); want = np.zeros_like(x)
+    xm = np.maximum(x, y)
+    P.port_expf_array((x - xm).ctypes.data, ex.ctypes.data, len(x)); P.port_expf_array((y - xm).ctypes.data, ey.ctypes.data, len(x))
+    s = (ex + ey).astype(np.float32); lg = np.zeros_like(x)
+    P.port_logf_array(s.ctypes.data, lg.ctypes.data, len(x))
+    want = (lg + xm).astype(np.float32)
+    neg = np.float32(-3.4028234663852886e38)
+    want = np.where(x <= neg, y, np.where(y <= neg, x, want))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "log_sum_exp"
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(37, 128, 64, 1), (300, 256, 512, 0), (129, 128, 2048, 1), (16, 384, 128, 0)])
+def test_dense_kernel(M, N, K, epi):
+    rng = np.random.default_rng(M + N + K)
+    x = rng.standard_normal((M, K)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float16).astype(np.float32)   # asymmetric on purpose (transpose detecting)
+    w[:, 0] += 0.5; x[0, :] += 0.25
+    bias = rng.standard_normal(N).astype(np.float32)
+    y = np.zeros((M, N), dtype=np.float32)
+    assert native.lib().STTX_TestDense(M, N, K, x.ctypes.data, w.ctypes.data, bias.ctypes.data, 20.0, epi, y.ctypes.data) == 0
+    ref = x.astype(np.float64) @ w.astype(np.float64) + bias
+    if epi == 0:
+        ref = np.minimum(np.maximum(ref, 0), 20.0)
+    err = np.abs(y - ref) / (1 + np.abs(ref))
+    dump("dense_%d_%d_%d_%d" % (M, N, K, epi), y=y, ref=ref)
+    assert err.max() < (2e-3 if epi == 0 else 1e-3), (err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+@pytest.mark.parametrize("n", [46797, 0, 100, 512, 832, 16000])
+def test_mfcc_kernel(small_model, n):
+    model, _ = small_model
+    a = synth.synth_audio(n, seed=n + 1)
+    got = model.computeMfcc(a)
+    want = am_ref.mfcc_utterance(a)
+    assert got.shape == want.shape == (am_ref.n_frames_for(n), 26)
+    dump("mfcc_%d" % n, got=got, want=want)
+    assert np.abs(got - want).max() <= 2e-4, np.abs(got - want).max()
+
+
+def test_infer_chunk_matches_oracle(small_model):
+    """ModelState::infer semantics: 16 windows + carried (c, h) -> probs + new state; two chained chunks."""
+    model, w = small_model
+    rng = np.random.default_rng(11)
+    a = synth.synth_audio(16000, seed=3)
+    win = am_ref.context_windows(am_ref.MfccSpec().frames_fast(a))
+    c = np.zeros(256, np.float32); h = np.zeros(256, np.float32)
+    c_o = h_o = None
+    for i in range(0, 32, 16):
+        probs, c, h = model.inferChunk(win[i:i + 16], c, h)
+        want, c_o, h_o = am_ref.am_forward(win[i:i + 16], w, c0=c_o, h0=h_o, weight_round=np.float16)
+        dump("infer_%d" % i, probs=probs, want=want, c=c, c_o=c_o, h=h, h_o=h_o)
+        assert np.abs(probs - want).max() < 3e-3, np.abs(probs - want).max()
+        assert np.abs(c - c_o).max() < 1e-2 and np.abs(h - h_o).max() < 1e-2
+        assert np.allclose(probs.sum(1), 1.0, atol=1e-4)
+
+
+def test_batch_acoustic_probs(small_model):
+    """Variable-length batch through MFCC -> context -> dense -> LSTM -> softmax; each utterance vs the oracle."""
+    model, w = small_model
+    lens = [8000, 16000, 700, 0, 12345]
+    audio = [synth.synth_audio(n, seed=20 + i) for i, n in enumerate(lens)]
+    got = model.acousticProbs(audio)
+    for i, a in enumerate(audio):
+        want16 = am_ref.utterance_probs(a, w, weight_round=np.float16)
+        want64 = am_ref.utterance_probs(a, w)
+        assert got[i].shape == want16.shape
+        dump("am_batch_%d" % i, got=got[i], want16=want16, want64=want64)
+        assert np.abs(got[i] - want16).max() < 3e-3, (i, np.abs(got[i] - want16).max())
+        assert np.abs(got[i] - want64).max() < 2e-2, (i, np.abs(got[i] - want64).max())
+    # batch composition must not change a row: same utterance alone == inside the batch (bitwise)
+    alone = model.acousticProbs([audio[1]])[0]
+    assert np.array_equal(alone, got[1])

@@ -1,0 +1,125 @@
+"""Host-side logic that needs no GPU: alphabet formats, model container, frame bookkeeping, weight packing."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import am_ref
+from stt_amd import modelfile, synth
+
+
+def test_alphabet_text_formats(port, fix):
+    labels, space = port.parse_alphabet_file(os.path.join(fix, "alphabet.txt"))
+    assert len(labels) == 28 and space == 0 and labels[1] == b"a" and labels[27] == b"'"
+    # tests/test_text.py of the reference: the three line-ending conventions parse identically
+    got = [port.parse_alphabet_file(os.path.join(fix, "alphabet_%s.txt" % k))[0] for k in ("unix", "macos", "windows")]
+    assert got[0] == got[1] == got[2] == [b"a", b"b", b"c"]
+    assert synth.ENGLISH_LABELS == labels
+
+
+def test_alphabet_binary_format_matches_reference(ref, fix):
+    A = ref.Alphabet(os.path.join(fix, "alphabet.txt"))
+    assert modelfile.serialize_alphabet(synth.ENGLISH_LABELS) == A.serialize()   # alphabet.cc:102-131
+
+
+def test_frame_count_follows_stt_cc():
+    # 5 s -> 250, LDC93S1 -> 146, < 512 samples -> 1
+    assert [am_ref.n_frames_for(n) for n in (80000, 46797, 0, 100, 511, 512, 831, 832, 240000)] == [250, 146, 1, 1, 1, 2, 2, 3, 750]
+    # explicit simulation of the feedAudioContent / flushBuffers buffer logic (stt.cc:105-128, 236-254)
+    for n in (0, 1, 511, 512, 513, 832, 5000, 46797):
+        buf, frames = 0, 0
+        for _ in range(n):
+            buf += 1
+            if buf == 512:
+                frames += 1
+                buf -= 320
+        frames += 1  # flush
+        assert frames == am_ref.n_frames_for(n), n
+
+
+def test_model_container_layout():
+    w = synth.synth_weights(0, n_hidden=128)
+    blob = modelfile.model_bytes(w, synth.ENGLISH_LABELS, beam_width=77)
+    assert blob[:8] == b"STTAMDW1"
+    hdr = struct.unpack("<10I", blob[8:48])
+    assert hdr == (1, 26, 9, 128, 29, 16, 16000, 512, 320, 77)
+    alen = struct.unpack("<I", blob[52:56])[0]
+    off = 64 + ((alen + 7) // 8) * 8
+    l1 = np.frombuffer(blob, dtype="<f4", count=494 * 128, offset=off).reshape(494, 128)
+    assert np.array_equal(l1, w["layer_1/weights"])
+    assert len(blob) == off + 4 * sum(int(np.prod(w[k].shape)) for k in modelfile.TENSOR_ORDER)
+
+
+def _emulate_lstm_kernel(packed, hp, xproj_t, c, H, B, NT):
+    """numpy emulation of lstm_step_kernel's index arithmetic under the documented MFMA 16x16x32 fragment layout:
+    A[i = lane&15][k = 8*(lane>>4)+e], B[k][j = lane&15], D[i = 4*(lane>>4)+r][j = lane&15]."""
+    ksteps = H // 128
+    z = np.zeros((H // 8, 32, NT * 16), dtype=np.float64)
+    lane = np.arange(64)
+    for wg in range(H // 8):
+        for q in range(4):
+            for s in range(ksteps):
+                for mt in range(2):
+                    a = packed[(((wg * 4 + q) * ksteps + s) * 2 + mt)].astype(np.float64)   # [64 lanes][8]
+                    A = np.zeros((16, 32)); A[(lane & 15)[:, None], (lane >> 4)[:, None] * 8 + np.arange(8)[None, :]] = a
+                    for nt in range(NT):
+                        bfr = hp[(q * ksteps + s) * NT + nt].astype(np.float64)
+                        Bm = np.zeros((32, 16)); Bm[(lane >> 4)[:, None] * 8 + np.arange(8)[None, :], (lane & 15)[:, None]] = bfr
+                        z[wg, mt * 16:(mt + 1) * 16, nt * 16:(nt + 1) * 16] += A @ Bm
+    sig = lambda x: 1 / (1 + np.exp(-x))
+    h_new = np.zeros((B, H)); c_new = np.zeros((B, H))
+    for wg in range(H // 8):
+        for u in range(8):
+            unit = wg * 8 + u
+            for b in range(B):
+                zi, zj, zf, zo = (z[wg, g * 8 + u, b] + xproj_t[b, g * H + unit] for g in range(4))
+                cn = sig(zf) * c[b, unit] + sig(zi) * np.tanh(zj)
+                c_new[b, unit] = cn; h_new[b, unit] = sig(zo) * np.tanh(cn)
+    return h_new, c_new
+
+
+def test_lstm_weight_packing_matches_kernel_indexing():
+    """pack_lstm_recurrent_host (model.cpp) + the hp fragment order reproduce h.K[H:] under the kernel's indexing."""
+    from stt_amd import native
+    if not os.path.exists(native.LIB_PATH):
+        pytest.skip("libstt.so not built")
+    H, B, NT = 128, 5, 1
+    rng = np.random.default_rng(3)
+    kernel = rng.standard_normal((2 * H, 4 * H)).astype(np.float32)
+    out = np.zeros(4 * H * H, dtype=np.uint16)
+    assert native.lib().STTX_PackLstmRecurrent(kernel.ctypes.data, H, out.ctypes.data) == 0
+    packed = out.view(np.float16).reshape(-1, 64, 8)
+    h = rng.standard_normal((B, H)).astype(np.float16)
+    hp = np.zeros((H // 32, NT, 64, 8), dtype=np.float16)   # pack_h_kernel's order
+    for b in range(B):
+        for k in range(H):
+            hp[k >> 5, b >> 4, ((k & 31) >> 3) * 16 + (b & 15), k & 7] = h[b, k]
+    xproj = rng.standard_normal((B, 4 * H))
+    c = rng.standard_normal((B, H))
+    h_new, c_new = _emulate_lstm_kernel(packed, hp.reshape(-1, 64, 8), xproj, c, H, B, NT)
+    Kh = kernel[H:].astype(np.float16).astype(np.float64)
+    z = xproj + h.astype(np.float64) @ Kh
+    i, j, f, o = np.split(z, 4, axis=1)
+    sig = lambda x: 1 / (1 + np.exp(-x))
+    c_ref = sig(f) * c + sig(i) * np.tanh(j)
+    h_ref = sig(o) * np.tanh(c_ref)
+    np.testing.assert_allclose(c_new, c_ref, atol=1e-9)
+    np.testing.assert_allclose(h_new, h_ref, atol=1e-9)
+
+
+def test_am_oracle_self_consistency():
+    """MFCC slow (op-order faithful) vs vectorised path; chunked (n_steps=16, carried state) vs whole-utterance forward."""
+    spec = am_ref.MfccSpec()
+    a = synth.synth_audio(9000, seed=5)
+    np.testing.assert_allclose(am_ref.mfcc_utterance(a, spec), spec.frames_fast(a), atol=2e-5)
+    w = am_ref.synth_weights(1, n_hidden=128)
+    win = am_ref.context_windows(spec.frames_fast(a))
+    full, cF, hF = am_ref.am_forward(win, w)
+    parts, c, h = [], None, None
+    for i in range(0, len(win), 16):
+        p, c, h = am_ref.am_forward(win[i:i + 16], w, c0=c, h0=h)
+        parts.append(p)
+    np.testing.assert_allclose(np.concatenate(parts), full, atol=1e-6)
+    assert np.allclose(full.sum(1), 1.0, atol=1e-5)

@@ -1,0 +1,115 @@
+"""The plain-C port oracle (oracle/stt_port.c) against (a) the committed golden vectors produced by the real
+reference (tests/golden/make_golden.py) and (b) the real reference itself when oracle/_ref is present."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, canon, case_emissions, golden_results
+
+
+def _port_decode(port, english, fix, case, probs=None):
+    if case["mode"] == "bytes":
+        labels, space = port.utf8_alphabet()
+        sc = port.Scorer(os.path.join(fix, "pruned_lm.bytes.scorer")) if case["lm"] else None
+    else:
+        labels, space = english
+        sc = port.Scorer(os.path.join(fix, "pruned_lm.scorer")) if case["lm"] else None
+    d = port.Decoder(labels, space, case["beam"], sc, cutoff_prob=case.get("cutoff_prob", 1.0),
+                     cutoff_top_n=case.get("cutoff_top_n", 40), hot_words=case.get("hot"))
+    p = case_emissions(case) if probs is None else probs
+    if case.get("chunk"):
+        for i in range(0, len(p), case["chunk"]):
+            d.next(p[i:i + case["chunk"]])
+    else:
+        d.next(p)
+    return d.decode(min(case["beam"], 50))
+
+
+def test_port_matches_reference_goldens(port, english, fix, decoder_cases):
+    cases, gold = decoder_cases
+    for case in cases:
+        got = _port_decode(port, english, fix, case)
+        want = golden_results(gold, case["name"])
+        assert canon(got) == sorted(want), case["name"]  # tokens, timesteps and float confidences, bit for bit
+
+
+def test_port_kenlm_known_answers(port, fix):
+    """Known answers of native_client/kenlm/lm/model_test.cc:66-101 (Continuation test, test.arpa), tolerance as
+    SLOPPY_CHECK_CLOSE there (0.001 for the unquantised trie), plus exact equality with the reference library."""
+    with open(os.path.join(GOLD, "kenlm_golden.json")) as f:
+        kg = json.load(f)
+    s = port.Scorer(os.path.join(fix, "kenlm_test_trie.bin"), lm_only=True)
+    pr, ln = s.score(["looking", "on", "a", "little"], bos=True)
+    np.testing.assert_allclose(pr, [-0.484652, -0.348837, -0.0155266, -0.00306122], atol=1e-3)
+    assert list(ln) == [2, 3, 4, 5]
+    pr, ln = s.score(["looking", "on", "a", "little", "the", "biarritz", "not_found", "more", ".", "</s>"], bos=True)
+    np.testing.assert_allclose(pr[4:], [-4.04005, -1.9889, -2.29666, -1.20632 - 20.0, -0.51363, -0.0191651], atol=1e-3)
+    assert list(ln[4:]) == [1, 1, 1, 1, 2, 3]
+    pr, ln = s.score(["also", "would", "consider", "higher", "looking"], bos=False)   # Blanks test, model_test.cc:103-118
+    np.testing.assert_allclose(pr, [-1.687872, -2, -3, -4, -5], atol=1e-3)
+    assert list(ln) == [1, 2, 3, 4, 5]
+    for name, rows in kg["kenlm"].items():
+        s = port.Scorer(os.path.join(fix, "kenlm_test_%s.bin" % name), lm_only=True)
+        for row in rows:
+            pr, ln = s.score(row["words"], row["bos"])
+            assert [float(x) for x in pr] == row["probs"], (name, row["words"])
+            assert [int(x) for x in ln] == row["lens"], (name, row["words"])
+
+
+def test_port_scorer_queries(port, fix):
+    with open(os.path.join(GOLD, "kenlm_golden.json")) as f:
+        kg = json.load(f)
+    s = port.Scorer(os.path.join(fix, "pruned_lm.scorer"))
+    assert (s.utf8, s.order, s.model_type) == (False, 4, 5)
+    assert abs(s.alpha - 0.75) < 1e-9 and abs(s.beta - 1.85) < 1e-6
+    for row in kg["scorer"]:
+        assert s.log_cond_prob(row["words"], row["bos"]) == row["value"]
+    assert s.log_cond_prob(["zzzz"]) == -1000.0  # OOV_SCORE, scorer.h:16
+    su = port.Scorer(os.path.join(fix, "pruned_lm.bytes.scorer"))
+    assert (su.utf8, su.order, su.model_type) == (True, 2, 2)
+    for row in kg["scorer_bytes"]:
+        assert su.log_cond_prob(row["words"], row["bos"]) == row["value"]
+    start, arcs, finals = s.fst()
+    assert start == 0 and len(finals) == 3451 and arcs.shape == (6488, 3)
+
+
+def test_port_error_codes(port, fix):
+    data = open(os.path.join(fix, "pruned_lm.scorer"), "rb").read()
+    with pytest.raises(RuntimeError, match="0x2006"):
+        port.Scorer(data=b"not a kenlm file" * 20)
+    lm_end = port.lib().port_scorer_lm_end(port.Scorer(data=data).h)
+    with pytest.raises(RuntimeError, match="0x2007"):
+        port.Scorer(data=data[:lm_end])
+    bad = bytearray(data); bad[lm_end] ^= 0xFF
+    with pytest.raises(RuntimeError, match="0x2008"):
+        port.Scorer(data=bytes(bad))
+    bad = bytearray(data); bad[lm_end + 4] = 5
+    with pytest.raises(RuntimeError, match="0x2009"):
+        port.Scorer(data=bytes(bad))
+
+
+def test_port_vs_live_reference(port, ref, english, fix):
+    """Fresh seeds against the compiled reference (only where oracle/_ref exists)."""
+    A = ref.Alphabet(os.path.join(fix, "alphabet.txt"))
+    S = ref.Scorer(os.path.join(fix, "pruned_lm.scorer"), A)
+    P = port.Scorer(os.path.join(fix, "pruned_lm.scorer"))
+    labels, space = english
+    rng = np.random.RandomState(99)
+    vocab = open(os.path.join(fix, "vocab.pruned.txt")).read().split()
+    from stt_amd import synth
+    for it in range(4):
+        sent = " ".join(rng.choice(vocab, size=rng.randint(2, 7)))
+        lab = [0 if ch == " " else (27 if ch == "'" else ord(ch) - ord("a") + 1) for ch in sent]
+        p = synth.peaky_emissions(lab, 30 + 5 * len(lab), 29, 28, seed=500 + it, noise=[0.02, 0.1, 0.5, 1.0][it])
+        for beam, lm in [(50, False), (200, True)]:
+            dr = ref.Decoder(A, beam, S if lm else None); dp = port.Decoder(labels, space, beam, P if lm else None)
+            dr.next(p.astype(np.float64)); dp.next(p)
+            assert canon(dr.decode(beam)) == canon(dp.decode(beam)), (it, beam, lm)
+    # empty / degenerate inputs
+    dr = ref.Decoder(A, 10, S); dp = port.Decoder(labels, space, 10, P)
+    assert canon(dr.decode(3)) == canon(dp.decode(3))
+    allblank = np.zeros((5, 29), np.float32); allblank[:, 28] = 1.0
+    dr.next(allblank.astype(np.float64)); dp.next(allblank)
+    assert canon(dr.decode(3)) == canon(dp.decode(3))
