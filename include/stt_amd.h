@@ -53,6 +53,9 @@ STTX_EXPORT int STTX_SetProfiling(ModelState* aCtx, int aEnable);
 STTX_EXPORT int STTX_GetStageTimes(ModelState* aCtx, float* aMs, int aCap);
 /* Decoder counters accumulated over the last batch call: steps, candidates, lm queries, lm memory probes. */
 STTX_EXPORT int STTX_GetDecoderStats(ModelState* aCtx, unsigned long long* aOut4);
+/* Shader cycles spent per decoder phase (summed over streams) in the last batch call: emissions, hash, expand, LM,
+ * merge, select, sort, write. */
+STTX_EXPORT int STTX_GetDecoderPhaseCycles(ModelState* aCtx, unsigned long long* aOut8);
 
 /* ---- stage-level entry points (host buffers in and out) --------------------------------------- */
 /* aOut: [aCapFrames][n_input] floats; *aNumFrames = frames produced for aNumSamples samples. */

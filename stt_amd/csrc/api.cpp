@@ -22,6 +22,7 @@ struct Prof {
   hipEvent_t ev[8] = {};
   float ms[8] = {};
   unsigned long long dec_stats[4] = {};
+  unsigned long long dec_phase[8] = {};
 };
 std::unordered_map<ModelState*, Prof> g_prof;
 
@@ -115,7 +116,7 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
   std::vector<std::vector<Output>> all;
   HIP_CHECK(hipSetDevice(m->device));
   Prof& pr = prof_of(m);
-  if (pr.on) { for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; }
+  if (pr.on) { for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; }
   for (unsigned g0 = 0; g0 < B; g0 += 64) {
     const int Bg = (int)std::min(64u, B - g0);
     std::vector<int> hn(Bg), nfr;
@@ -150,7 +151,7 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
       pr.ms[6] += (float)t_max; pr.ms[7] += (float)t_max * Bg;
       std::vector<DecStream> tb(Bg);
       HIP_CHECK(hipMemcpy(tb.data(), db.table.p, sizeof(DecStream) * Bg, hipMemcpyDeviceToHost));
-      for (auto& S : tb) for (int k = 0; k < 4; ++k) pr.dec_stats[k] += S.stat[k];
+      for (auto& S : tb) { for (int k = 0; k < 4; ++k) pr.dec_stats[k] += S.stat[k]; for (int k = 0; k < 8; ++k) pr.dec_phase[k] += S.phase[k]; }
     }
     for (auto& o : outs) all.push_back(std::move(o));
   }
@@ -423,6 +424,12 @@ int STTX_GetStageTimes(ModelState* aCtx, float* aMs, int aCap) {
 int STTX_GetDecoderStats(ModelState* aCtx, unsigned long long* aOut4) {
   Prof& p = prof_of(aCtx);
   for (int i = 0; i < 4; ++i) aOut4[i] = p.dec_stats[i];
+  return STT_ERR_OK;
+}
+
+int STTX_GetDecoderPhaseCycles(ModelState* aCtx, unsigned long long* aOut8) {
+  Prof& p = prof_of(aCtx);
+  for (int i = 0; i < 8; ++i) aOut8[i] = p.dec_phase[i];
   return STT_ERR_OK;
 }
 

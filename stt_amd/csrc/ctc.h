@@ -73,6 +73,7 @@ struct DecStream {
   uint64_t* key;
   uint2* pa;  // {parent, character}; entry 0 = root
   uint2* ta;  // {parent, timestep};  entry 0 = timestep_tree_root_
+  double* pa_lm;  // per path node: cached (log_cond_prob + hot_boost) of "this prefix, then a word boundary" (NaN = not yet computed)
   // per-step candidate workspace [cand_cap]
   float* c_logp;
   uint32_t* c_pi;  // parent beam index | class position << 16 | needs_lm << 31
@@ -82,6 +83,8 @@ struct DecStream {
   uint32_t cand_cap;
   // statistics (DESIGN.md roofline accounting): steps, candidates, lm queries, lm memory probes
   unsigned long long stat[4];
+  // shader cycles (s_memtime, thread 0) per phase: P0 emissions, P1 hash, P2 expand, P3 LM, P4 merge, P5a select, P5b sort, P6 write
+  unsigned long long phase[8];
 };
 
 struct DecParams {

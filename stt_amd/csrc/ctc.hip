@@ -190,8 +190,9 @@ __device__ uint64_t hash_labels_reversed(const DevAlphabet& al, const uint32_t* 
 
 // Scorer::make_ngram (scorer.cpp:370-396) + get_log_cond_prob (:308-344) + hot words (ctc_beam_search_decoder.cpp:224-236).
 // The prefix to score is `first` (a virtual last label, or STT_ROOT_CH for none) on top of path-arena node `node`.
-// Returns (log_cond_prob + hot_boost) * alpha rounded to float, exactly as the reference's `float score`.
-__device__ float lm_score(const DevScorer& s, const DevAlphabet& al, const uint2* pa, uint32_t node, uint32_t first, bool with_hot, unsigned& probes) {
+// Returns log_cond_prob + hot_boost as a double; the caller multiplies by alpha and rounds to float exactly like the
+// reference's `float score = (get_log_cond_prob(...) + hot_boost) * alpha`.
+__device__ double lm_score(const DevScorer& s, const DevAlphabet& al, const uint2* pa, uint32_t node, uint32_t first, bool with_hot, unsigned& probes) {
   uint64_t hashes[STT_KENLM_MAX_ORDER];
   int n = 0;
   uint32_t cur = node;
@@ -250,7 +251,7 @@ __device__ float lm_score(const DevScorer& s, const DevAlphabet& al, const uint2
     KState* t = in; in = out; out = t;
   }
   const double lcp = oov ? OOV_SCORE_D : __ddiv_rn(cond_prob, (double)0.4342944819f);  // / NUM_FLT_LOGE (a float constant)
-  return (float)__dmul_rn(__dadd_rn(lcp, (double)hot_boost), s.alpha);
+  return __dadd_rn(lcp, (double)hot_boost);
 }
 
 // Scorer::is_scoring_boundary (scorer.cpp:272-299) for the prefix (`first` on top of `node`) and label `new_label`
@@ -293,6 +294,7 @@ struct Lds {
   uint64_t* skey; uint32_t* ssrc;
   int* sc;  // scalars
 };
+#define TICK(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); S.phase[k] += now_ - tick_; tick_ = now_; } } while (0)
 enum { SC_M = 0, SC_CUTLEN, SC_FULL, SC_KEEP, SC_START, SC_DIGIT, SC_NEED, SC_SKIP, SC_LMQ, SC_PROBES, SC_ERR, SC_MINCUT, SC_COUNT = 16 };
 
 __host__ __device__ inline uint32_t pow2_ge(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
@@ -369,6 +371,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   int* sc = L.sc;
   const float NEG = STT_NEG_INF;
 
+  unsigned long long tick_ = __builtin_readcyclecounter();
   // ---- P0: emissions
   for (int c = tid; c < C; c += NTHREADS) L.pf[c] = prob_row[c];
   if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; }
@@ -418,6 +421,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
     L.pos[c] = (uint16_t)k;
     L.lp[k] = stt_logf(__fadd_rn(L.pf[c], STT_FLT_MIN));  // log(prob + NUM_FLT_MIN), :355
   }
+  TICK(0);
   // ---- P1: hash of live keys, clear events
   for (uint32_t h = tid; h <= L.ht_mask; h += NTHREADS) L.ht_key[h] = 0;
   for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
@@ -433,6 +437,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   }
   __syncthreads();
 
+  TICK(1);
   // ---- P2: expand every live prefix
   unsigned probes = 0;
   for (int i = tid; i < n; i += NTHREADS) {
@@ -491,6 +496,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   int m = sc[SC_M];
   if ((uint32_t)m > S.cand_cap) { m = (int)S.cand_cap; if (tid == 0) sc[SC_ERR] |= 4; }
 
+  TICK(2);
   // ---- P3: language model on scoring boundaries (:209-243)
   if (s.enabled) {
     unsigned lmq = 0;
@@ -502,8 +508,18 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
       const int i = (int)(pi & 0xFFFFu);
       uint32_t first = STT_ROOT_CH;
       if (s.utf8) first = (x < m) ? (uint32_t)L.cls[(pi >> 16) & 0x7FFFu] : L.ch[cur][x - m];  // score the *new* prefix
-      const float lms = lm_score(s, al, S.pa, L.node[cur][i], first, true, probes);
-      ++lmq;
+      // The boundary score of a word-mode prefix depends only on the prefix (its path node): compute it once per node and
+      // keep it in the arena; later timesteps that retry "prefix + space" reuse it (the reference recomputes it every time).
+      const uint32_t nodei = L.node[cur][i];
+      double raw;
+      if (!s.utf8) {
+        raw = S.pa_lm[nodei];
+        if (raw != raw) { raw = lm_score(s, al, S.pa, nodei, first, true, probes); S.pa_lm[nodei] = raw; ++lmq; }
+      } else {
+        raw = lm_score(s, al, S.pa, nodei, first, true, probes);
+        ++lmq;
+      }
+      const float lms = (float)__dmul_rn(raw, s.alpha);
       float lpv = __fadd_rn(lp0, lms);                       // log_p += score;
       lpv = (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
       if (x < m) S.c_logp[x] = lpv; else L.ev_ext[x - m] = lpv;
@@ -513,6 +529,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   if (probes) atomicAdd(&sc[SC_PROBES], (int)probes);
   __syncthreads();
 
+  TICK(3);
   // ---- P4: merge events of live prefixes in the reference's visiting order (class position, then beam index)
   for (int j = tid; j < n; j += NTHREADS) {
     const float e_self = L.ev_self[j], e_blank = L.ev_blank[j], e_ext = L.ev_ext[j];
@@ -539,6 +556,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   }
   __syncthreads();
 
+  TICK(4);
   // ---- P5: keep the best beam_size (nth_element + resize, :263-274), fully sorted
   const int total = n + m;
   const int keep = total < beam ? total : beam;
@@ -576,7 +594,9 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
     if (k <= threshold) { const int r = atomicAdd(&sc[SC_KEEP], 1); if (r < (int)sortn) { L.skey[r] = k; L.ssrc[r] = (uint32_t)x; } }
   }
   __syncthreads();
+  TICK(5);
   bitonic_sort(L.skey, L.ssrc, sortn);
+  TICK(6);
 
   // ---- P6: new beam
   const int nxt = cur ^ 1;
@@ -596,7 +616,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
       L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
       L.ch[nxt][r] = c; L.fst[nxt][r] = S.c_fst[cx]; L.key[nxt][r] = S.c_key[cx];
       const uint32_t slot = atomicAdd(&S.pa_n, 1u);
-      if (slot < S.pa_cap) { S.pa[slot] = make_uint2(L.node[cur][i], c); L.node[nxt][r] = slot; }
+      if (slot < S.pa_cap) { S.pa[slot] = make_uint2(L.node[cur][i], c); S.pa_lm[slot] = __longlong_as_double(0x7ff8000000000000LL); L.node[nxt][r] = slot; }
       else { L.node[nxt][r] = 0; atomicOr(&sc[SC_ERR], 1); }
       pend = (NEG < lpv) ? L.ts[cur][i] : 0xFFFFFFFEu;  // :246-251 with log_prob_nb_cur == -inf
       ts_new = STT_ROOT_CH;                              // timesteps == nullptr
@@ -616,6 +636,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   cur = nxt;
   n = keep;
   __syncthreads();
+  TICK(7);
 }
 
 __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScorer s, DevAlphabet al, DecStream* streams,
@@ -669,7 +690,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevSc
         do_score = (par != STT_ROOT_CH) && !((int)chi == al.space_id);
       }
       if (do_score) {
-        float v = lm_score(s, al, S.pa, node, STT_ROOT_CH, false, probes);  // :293-297, no hot-word boost here
+        float v = (float)__dmul_rn(lm_score(s, al, S.pa, node, STT_ROOT_CH, false, probes), s.alpha);  // :293-297, no hot-word boost here
         v = (float)__dadd_rn((double)v, s.beta);
         sc = __fadd_rn(sc, v);
       }
@@ -707,8 +728,10 @@ __global__ void ctc_init_kernel(DecStream* streams, int n_streams, int fst_start
   S.score[0] = 0.0f; S.pb[0] = 0.0f; S.pnb[0] = STT_NEG_INF; S.ch[0] = STT_ROOT_CH; S.node[0] = 0; S.ts[0] = 0;
   S.fst[0] = fst_start; S.key[0] = 0x5151515151515151ULL;
   S.pa[0] = make_uint2(STT_ROOT_CH, STT_ROOT_CH); S.ta[0] = make_uint2(STT_ROOT_CH, 0);
+  S.pa_lm[0] = __longlong_as_double(0x7ff8000000000000LL);
   S.n = 1; S.abs_t = 0; S.start_expanding = 0; S.error = 0; S.pa_n = 1; S.ta_n = 1;
   S.stat[0] = S.stat[1] = S.stat[2] = S.stat[3] = 0;
+  for (int k = 0; k < 8; ++k) S.phase[k] = 0;
 }
 void launch_ctc_init(DecStream* streams, int n_streams, int fst_start, hipStream_t st) {
   hipLaunchKernelGGL(ctc_init_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, st, streams, n_streams, fst_start);

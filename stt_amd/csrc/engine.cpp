@@ -115,7 +115,7 @@ void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int e
   const uint32_t cand_cap = (uint32_t)beam * (uint32_t)(C - 1);
   const uint32_t arena = (uint32_t)(expected_frames + 2) * (uint32_t)beam + 2;
   const size_t fixed = al256(cap * 8) + 7 * al256(cap * 4) + al256(cand_cap * 4) * 3 + al256(cand_cap * 8) + al256(((size_t)cap + cand_cap) * 8);
-  const size_t per = fixed + 2 * al256((size_t)arena * 8);
+  const size_t per = fixed + 3 * al256((size_t)arena * 8);
   db.per_stream_fixed = fixed;
   db.slab.reserve(per * n_streams);
   db.host.assign(n_streams, DecStream{});
@@ -130,7 +130,7 @@ void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int e
     S.ch = (uint32_t*)take(cap * 4); S.node = (uint32_t*)take(cap * 4); S.ts = (uint32_t*)take(cap * 4); S.fst = (int*)take(cap * 4);
     S.c_logp = (float*)take(cand_cap * 4); S.c_pi = (uint32_t*)take(cand_cap * 4); S.c_fst = (int*)take(cand_cap * 4);
     S.c_key = (uint64_t*)take(cand_cap * 8); S.sel_keys = (uint64_t*)take(((size_t)cap + cand_cap) * 8);
-    S.pa = (uint2*)take((size_t)arena * 8); S.ta = (uint2*)take((size_t)arena * 8);
+    S.pa = (uint2*)take((size_t)arena * 8); S.ta = (uint2*)take((size_t)arena * 8); S.pa_lm = (double*)take((size_t)arena * 8);
     S.cand_cap = cand_cap; S.pa_cap = arena; S.ta_cap = arena;
   }
   db.table.upload(db.host.data(), sizeof(DecStream) * n_streams, stream);
@@ -151,10 +151,10 @@ void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_
   }
   if (!grow) return;
   const uint32_t arena = need * 2;
-  const size_t per = db.per_stream_fixed + 2 * al256((size_t)arena * 8);
+  const size_t per = db.per_stream_fixed + 3 * al256((size_t)arena * 8);
   DevBuf ns;
   ns.reserve(per * db.n_streams);
-  const size_t old_per = db.per_stream_fixed + 2 * al256((size_t)db.host[0].pa_cap * 8);
+  const size_t old_per = db.per_stream_fixed + 3 * al256((size_t)db.host[0].pa_cap * 8);
   std::vector<DecStream> nh = db.host;
   for (int i = 0; i < db.n_streams; ++i) {
     uint8_t* ob = db.slab.as<uint8_t>() + old_per * i;
@@ -168,8 +168,10 @@ void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_
     uint2* npa = reinterpret_cast<uint2*>(nb + db.per_stream_fixed);
     uint2* nta = reinterpret_cast<uint2*>(nb + db.per_stream_fixed + al256((size_t)arena * 8));
     HIP_CHECK(hipMemcpyAsync(npa, db.host[i].pa, (size_t)db.host[i].pa_n * 8, hipMemcpyDeviceToDevice, stream));
+    double* nlm = reinterpret_cast<double*>(nb + db.per_stream_fixed + 2 * al256((size_t)arena * 8));
     HIP_CHECK(hipMemcpyAsync(nta, db.host[i].ta, (size_t)db.host[i].ta_n * 8, hipMemcpyDeviceToDevice, stream));
-    S.pa = npa; S.ta = nta; S.pa_cap = arena; S.ta_cap = arena;
+    HIP_CHECK(hipMemcpyAsync(nlm, db.host[i].pa_lm, (size_t)db.host[i].pa_n * 8, hipMemcpyDeviceToDevice, stream));
+    S.pa = npa; S.ta = nta; S.pa_lm = nlm; S.pa_cap = arena; S.ta_cap = arena;
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   std::swap(db.slab.p, ns.p); std::swap(db.slab.cap, ns.cap);

@@ -176,6 +176,11 @@ class Model(object):
         native.lib().STTX_GetDecoderStats(self._impl, st)
         return dict(steps=st[0], candidates=st[1], lm_queries=st[2], lm_probes=st[3])
 
+    def decoderPhaseCycles(self):
+        st = (C.c_ulonglong * 8)()
+        native.lib().STTX_GetDecoderPhaseCycles(self._impl, st)
+        return dict(zip(["emissions", "hash", "expand", "lm", "merge", "select", "sort", "write"], [int(x) for x in st]))
+
     def computeMfcc(self, audio_buffer):
         a, p, n = _audio(audio_buffer)
         g = self.geometry()

@@ -1,0 +1,60 @@
+"""The N>1 path on CPU: world_size-2 gloo run of the utterance sharding and the transcript gather (no GPU)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import ROOT
+from stt_amd import dist as sdist
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from stt_amd import dist as sdist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% os.environ["PORT"], rank=int(os.environ["RANK"]), world_size=2)
+rank = dist.get_rank()
+lengths = [16000 * (1 + (7 * i) %% 15) for i in range(23)]
+shards = sdist.shard_utterances(lengths, 2)
+mine = ["utt%%d-len%%d-é" %% (i, lengths[i]) if i %% 5 else "" for i in shards[rank]]
+allr = sdist.gather_transcripts(mine, device=torch.device("cpu"))
+if rank == 0:
+    print(json.dumps({"shards": shards, "all": allr}))
+dist.destroy_process_group()
+'''
+
+
+def test_lpt_sharding_balances_and_covers():
+    rng = np.random.default_rng(2)
+    lengths = rng.integers(16000, 240000, 1000)
+    for w in (1, 2, 4, 8):
+        sh = sdist.shard_utterances(lengths, w)
+        assert sorted(i for s in sh for i in s) == list(range(1000))
+        loads = [int(lengths[s].sum()) for s in sh]
+        assert max(loads) - min(loads) <= lengths.max()
+        for s in sh:
+            assert all(lengths[s[k]] >= lengths[s[k + 1]] for k in range(len(s) - 1))
+
+
+def test_gather_transcripts_two_ranks_gloo(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    import json
+    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    lengths = [16000 * (1 + (7 * i) % 15) for i in range(23)]
+    for rank in range(2):
+        want = ["utt%d-len%d-é" % (i, lengths[i]) if i % 5 else "" for i in res["shards"][rank]]
+        assert res["all"][rank] == want
+
+
+def test_gather_without_process_group_is_identity():
+    assert sdist.gather_transcripts(["a", "b"]) == [["a", "b"]]

@@ -62,9 +62,9 @@ def test_device_math_bit_exact(port):
 @pytest.mark.parametrize("M,N,K,epi", [(37, 128, 64, 1), (300, 256, 512, 0), (129, 128, 2048, 1), (16, 384, 128, 0)])
 def test_dense_kernel(M, N, K, epi):
     rng = np.random.default_rng(M + N + K)
-    x = rng.standard_normal((M, K)).astype(np.float16).astype(np.float32)
-    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float16).astype(np.float32)   # asymmetric on purpose (transpose detecting)
-    w[:, 0] += 0.5; x[0, :] += 0.25
+    x = rng.standard_normal((M, K)); w = rng.standard_normal((K, N)) / np.sqrt(K)
+    w[:, 0] += 0.5; x[0, :] += 0.25                                      # asymmetric on purpose (transpose detecting)
+    x = x.astype(np.float16).astype(np.float32); w = w.astype(np.float16).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
     y = np.zeros((M, N), dtype=np.float32)
     assert native.lib().STTX_TestDense(M, N, K, x.ctypes.data, w.ctypes.data, bias.ctypes.data, 20.0, epi, y.ctypes.data) == 0
