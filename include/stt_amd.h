@@ -53,8 +53,8 @@ STTX_EXPORT int STTX_SetProfiling(ModelState* aCtx, int aEnable);
 STTX_EXPORT int STTX_GetStageTimes(ModelState* aCtx, float* aMs, int aCap);
 /* Decoder counters accumulated over the last batch call: steps, candidates, lm queries, lm memory probes. */
 STTX_EXPORT int STTX_GetDecoderStats(ModelState* aCtx, unsigned long long* aOut4);
-/* Shader cycles spent per decoder phase (summed over streams) in the last batch call: emissions, hash, expand, LM,
- * merge, select, sort, write. */
+/* Shader cycles spent per decoder phase (summed over streams) in the last batch call: emissions + hash, expand
+ * prefix-sum, expand items, LM, merge, select, rank + write, end of step. */
 STTX_EXPORT int STTX_GetDecoderPhaseCycles(ModelState* aCtx, unsigned long long* aOut8);
 
 /* ---- stage-level entry points (host buffers in and out) --------------------------------------- */

@@ -16,6 +16,25 @@
 #define STT_MAX_BEAM 1024
 #define STT_MAX_CLASSES 8192
 
+// KenLM's lm::ngram::State (kenlm/lm/state.hh:15-48) at KENLM_MAX_ORDER = 6
+struct KState { uint32_t words[STT_KENLM_MAX_ORDER - 1]; float backoff[STT_KENLM_MAX_ORDER - 1]; int length; };
+
+// Word-mode scorer cache: one entry per scored word boundary ("prefix X, then a space").  The reference rebuilds the
+// n-gram strings and re-walks the KenLM trie from a null/BOS context for every such event (scorer.cpp:308-396); the
+// score only depends on the last `order` words, so the KenLM state after the word is kept here and the next word's
+// query is a single FullScore from it.  Entry 0 is the root (BeginSentence state).
+struct __attribute__((aligned(16))) BEntry {
+  double raw;         // log_cond_prob + hot_boost of the n-gram ending with this word (before alpha/beta)
+  uint32_t prev;      // entry of the previous word boundary (STT_NONE for the root entry)
+  uint16_t oov_hist;  // bit k: the word k back (bit 0 = this word) is out of vocabulary
+  uint16_t pad;
+  float hot_self;     // hot-word boost of this word (0 if none)
+  KState st;          // state after this word
+};
+#define STT_NONE 0xFFFFFFFFu
+
+struct DevVocabSlot { uint64_t hash; uint32_t index; uint32_t used; };
+
 struct DevBitPacked {
   const uint8_t* base;
   uint64_t word_mask, next_mask;
@@ -30,8 +49,10 @@ struct DevScorer {
   int enabled;
   int order, quant, utf8;
   double alpha, beta;
-  const uint64_t* vocab;
+  const uint64_t* vocab;       // KenLM SortedVocabulary: sorted MurmurHash64A of the words
   uint64_t vocab_n;
+  const DevVocabSlot* vtab;    // open-addressing table over the same hashes (built at load): 1-2 probes instead of log2(n)
+  uint32_t vtab_mask;
   const uint8_t* unigram;
   const float* qprob[STT_KENLM_MAX_ORDER];
   const float* qbackoff[STT_KENLM_MAX_ORDER];
@@ -41,10 +62,10 @@ struct DevScorer {
   uint8_t prob_bits, backoff_bits;
   uint32_t bos_index;
   float bos_backoff;
-  // dictionary FST, repacked: state s -> arcs [state_pos[s], state_pos[s+1]); arc = {ilabel, nextstate}
+  // dictionary FST, repacked: state s -> arcs [state_pos[s], state_pos[s+1]); arc = {ilabel, child state} where
+  // child state = Start() if the arc's target is final (path_trie.cpp:79-87), else the target
   int fst_start;
   const uint32_t* fst_state_pos;
-  const uint8_t* fst_final;
   const uint2* fst_arcs;
   // hot words (murmur hashes of the words)
   int n_hot;
@@ -73,7 +94,10 @@ struct DecStream {
   uint64_t* key;
   uint2* pa;  // {parent, character}; entry 0 = root
   uint2* ta;  // {parent, timestep};  entry 0 = timestep_tree_root_
-  double* pa_lm;  // per path node: cached (log_cond_prob + hot_boost) of "this prefix, then a word boundary" (NaN = not yet computed)
+  uint32_t* bnd;  // beam array: BEntry of the last word boundary at or above the prefix (STT_NONE = unknown -> uncached query)
+  uint32_t* pq;   // per path node: BEntry created by scoring "this prefix, then a word boundary" (STT_NONE = not yet)
+  BEntry* be;     // boundary-entry arena
+  uint32_t be_n, be_cap;
   // per-step candidate workspace [cand_cap]
   float* c_logp;
   uint32_t* c_pi;  // parent beam index | class position << 16 | needs_lm << 31
@@ -107,4 +131,4 @@ void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& 
 void launch_ctc_decode(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const DecStream* streams, int n_streams,
                        const DecodeOut& out, hipStream_t st);
 size_t ctc_next_lds_bytes(int beam, int C);
-void launch_ctc_init(DecStream* streams, int n_streams, int fst_start, hipStream_t st);
+void launch_ctc_init(DecStream* streams, int n_streams, const DevScorer* scorer_or_null, hipStream_t st);

@@ -6,13 +6,16 @@
 // lm/quantize.hh:152-209) plus OpenFst's SortedMatcher::Find on the dictionary (matcher.h:347-386).
 //
 // One 1024-thread workgroup per stream walks the timesteps of its chunk; a timestep is
-//   P0  class log-probs (glibc-exact logf), optional class sort/cut-off        get_pruned_emissions :328-358
-//   P1  LDS hash of the live prefixes' path keys
-//   P2  expand: blank / repeat / extend events per live prefix (FST arc scan)   :150-207, path_trie.cpp:37-100
-//   P3  language-model scores of boundary extensions (trie walk in HBM)        :209-243, scorer.cpp:308-396
+//   A/B class log-probs (glibc-exact logf), optional class sort/cut-off        get_pruned_emissions :328-358
+//       LDS hash of the live prefixes' path keys
+//   P2  expand: blank / repeat events per live prefix, then one work item per (prefix, FST out-arc) found through a
+//       workgroup prefix sum                                                    :150-207, path_trie.cpp:37-100
+//   P3  language-model scores of boundary extensions (trie walk in HBM); in word mode one KenLM FullScore from the
+//       cached state of the previous word boundary                            :209-243, scorer.cpp:308-396
 //   P4  merge the <=3 events of every live prefix in the reference's visiting order :166-193,245-253
-//   P5  scores (iterate_to_vec), radix-select the top beam_size, bitonic sort   path_trie.cpp:159-190, :263-274
-//   P6  write the new beam, append arena nodes
+//   P5  scores (iterate_to_vec); bucket histogram + prefix sum finds the beam_size-th key, kept keys are ranked inside
+//       their bucket segment (rank == position in the new beam)               path_trie.cpp:159-190, :263-274
+//   P6  (fused with the ranking) write the new beam, append arena nodes
 // Float arithmetic uses sttmath.h (bit-exact glibc expf/logf), so scores are bit-identical to the
 // reference; ties the reference leaves to libstdc++ are broken by (live-before-new, beam index).
 #include <hip/hip_runtime.h>
@@ -49,7 +52,6 @@ __device__ __forceinline__ uint64_t sel_key(float score, uint32_t ch, uint32_t i
 }
 
 // ------------------------------------------------------------------------------------ KenLM trie query
-struct KState { uint32_t words[STT_KENLM_MAX_ORDER - 1]; float backoff[STT_KENLM_MAX_ORDER - 1]; int length; };
 struct KNode { uint64_t begin, end; };
 
 __device__ __forceinline__ uint64_t read_int57(const uint8_t* base, uint64_t bit_off, uint64_t mask) {
@@ -57,15 +59,17 @@ __device__ __forceinline__ uint64_t read_int57(const uint8_t* base, uint64_t bit
 }
 __device__ __forceinline__ bool has_extension(float backoff) { return __float_as_uint(backoff) != 0x80000000u; }
 
-__device__ uint32_t vocab_index(const DevScorer& s, uint64_t h, unsigned& probes) {
-  uint64_t lo = 0, hi = s.vocab_n;
-  while (lo < hi) {
-    const uint64_t mid = lo + (hi - lo) / 2;
-    const uint64_t v = s.vocab[mid];
+// SortedVocabulary::Index (kenlm/lm/vocab.hh:72-83): position of the hash in the sorted array + 1, 0 = <unk>.  The
+// open-addressing table built at load time (scorer_dev.cpp) answers the same question in 1-2 probes.
+__device__ __forceinline__ uint32_t vocab_index(const DevScorer& s, uint64_t h, unsigned& probes) {
+  uint32_t slot = (uint32_t)h & s.vtab_mask;
+  for (;;) {
+    const DevVocabSlot e = s.vtab[slot];
     ++probes;
-    if (v < h) lo = mid + 1; else if (v > h) hi = mid; else return (uint32_t)(mid + 1);
+    if (!e.used) return 0;
+    if (e.hash == h) return e.index;
+    slot = (slot + 1) & s.vtab_mask;
   }
-  return 0;
 }
 __device__ bool find_bitpacked(const DevBitPacked& bp, uint64_t begin, uint64_t end, uint64_t key, uint64_t& at, unsigned& probes) {
   while (begin < end) {
@@ -280,41 +284,97 @@ __device__ bool is_scoring_boundary(const DevScorer& s, const DevAlphabet& al, c
   return dist == needed;
 }
 
+// ------------------------------------------------------------------------------------ word-mode scorer cache
+// Score "prefix X, then a word boundary" for a live word-mode prefix X whose last label is neither space nor root,
+// given the cached KenLM state of the previous boundary (entry e_prev).  Equivalent to lm_score(): the reference scores
+// the last `order` words from a null context (or all words from BeginSentence when there are fewer), and a KenLM state
+// holds at most order-1 words, so the state carried from the previous boundary is the state the reference rebuilds.
+// Appends a BEntry and records it in S.pq[node]; returns log_cond_prob + hot_boost.
+__device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al, DecStream& S, uint32_t node, uint32_t e_prev, unsigned& probes) {
+  uint32_t labs[MAX_UNIT_LABELS];
+  int nl = 0;
+  for (uint32_t cur = node; cur != STT_ROOT_CH;) {
+    const uint2 pn = S.pa[cur];
+    ++probes;
+    if (pn.y == (uint32_t)al.space_id || pn.y == STT_ROOT_CH) break;
+    if (nl < MAX_UNIT_LABELS) labs[nl++] = pn.y;
+    cur = pn.x;
+  }
+  const uint64_t h = hash_labels_reversed(al, labs, nl);
+  const uint32_t wi = vocab_index(s, h, probes);
+  const BEntry ep = S.be[e_prev];
+  ++probes;
+  BEntry en;
+  const float prob = kenlm_full_score(s, ep.st, wi, en.st, probes);
+  en.oov_hist = (uint16_t)((ep.oov_hist << 1) | (wi == 0 ? 1u : 0u));
+  const bool oov = (en.oov_hist & ((1u << s.order) - 1u)) != 0;  // this word + the order-1 before it
+  float hot_self = 0.0f, hot_total = 0.0f;
+  if (s.n_hot) {
+    for (int j = 0; j < s.n_hot; ++j)
+      if (h == s.hot_hash[j]) hot_self = __fadd_rn(hot_self, s.hot_boost[j]);
+    float hs[STT_KENLM_MAX_ORDER];
+    int k = 0;
+    uint32_t e = e_prev;
+    BEntry cur = ep;
+    while (k < s.order - 1 && e != 0 && e != STT_NONE) {  // entry 0 = root: no word
+      hs[k++] = cur.hot_self;
+      e = cur.prev;
+      if (e != 0 && e != STT_NONE) { cur = S.be[e]; ++probes; }
+    }
+    for (int i = k - 1; i >= 0; --i) hot_total = __fadd_rn(hot_total, hs[i]);  // oldest word first, like the reference's loop
+    hot_total = __fadd_rn(hot_total, hot_self);
+  }
+  const double lcp = oov ? OOV_SCORE_D : __ddiv_rn((double)prob, (double)0.4342944819f);
+  en.raw = __dadd_rn(lcp, (double)hot_total);
+  en.prev = e_prev; en.pad = 0; en.hot_self = hot_self;
+  const uint32_t idx = atomicAdd(&S.be_n, 1u);
+  if (idx < S.be_cap) { S.be[idx] = en; S.pq[node] = idx; }
+  return en.raw;
+}
+
 // ------------------------------------------------------------------------------------ LDS layout
+#define NWAVES (NTHREADS / 64)
+#define NBUCKET 1024   // selection histogram bins (one per thread)
+#define RCAP 128       // a threshold bucket with more members than this is subdivided instead of ranked pairwise
+#define HTN 2048       // LDS hash slots (>= 2 * STT_MAX_BEAM); the same storage later holds up to HTN selection keys
+
 struct Lds {
   float *score[2], *pb[2], *pnb[2];
-  uint32_t *ch[2], *node[2], *ts[2];
+  uint32_t *ch[2], *node[2], *ts[2], *bnd[2];
   int* fst[2];
   uint64_t* key[2];
   float *ev_self, *ev_blank, *ev_ext;  // reused as new pnb / new pb / new score in P4
   uint32_t* ev_exti;                   // parent beam index | needs_lm << 31 ; reused as pending timestep parent
-  uint64_t* ht_key; uint16_t* ht_idx; uint32_t ht_mask;
+  uint32_t *off, *a0;                  // expand work list: first item of prefix i, first FST arc of prefix i
+  uint64_t* ht_key; uint16_t* ht_idx;  // ht_key doubles as the selection-key buffer (kbuf) after P2
   float *pf, *lp; uint16_t *cls, *pos;
-  uint32_t* hist;
-  uint64_t* skey; uint32_t* ssrc;
+  uint32_t *hist, *cumb;
+  uint64_t* skey; uint32_t *ssrc, *sseg;
+  uint32_t* wtot;
   int* sc;  // scalars
 };
 #define TICK(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); S.phase[k] += now_ - tick_; tick_ = now_; } } while (0)
-enum { SC_M = 0, SC_CUTLEN, SC_FULL, SC_KEEP, SC_START, SC_DIGIT, SC_NEED, SC_SKIP, SC_LMQ, SC_PROBES, SC_ERR, SC_MINCUT, SC_COUNT = 16 };
+enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_COUNT = 16 };
 
 __host__ __device__ inline uint32_t pow2_ge(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
 __host__ __device__ inline size_t lds_carve(int beam, int C, Lds* l, unsigned char* base) {
   const uint32_t cap = (uint32_t)((beam + 63) & ~63);
-  const uint32_t sortn = pow2_ge((uint32_t)beam);
-  const uint32_t htn = 2 * pow2_ge(cap);
+  const uint32_t sn = cap + RCAP;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
   size_t offs[64]; int k = 0;
   for (int d = 0; d < 2; ++d) {
     offs[k++] = take(cap * 8);                                     // key
-    for (int a = 0; a < 7; ++a) offs[k++] = take(cap * 4);         // score pb pnb ch node ts fst
+    for (int a = 0; a < 8; ++a) offs[k++] = take(cap * 4);         // score pb pnb ch node ts fst bnd
   }
   for (int a = 0; a < 4; ++a) offs[k++] = take(cap * 4);           // events
-  offs[k++] = take(htn * 8); offs[k++] = take(htn * 2);            // hash
+  offs[k++] = take((cap + 1) * 4); offs[k++] = take(cap * 4);      // off, a0
+  offs[k++] = take(HTN * 8); offs[k++] = take(HTN * 2);            // hash / kbuf
   offs[k++] = take((size_t)C * 4); offs[k++] = take((size_t)C * 4); offs[k++] = take((size_t)C * 2); offs[k++] = take((size_t)C * 2);
-  offs[k++] = take(256 * 4);
-  offs[k++] = take(sortn * 8); offs[k++] = take(sortn * 4);
+  offs[k++] = take(NBUCKET * 4); offs[k++] = take((NBUCKET + 1) * 4);
+  offs[k++] = take(sn * 8); offs[k++] = take(sn * 4); offs[k++] = take(sn * 4);
+  offs[k++] = take(64 * 4);
   offs[k++] = take(SC_COUNT * 4);
   if (l) {
     k = 0;
@@ -322,14 +382,16 @@ __host__ __device__ inline size_t lds_carve(int beam, int C, Lds* l, unsigned ch
       l->key[d] = (uint64_t*)(base + offs[k++]);
       l->score[d] = (float*)(base + offs[k++]); l->pb[d] = (float*)(base + offs[k++]); l->pnb[d] = (float*)(base + offs[k++]);
       l->ch[d] = (uint32_t*)(base + offs[k++]); l->node[d] = (uint32_t*)(base + offs[k++]); l->ts[d] = (uint32_t*)(base + offs[k++]);
-      l->fst[d] = (int*)(base + offs[k++]);
+      l->fst[d] = (int*)(base + offs[k++]); l->bnd[d] = (uint32_t*)(base + offs[k++]);
     }
     l->ev_self = (float*)(base + offs[k++]); l->ev_blank = (float*)(base + offs[k++]); l->ev_ext = (float*)(base + offs[k++]);
     l->ev_exti = (uint32_t*)(base + offs[k++]);
-    l->ht_key = (uint64_t*)(base + offs[k++]); l->ht_idx = (uint16_t*)(base + offs[k++]); l->ht_mask = htn - 1;
+    l->off = (uint32_t*)(base + offs[k++]); l->a0 = (uint32_t*)(base + offs[k++]);
+    l->ht_key = (uint64_t*)(base + offs[k++]); l->ht_idx = (uint16_t*)(base + offs[k++]);
     l->pf = (float*)(base + offs[k++]); l->lp = (float*)(base + offs[k++]); l->cls = (uint16_t*)(base + offs[k++]); l->pos = (uint16_t*)(base + offs[k++]);
-    l->hist = (uint32_t*)(base + offs[k++]);
-    l->skey = (uint64_t*)(base + offs[k++]); l->ssrc = (uint32_t*)(base + offs[k++]);
+    l->hist = (uint32_t*)(base + offs[k++]); l->cumb = (uint32_t*)(base + offs[k++]);
+    l->skey = (uint64_t*)(base + offs[k++]); l->ssrc = (uint32_t*)(base + offs[k++]); l->sseg = (uint32_t*)(base + offs[k++]);
+    l->wtot = (uint32_t*)(base + offs[k++]);
     l->sc = (int*)(base + offs[k++]);
   }
   return o;
@@ -337,12 +399,12 @@ __host__ __device__ inline size_t lds_carve(int beam, int C, Lds* l, unsigned ch
 size_t ctc_next_lds_bytes(int beam, int C) { return lds_carve(beam, C, nullptr, nullptr); }
 
 __device__ __forceinline__ int ht_find(const Lds& L, uint64_t k) {
-  uint32_t h = (uint32_t)(k >> 17) & L.ht_mask;
+  uint32_t h = (uint32_t)(k >> 17) & (HTN - 1);
   for (;;) {
     const uint64_t v = L.ht_key[h];
     if (v == k) return (int)L.ht_idx[h];
     if (v == 0) return -1;
-    h = (h + 1) & L.ht_mask;
+    h = (h + 1) & (HTN - 1);
   }
 }
 
@@ -363,161 +425,211 @@ __device__ void bitonic_sort(uint64_t* key, uint32_t* src, uint32_t n) {
   }
 }
 
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) v += t; }
+  return v;
+}
+// Exclusive prefix sum of one value per thread over the workgroup (contains one __syncthreads; the caller separates
+// two calls by another barrier because `wtot` is reused).
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wtot, uint32_t& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t inc = wave_incl_scan(v, lane);
+  if (lane == 63) wtot[w] = inc;
+  __syncthreads();
+  const uint32_t t = lane < NWAVES ? wtot[lane] : 0u;
+  const uint32_t tinc = wave_incl_scan(t, lane);
+  const uint32_t wbase = __shfl(tinc, w > 0 ? w - 1 : 0);
+  total = __shfl(tinc, NWAVES - 1);
+  return (w > 0 ? wbase : 0u) + inc - v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { const uint32_t t = __shfl_xor(v, d); v = t < v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { const uint32_t t = __shfl_xor(v, d); v = t > v ? t : v; }
+  return v;
+}
+
 // ------------------------------------------------------------------------------------ one timestep
 __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphabet& al, DecStream& S, const Lds& L, int& cur, int& n,
-                         const float* prob_row) {
+                         int& start_expanding, const float* prob_row) {
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const int C = p.C, beam = p.beam;
   int* sc = L.sc;
   const float NEG = STT_NEG_INF;
 
   unsigned long long tick_ = __builtin_readcyclecounter();
-  // ---- P0: emissions
+  // ---- A: emissions to LDS; clear the hash, the per-prefix events and the selection histogram
   for (int c = tid; c < C; c += NTHREADS) L.pf[c] = prob_row[c];
-  if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; }
+  for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
+  for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
+  L.hist[tid] = 0;
+  if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; }
   __syncthreads();
-  if (tid == 0) {
-    if ((double)L.pf[p.blank] < 0.999) S.start_expanding = 1;
-    sc[SC_START] = S.start_expanding;
-  }
-  __syncthreads();
-  if (!sc[SC_START]) { if (tid == 0) S.abs_t++; __syncthreads(); return; }
+  if ((double)L.pf[p.blank] < 0.999) start_expanding = 1;  // :125-132 (uniform: every thread reads the same value)
+  if (!start_expanding) { if (tid == 0) S.abs_t++; __syncthreads(); return; }
 
+  // ---- B: class log-probs (get_pruned_emissions, :328-358) and the LDS hash of the live prefixes
   const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
+  int cutoff_len = C;
   if (sort_classes) {  // std::sort by probability, descending (ties: class index)
     for (int c = tid; c < C; c += NTHREADS) {
       const float v = L.pf[c];
       int rank = 0;
       for (int o = 0; o < C; ++o) { const float w = L.pf[o]; rank += (w > v) || (w == v && o < c); }
       L.cls[rank] = (uint16_t)c;
+      L.pos[c] = 0xFFFF;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int cl = C;
+      if (p.cutoff_prob < 1.0) {
+        double cum = 0.0; cl = 0;
+        for (int i = 0; i < C; ++i) { cum = __dadd_rn(cum, (double)L.pf[L.cls[i]]); cl += 1; if (cum >= p.cutoff_prob || cl >= p.cutoff_top_n) break; }
+      }
+      sc[SC_CUTLEN] = cl;
+    }
+    __syncthreads();
+    cutoff_len = sc[SC_CUTLEN];
+    for (int k = tid; k < cutoff_len; k += NTHREADS) {
+      const int c = L.cls[k];
+      L.pos[c] = (uint16_t)k;
+      L.lp[k] = stt_logf(__fadd_rn(L.pf[c], STT_FLT_MIN));  // log(prob + NUM_FLT_MIN), :355
     }
   } else {
-    for (int c = tid; c < C; c += NTHREADS) L.cls[c] = (uint16_t)c;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int cutoff_len = C;
-    if (sort_classes && p.cutoff_prob < 1.0) {
-      double cum = 0.0; cutoff_len = 0;
-      for (int i = 0; i < C; ++i) { cum = __dadd_rn(cum, (double)L.pf[L.cls[i]]); cutoff_len += 1; if (cum >= p.cutoff_prob || cutoff_len >= p.cutoff_top_n) break; }
+    for (int c = tid; c < C; c += NTHREADS) {
+      L.cls[c] = (uint16_t)c; L.pos[c] = (uint16_t)c;
+      L.lp[c] = stt_logf(__fadd_rn(L.pf[c], STT_FLT_MIN));
     }
-    sc[SC_CUTLEN] = cutoff_len;
-    float min_cutoff = NEG; int full = 0;
-    if (s.enabled) {  // :136-146 (the beam is kept in prefix_compare order, so no partial_sort is needed)
-      const double mc = __dadd_rn(__dadd_rn((double)L.score[cur][n - 1], log((double)L.pf[p.blank])), -fmax(0.0, s.beta));
-      min_cutoff = (float)mc;
-      full = (n == beam);
-    }
-    sc[SC_FULL] = full;
-    ((float*)sc)[SC_MINCUT] = min_cutoff;
   }
-  for (int c = tid; c < C; c += NTHREADS) L.pos[c] = 0xFFFF;
-  __syncthreads();
-  const int cutoff_len = sc[SC_CUTLEN];
-  const bool full_beam = sc[SC_FULL] != 0;
-  const float min_cutoff = ((float*)sc)[SC_MINCUT];
-  for (int k = tid; k < cutoff_len; k += NTHREADS) {
-    const int c = L.cls[k];
-    L.pos[c] = (uint16_t)k;
-    L.lp[k] = stt_logf(__fadd_rn(L.pf[c], STT_FLT_MIN));  // log(prob + NUM_FLT_MIN), :355
+  float min_cutoff = NEG;
+  bool full_beam = false;
+  if (s.enabled) {  // :136-146 (the beam is kept in prefix_compare order, so no partial_sort is needed)
+    const double mc = __dadd_rn(__dadd_rn((double)L.score[cur][n - 1], log((double)L.pf[p.blank])), -fmax(0.0, s.beta));
+    min_cutoff = (float)mc;
+    full_beam = (n == beam);
   }
-  TICK(0);
-  // ---- P1: hash of live keys, clear events
-  for (uint32_t h = tid; h <= L.ht_mask; h += NTHREADS) L.ht_key[h] = 0;
-  for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
-  __syncthreads();
   for (int i = tid; i < n; i += NTHREADS) {
     const uint64_t k = L.key[cur][i];
-    uint32_t h = (uint32_t)(k >> 17) & L.ht_mask;
+    uint32_t h = (uint32_t)(k >> 17) & (HTN - 1);
     for (;;) {
       const unsigned long long old = atomicCAS((unsigned long long*)&L.ht_key[h], 0ULL, (unsigned long long)k);
       if (old == 0ULL) { L.ht_idx[h] = (uint16_t)i; break; }
-      h = (h + 1) & L.ht_mask;
+      h = (h + 1) & (HTN - 1);
     }
   }
   __syncthreads();
+  TICK(0);
 
-  TICK(1);
-  // ---- P2: expand every live prefix
+  // ---- P2: expand.  Blank / repeat events per live prefix, then one work item per (prefix, candidate label): with a
+  // dictionary only the out-arcs of the prefix's FST state can succeed (path_trie.cpp:54-64), otherwise every kept class.
   unsigned probes = 0;
-  for (int i = tid; i < n; i += NTHREADS) {
+  uint32_t cnt = 0;
+  if (tid < n) {
+    const int i = tid;
     const float sci = L.score[cur][i];
-    if (sci == NEG) continue;  // :160-162
-    const uint32_t chi = L.ch[cur][i];
-    const uint64_t keyi = L.key[cur][i];
-    {  // blank, :166-179
-      const int kb = L.pos[p.blank];
-      if (kb != 0xFFFF) { const float lpc = L.lp[kb]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_blank[i] = __fadd_rn(lpc, sci); }
-    }
-    if (chi != STT_ROOT_CH) {  // repeated character, :182-193
-      const int ks = L.pos[chi];
-      if (ks != 0xFFFF) { const float lpc = L.lp[ks]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_self[i] = __fadd_rn(lpc, L.pnb[cur][i]); }
-    }
-    // extensions: with a dictionary only the out-arcs of the prefix's FST state can succeed (path_trie.cpp:54-64)
-    uint32_t a0 = 0, a1 = (uint32_t)(C - 1);
-    if (s.enabled) { const int st = L.fst[cur][i]; a0 = s.fst_state_pos[st]; a1 = s.fst_state_pos[st + 1]; }
-    for (uint32_t a = a0; a < a1; ++a) {
-      uint32_t c; int child_fst = 0;
-      if (s.enabled) {
-        const uint2 arc = s.fst_arcs[a];
-        if (arc.x == 0 || arc.x > (uint32_t)(C - 1)) continue;  // epsilon / label outside the alphabet: never matched
-        c = arc.x - 1;
-        child_fst = s.fst_final[arc.y] ? s.fst_start : (int)arc.y;  // path_trie.cpp:79-87
-      } else {
-        c = a;
+    if (sci != NEG) {  // :160-162
+      const uint32_t chi = L.ch[cur][i];
+      {  // blank, :166-179
+        const int kb = L.pos[p.blank];
+        if (kb != 0xFFFF) { const float lpc = L.lp[kb]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_blank[i] = __fadd_rn(lpc, sci); }
       }
-      if ((int)c == p.blank) continue;
-      const int k = L.pos[c];
-      if (k == 0xFFFF) continue;
-      const float lpc = L.lp[k];
-      if (full_beam && __fadd_rn(lpc, sci) < min_cutoff) continue;  // the `break` of :157-159 (beam is sorted by score)
-      float log_p = NEG;  // :199-207
-      if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
-      else log_p = __fadd_rn(lpc, sci);
-      uint32_t needs_lm = 0;
-      if (s.enabled) needs_lm = s.utf8 ? (is_scoring_boundary(s, al, S.pa, L.node[cur][i], c, c, probes) ? 1u : 0u) : ((int)c == al.space_id ? 1u : 0u);
-      const uint64_t ck = child_key(keyi, c);
-      const int j = ht_find(L, ck);
-      if (j >= 0) {  // the child is a live prefix: one extension event per live prefix per step
-        L.ev_ext[j] = log_p;
-        L.ev_exti[j] = (uint32_t)i | (needs_lm << 31) ;
+      if (chi != STT_ROOT_CH) {  // repeated character, :182-193
+        const int ks = L.pos[chi];
+        if (ks != 0xFFFF) { const float lpc = L.lp[ks]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_self[i] = __fadd_rn(lpc, L.pnb[cur][i]); }
+      }
+      if (s.enabled) {
+        const int st = L.fst[cur][i];
+        const uint32_t a0 = s.fst_state_pos[st];
+        cnt = s.fst_state_pos[st + 1] - a0;
+        L.a0[i] = a0;
       } else {
-        const int slot = atomicAdd(&sc[SC_M], 1);
-        if ((uint32_t)slot < S.cand_cap) {
-          S.c_logp[slot] = log_p;
-          S.c_pi[slot] = (uint32_t)i | ((uint32_t)k << 16) | (needs_lm << 31);
-          S.c_fst[slot] = child_fst;
-          S.c_key[slot] = ck;
-        }
+        cnt = (uint32_t)cutoff_len;
+      }
+    }
+  }
+  uint32_t n_items;
+  const uint32_t excl = block_excl_scan(cnt, L.wtot, n_items);
+  if (tid < n) L.off[tid] = excl;
+  if (tid == 0) L.off[n] = n_items;
+  __syncthreads();
+  TICK(1);
+  for (uint32_t x = tid; x < n_items; x += NTHREADS) {
+    int lo = 0, hi = n - 1;  // largest i with off[i] <= x
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L.off[mid] <= x) lo = mid; else hi = mid - 1; }
+    const int i = lo;
+    const uint32_t kk = x - L.off[i];
+    uint32_t c; int k; int child_fst = 0;
+    if (s.enabled) {
+      const uint2 arc = s.fst_arcs[L.a0[i] + kk];
+      if (arc.x == 0 || arc.x > (uint32_t)(C - 1)) continue;  // epsilon / label outside the alphabet: never matched
+      c = arc.x - 1;
+      child_fst = (int)arc.y;
+      k = L.pos[c];
+      if (k == 0xFFFF) continue;
+    } else {
+      k = (int)kk;
+      c = L.cls[k];
+    }
+    if ((int)c == p.blank) continue;
+    const float sci = L.score[cur][i];
+    const uint32_t chi = L.ch[cur][i];
+    const float lpc = L.lp[k];
+    if (full_beam && __fadd_rn(lpc, sci) < min_cutoff) continue;  // the `break` of :157-159 (beam is sorted by score)
+    float log_p = NEG;  // :199-207
+    if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
+    else log_p = __fadd_rn(lpc, sci);
+    uint32_t needs_lm = 0;
+    if (s.enabled) needs_lm = s.utf8 ? (is_scoring_boundary(s, al, S.pa, L.node[cur][i], c, c, probes) ? 1u : 0u) : ((int)c == al.space_id ? 1u : 0u);
+    const uint64_t ck = child_key(L.key[cur][i], c);
+    const int j = ht_find(L, ck);
+    if (j >= 0) {  // the child is a live prefix: one extension event per live prefix per step
+      L.ev_ext[j] = log_p;
+      L.ev_exti[j] = (uint32_t)i | (needs_lm << 31);
+    } else {
+      const int slot = atomicAdd(&sc[SC_M], 1);
+      if ((uint32_t)slot < S.cand_cap) {
+        S.c_logp[slot] = log_p;
+        S.c_pi[slot] = (uint32_t)i | ((uint32_t)k << 16) | (needs_lm << 31);
+        S.c_fst[slot] = child_fst;
+        S.c_key[slot] = ck;
       }
     }
   }
   __syncthreads();
   int m = sc[SC_M];
   if ((uint32_t)m > S.cand_cap) { m = (int)S.cand_cap; if (tid == 0) sc[SC_ERR] |= 4; }
-
   TICK(2);
+
   // ---- P3: language model on scoring boundaries (:209-243)
   if (s.enabled) {
     unsigned lmq = 0;
     for (int x = tid; x < m + n; x += NTHREADS) {
       uint32_t pi; float lp0;
-      if (x < m) { pi = S.c_pi[x]; lp0 = S.c_logp[x]; }
-      else { const int j = x - m; if (is_absent(L.ev_ext[j])) continue; pi = L.ev_exti[j]; lp0 = L.ev_ext[j]; }
-      if (!(pi >> 31)) continue;
+      if (x < m) { pi = S.c_pi[x]; if (!(pi >> 31)) continue; lp0 = S.c_logp[x]; }
+      else { const int j = x - m; pi = L.ev_exti[j]; if (!(pi >> 31) || is_absent(L.ev_ext[j])) continue; lp0 = L.ev_ext[j]; }
       const int i = (int)(pi & 0xFFFFu);
-      uint32_t first = STT_ROOT_CH;
-      if (s.utf8) first = (x < m) ? (uint32_t)L.cls[(pi >> 16) & 0x7FFFu] : L.ch[cur][x - m];  // score the *new* prefix
-      // The boundary score of a word-mode prefix depends only on the prefix (its path node): compute it once per node and
-      // keep it in the arena; later timesteps that retry "prefix + space" reuse it (the reference recomputes it every time).
       const uint32_t nodei = L.node[cur][i];
       double raw;
       if (!s.utf8) {
-        raw = S.pa_lm[nodei];
-        if (raw != raw) { raw = lm_score(s, al, S.pa, nodei, first, true, probes); S.pa_lm[nodei] = raw; ++lmq; }
+        // word mode scores the prefix *before* the space (:211-216); the score depends only on that prefix, so it is
+        // computed once per path node and kept (BEntry); later timesteps that retry "prefix + space" reuse it.
+        const uint32_t chi = L.ch[cur][i], bndi = L.bnd[cur][i];
+        if (bndi != STT_NONE && chi != STT_ROOT_CH && (int)chi != al.space_id) {
+          const uint32_t e = S.pq[nodei];
+          if (e != STT_NONE) raw = S.be[e].raw;
+          else { raw = lm_word_query_cached(s, al, S, nodei, bndi, probes); ++lmq; }
+        } else {
+          raw = lm_score(s, al, S.pa, nodei, STT_ROOT_CH, true, probes); ++lmq;
+        }
       } else {
-        raw = lm_score(s, al, S.pa, nodei, first, true, probes);
-        ++lmq;
+        const uint32_t first = (x < m) ? (uint32_t)L.cls[(pi >> 16) & 0x7FFFu] : L.ch[cur][x - m];  // score the *new* prefix
+        raw = lm_score(s, al, S.pa, nodei, first, true, probes); ++lmq;
       }
       const float lms = (float)__dmul_rn(raw, s.alpha);
       float lpv = __fadd_rn(lp0, lms);                       // log_p += score;
@@ -528,9 +640,13 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   }
   if (probes) atomicAdd(&sc[SC_PROBES], (int)probes);
   __syncthreads();
-
   TICK(3);
-  // ---- P4: merge events of live prefixes in the reference's visiting order (class position, then beam index)
+
+  // ---- P4: merge events of live prefixes in the reference's visiting order (class position, then beam index);
+  // selection keys of live prefixes and candidates
+  const int total = n + m;
+  uint64_t* keys = (total <= HTN) ? L.ht_key : S.sel_keys;  // the hash is dead from here on
+  uint32_t hmin = 0xFFFFFFFFu, hmax = 0;
   for (int j = tid; j < n; j += NTHREADS) {
     const float e_self = L.ev_self[j], e_blank = L.ev_blank[j], e_ext = L.ev_ext[j];
     const uint32_t ei = L.ev_exti[j] & 0x7FFFFFFFu;
@@ -548,87 +664,124 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
     if (!blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
     const float nscore = stt_log_sum_exp(bb, nb);  // iterate_to_vec, path_trie.cpp:170
     L.ev_blank[j] = bb; L.ev_self[j] = nb; L.ev_ext[j] = nscore; L.ev_exti[j] = pend;
-    S.sel_keys[j] = sel_key(nscore, chj, 0, (uint32_t)j);
+    const uint64_t k = sel_key(nscore, chj, 0, (uint32_t)j);
+    keys[j] = k;
+    const uint32_t kh = (uint32_t)(k >> 32);
+    hmin = kh < hmin ? kh : hmin; hmax = kh > hmax ? kh : hmax;
   }
   for (int x = tid; x < m; x += NTHREADS) {
     const uint32_t pi = S.c_pi[x];
-    S.sel_keys[n + x] = sel_key(S.c_logp[x], (uint32_t)L.cls[(pi >> 16) & 0x7FFFu], 1, pi & 0xFFFFu);
+    const uint64_t k = sel_key(S.c_logp[x], (uint32_t)L.cls[(pi >> 16) & 0x7FFFu], 1, pi & 0xFFFFu);
+    keys[n + x] = k;
+    const uint32_t kh = (uint32_t)(k >> 32);
+    hmin = kh < hmin ? kh : hmin; hmax = kh > hmax ? kh : hmax;
   }
+  hmin = wave_min_u32(hmin); hmax = wave_max_u32(hmax);
+  if (lane == 0) { atomicMin((unsigned int*)&sc[SC_KMIN], hmin); atomicMax((unsigned int*)&sc[SC_KMAX], hmax); }
   __syncthreads();
-
   TICK(4);
-  // ---- P5: keep the best beam_size (nth_element + resize, :263-274), fully sorted
-  const int total = n + m;
-  const int keep = total < beam ? total : beam;
-  const uint32_t sortn = pow2_ge((uint32_t)(keep > 0 ? keep : 1));
-  uint64_t threshold = ~0ULL;
-  if (total > beam) {
-    uint64_t prefix = 0, mask = 0;
-    if (tid == 0) sc[SC_NEED] = keep;
-    for (int pass = 0; pass < 8; ++pass) {
-      const int shift = 56 - 8 * pass;
-      for (int d = tid; d < 256; d += NTHREADS) L.hist[d] = 0;
-      __syncthreads();
-      for (int x = tid; x < total; x += NTHREADS) {
-        const uint64_t k = S.sel_keys[x];
-        if ((k & mask) == prefix) atomicAdd(&L.hist[(k >> shift) & 255], 1u);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int need = sc[SC_NEED];
-        uint32_t cum = 0; int d = 0;
-        for (; d < 256; ++d) { if (cum + L.hist[d] >= (uint32_t)need) break; cum += L.hist[d]; }
-        sc[SC_DIGIT] = d; sc[SC_NEED] = need - (int)cum;
-      }
-      __syncthreads();
-      prefix |= (uint64_t)sc[SC_DIGIT] << shift;
-      mask |= 0xFFULL << shift;
-    }
-    threshold = prefix;  // keys are unique, so exactly `keep` keys are <= threshold
-  }
-  if (tid == 0) sc[SC_KEEP] = 0;
-  for (uint32_t x = tid; x < sortn; x += NTHREADS) { L.skey[x] = ~0ULL; L.ssrc[x] = 0; }
-  __syncthreads();
-  for (int x = tid; x < total; x += NTHREADS) {
-    const uint64_t k = S.sel_keys[x];
-    if (k <= threshold) { const int r = atomicAdd(&sc[SC_KEEP], 1); if (r < (int)sortn) { L.skey[r] = k; L.ssrc[r] = (uint32_t)x; } }
-  }
-  __syncthreads();
-  TICK(5);
-  bitonic_sort(L.skey, L.ssrc, sortn);
-  TICK(6);
 
-  // ---- P6: new beam
+  // ---- P5: keep the best beam_size (nth_element + resize, :263-274) in sorted order.  Keys are unique, so the rank of
+  // a key is its position in the new beam.  Bucket the keys over their live range (NBUCKET bins of 2^sh), prefix-sum the
+  // histogram, and find the bucket that holds the keep-th key.  Whole buckets below it are kept; every kept key is
+  // scattered to its bucket's segment and ranked inside the segment by pairwise comparison.  A threshold bucket with
+  // more than RCAP members is subdivided (next level) instead.
+  const int keep = total < beam ? total : beam;
   const int nxt = cur ^ 1;
-  for (int r = tid; r < keep; r += NTHREADS) {
-    const uint32_t x = L.ssrc[r];
-    uint32_t ts_new, pend;
-    if ((int)x < n) {
-      L.score[nxt][r] = L.ev_ext[x]; L.pb[nxt][r] = L.ev_blank[x]; L.pnb[nxt][r] = L.ev_self[x];
-      L.ch[nxt][r] = L.ch[cur][x]; L.node[nxt][r] = L.node[cur][x]; L.fst[nxt][r] = L.fst[cur][x]; L.key[nxt][r] = L.key[cur][x];
-      pend = L.ev_exti[x]; ts_new = L.ts[cur][x];
-    } else {
-      const int cx = (int)x - n;
-      const uint32_t pi = S.c_pi[cx];
-      const int i = (int)(pi & 0xFFFFu);
-      const uint32_t c = (uint32_t)L.cls[(pi >> 16) & 0x7FFFu];
-      const float lpv = S.c_logp[cx];
-      L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
-      L.ch[nxt][r] = c; L.fst[nxt][r] = S.c_fst[cx]; L.key[nxt][r] = S.c_key[cx];
-      const uint32_t slot = atomicAdd(&S.pa_n, 1u);
-      if (slot < S.pa_cap) { S.pa[slot] = make_uint2(L.node[cur][i], c); S.pa_lm[slot] = __longlong_as_double(0x7ff8000000000000LL); L.node[nxt][r] = slot; }
-      else { L.node[nxt][r] = 0; atomicOr(&sc[SC_ERR], 1); }
-      pend = (NEG < lpv) ? L.ts[cur][i] : 0xFFFFFFFEu;  // :246-251 with log_prob_nb_cur == -inf
-      ts_new = STT_ROOT_CH;                              // timesteps == nullptr
+  {
+    uint64_t base = (uint64_t)(uint32_t)sc[SC_KMIN] << 32;
+    const uint64_t range = ((uint64_t)((uint32_t)sc[SC_KMAX] - (uint32_t)sc[SC_KMIN]) << 32) | 0xFFFFFFFFull;
+    int sh = 64 - __clzll((long long)range) - 10;  // range < 2^(sh+10)
+    if (sh < 0) sh = 0;
+    int width_sh = 64;  // keys of the current level satisfy (k - base) >> width_sh == 0
+    int need = keep, off = 0;
+    uint32_t placed = 0;
+    for (;;) {
+      for (int x = tid; x < total; x += NTHREADS) {
+        const uint64_t k = keys[x];
+        if (k < base) continue;
+        const uint64_t d = k - base;
+        if (width_sh < 64 && (d >> width_sh) != 0) continue;
+        atomicAdd(&L.hist[(uint32_t)(d >> sh)], 1u);
+      }
+      __syncthreads();
+      const uint32_t h = L.hist[tid];
+      uint32_t in_level;
+      const uint32_t ex = block_excl_scan(h, L.wtot, in_level);
+      L.cumb[tid] = ex;
+      if (tid == 0) L.cumb[NBUCKET] = in_level;
+      if (ex < (uint32_t)need && (uint32_t)need <= ex + h) { sc[SC_BT] = tid; sc[SC_BTH] = (int)h; sc[SC_BTCUM] = (int)ex; }
+      __syncthreads();
+      const uint32_t bt = (uint32_t)sc[SC_BT], bth = (uint32_t)sc[SC_BTH], btcum = (uint32_t)sc[SC_BTCUM];
+      const bool last = (bth <= RCAP) || sh == 0;
+      for (int x = tid; x < total; x += NTHREADS) {
+        const uint64_t k = keys[x];
+        if (k < base) continue;
+        const uint64_t d = k - base;
+        if (width_sh < 64 && (d >> width_sh) != 0) continue;
+        const uint32_t b = (uint32_t)(d >> sh);
+        if (b < bt || (last && b == bt)) {
+          const uint32_t seg0 = (uint32_t)off + L.cumb[b];
+          const uint32_t len = L.cumb[b + 1] - L.cumb[b];
+          const uint32_t at = seg0 + (atomicSub(&L.hist[b], 1u) - 1u);
+          L.skey[at] = k; L.ssrc[at] = (uint32_t)x; L.sseg[at] = seg0 | (len << 16);
+        }
+      }
+      if (last) { placed = (uint32_t)off + btcum + bth; break; }
+      off += (int)btcum; need -= (int)btcum;
+      base += (uint64_t)bt << sh;
+      width_sh = sh;
+      sh = sh > 10 ? sh - 10 : 0;
+      __syncthreads();
+      L.hist[tid] = 0;
+      __syncthreads();
     }
-    if (pend != 0xFFFFFFFEu) {  // path_trie.cpp:172-184
-      const uint32_t slot = atomicAdd(&S.ta_n, 1u);
-      if (slot < S.ta_cap) { S.ta[slot] = make_uint2(pend, (uint32_t)S.abs_t); ts_new = slot; }
-      else atomicOr(&sc[SC_ERR], 2);
+    __syncthreads();
+    TICK(5);
+
+    // rank inside the segment -> position r in the new beam; write the new beam entry (P6)
+    for (uint32_t q = tid; q < placed; q += NTHREADS) {
+      const uint64_t k = L.skey[q];
+      const uint32_t seg = L.sseg[q];
+      const uint32_t seg0 = seg & 0xFFFFu, len = seg >> 16;
+      uint32_t r = seg0;
+      for (uint32_t t = 0; t < len; ++t) r += (L.skey[seg0 + t] < k) ? 1u : 0u;
+      if ((int)r >= keep) continue;
+      const uint32_t x = L.ssrc[q];
+      uint32_t ts_new, pend;
+      if ((int)x < n) {
+        L.score[nxt][r] = L.ev_ext[x]; L.pb[nxt][r] = L.ev_blank[x]; L.pnb[nxt][r] = L.ev_self[x];
+        L.ch[nxt][r] = L.ch[cur][x]; L.node[nxt][r] = L.node[cur][x]; L.fst[nxt][r] = L.fst[cur][x]; L.key[nxt][r] = L.key[cur][x];
+        L.bnd[nxt][r] = L.bnd[cur][x];
+        pend = L.ev_exti[x]; ts_new = L.ts[cur][x];
+      } else {
+        const int cx = (int)x - n;
+        const uint32_t pi = S.c_pi[cx];
+        const int i = (int)(pi & 0xFFFFu);
+        const uint32_t c = (uint32_t)L.cls[(pi >> 16) & 0x7FFFu];
+        const float lpv = S.c_logp[cx];
+        const uint32_t pnode = L.node[cur][i];
+        L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
+        L.ch[nxt][r] = c; L.fst[nxt][r] = S.c_fst[cx]; L.key[nxt][r] = S.c_key[cx];
+        uint32_t b = L.bnd[cur][i];
+        if (s.enabled && !s.utf8 && (int)c == al.space_id) b = S.pq[pnode];  // the boundary entry scored in P3 (or earlier)
+        L.bnd[nxt][r] = b;
+        const uint32_t slot = atomicAdd(&S.pa_n, 1u);
+        if (slot < S.pa_cap) { S.pa[slot] = make_uint2(pnode, c); S.pq[slot] = STT_NONE; L.node[nxt][r] = slot; }
+        else { L.node[nxt][r] = 0; atomicOr(&sc[SC_ERR], 1); }
+        pend = (NEG < lpv) ? L.ts[cur][i] : 0xFFFFFFFEu;  // :246-251 with log_prob_nb_cur == -inf
+        ts_new = STT_ROOT_CH;                              // timesteps == nullptr
+      }
+      if (pend != 0xFFFFFFFEu) {  // path_trie.cpp:172-184
+        const uint32_t slot = atomicAdd(&S.ta_n, 1u);
+        if (slot < S.ta_cap) { S.ta[slot] = make_uint2(pend, (uint32_t)S.abs_t); ts_new = slot; }
+        else atomicOr(&sc[SC_ERR], 2);
+      }
+      L.ts[nxt][r] = ts_new;
     }
-    L.ts[nxt][r] = ts_new;
   }
   __syncthreads();
+  TICK(6);
   if (tid == 0) {
     S.abs_t++;
     S.stat[0] += 1; S.stat[1] += (unsigned long long)m; S.stat[2] += (unsigned long long)sc[SC_LMQ]; S.stat[3] += (unsigned long long)(unsigned)sc[SC_PROBES];
@@ -650,19 +803,22 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   const int tid = threadIdx.x;
   int n = S.n;
   int cur = 0;
+  int start_expanding = S.start_expanding;
   for (int i = tid; i < n; i += NTHREADS) {
     L.score[0][i] = S.score[i]; L.pb[0][i] = S.pb[i]; L.pnb[0][i] = S.pnb[i];
     L.ch[0][i] = S.ch[i]; L.node[0][i] = S.node[i]; L.ts[0][i] = S.ts[i]; L.fst[0][i] = S.fst[i]; L.key[0][i] = S.key[i];
+    L.bnd[0][i] = S.bnd[i];
   }
   if (tid == 0) L.sc[SC_ERR] = 0;
   __syncthreads();
   const float* row = probs + ((size_t)blockIdx.x * p.t_max + frame_begin[blockIdx.x]) * p.C;
-  for (int t = 0; t < nfr; ++t) ctc_step(p, s, al, S, L, cur, n, row + (size_t)t * p.C);
+  for (int t = 0; t < nfr; ++t) ctc_step(p, s, al, S, L, cur, n, start_expanding, row + (size_t)t * p.C);
   for (int i = tid; i < n; i += NTHREADS) {
     S.score[i] = L.score[cur][i]; S.pb[i] = L.pb[cur][i]; S.pnb[i] = L.pnb[cur][i];
     S.ch[i] = L.ch[cur][i]; S.node[i] = L.node[cur][i]; S.ts[i] = L.ts[cur][i]; S.fst[i] = L.fst[cur][i]; S.key[i] = L.key[cur][i];
+    S.bnd[i] = L.bnd[cur][i];
   }
-  if (tid == 0) { S.n = n; S.error |= L.sc[SC_ERR]; }
+  if (tid == 0) { S.n = n; S.start_expanding = start_expanding; S.error |= L.sc[SC_ERR]; }
 }
 
 // ------------------------------------------------------------------------------------ decode
@@ -721,20 +877,25 @@ __global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevSc
 }
 
 // root prefix of every stream (DecoderState::init, ctc_beam_search_decoder.cpp:43-56)
-__global__ void ctc_init_kernel(DecStream* streams, int n_streams, int fst_start) {
+__global__ void ctc_init_kernel(DecStream* streams, int n_streams, int fst_start, uint32_t bos_index, float bos_backoff) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_streams) return;
   DecStream& S = streams[i];
   S.score[0] = 0.0f; S.pb[0] = 0.0f; S.pnb[0] = STT_NEG_INF; S.ch[0] = STT_ROOT_CH; S.node[0] = 0; S.ts[0] = 0;
-  S.fst[0] = fst_start; S.key[0] = 0x5151515151515151ULL;
+  S.fst[0] = fst_start; S.key[0] = 0x5151515151515151ULL; S.bnd[0] = 0;
   S.pa[0] = make_uint2(STT_ROOT_CH, STT_ROOT_CH); S.ta[0] = make_uint2(STT_ROOT_CH, 0);
-  S.pa_lm[0] = __longlong_as_double(0x7ff8000000000000LL);
+  S.pq[0] = STT_NONE;
+  BEntry e{};  // boundary entry 0: the empty prefix, KenLM BeginSentence state (lm/model.cc:115-124)
+  e.raw = 0.0; e.prev = STT_NONE; e.oov_hist = 0; e.pad = 0; e.hot_self = 0.0f;
+  e.st.words[0] = bos_index; e.st.backoff[0] = bos_backoff; e.st.length = 1;
+  S.be[0] = e; S.be_n = 1;
   S.n = 1; S.abs_t = 0; S.start_expanding = 0; S.error = 0; S.pa_n = 1; S.ta_n = 1;
   S.stat[0] = S.stat[1] = S.stat[2] = S.stat[3] = 0;
   for (int k = 0; k < 8; ++k) S.phase[k] = 0;
 }
-void launch_ctc_init(DecStream* streams, int n_streams, int fst_start, hipStream_t st) {
-  hipLaunchKernelGGL(ctc_init_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, st, streams, n_streams, fst_start);
+void launch_ctc_init(DecStream* streams, int n_streams, const DevScorer* sc, hipStream_t st) {
+  hipLaunchKernelGGL(ctc_init_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, st, streams, n_streams, sc ? sc->fst_start : 0,
+                     sc ? sc->bos_index : 0u, sc ? sc->bos_backoff : 0.0f);
 }
 
 // ------------------------------------------------------------------------------------ launchers

@@ -105,8 +105,28 @@ DevScorer ModelState::current_scorer(std::shared_ptr<ScorerDev> sc, const std::m
 
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// Lays out every stream's arrays in one slab and uploads the pointer table.  Arena capacity covers
-// `expected_frames` timesteps (each step appends at most beam path nodes and beam time nodes).
+// Per-stream slab: [fixed: beam arrays + per-step candidate workspace][path arena][time arena][pq][boundary entries].
+// Arena capacity covers `expected_frames` timesteps (each step appends at most beam path nodes and beam time nodes);
+// boundary entries (one per scored word end) are far rarer than nodes: a quarter of the node capacity, and the kernel
+// falls back to uncached scoring if that ever runs out.
+namespace {
+struct SlabLayout {
+  size_t fixed, o_pa, o_ta, o_pq, o_be, per;
+  uint32_t arena, be_cap;
+};
+SlabLayout slab_layout(size_t fixed, uint32_t arena) {
+  SlabLayout l{};
+  l.fixed = fixed; l.arena = arena; l.be_cap = arena / 4 + 64;
+  l.o_pa = fixed; l.o_ta = l.o_pa + al256((size_t)arena * 8); l.o_pq = l.o_ta + al256((size_t)arena * 8);
+  l.o_be = l.o_pq + al256((size_t)arena * 4); l.per = l.o_be + al256((size_t)l.be_cap * sizeof(BEntry));
+  return l;
+}
+void point_arenas(DecStream& S, uint8_t* base, const SlabLayout& l) {
+  S.pa = (uint2*)(base + l.o_pa); S.ta = (uint2*)(base + l.o_ta); S.pq = (uint32_t*)(base + l.o_pq); S.be = (BEntry*)(base + l.o_be);
+  S.pa_cap = l.arena; S.ta_cap = l.arena; S.be_cap = l.be_cap;
+}
+}  // namespace
+
 void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc) {
   const int C = g.n_classes;
   if (beam < 1 || beam > STT_MAX_BEAM) throw std::runtime_error("beam width must be in [1, 1024]");
@@ -114,27 +134,28 @@ void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int e
   const uint32_t cap = (uint32_t)((beam + 63) & ~63);
   const uint32_t cand_cap = (uint32_t)beam * (uint32_t)(C - 1);
   const uint32_t arena = (uint32_t)(expected_frames + 2) * (uint32_t)beam + 2;
-  const size_t fixed = al256(cap * 8) + 7 * al256(cap * 4) + al256(cand_cap * 4) * 3 + al256(cand_cap * 8) + al256(((size_t)cap + cand_cap) * 8);
-  const size_t per = fixed + 3 * al256((size_t)arena * 8);
+  const size_t fixed = al256(cap * 8) + 8 * al256(cap * 4) + al256(cand_cap * 4) * 3 + al256(cand_cap * 8) + al256(((size_t)cap + cand_cap) * 8);
+  const SlabLayout l = slab_layout(fixed, arena);
   db.per_stream_fixed = fixed;
-  db.slab.reserve(per * n_streams);
+  db.slab.reserve(l.per * n_streams);
   db.host.assign(n_streams, DecStream{});
   db.pa_cap.assign(n_streams, arena); db.ta_cap.assign(n_streams, arena);
   uint8_t* base = db.slab.as<uint8_t>();
   for (int i = 0; i < n_streams; ++i) {
-    uint8_t* p = base + per * i;
+    uint8_t* p = base + l.per * i;
     DecStream& S = db.host[i];
     auto take = [&](size_t bytes) { uint8_t* r = p; p += al256(bytes); return r; };
     S.key = (uint64_t*)take(cap * 8);
     S.score = (float*)take(cap * 4); S.pb = (float*)take(cap * 4); S.pnb = (float*)take(cap * 4);
     S.ch = (uint32_t*)take(cap * 4); S.node = (uint32_t*)take(cap * 4); S.ts = (uint32_t*)take(cap * 4); S.fst = (int*)take(cap * 4);
+    S.bnd = (uint32_t*)take(cap * 4);
     S.c_logp = (float*)take(cand_cap * 4); S.c_pi = (uint32_t*)take(cand_cap * 4); S.c_fst = (int*)take(cand_cap * 4);
     S.c_key = (uint64_t*)take(cand_cap * 8); S.sel_keys = (uint64_t*)take(((size_t)cap + cand_cap) * 8);
-    S.pa = (uint2*)take((size_t)arena * 8); S.ta = (uint2*)take((size_t)arena * 8); S.pa_lm = (double*)take((size_t)arena * 8);
-    S.cand_cap = cand_cap; S.pa_cap = arena; S.ta_cap = arena;
+    point_arenas(S, base + l.per * i, l);
+    S.cand_cap = cand_cap;
   }
   db.table.upload(db.host.data(), sizeof(DecStream) * n_streams, stream);
-  launch_ctc_init(db.table.as<DecStream>(), n_streams, sc ? sc->dev.fst_start : 0, stream);
+  launch_ctc_init(db.table.as<DecStream>(), n_streams, sc ? &sc->dev : nullptr, stream);
 }
 
 // Streaming use: make sure stream i can append `more_frames[i]` further timesteps.  Grows the whole slab
@@ -150,28 +171,26 @@ void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_
     need = std::max(need, want);
   }
   if (!grow) return;
-  const uint32_t arena = need * 2;
-  const size_t per = db.per_stream_fixed + 3 * al256((size_t)arena * 8);
+  const SlabLayout ol = slab_layout(db.per_stream_fixed, db.host[0].pa_cap);
+  const SlabLayout nl = slab_layout(db.per_stream_fixed, need * 2);
   DevBuf ns;
-  ns.reserve(per * db.n_streams);
-  const size_t old_per = db.per_stream_fixed + 3 * al256((size_t)db.host[0].pa_cap * 8);
+  ns.reserve(nl.per * db.n_streams);
   std::vector<DecStream> nh = db.host;
   for (int i = 0; i < db.n_streams; ++i) {
-    uint8_t* ob = db.slab.as<uint8_t>() + old_per * i;
-    uint8_t* nb = ns.as<uint8_t>() + per * i;
+    uint8_t* ob = db.slab.as<uint8_t>() + ol.per * i;
+    uint8_t* nb = ns.as<uint8_t>() + nl.per * i;
     HIP_CHECK(hipMemcpyAsync(nb, ob, db.per_stream_fixed, hipMemcpyDeviceToDevice, stream));
     const ptrdiff_t delta = nb - ob;
     DecStream& S = nh[i];
     auto mv = [&](auto*& ptr) { ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(reinterpret_cast<uint8_t*>(ptr) + delta); };
-    mv(S.key); mv(S.score); mv(S.pb); mv(S.pnb); mv(S.ch); mv(S.node); mv(S.ts); mv(S.fst);
+    mv(S.key); mv(S.score); mv(S.pb); mv(S.pnb); mv(S.ch); mv(S.node); mv(S.ts); mv(S.fst); mv(S.bnd);
     mv(S.c_logp); mv(S.c_pi); mv(S.c_fst); mv(S.c_key); mv(S.sel_keys);
-    uint2* npa = reinterpret_cast<uint2*>(nb + db.per_stream_fixed);
-    uint2* nta = reinterpret_cast<uint2*>(nb + db.per_stream_fixed + al256((size_t)arena * 8));
-    HIP_CHECK(hipMemcpyAsync(npa, db.host[i].pa, (size_t)db.host[i].pa_n * 8, hipMemcpyDeviceToDevice, stream));
-    double* nlm = reinterpret_cast<double*>(nb + db.per_stream_fixed + 2 * al256((size_t)arena * 8));
-    HIP_CHECK(hipMemcpyAsync(nta, db.host[i].ta, (size_t)db.host[i].ta_n * 8, hipMemcpyDeviceToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(nlm, db.host[i].pa_lm, (size_t)db.host[i].pa_n * 8, hipMemcpyDeviceToDevice, stream));
-    S.pa = npa; S.ta = nta; S.pa_lm = nlm; S.pa_cap = arena; S.ta_cap = arena;
+    const DecStream& O = db.host[i];
+    point_arenas(S, nb, nl);
+    HIP_CHECK(hipMemcpyAsync(S.pa, O.pa, (size_t)std::min(O.pa_n, O.pa_cap) * 8, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(S.ta, O.ta, (size_t)std::min(O.ta_n, O.ta_cap) * 8, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(S.pq, O.pq, (size_t)std::min(O.pa_n, O.pa_cap) * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(S.be, O.be, (size_t)std::min(O.be_n, O.be_cap) * sizeof(BEntry), hipMemcpyDeviceToDevice, stream));
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   std::swap(db.slab.p, ns.p); std::swap(db.slab.cap, ns.cap);

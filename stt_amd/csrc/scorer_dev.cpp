@@ -145,32 +145,50 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len) {
   if (o > len || nstates <= 0) return STT_ERR_SCORER_INVALID_TRIE;
 
   // ---- repack the dictionary: arcs sorted by ilabel within a state (SortedMatcher's precondition)
+  // The arc's second field is the dictionary state of the child prefix: Start() when the arc's target is final
+  // (a completed word, path_trie.cpp:79-87), the target otherwise -- resolved here so the kernel needs one read.
   std::vector<uint32_t> pos((size_t)nstates + 1);
   std::vector<uint8_t> fin((size_t)nstates);
   std::vector<uint2> arcv((size_t)narcs);
+  for (int64_t s = 0; s < nstates; ++s) fin[s] = !(rdf(states + 20 * s) == INFINITY);  // Final(s) != TropicalWeight::Zero()
   uint32_t w = 0;
   for (int64_t s = 0; s < nstates; ++s) {
     const uint8_t* S = states + 20 * s;
-    fin[s] = !(rdf(S) == INFINITY);  // Final(s) != TropicalWeight::Zero()
     const uint32_t ap = rd32(S + 4), an = rd32(S + 8);
     pos[s] = w;
     for (uint32_t k = 0; k < an; ++k) {
       const uint8_t* A = arcs + 16 * (uint64_t)(ap + k);
-      arcv[w++] = make_uint2(rd32(A), rd32(A + 12));
+      if ((uint64_t)ap + k >= (uint64_t)narcs) return STT_ERR_SCORER_INVALID_TRIE;
+      const uint32_t next = rd32(A + 12);
+      if (next >= (uint64_t)nstates) return STT_ERR_SCORER_INVALID_TRIE;
+      arcv[w++] = make_uint2(rd32(A), fin[next] ? (uint32_t)fst_start : next);
     }
   }
   pos[nstates] = w;
 
+  // ---- vocabulary hash table over KenLM's sorted hash array (index = position + 1, vocab.hh:72-83)
+  uint32_t vt_n = 16;
+  while ((uint64_t)vt_n < 2 * vocab_n + 2) vt_n <<= 1;
+  std::vector<DevVocabSlot> vtab(vt_n, DevVocabSlot{0, 0, 0});
+  if (vocab_off + 8 * vocab_n > len) return STT_ERR_SCORER_INVALID_LM;
+  for (uint64_t i = 0; i < vocab_n; ++i) {
+    const uint64_t h = rd64(buf + vocab_off + 8 * i);
+    uint32_t slot = (uint32_t)h & (vt_n - 1);
+    while (vtab[slot].used) slot = (slot + 1) & (vt_n - 1);
+    vtab[slot] = DevVocabSlot{h, (uint32_t)(i + 1), 1};
+  }
+
   // ---- upload
   blob_.upload(buf, lm_end + 16);  // +16: the 64-bit bit-packed reads may touch up to 8 bytes past the last record
   fst_pos_.upload(pos.data(), pos.size() * 4);
-  fst_final_.upload(fin.data(), fin.size());
+  vtab_.upload(vtab.data(), vtab.size() * sizeof(DevVocabSlot));
   fst_arcs_.upload(arcv.data(), arcv.size() * sizeof(uint2));
   const uint8_t* d = blob_.as<uint8_t>();
   DevScorer ds{};
   ds.enabled = 1; ds.order = ord; ds.quant = quant; ds.utf8 = utf8;
   ds.alpha = (double)(float)a; ds.beta = (double)(float)b;  // Scorer::reset_params(float, float)
   ds.vocab = reinterpret_cast<const uint64_t*>(d + vocab_off); ds.vocab_n = vocab_n;
+  ds.vtab = vtab_.as<DevVocabSlot>(); ds.vtab_mask = vt_n - 1;
   ds.unigram = d + unigram_off;
   for (int i = 0; i < STT_KENLM_MAX_ORDER; ++i) {
     ds.qprob[i] = quant && qprob_off[i] ? reinterpret_cast<const float*>(d + qprob_off[i]) : nullptr;
@@ -195,7 +213,7 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len) {
     ds.bos_backoff = rdf(buf + unigram_off + 16 * (uint64_t)idx + 4);
   }
   ds.fst_start = (int)fst_start;
-  ds.fst_state_pos = fst_pos_.as<uint32_t>(); ds.fst_final = fst_final_.as<uint8_t>(); ds.fst_arcs = fst_arcs_.as<uint2>();
+  ds.fst_state_pos = fst_pos_.as<uint32_t>(); ds.fst_arcs = fst_arcs_.as<uint2>();
   dev = ds;
   is_utf8 = utf8; order = ord; blob_bytes = lm_end;
   return STT_ERR_OK;
