@@ -127,7 +127,7 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
     mark(m, 1);
     m->run_acoustic(m->ws_feats.as<float>(), m->ws_nframes.as<int>(), Bg, t_max, nullptr, nullptr, false);
     mark(m, 4);
-    DecoderBatch db;
+    DecoderBatch& db = m->batch_dec_;  // slab and table stay allocated between calls (grow-only)
     m->decoder_create(db, Bg, (int)m->beam_width_, t_max, m->scorer_);
     std::vector<int> zeros(Bg, 0);
     m->ws_fbegin.upload(zeros.data(), Bg * 4, m->stream);

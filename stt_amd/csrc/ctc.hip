@@ -126,41 +126,40 @@ __device__ bool lookup_longest(const DevScorer& s, uint32_t word, const KNode& n
   ++probes;
   return true;
 }
-// GenericModel::FullScore (model.cc:170-176) = ScoreExceptBackoff (:285-310) + ResumeScore (:312-338)
-__device__ float kenlm_full_score(const DevScorer& s, const KState& in, uint32_t new_word, KState& out, unsigned& probes) {
+// GenericModel::FullScore (model.cc:170-176) = ScoreExceptBackoff (:285-310) + ResumeScore (:312-338).
+// Written with compile-time indices only (fully unrolled over KENLM_MAX_ORDER) so that both states stay in registers.
+__device__ __forceinline__ float kenlm_full_score(const DevScorer& s, const KState& in, uint32_t new_word, KState& out, unsigned& probes) {
   KNode node;
   const uint8_t* u = s.unigram + 16 * (uint64_t)new_word;
-  float prob = __uint_as_float(ld32u(u));
-  out.backoff[0] = __uint_as_float(ld32u(u + 4));
+  const uint64_t pb = ld64u(u);  // {float prob, float backoff, uint64 next}; the three loads are independent
   node.begin = ld64u(u + 8);
   node.end = ld64u(u + 24);
+  float prob = __uint_as_float((uint32_t)pb);
+  out.backoff[0] = __uint_as_float((uint32_t)(pb >> 32));
   probes += 2;
   bool independent_left = (node.begin == node.end);
   int nl = 1;
-  out.length = has_extension(out.backoff[0]) ? 1 : 0;
+  int out_len = has_extension(out.backoff[0]) ? 1 : 0;
   out.words[0] = new_word;
-  if (in.length != 0) {
-    int hi = 0;
-    int om2 = 0;
-    bool at_longest = false;
-    for (;; ++om2, ++hi) {
-      if (hi == in.length) break;
-      if (independent_left) break;
-      if (om2 == s.order - 2) { at_longest = true; break; }
-      float p, b;
-      if (!lookup_middle(s, om2, in.words[hi], node, independent_left, p, b, probes)) break;
-      out.backoff[om2 + 1] = b;
-      prob = p;
-      nl = om2 + 2;
-      if (has_extension(b)) out.length = nl;
+  bool go = in.length != 0, at_longest = false;
+#pragma unroll
+  for (int om2 = 0; om2 < STT_KENLM_MAX_ORDER - 1; ++om2) {  // history word index hi == om2
+    if (om2 + 1 < STT_KENLM_MAX_ORDER - 1) { out.words[om2 + 1] = in.words[om2]; out.backoff[om2 + 1] = 0.0f; }  // entries past length are unused
+    if (go) {
+      if (om2 == in.length || independent_left) go = false;
+      else if (om2 == s.order - 2) { at_longest = true; go = false; float p; if (lookup_longest(s, in.words[om2], node, p, probes)) { prob = p; nl = s.order; } }
+      else if (om2 < STT_KENLM_MAX_ORDER - 2) {
+        float p, b;
+        if (!lookup_middle(s, om2, in.words[om2], node, independent_left, p, b, probes)) go = false;
+        else { out.backoff[om2 + 1] = b; prob = p; nl = om2 + 2; if (has_extension(b)) out_len = nl; }
+      }
     }
-    if (at_longest) {
-      float p;
-      if (lookup_longest(s, in.words[hi], node, p, probes)) { prob = p; nl = s.order; }
-    }
-    for (int i = 0; i + 1 < out.length; ++i) out.words[i + 1] = in.words[i];
   }
-  for (int i = nl - 1; i < in.length; ++i) prob = __fadd_rn(prob, in.backoff[i]);
+  (void)at_longest;
+  out.length = out_len;
+#pragma unroll
+  for (int i = 0; i < STT_KENLM_MAX_ORDER - 1; ++i)
+    if (i >= nl - 1 && i < in.length) prob = __fadd_rn(prob, in.backoff[i]);
   return prob;
 }
 
@@ -290,17 +289,59 @@ __device__ bool is_scoring_boundary(const DevScorer& s, const DevAlphabet& al, c
 // the last `order` words from a null context (or all words from BeginSentence when there are fewer), and a KenLM state
 // holds at most order-1 words, so the state carried from the previous boundary is the state the reference rebuilds.
 // Appends a BEntry and records it in S.pq[node]; returns log_cond_prob + hot_boost.
-__device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al, DecStream& S, uint32_t node, uint32_t e_prev, unsigned& probes) {
-  uint32_t labs[MAX_UNIT_LABELS];
-  int nl = 0;
+__device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al, const DecStream& S, const uint8_t* lab1, uint32_t* be_n, uint32_t node, uint32_t e_prev, unsigned& probes) {
+  // Walk back to the previous boundary collecting the word's UTF-8 bytes.  Labels arrive newest first, so shifting each
+  // byte in from the low end leaves the word in little-endian order (first byte lowest): exactly the two 8-byte blocks
+  // MurmurHash64A consumes.  Words longer than 16 bytes take the generic label-array path.
+  uint64_t lo = 0, hi = 0;
+  int nbytes = 0;
+  bool overflow = false;
   for (uint32_t cur = node; cur != STT_ROOT_CH;) {
     const uint2 pn = S.pa[cur];
     ++probes;
     if (pn.y == (uint32_t)al.space_id || pn.y == STT_ROOT_CH) break;
-    if (nl < MAX_UNIT_LABELS) labs[nl++] = pn.y;
+    const uint8_t one = lab1[pn.y];  // LDS copy of single-byte labels (0 = multi-byte label: read it from HBM)
+    if (one) {
+      hi = (hi << 8) | (lo >> 56);
+      lo = (lo << 8) | (uint64_t)one;
+      if (++nbytes > 16) overflow = true;
+    } else {
+      const int b0 = pn.y ? al.label_off[pn.y - 1] : 0, b1 = al.label_off[pn.y];
+      for (int b = b1 - 1; b >= b0; --b) {
+        hi = (hi << 8) | (lo >> 56);
+        lo = (lo << 8) | (uint64_t)al.label_bytes[b];
+        if (++nbytes > 16) overflow = true;
+      }
+    }
     cur = pn.x;
   }
-  const uint64_t h = hash_labels_reversed(al, labs, nl);
+  uint64_t h;
+  if (!overflow) {
+    const uint64_t m = 0xc6a4a7935bd1e995ULL;
+    const int r = 47;
+    h = 0 ^ ((uint64_t)nbytes * m);
+    if (nbytes >= 8) {
+      uint64_t k = lo;
+      k *= m; k ^= k >> r; k *= m;
+      h ^= k; h *= m;
+      if (nbytes == 16) { k = hi; k *= m; k ^= k >> r; k *= m; h ^= k; h *= m; }
+      else if (nbytes > 8) { h ^= hi; h *= m; }
+    } else if (nbytes > 0) {
+      h ^= lo; h *= m;
+    }
+    h ^= h >> r; h *= m; h ^= h >> r;
+  } else {
+    uint32_t labs[MAX_UNIT_LABELS];
+    int nl = 0;
+    for (uint32_t cur = node; cur != STT_ROOT_CH;) {
+      const uint2 pn = S.pa[cur];
+      ++probes;
+      if (pn.y == (uint32_t)al.space_id || pn.y == STT_ROOT_CH) break;
+      if (nl < MAX_UNIT_LABELS) labs[nl++] = pn.y;
+      cur = pn.x;
+    }
+    h = hash_labels_reversed(al, labs, nl);
+  }
   const uint32_t wi = vocab_index(s, h, probes);
   const BEntry ep = S.be[e_prev];
   ++probes;
@@ -327,7 +368,7 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
   const double lcp = oov ? OOV_SCORE_D : __ddiv_rn((double)prob, (double)0.4342944819f);
   en.raw = __dadd_rn(lcp, (double)hot_total);
   en.prev = e_prev; en.pad = 0; en.hot_self = hot_self;
-  const uint32_t idx = atomicAdd(&S.be_n, 1u);
+  const uint32_t idx = atomicAdd(be_n, 1u);  // LDS copy of the arena fill (written back when the launch ends)
   if (idx < S.be_cap) { S.be[idx] = en; S.pq[node] = idx; }
   return en.raw;
 }
@@ -348,13 +389,18 @@ struct Lds {
   uint32_t *off, *a0;                  // expand work list: first item of prefix i, first FST arc of prefix i
   uint64_t* ht_key; uint16_t* ht_idx;  // ht_key doubles as the selection-key buffer (kbuf) after P2
   float *pf, *lp; uint16_t *cls, *pos;
+  uint8_t* lab1;                       // [C] the byte of every single-byte label (0 otherwise)
   uint32_t *hist, *cumb;
   uint64_t* skey; uint32_t *ssrc, *sseg;
   uint32_t* wtot;
+  // the first `mcap` candidates of a step live in LDS, the rest in the stream's HBM workspace
+  float* lc_logp; uint32_t* lc_pi; int* lc_fst; uint32_t mcap;
+  unsigned long long* acc;  // [0..3] stat counters, [4..11] phase cycles (accumulated in LDS, flushed when the launch ends)
   int* sc;  // scalars
 };
-#define TICK(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); S.phase[k] += now_ - tick_; tick_ = now_; } } while (0)
-enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_COUNT = 16 };
+#define TICK(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); L.acc[4 + (k)] += now_ - tick_; tick_ = now_; } } while (0)
+enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_COUNT = 16 };
+#define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
 __host__ __device__ inline uint32_t pow2_ge(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
@@ -372,10 +418,20 @@ __host__ __device__ inline size_t lds_carve(int beam, int C, Lds* l, unsigned ch
   offs[k++] = take((cap + 1) * 4); offs[k++] = take(cap * 4);      // off, a0
   offs[k++] = take(HTN * 8); offs[k++] = take(HTN * 2);            // hash / kbuf
   offs[k++] = take((size_t)C * 4); offs[k++] = take((size_t)C * 4); offs[k++] = take((size_t)C * 2); offs[k++] = take((size_t)C * 2);
+  offs[k++] = take((size_t)C);
   offs[k++] = take(NBUCKET * 4); offs[k++] = take((NBUCKET + 1) * 4);
   offs[k++] = take(sn * 8); offs[k++] = take(sn * 4); offs[k++] = take(sn * 4);
   offs[k++] = take(64 * 4);
+  offs[k++] = take(12 * 8);
   offs[k++] = take(SC_COUNT * 4);
+  // candidate staging: whatever fits under ~118 KiB (leaves room for a co-resident acoustic-model workgroup), at most 2048
+  uint32_t mcap = 0;
+  {
+    const size_t budget = 118 * 1024;
+    if (o + 256 * 12 <= budget) { mcap = (uint32_t)((budget - o) / 12) & ~63u; if (mcap > 2048) mcap = 2048; }
+  }
+  const size_t o_lc = o;
+  o += (size_t)mcap * 12;
   if (l) {
     k = 0;
     for (int d = 0; d < 2; ++d) {
@@ -389,10 +445,14 @@ __host__ __device__ inline size_t lds_carve(int beam, int C, Lds* l, unsigned ch
     l->off = (uint32_t*)(base + offs[k++]); l->a0 = (uint32_t*)(base + offs[k++]);
     l->ht_key = (uint64_t*)(base + offs[k++]); l->ht_idx = (uint16_t*)(base + offs[k++]);
     l->pf = (float*)(base + offs[k++]); l->lp = (float*)(base + offs[k++]); l->cls = (uint16_t*)(base + offs[k++]); l->pos = (uint16_t*)(base + offs[k++]);
+    l->lab1 = (uint8_t*)(base + offs[k++]);
     l->hist = (uint32_t*)(base + offs[k++]); l->cumb = (uint32_t*)(base + offs[k++]);
     l->skey = (uint64_t*)(base + offs[k++]); l->ssrc = (uint32_t*)(base + offs[k++]); l->sseg = (uint32_t*)(base + offs[k++]);
     l->wtot = (uint32_t*)(base + offs[k++]);
+    l->acc = (unsigned long long*)(base + offs[k++]);
     l->sc = (int*)(base + offs[k++]);
+    l->mcap = mcap;
+    l->lc_logp = (float*)(base + o_lc); l->lc_pi = (uint32_t*)(base + o_lc + (size_t)mcap * 4); l->lc_fst = (int*)(base + o_lc + (size_t)mcap * 8);
   }
   return o;
 }
@@ -454,9 +514,12 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return v;
 }
 
+#define CAND_PI(x) (((uint32_t)(x) < L.mcap) ? L.lc_pi[x] : S.c_pi[x])
+#define CAND_LOGP(x) (((uint32_t)(x) < L.mcap) ? L.lc_logp[x] : S.c_logp[x])
+
 // ------------------------------------------------------------------------------------ one timestep
-__device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphabet& al, DecStream& S, const Lds& L, int& cur, int& n,
-                         int& start_expanding, const float* prob_row) {
+__device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const DecStream& S, const Lds& L, int& cur, int& n,
+                         int& start_expanding, int& abs_t, const float* prob_row, const float* next_row, float& pre, bool has_pre) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int C = p.C, beam = p.beam;
@@ -465,14 +528,16 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
 
   unsigned long long tick_ = __builtin_readcyclecounter();
   // ---- A: emissions to LDS; clear the hash, the per-prefix events and the selection histogram
-  for (int c = tid; c < C; c += NTHREADS) L.pf[c] = prob_row[c];
+  // (the first NTHREADS classes of this row were fetched into `pre` during the previous step)
+  for (int c = tid; c < C; c += NTHREADS) L.pf[c] = (has_pre && c == tid) ? pre : prob_row[c];
+  if (next_row && tid < C) pre = next_row[tid];
   for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
   for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
   L.hist[tid] = 0;
   if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; }
   __syncthreads();
   if ((double)L.pf[p.blank] < 0.999) start_expanding = 1;  // :125-132 (uniform: every thread reads the same value)
-  if (!start_expanding) { if (tid == 0) S.abs_t++; __syncthreads(); return; }
+  if (!start_expanding) { abs_t++; __syncthreads(); return; }
 
   // ---- B: class log-probs (get_pruned_emissions, :328-358) and the LDS hash of the live prefixes
   const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
@@ -594,10 +659,9 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
     } else {
       const int slot = atomicAdd(&sc[SC_M], 1);
       if ((uint32_t)slot < S.cand_cap) {
-        S.c_logp[slot] = log_p;
-        S.c_pi[slot] = (uint32_t)i | ((uint32_t)k << 16) | (needs_lm << 31);
-        S.c_fst[slot] = child_fst;
-        S.c_key[slot] = ck;
+        const uint32_t piv = (uint32_t)i | ((uint32_t)k << 16) | (needs_lm << 31);
+        if ((uint32_t)slot < L.mcap) { L.lc_logp[slot] = log_p; L.lc_pi[slot] = piv; L.lc_fst[slot] = child_fst; }
+        else { S.c_logp[slot] = log_p; S.c_pi[slot] = piv; S.c_fst[slot] = child_fst; }
       }
     }
   }
@@ -611,7 +675,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
     unsigned lmq = 0;
     for (int x = tid; x < m + n; x += NTHREADS) {
       uint32_t pi; float lp0;
-      if (x < m) { pi = S.c_pi[x]; if (!(pi >> 31)) continue; lp0 = S.c_logp[x]; }
+      if (x < m) { pi = CAND_PI(x); if (!(pi >> 31)) continue; lp0 = CAND_LOGP(x); }
       else { const int j = x - m; pi = L.ev_exti[j]; if (!(pi >> 31) || is_absent(L.ev_ext[j])) continue; lp0 = L.ev_ext[j]; }
       const int i = (int)(pi & 0xFFFFu);
       const uint32_t nodei = L.node[cur][i];
@@ -623,7 +687,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
         if (bndi != STT_NONE && chi != STT_ROOT_CH && (int)chi != al.space_id) {
           const uint32_t e = S.pq[nodei];
           if (e != STT_NONE) raw = S.be[e].raw;
-          else { raw = lm_word_query_cached(s, al, S, nodei, bndi, probes); ++lmq; }
+          else { raw = lm_word_query_cached(s, al, S, L.lab1, (uint32_t*)&sc[SC_BEN], nodei, bndi, probes); ++lmq; }
         } else {
           raw = lm_score(s, al, S.pa, nodei, STT_ROOT_CH, true, probes); ++lmq;
         }
@@ -634,7 +698,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
       const float lms = (float)__dmul_rn(raw, s.alpha);
       float lpv = __fadd_rn(lp0, lms);                       // log_p += score;
       lpv = (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
-      if (x < m) S.c_logp[x] = lpv; else L.ev_ext[x - m] = lpv;
+      if (x < m) { if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpv; else S.c_logp[x] = lpv; } else L.ev_ext[x - m] = lpv;
     }
     if (lmq) atomicAdd(&sc[SC_LMQ], (int)lmq);
   }
@@ -667,14 +731,14 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
     const uint64_t k = sel_key(nscore, chj, 0, (uint32_t)j);
     keys[j] = k;
     const uint32_t kh = (uint32_t)(k >> 32);
-    hmin = kh < hmin ? kh : hmin; hmax = kh > hmax ? kh : hmax;
+    hmin = kh < hmin ? kh : hmin; if (kh != NEG_HI) hmax = kh > hmax ? kh : hmax;
   }
   for (int x = tid; x < m; x += NTHREADS) {
-    const uint32_t pi = S.c_pi[x];
-    const uint64_t k = sel_key(S.c_logp[x], (uint32_t)L.cls[(pi >> 16) & 0x7FFFu], 1, pi & 0xFFFFu);
+    const uint32_t pi = CAND_PI(x);
+    const uint64_t k = sel_key(CAND_LOGP(x), (uint32_t)L.cls[(pi >> 16) & 0x7FFFu], 1, pi & 0xFFFFu);
     keys[n + x] = k;
     const uint32_t kh = (uint32_t)(k >> 32);
-    hmin = kh < hmin ? kh : hmin; hmax = kh > hmax ? kh : hmax;
+    hmin = kh < hmin ? kh : hmin; if (kh != NEG_HI) hmax = kh > hmax ? kh : hmax;
   }
   hmin = wave_min_u32(hmin); hmax = wave_max_u32(hmax);
   if (lane == 0) { atomicMin((unsigned int*)&sc[SC_KMIN], hmin); atomicMax((unsigned int*)&sc[SC_KMAX], hmax); }
@@ -689,8 +753,13 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   const int keep = total < beam ? total : beam;
   const int nxt = cur ^ 1;
   {
-    uint64_t base = (uint64_t)(uint32_t)sc[SC_KMIN] << 32;
-    const uint64_t range = ((uint64_t)((uint32_t)sc[SC_KMAX] - (uint32_t)sc[SC_KMIN]) << 32) | 0xFFFFFFFFull;
+    // Scores equal to -NUM_FLT_INF (a repeated label on a prefix whose blank probability is still -inf) would stretch
+    // the range over the whole float line; they are re-based right after the worst finite score (monotone, injective).
+    const uint32_t kmin = (uint32_t)sc[SC_KMIN], kmaxf = (uint32_t)sc[SC_KMAX];
+    const uint32_t neg_to = (kmaxf >= kmin && kmaxf < NEG_HI) ? kmaxf + 1u : NEG_HI;
+#define REKEY(k) (((uint32_t)((k) >> 32) == NEG_HI) ? (((uint64_t)neg_to << 32) | ((k) & 0xFFFFFFFFull)) : (k))
+    uint64_t base = (uint64_t)kmin << 32;
+    const uint64_t range = ((uint64_t)(neg_to - kmin) << 32) | 0xFFFFFFFFull;
     int sh = 64 - __clzll((long long)range) - 10;  // range < 2^(sh+10)
     if (sh < 0) sh = 0;
     int width_sh = 64;  // keys of the current level satisfy (k - base) >> width_sh == 0
@@ -698,7 +767,8 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
     uint32_t placed = 0;
     for (;;) {
       for (int x = tid; x < total; x += NTHREADS) {
-        const uint64_t k = keys[x];
+        const uint64_t k0 = keys[x];
+        const uint64_t k = REKEY(k0);
         if (k < base) continue;
         const uint64_t d = k - base;
         if (width_sh < 64 && (d >> width_sh) != 0) continue;
@@ -715,7 +785,8 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
       const uint32_t bt = (uint32_t)sc[SC_BT], bth = (uint32_t)sc[SC_BTH], btcum = (uint32_t)sc[SC_BTCUM];
       const bool last = (bth <= RCAP) || sh == 0;
       for (int x = tid; x < total; x += NTHREADS) {
-        const uint64_t k = keys[x];
+        const uint64_t k0 = keys[x];
+        const uint64_t k = REKEY(k0);
         if (k < base) continue;
         const uint64_t d = k - base;
         if (width_sh < 64 && (d >> width_sh) != 0) continue;
@@ -756,25 +827,25 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
         pend = L.ev_exti[x]; ts_new = L.ts[cur][x];
       } else {
         const int cx = (int)x - n;
-        const uint32_t pi = S.c_pi[cx];
+        const uint32_t pi = CAND_PI(cx);
         const int i = (int)(pi & 0xFFFFu);
         const uint32_t c = (uint32_t)L.cls[(pi >> 16) & 0x7FFFu];
-        const float lpv = S.c_logp[cx];
+        const float lpv = CAND_LOGP(cx);
         const uint32_t pnode = L.node[cur][i];
         L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
-        L.ch[nxt][r] = c; L.fst[nxt][r] = S.c_fst[cx]; L.key[nxt][r] = S.c_key[cx];
+        L.ch[nxt][r] = c; L.fst[nxt][r] = ((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst[cx]; L.key[nxt][r] = child_key(L.key[cur][i], c);
         uint32_t b = L.bnd[cur][i];
         if (s.enabled && !s.utf8 && (int)c == al.space_id) b = S.pq[pnode];  // the boundary entry scored in P3 (or earlier)
         L.bnd[nxt][r] = b;
-        const uint32_t slot = atomicAdd(&S.pa_n, 1u);
+        const uint32_t slot = atomicAdd((uint32_t*)&sc[SC_PAN], 1u);
         if (slot < S.pa_cap) { S.pa[slot] = make_uint2(pnode, c); S.pq[slot] = STT_NONE; L.node[nxt][r] = slot; }
         else { L.node[nxt][r] = 0; atomicOr(&sc[SC_ERR], 1); }
         pend = (NEG < lpv) ? L.ts[cur][i] : 0xFFFFFFFEu;  // :246-251 with log_prob_nb_cur == -inf
         ts_new = STT_ROOT_CH;                              // timesteps == nullptr
       }
       if (pend != 0xFFFFFFFEu) {  // path_trie.cpp:172-184
-        const uint32_t slot = atomicAdd(&S.ta_n, 1u);
-        if (slot < S.ta_cap) { S.ta[slot] = make_uint2(pend, (uint32_t)S.abs_t); ts_new = slot; }
+        const uint32_t slot = atomicAdd((uint32_t*)&sc[SC_TAN], 1u);
+        if (slot < S.ta_cap) { S.ta[slot] = make_uint2(pend, (uint32_t)abs_t); ts_new = slot; }
         else atomicOr(&sc[SC_ERR], 2);
       }
       L.ts[nxt][r] = ts_new;
@@ -782,10 +853,11 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   }
   __syncthreads();
   TICK(6);
+#undef REKEY
   if (tid == 0) {
-    S.abs_t++;
-    S.stat[0] += 1; S.stat[1] += (unsigned long long)m; S.stat[2] += (unsigned long long)sc[SC_LMQ]; S.stat[3] += (unsigned long long)(unsigned)sc[SC_PROBES];
+    L.acc[0] += 1; L.acc[1] += (unsigned long long)m; L.acc[2] += (unsigned long long)sc[SC_LMQ]; L.acc[3] += (unsigned long long)(unsigned)sc[SC_PROBES];
   }
+  abs_t++;
   cur = nxt;
   n = keep;
   __syncthreads();
@@ -797,28 +869,43 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Lds L;
   lds_carve(p.beam, p.C, &L, smem);
-  DecStream& S = streams[blockIdx.x];
+  DecStream& G = streams[blockIdx.x];
+  const DecStream S = G;  // pointers and capacities in registers: no pointer-chasing through the stream table
   const int nfr = frame_count[blockIdx.x];
   if (nfr <= 0) return;
   const int tid = threadIdx.x;
   int n = S.n;
   int cur = 0;
   int start_expanding = S.start_expanding;
+  int abs_t = S.abs_t;
   for (int i = tid; i < n; i += NTHREADS) {
     L.score[0][i] = S.score[i]; L.pb[0][i] = S.pb[i]; L.pnb[0][i] = S.pnb[i];
     L.ch[0][i] = S.ch[i]; L.node[0][i] = S.node[i]; L.ts[0][i] = S.ts[i]; L.fst[0][i] = S.fst[i]; L.key[0][i] = S.key[i];
     L.bnd[0][i] = S.bnd[i];
   }
-  if (tid == 0) L.sc[SC_ERR] = 0;
+  for (int c = tid; c < p.C; c += NTHREADS) {
+    uint8_t one = 0;
+    if (c < al.n_labels) { const int b0 = c ? al.label_off[c - 1] : 0; if (al.label_off[c] - b0 == 1) one = al.label_bytes[b0]; }
+    L.lab1[c] = one;
+  }
+  if (tid == 0) { L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)S.pa_n; L.sc[SC_TAN] = (int)S.ta_n; L.sc[SC_BEN] = (int)S.be_n; }
+  if (tid < 12) L.acc[tid] = 0;
   __syncthreads();
   const float* row = probs + ((size_t)blockIdx.x * p.t_max + frame_begin[blockIdx.x]) * p.C;
-  for (int t = 0; t < nfr; ++t) ctc_step(p, s, al, S, L, cur, n, start_expanding, row + (size_t)t * p.C);
+  float pre = 0.0f;
+  for (int t = 0; t < nfr; ++t)
+    ctc_step(p, s, al, S, L, cur, n, start_expanding, abs_t, row + (size_t)t * p.C, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr, pre, t > 0);
   for (int i = tid; i < n; i += NTHREADS) {
     S.score[i] = L.score[cur][i]; S.pb[i] = L.pb[cur][i]; S.pnb[i] = L.pnb[cur][i];
     S.ch[i] = L.ch[cur][i]; S.node[i] = L.node[cur][i]; S.ts[i] = L.ts[cur][i]; S.fst[i] = L.fst[cur][i]; S.key[i] = L.key[cur][i];
     S.bnd[i] = L.bnd[cur][i];
   }
-  if (tid == 0) { S.n = n; S.start_expanding = start_expanding; S.error |= L.sc[SC_ERR]; }
+  if (tid == 0) {
+    G.n = n; G.start_expanding = start_expanding; G.abs_t = abs_t; G.error = S.error | L.sc[SC_ERR];
+    G.pa_n = (uint32_t)L.sc[SC_PAN]; G.ta_n = (uint32_t)L.sc[SC_TAN]; G.be_n = (uint32_t)L.sc[SC_BEN];
+    for (int k = 0; k < 4; ++k) G.stat[k] = S.stat[k] + L.acc[k];
+    for (int k = 0; k < 8; ++k) G.phase[k] = S.phase[k] + L.acc[4 + k];
+  }
 }
 
 // ------------------------------------------------------------------------------------ decode

@@ -119,6 +119,7 @@ struct ModelState {
   DevBuf ws_audio, ws_nsamp, ws_nframes, ws_feats, ws_x1, ws_a, ws_b, ws_xproj, ws_hall, ws_logits, ws_probs;
   DevBuf ws_c, ws_hp0, ws_hp1, ws_hf32, ws_fbegin, ws_fcount;
   DevBuf ws_out_tok, ws_out_ts, ws_out_len, ws_out_conf, ws_out_n, ws_hot_hash, ws_hot_boost;
+  DecoderBatch batch_dec_;  // decoder streams of the STTX_SpeechToTextBatch* path, reused across calls
 
   ~ModelState();
   int InitFromBuffer(const char* buf, size_t len);  // STT_ERR_* code
