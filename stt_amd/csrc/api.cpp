@@ -17,9 +17,14 @@ namespace {
 int g_device = 0;
 const char* kVersion = "1.4.0";  // training/coqui_stt_training/VERSION of the reference this ABI mirrors
 
+// Stage timing with HIP events on the engine's own streams.  A mark says "stage `id` starts now on this stream"; the time
+// up to the next mark on the same stream is charged to that stage (id < 0 = idle / end).  Stage ids: 0 features,
+// 1 dense layers 1-3 + x-projection, 2 LSTM recurrence, 3 layers 5-6 + softmax, 4 decoder next, 5 decoder decode + D2H.
 struct Prof {
   bool on = false;
-  hipEvent_t ev[8] = {};
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  std::vector<std::pair<int, hipEvent_t>> marks[2];  // [0] = acoustic stream, [1] = decoder stream
   float ms[8] = {};
   unsigned long long dec_stats[4] = {};
   unsigned long long dec_phase[8] = {};
@@ -27,11 +32,25 @@ struct Prof {
 std::unordered_map<ModelState*, Prof> g_prof;
 
 Prof& prof_of(ModelState* m) { return g_prof[m]; }
-void mark(ModelState* m, int i) {
+void mark_on(ModelState* m, int id, int which) {
   Prof& p = prof_of(m);
   if (!p.on) return;
-  if (!p.ev[i]) HIP_CHECK(hipEventCreate(&p.ev[i]));
-  HIP_CHECK(hipEventRecord(p.ev[i], m->stream));
+  if (p.used == p.pool.size()) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); p.pool.push_back(e); }
+  hipEvent_t e = p.pool[p.used++];
+  HIP_CHECK(hipEventRecord(e, which ? m->stream_dec : m->stream));
+  p.marks[which].push_back({id, e});
+}
+void mark(ModelState* m, int id) { mark_on(m, id, 0); }
+void prof_reset(Prof& p) { p.used = 0; p.marks[0].clear(); p.marks[1].clear(); }
+void prof_collect(Prof& p) {  // both streams must be idle
+  for (auto& mk : p.marks)
+    for (size_t i = 0; i + 1 < mk.size(); ++i) {
+      if (mk[i].first < 0 || mk[i].first >= 6) continue;
+      float t = 0;
+      HIP_CHECK(hipEventElapsedTime(&t, mk[i].second, mk[i + 1].second));
+      p.ms[mk[i].first] += t;
+    }
+  prof_reset(p);
 }
 
 template <class F> int guarded(F&& f, int fail_code) {
@@ -112,42 +131,61 @@ int create_stream(ModelState* aCtx, StreamingState** retval, bool keep_emissions
 }
 
 // ---- batch path: every utterance goes through exactly the arithmetic of STT_SpeechToText ---------------------
+// Groups of <= 64 utterances.  Within a group the acoustic model runs in time-chunks on `stream` and the beam search of
+// chunk k runs on `stream_dec` while chunk k+1 is being computed (the search only occupies one workgroup per utterance).
+int batch_chunk_frames() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("STT_AMD_CHUNK"); v = e ? atoi(e) : 32; if (v < 1) v = 1 << 30; }
+  return v;
+}
 std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio, unsigned stride, const unsigned* sizes, unsigned B, unsigned num_results) {
   std::vector<std::vector<Output>> all;
   HIP_CHECK(hipSetDevice(m->device));
   Prof& pr = prof_of(m);
-  if (pr.on) { for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; }
+  if (pr.on) { for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; prof_reset(pr); }
+  if (!m->ev_chunk[0]) for (auto& e : m->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (unsigned g0 = 0; g0 < B; g0 += 64) {
     const int Bg = (int)std::min(64u, B - g0);
     std::vector<int> hn(Bg), nfr;
     int t_max = 1;
     for (int b = 0; b < Bg; ++b) { hn[b] = (int)sizes[g0 + b]; t_max = std::max(t_max, n_frames_for(m->g, hn[b])); }
+    const int Tc = std::min(batch_chunk_frames(), t_max);
+    const int n_chunks = (t_max + Tc - 1) / Tc;
     mark(m, 0);
     m->run_mfcc(d_audio + (size_t)g0 * stride, hn.data(), Bg, (int)stride, t_max, nfr);
-    mark(m, 1);
-    m->run_acoustic(m->ws_feats.as<float>(), m->ws_nframes.as<int>(), Bg, t_max, nullptr, nullptr, false);
-    mark(m, 4);
+    // decoder streams + per-chunk frame tables (begin, count per utterance), all enqueued on `stream`
     DecoderBatch& db = m->batch_dec_;  // slab and table stay allocated between calls (grow-only)
     m->decoder_create(db, Bg, (int)m->beam_width_, t_max, m->scorer_);
-    std::vector<int> zeros(Bg, 0);
-    m->ws_fbegin.upload(zeros.data(), Bg * 4, m->stream);
-    m->ws_fcount.upload(nfr.data(), Bg * 4, m->stream);
+    std::vector<int> tab((size_t)2 * n_chunks * Bg);
+    for (int k = 0; k < n_chunks; ++k)
+      for (int b = 0; b < Bg; ++b) {
+        tab[(size_t)(2 * k) * Bg + b] = k * Tc;
+        tab[(size_t)(2 * k + 1) * Bg + b] = std::max(0, std::min(Tc, nfr[b] - k * Tc));
+      }
+    m->ws_fbegin.upload(tab.data(), tab.size() * 4, m->stream);
     DecParams p{};
     p.C = m->g.n_classes; p.blank = p.C - 1; p.beam = db.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = t_max;
     DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
-    launch_ctc_next(p, ds, m->dev_alphabet, db.table.as<DecStream>(), Bg, m->ws_probs.as<float>(), m->ws_fbegin.as<int>(), m->ws_fcount.as<int>(), m->stream);
+    for (int k = 0; k < n_chunks; ++k) {
+      const int t0 = k * Tc, T = std::min(Tc, t_max - t0);
+      m->run_acoustic_chunk(m->ws_feats.as<float>(), m->ws_nframes.as<int>(), Bg, t_max, t0, T);  // marks 1, 2, 3
+      mark(m, -1);
+      hipEvent_t ev = m->ev_chunk[k % 2];  // an event may be re-recorded once the wait on it has been enqueued
+      HIP_CHECK(hipEventRecord(ev, m->stream));
+      HIP_CHECK(hipStreamWaitEvent(m->stream_dec, ev, 0));
+      mark_on(m, 4, 1);
+      const int* fb = m->ws_fbegin.as<int>() + (size_t)(2 * k) * Bg;
+      launch_ctc_next(p, ds, m->dev_alphabet, db.table.as<DecStream>(), Bg, m->ws_probs.as<float>(), fb, fb + Bg, m->stream_dec);
+      mark_on(m, -1, 1);
+    }
+    HIP_CHECK(hipEventRecord(m->ev_chunk[2], m->stream_dec));
+    HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_chunk[2], 0));
     mark(m, 5);
-    auto outs = decode_streams(*m, db, m->scorer_, m->hot_words_, num_results, 4096);
-    mark(m, 6);
+    auto outs = decode_streams(*m, db, m->scorer_, m->hot_words_, num_results, 4096);  // synchronises `stream`
+    mark(m, -1);
     if (pr.on) {
       HIP_CHECK(hipStreamSynchronize(m->stream));
-      float t;
-      HIP_CHECK(hipEventElapsedTime(&t, pr.ev[0], pr.ev[1])); pr.ms[0] += t;
-      HIP_CHECK(hipEventElapsedTime(&t, pr.ev[1], pr.ev[2])); pr.ms[1] += t;
-      HIP_CHECK(hipEventElapsedTime(&t, pr.ev[2], pr.ev[3])); pr.ms[2] += t;
-      HIP_CHECK(hipEventElapsedTime(&t, pr.ev[3], pr.ev[4])); pr.ms[3] += t;
-      HIP_CHECK(hipEventElapsedTime(&t, pr.ev[4], pr.ev[5])); pr.ms[4] += t;
-      HIP_CHECK(hipEventElapsedTime(&t, pr.ev[5], pr.ev[6])); pr.ms[5] += t;
+      prof_collect(pr);
       pr.ms[6] += (float)t_max; pr.ms[7] += (float)t_max * Bg;
       std::vector<DecStream> tb(Bg);
       HIP_CHECK(hipMemcpy(tb.data(), db.table.p, sizeof(DecStream) * Bg, hipMemcpyDeviceToHost));
@@ -218,7 +256,7 @@ int STT_GetModelSampleRate(const ModelState* aCtx) { return aCtx->g.sample_rate;
 void STT_FreeModel(ModelState* ctx) {
   if (!ctx) return;
   auto it = g_prof.find(ctx);
-  if (it != g_prof.end()) { for (auto e : it->second.ev) if (e) (void)hipEventDestroy(e); g_prof.erase(it); }
+  if (it != g_prof.end()) { for (auto e : it->second.pool) (void)hipEventDestroy(e); g_prof.erase(it); }
   delete ctx;
 }
 

@@ -28,53 +28,65 @@ void ModelState::run_mfcc(const int16_t* d_audio, const int* h_nsamples, int B, 
 
 // ------------------------------------------------------------------------------------------- acoustic model
 // rows: x1 [T*B][k1_pad] f16, row = t*B + b.  B <= 64.
-void ModelState::run_acoustic_rows(const _Float16* d_x1, int B, int T, float* d_c, float* d_h, bool carry_in, float* d_probs_out, int probs_t_max) {
+// carry: 0 = zero state, 1 = state from the f32 vectors d_c/d_h (streaming), 2 = continue from the engine's own
+// buffers (next time-chunk of the same batch; `t_par` = number of steps already run, for the h ping-pong parity).
+static void acoustic_rows(ModelState& m, const _Float16* d_x1, int B, int T, float* d_c, float* d_h, int carry, int t_par,
+                          float* d_probs_out, int probs_t_max) {
+  const Geometry& g = m.g;
+  hipStream_t stream = m.stream;
   const int H = g.n_hidden, M = T * B, C = g.n_classes;
   const int NT = lstm_nt_for_batch(B);
   if (NT < 0) throw std::runtime_error("run_acoustic_rows: batch > 64");
-  ws_a.reserve((size_t)M * H * 2); ws_b.reserve((size_t)M * H * 2);
-  ws_xproj.reserve((size_t)M * 4 * H * 4); ws_hall.reserve((size_t)M * H * 2);
-  ws_logits.reserve((size_t)M * g.c_pad() * 4);
+  m.ws_a.reserve((size_t)M * H * 2); m.ws_b.reserve((size_t)M * H * 2);
+  m.ws_xproj.reserve((size_t)M * 4 * H * 4); m.ws_hall.reserve((size_t)M * H * 2);
+  m.ws_logits.reserve((size_t)M * g.c_pad() * 4);
   const size_t hp_bytes = (size_t)(H / 32) * NT * 64 * 16;
-  ws_hp0.reserve(hp_bytes); ws_hp1.reserve(hp_bytes);
-  ws_c.reserve((size_t)B * H * 4);
+  m.ws_hp0.reserve(hp_bytes); m.ws_hp1.reserve(hp_bytes);
+  m.ws_c.reserve((size_t)B * H * 4);
   DenseArgs d{};
   d.relu_clip = g.relu_clip; d.M = M;
+  stt_prof_mark(&m, 1);
   // layers 1-3 (deepspeech_model.py:204-224)
-  d.wt = w1t.as<_Float16>(); d.x = d_x1; d.bias = b1.as<float>(); d.y = ws_a.p; d.N = H; d.K = g.k1_pad(); d.ldx = g.k1_pad(); d.ldy = H;
+  d.wt = m.w1t.as<_Float16>(); d.x = d_x1; d.bias = m.b1.as<float>(); d.y = m.ws_a.p; d.N = H; d.K = g.k1_pad(); d.ldx = g.k1_pad(); d.ldy = H;
   launch_dense(d, DENSE_EPI_RELU_F16, stream);
-  d.wt = w2t.as<_Float16>(); d.x = ws_a.as<_Float16>(); d.bias = b2.as<float>(); d.y = ws_b.p; d.K = H; d.ldx = H;
+  d.wt = m.w2t.as<_Float16>(); d.x = m.ws_a.as<_Float16>(); d.bias = m.b2.as<float>(); d.y = m.ws_b.p; d.K = H; d.ldx = H;
   launch_dense(d, DENSE_EPI_RELU_F16, stream);
-  d.wt = w3t.as<_Float16>(); d.x = ws_b.as<_Float16>(); d.bias = b3.as<float>(); d.y = ws_a.p;
+  d.wt = m.w3t.as<_Float16>(); d.x = m.ws_b.as<_Float16>(); d.bias = m.b3.as<float>(); d.y = m.ws_a.p;
   launch_dense(d, DENSE_EPI_RELU_F16, stream);
   // x-projection of all timesteps at once: [M][H] x [H][4H] + lstm bias
-  d.wt = wxt.as<_Float16>(); d.x = ws_a.as<_Float16>(); d.bias = bl.as<float>(); d.y = ws_xproj.p; d.N = 4 * H; d.ldy = 4 * H;
+  d.wt = m.wxt.as<_Float16>(); d.x = m.ws_a.as<_Float16>(); d.bias = m.bl.as<float>(); d.y = m.ws_xproj.p; d.N = 4 * H; d.ldy = 4 * H;
   launch_dense(d, DENSE_EPI_BIAS_F32, stream);
-  stt_prof_mark(this, 2);
+  stt_prof_mark(&m, 2);
   // recurrence
-  float* cbuf = d_c ? d_c : ws_c.as<float>();
-  if (!carry_in || !d_c) HIP_CHECK(hipMemsetAsync(cbuf, 0, (size_t)B * H * 4, stream));
-  if (carry_in && d_h) launch_pack_h(d_h, ws_hp0.p, B, H, NT, stream);
-  else HIP_CHECK(hipMemsetAsync(ws_hp0.p, 0, hp_bytes, stream));
+  float* cbuf = (carry != 2 && d_c) ? d_c : m.ws_c.as<float>();
+  if (carry == 0 || (carry == 1 && !d_c)) HIP_CHECK(hipMemsetAsync(cbuf, 0, (size_t)B * H * 4, stream));
+  void* hp_a = (t_par & 1) ? m.ws_hp1.p : m.ws_hp0.p;  // holds h_{t-1} for the first step of this call
+  if (carry == 1 && d_h) launch_pack_h(d_h, hp_a, B, H, NT, stream);
+  else if (carry != 2) HIP_CHECK(hipMemsetAsync(hp_a, 0, hp_bytes, stream));
   LstmArgs l{};
-  l.whp = whp.as<_Float16>(); l.xproj = ws_xproj.as<float>(); l.c = cbuf; l.h_all = ws_hall.as<_Float16>();
+  l.whp = m.whp.as<_Float16>(); l.xproj = m.ws_xproj.as<float>(); l.c = cbuf; l.h_all = m.ws_hall.as<_Float16>();
   l.n_hidden = H; l.batch = B;
   for (int t = 0; t < T; ++t) {
-    l.hp_in = (t & 1) ? ws_hp1.as<_Float16>() : ws_hp0.as<_Float16>();
-    l.hp_out = (t & 1) ? ws_hp0.as<_Float16>() : ws_hp1.as<_Float16>();
+    const bool odd = ((t_par + t) & 1) != 0;
+    l.hp_in = odd ? m.ws_hp1.as<_Float16>() : m.ws_hp0.as<_Float16>();
+    l.hp_out = odd ? m.ws_hp0.as<_Float16>() : m.ws_hp1.as<_Float16>();
     l.t = t;
     l.h_f32 = (t == T - 1) ? d_h : nullptr;
     launch_lstm_step(l, NT, stream);
   }
-  stt_prof_mark(this, 3);
+  stt_prof_mark(&m, 3);
   // layer 5, layer 6, softmax (deepspeech_model.py:241-252, 357)
-  d.wt = w5t.as<_Float16>(); d.x = ws_hall.as<_Float16>(); d.bias = b5.as<float>(); d.y = ws_b.p; d.N = H; d.K = H; d.ldx = H; d.ldy = H;
+  d.wt = m.w5t.as<_Float16>(); d.x = m.ws_hall.as<_Float16>(); d.bias = m.b5.as<float>(); d.y = m.ws_b.p; d.N = H; d.K = H; d.ldx = H; d.ldy = H;
   launch_dense(d, DENSE_EPI_RELU_F16, stream);
-  d.wt = w6t.as<_Float16>(); d.x = ws_b.as<_Float16>(); d.bias = b6.as<float>(); d.y = ws_logits.p; d.N = g.c_pad(); d.ldy = g.c_pad();
+  d.wt = m.w6t.as<_Float16>(); d.x = m.ws_b.as<_Float16>(); d.bias = m.b6.as<float>(); d.y = m.ws_logits.p; d.N = g.c_pad(); d.ldy = g.c_pad();
   launch_dense(d, DENSE_EPI_BIAS_F32, stream);
   SoftmaxArgs s{};
-  s.logits = ws_logits.as<float>(); s.probs = d_probs_out; s.M = M; s.C = C; s.ldl = g.c_pad(); s.batch = B; s.t_max = probs_t_max;
+  s.logits = m.ws_logits.as<float>(); s.probs = d_probs_out; s.M = M; s.C = C; s.ldl = g.c_pad(); s.batch = B; s.t_max = probs_t_max;
   launch_softmax(s, stream);
+}
+
+void ModelState::run_acoustic_rows(const _Float16* d_x1, int B, int T, float* d_c, float* d_h, bool carry_in, float* d_probs_out, int probs_t_max) {
+  acoustic_rows(*this, d_x1, B, T, d_c, d_h, carry_in ? 1 : 0, 0, d_probs_out, probs_t_max);
 }
 
 void ModelState::run_acoustic(const float* d_feats, const int* d_nframes, int B, int t_max, float* d_c, float* d_h, bool carry_in) {
@@ -83,9 +95,21 @@ void ModelState::run_acoustic(const float* d_feats, const int* d_nframes, int B,
   ws_probs.reserve((size_t)B * t_max * g.n_classes * 4);
   ContextArgs c{};
   c.feats = d_feats; c.n_frames = d_nframes; c.x1 = ws_x1.as<_Float16>();
-  c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = g.k1_pad();
+  c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = g.k1_pad(); c.t0 = 0;
   launch_context(c, M, stream);
   run_acoustic_rows(ws_x1.as<_Float16>(), B, t_max, d_c, d_h, carry_in, ws_probs.as<float>(), t_max);
+}
+
+void ModelState::run_acoustic_chunk(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T) {
+  const int M = T * B;
+  ws_x1.reserve((size_t)M * g.k1_pad() * 2);
+  ws_probs.reserve((size_t)B * t_max * g.n_classes * 4);
+  ContextArgs c{};
+  c.feats = d_feats; c.n_frames = d_nframes; c.x1 = ws_x1.as<_Float16>();
+  c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = g.k1_pad(); c.t0 = t0;
+  launch_context(c, M, stream);
+  // probs[b][t0 + t][:]: the softmax writes row (t, b) at probs + ((b*t_max + t)*C), so offsetting the base by t0*C lands it
+  acoustic_rows(*this, ws_x1.as<_Float16>(), B, T, nullptr, nullptr, t0 == 0 ? 0 : 2, t0, ws_probs.as<float>() + (size_t)t0 * g.n_classes, t_max);
 }
 
 // ------------------------------------------------------------------------------------------- decoder state

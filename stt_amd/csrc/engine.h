@@ -104,7 +104,8 @@ struct ModelState {
   std::shared_ptr<ScorerDev> scorer_;
   std::map<std::string, float> hot_words_;  // ordered => deterministic upload order
   unsigned beam_width_ = 500;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // acoustic model, streaming path, decode
+  hipStream_t stream_dec = nullptr;  // batch path: the beam search of chunk k runs here while `stream` computes chunk k+1
   int device = 0;
 
   // weights in HBM (f16, transposed / packed; see kernels_am.hip header)
@@ -120,6 +121,7 @@ struct ModelState {
   DevBuf ws_c, ws_hp0, ws_hp1, ws_hf32, ws_fbegin, ws_fcount;
   DevBuf ws_out_tok, ws_out_ts, ws_out_len, ws_out_conf, ws_out_n, ws_hot_hash, ws_hot_boost;
   DecoderBatch batch_dec_;  // decoder streams of the STTX_SpeechToTextBatch* path, reused across calls
+  hipEvent_t ev_chunk[3] = {};  // chunk hand-over acoustic stream -> decoder stream (2, alternating) and back (1)
 
   ~ModelState();
   int InitFromBuffer(const char* buf, size_t len);  // STT_ERR_* code
@@ -132,6 +134,9 @@ struct ModelState {
   void run_acoustic(const float* d_feats, const int* d_nframes, int B, int t_max, float* d_c, float* d_h, bool carry_in);
   // windows (device f16 [rows][k1_pad], row = t*B+b) -> probs; used by the chunked streaming path and STTX_InferChunk
   void run_acoustic_rows(const _Float16* d_x1, int B, int T, float* d_c, float* d_h, bool carry_in, float* d_probs_out, int probs_t_max);
+  // one time-chunk [t0, t0+T) of a batch: context rows from feats, then the layers; the LSTM state continues from the
+  // previous chunk (internal buffers) unless t0 == 0
+  void run_acoustic_chunk(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T);
 
   // ---- decoder ----
   DevScorer current_scorer(std::shared_ptr<ScorerDev> sc, const std::map<std::string, float>& hot, DevBuf& hh, DevBuf& hb) const;

@@ -23,6 +23,7 @@ struct ContextArgs {
   const int* n_frames;  // [B]
   _Float16* x1;         // [t_max*B][k_pad], row = t*B + b
   int batch, t_max, n_coef, n_context, k_pad;
+  int t0;               // first timestep of this launch (rows are local: row = (t - t0)*B + b)
 };
 
 // ---- dense --------------------------------------------------------------------------------------

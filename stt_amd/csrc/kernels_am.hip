@@ -98,9 +98,10 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccArgs a) {
 
 // context rows: x1[t*B+b][k] = feats[b][t - n_context + k/26][k%26] (zero outside [0, T_b)), k < 494; zero pad to 512
 __global__ __launch_bounds__(256) void context_kernel(ContextArgs a) {
-  const int row = blockIdx.x;  // t*B + b
-  const int t = row / a.batch;
-  const int b = row - t * a.batch;
+  const int row = blockIdx.x;  // (t - t0)*B + b
+  const int tl = row / a.batch;
+  const int b = row - tl * a.batch;
+  const int t = a.t0 + tl;
   const int nf = a.n_frames[b];
   const int kw = a.n_coef * (2 * a.n_context + 1);
   for (int k = threadIdx.x; k < a.k_pad; k += blockDim.x) {

@@ -68,6 +68,8 @@ void pack_lstm_recurrent_host(const float* kernel, int H, _Float16* out) {
 
 ModelState::~ModelState() {
   if (stream) (void)hipStreamDestroy(stream);
+  if (stream_dec) (void)hipStreamDestroy(stream_dec);
+  for (auto& e : ev_chunk) if (e) (void)hipEventDestroy(e);
 }
 
 int ModelState::InitFromBuffer(const char* buf, size_t len) {
@@ -98,6 +100,7 @@ int ModelState::InitFromBuffer(const char* buf, size_t len) {
 
   HIP_CHECK(hipSetDevice(device));
   if (!stream) HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  if (!stream_dec) HIP_CHECK(hipStreamCreateWithFlags(&stream_dec, hipStreamNonBlocking));
   {
     auto t = transpose_f16(l1w, K1, H, g.k1_pad(), H, H); w1t.upload(t.data(), t.size() * 2, stream);
     t = transpose_f16(l2w, H, H, H, H, H); w2t.upload(t.data(), t.size() * 2, stream);
