@@ -377,7 +377,7 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
 #define NWAVES (NTHREADS / 64)
 #define NBUCKET 1024   // selection histogram bins (one per thread)
 #define RCAP 128       // a threshold bucket with more members than this is subdivided instead of ranked pairwise
-#define HTN 2048       // LDS hash slots (>= 2 * STT_MAX_BEAM); the same storage later holds up to HTN selection keys
+#define HTN 2048       // LDS hash slots (>= 2 * STT_MAX_BEAM)
 
 struct Lds {
   float *score[2], *pb[2], *pnb[2];
@@ -386,9 +386,10 @@ struct Lds {
   uint64_t* key[2];
   float *ev_self, *ev_blank, *ev_ext;  // reused as new pnb / new pb / new score in P4
   uint32_t* ev_exti;                   // parent beam index | needs_lm << 31 ; reused as pending timestep parent
-  uint32_t *off, *a0;                  // expand work list: first item of prefix i, first FST arc of prefix i
-  uint64_t* ht_key; uint16_t* ht_idx;  // ht_key doubles as the selection-key buffer (kbuf) after P2
-  float *pf, *lp; uint16_t *cls, *pos;
+  uint64_t* ht_key; uint16_t* ht_idx;  // path key -> beam index of the live prefixes (rebuilt whenever the beam is written)
+  float *pf[2], *lp[2], *lps;          // emissions and their logs (double buffered: the next row is prepared one step ahead); lps = by class position when pruning sorts
+  double* lbl;                         // [2] log((double)prob[blank])
+  uint16_t *cls, *pos;
   uint8_t* lab1;                       // [C] the byte of every single-byte label (0 otherwise)
   uint32_t *hist, *cumb;
   uint64_t* skey; uint32_t *ssrc, *sseg;
@@ -415,9 +416,10 @@ __host__ __device__ inline size_t lds_carve(int beam, int C, Lds* l, unsigned ch
     for (int a = 0; a < 8; ++a) offs[k++] = take(cap * 4);         // score pb pnb ch node ts fst bnd
   }
   for (int a = 0; a < 4; ++a) offs[k++] = take(cap * 4);           // events
-  offs[k++] = take((cap + 1) * 4); offs[k++] = take(cap * 4);      // off, a0
-  offs[k++] = take(HTN * 8); offs[k++] = take(HTN * 2);            // hash / kbuf
-  offs[k++] = take((size_t)C * 4); offs[k++] = take((size_t)C * 4); offs[k++] = take((size_t)C * 2); offs[k++] = take((size_t)C * 2);
+  offs[k++] = take(HTN * 8); offs[k++] = take(HTN * 2);            // hash
+  for (int a = 0; a < 5; ++a) offs[k++] = take((size_t)C * 4);     // pf[2], lp[2], lps
+  offs[k++] = take(16);                                            // lbl[2]
+  offs[k++] = take((size_t)C * 2); offs[k++] = take((size_t)C * 2);
   offs[k++] = take((size_t)C);
   offs[k++] = take(NBUCKET * 4); offs[k++] = take((NBUCKET + 1) * 4);
   offs[k++] = take(sn * 8); offs[k++] = take(sn * 4); offs[k++] = take(sn * 4);
@@ -442,9 +444,11 @@ __host__ __device__ inline size_t lds_carve(int beam, int C, Lds* l, unsigned ch
     }
     l->ev_self = (float*)(base + offs[k++]); l->ev_blank = (float*)(base + offs[k++]); l->ev_ext = (float*)(base + offs[k++]);
     l->ev_exti = (uint32_t*)(base + offs[k++]);
-    l->off = (uint32_t*)(base + offs[k++]); l->a0 = (uint32_t*)(base + offs[k++]);
     l->ht_key = (uint64_t*)(base + offs[k++]); l->ht_idx = (uint16_t*)(base + offs[k++]);
-    l->pf = (float*)(base + offs[k++]); l->lp = (float*)(base + offs[k++]); l->cls = (uint16_t*)(base + offs[k++]); l->pos = (uint16_t*)(base + offs[k++]);
+    l->pf[0] = (float*)(base + offs[k++]); l->pf[1] = (float*)(base + offs[k++]);
+    l->lp[0] = (float*)(base + offs[k++]); l->lp[1] = (float*)(base + offs[k++]); l->lps = (float*)(base + offs[k++]);
+    l->lbl = (double*)(base + offs[k++]);
+    l->cls = (uint16_t*)(base + offs[k++]); l->pos = (uint16_t*)(base + offs[k++]);
     l->lab1 = (uint8_t*)(base + offs[k++]);
     l->hist = (uint32_t*)(base + offs[k++]); l->cumb = (uint32_t*)(base + offs[k++]);
     l->skey = (uint64_t*)(base + offs[k++]); l->ssrc = (uint32_t*)(base + offs[k++]); l->sseg = (uint32_t*)(base + offs[k++]);
@@ -518,35 +522,62 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #define CAND_LOGP(x) (((uint32_t)(x) < L.mcap) ? L.lc_logp[x] : S.c_logp[x])
 
 // ------------------------------------------------------------------------------------ one timestep
-__device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const DecStream& S, const Lds& L, int& cur, int& n,
-                         int& start_expanding, int& abs_t, const float* prob_row, const float* next_row, float& pre, bool has_pre) {
+// LDS hash insert of a live prefix key (value = beam index)
+__device__ __forceinline__ void ht_insert(const Lds& L, uint64_t k, int idx) {
+  uint32_t h = (uint32_t)(k >> 17) & (HTN - 1);
+  for (;;) {
+    const unsigned long long old = atomicCAS((unsigned long long*)&L.ht_key[h], 0ULL, (unsigned long long)k);
+    if (old == 0ULL) { L.ht_idx[h] = (uint16_t)idx; break; }
+    h = (h + 1) & (HTN - 1);
+  }
+}
+
+// Class log-probs of one emission row into buffer `buf` (get_pruned_emissions, :328-358, the part that does not depend
+// on the class order): pf = prob, lp = log(prob + NUM_FLT_MIN) in class order, lbl = log((double)prob[blank]) for the
+// min_cutoff of :142-143.  `v` is the caller's value for class `tid` (prefetched), classes >= NTHREADS are read here.
+__device__ __forceinline__ void prep_row(const DecParams& p, const Lds& L, int buf, const float* row, float v) {
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
+  for (int c = tid; c < p.C; c += NTHREADS) {
+    const float x = (c == tid) ? v : row[c];
+    L.pf[buf][c] = x;
+    L.lp[buf][c] = stt_logf(__fadd_rn(x, STT_FLT_MIN));
+    if (c == p.blank) L.lbl[buf] = log((double)x);
+  }
+}
+
+// `buf` holds this step's prepared emissions; `next_row` (or null) is prepared into buf^1 while the LM phase runs.
+__device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const DecStream& S, const Lds& L, int& cur, int& n,
+                         int& start_expanding, int& abs_t, int buf, const float* next_row) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int C = p.C, beam = p.beam;
   int* sc = L.sc;
   const float NEG = STT_NEG_INF;
+  const float* pf = L.pf[buf];
+  float* lp = L.lp[buf];
 
   unsigned long long tick_ = __builtin_readcyclecounter();
-  // ---- A: emissions to LDS; clear the hash, the per-prefix events and the selection histogram
-  // (the first NTHREADS classes of this row were fetched into `pre` during the previous step)
-  for (int c = tid; c < C; c += NTHREADS) L.pf[c] = (has_pre && c == tid) ? pre : prob_row[c];
-  if (next_row && tid < C) pre = next_row[tid];
-  for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
+  float pre = 0.0f;
+  if (next_row && tid < C) pre = next_row[tid];  // consumed in P3
+  if ((double)pf[p.blank] < 0.999) start_expanding = 1;  // :125-132 (uniform: every thread reads the same value)
+  if (!start_expanding) {
+    if (next_row) prep_row(p, L, buf ^ 1, next_row, pre);
+    abs_t++;
+    __syncthreads();
+    return;
+  }
+  // ---- A: clear the per-prefix events and the selection histogram (the hash of the live prefixes was built when the
+  // beam was written); class order / cut-off only when pruning is active
   for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
   L.hist[tid] = 0;
   if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; }
-  __syncthreads();
-  if ((double)L.pf[p.blank] < 0.999) start_expanding = 1;  // :125-132 (uniform: every thread reads the same value)
-  if (!start_expanding) { abs_t++; __syncthreads(); return; }
-
-  // ---- B: class log-probs (get_pruned_emissions, :328-358) and the LDS hash of the live prefixes
   const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
   int cutoff_len = C;
   if (sort_classes) {  // std::sort by probability, descending (ties: class index)
     for (int c = tid; c < C; c += NTHREADS) {
-      const float v = L.pf[c];
+      const float v = pf[c];
       int rank = 0;
-      for (int o = 0; o < C; ++o) { const float w = L.pf[o]; rank += (w > v) || (w == v && o < c); }
+      for (int o = 0; o < C; ++o) { const float w = pf[o]; rank += (w > v) || (w == v && o < c); }
       L.cls[rank] = (uint16_t)c;
       L.pos[c] = 0xFFFF;
     }
@@ -555,113 +586,104 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
       int cl = C;
       if (p.cutoff_prob < 1.0) {
         double cum = 0.0; cl = 0;
-        for (int i = 0; i < C; ++i) { cum = __dadd_rn(cum, (double)L.pf[L.cls[i]]); cl += 1; if (cum >= p.cutoff_prob || cl >= p.cutoff_top_n) break; }
+        for (int i = 0; i < C; ++i) { cum = __dadd_rn(cum, (double)pf[L.cls[i]]); cl += 1; if (cum >= p.cutoff_prob || cl >= p.cutoff_top_n) break; }
       }
       sc[SC_CUTLEN] = cl;
     }
     __syncthreads();
     cutoff_len = sc[SC_CUTLEN];
+    lp = L.lps;  // log-probs by class *position*
     for (int k = tid; k < cutoff_len; k += NTHREADS) {
       const int c = L.cls[k];
       L.pos[c] = (uint16_t)k;
-      L.lp[k] = stt_logf(__fadd_rn(L.pf[c], STT_FLT_MIN));  // log(prob + NUM_FLT_MIN), :355
-    }
-  } else {
-    for (int c = tid; c < C; c += NTHREADS) {
-      L.cls[c] = (uint16_t)c; L.pos[c] = (uint16_t)c;
-      L.lp[c] = stt_logf(__fadd_rn(L.pf[c], STT_FLT_MIN));
+      lp[k] = L.lp[buf][c];
     }
   }
   float min_cutoff = NEG;
   bool full_beam = false;
   if (s.enabled) {  // :136-146 (the beam is kept in prefix_compare order, so no partial_sort is needed)
-    const double mc = __dadd_rn(__dadd_rn((double)L.score[cur][n - 1], log((double)L.pf[p.blank])), -fmax(0.0, s.beta));
+    const double mc = __dadd_rn(__dadd_rn((double)L.score[cur][n - 1], L.lbl[buf]), -fmax(0.0, s.beta));
     min_cutoff = (float)mc;
     full_beam = (n == beam);
-  }
-  for (int i = tid; i < n; i += NTHREADS) {
-    const uint64_t k = L.key[cur][i];
-    uint32_t h = (uint32_t)(k >> 17) & (HTN - 1);
-    for (;;) {
-      const unsigned long long old = atomicCAS((unsigned long long*)&L.ht_key[h], 0ULL, (unsigned long long)k);
-      if (old == 0ULL) { L.ht_idx[h] = (uint16_t)i; break; }
-      h = (h + 1) & (HTN - 1);
-    }
   }
   __syncthreads();
   TICK(0);
 
-  // ---- P2: expand.  Blank / repeat events per live prefix, then one work item per (prefix, candidate label): with a
-  // dictionary only the out-arcs of the prefix's FST state can succeed (path_trie.cpp:54-64), otherwise every kept class.
+  // ---- P2: expand.  Wave w owns prefixes [w*ppw, (w+1)*ppw): blank / repeat events per prefix, then one work item per
+  // (prefix, candidate label) -- with a dictionary only the out-arcs of the prefix's FST state can succeed
+  // (path_trie.cpp:54-64), otherwise every kept class -- dealt to the lanes through a wave-local prefix sum.
   unsigned probes = 0;
-  uint32_t cnt = 0;
-  if (tid < n) {
-    const int i = tid;
-    const float sci = L.score[cur][i];
-    if (sci != NEG) {  // :160-162
-      const uint32_t chi = L.ch[cur][i];
-      {  // blank, :166-179
-        const int kb = L.pos[p.blank];
-        if (kb != 0xFFFF) { const float lpc = L.lp[kb]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_blank[i] = __fadd_rn(lpc, sci); }
+  {
+    uint32_t ppw = pow2_ge((uint32_t)((n + NWAVES - 1) / NWAVES));  // <= 64
+    const int i0 = wave * (int)ppw + lane;
+    uint32_t cnt = 0, a0 = 0;
+    if (lane < (int)ppw && i0 < n) {
+      const int i = i0;
+      const float sci = L.score[cur][i];
+      if (sci != NEG) {  // :160-162
+        const uint32_t chi = L.ch[cur][i];
+        {  // blank, :166-179
+          const int kb = L.pos[p.blank];
+          if (kb != 0xFFFF) { const float lpc = lp[kb]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_blank[i] = __fadd_rn(lpc, sci); }
+        }
+        if (chi != STT_ROOT_CH) {  // repeated character, :182-193
+          const int ks = L.pos[chi];
+          if (ks != 0xFFFF) { const float lpc = lp[ks]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_self[i] = __fadd_rn(lpc, L.pnb[cur][i]); }
+        }
+        if (s.enabled) {
+          const int st = L.fst[cur][i];
+          a0 = s.fst_state_pos[st];
+          cnt = s.fst_state_pos[st + 1] - a0;
+        } else {
+          cnt = (uint32_t)cutoff_len;
+        }
       }
-      if (chi != STT_ROOT_CH) {  // repeated character, :182-193
-        const int ks = L.pos[chi];
-        if (ks != 0xFFFF) { const float lpc = L.lp[ks]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_self[i] = __fadd_rn(lpc, L.pnb[cur][i]); }
-      }
+    }
+    const uint32_t inc = wave_incl_scan(cnt, lane);
+    const uint32_t off = inc - cnt;
+    const uint32_t n_items = __shfl(inc, 63);
+    for (uint32_t xb = 0; xb < n_items; xb += 64) {
+      const uint32_t x = xb + lane;
+      uint32_t j = 0;  // largest lane with off_j <= x (lanes with no items share their successor's offset)
+      for (uint32_t step = ppw >> 1; step >= 1; step >>= 1) { const uint32_t v = __shfl(off, (int)(j + step)); if (v <= x) j += step; }
+      const uint32_t offj = __shfl(off, (int)j), a0j = __shfl(a0, (int)j);
+      if (x >= n_items) continue;
+      const int i = wave * (int)ppw + (int)j;
+      const uint32_t kk = x - offj;
+      uint32_t c; int k; int child_fst = 0;
       if (s.enabled) {
-        const int st = L.fst[cur][i];
-        const uint32_t a0 = s.fst_state_pos[st];
-        cnt = s.fst_state_pos[st + 1] - a0;
-        L.a0[i] = a0;
+        const uint2 arc = s.fst_arcs[a0j + kk];
+        if (arc.x == 0 || arc.x > (uint32_t)(C - 1)) continue;  // epsilon / label outside the alphabet: never matched
+        c = arc.x - 1;
+        child_fst = (int)arc.y;
+        k = L.pos[c];
+        if (k == 0xFFFF) continue;
       } else {
-        cnt = (uint32_t)cutoff_len;
+        k = (int)kk;
+        c = L.cls[k];
       }
-    }
-  }
-  uint32_t n_items;
-  const uint32_t excl = block_excl_scan(cnt, L.wtot, n_items);
-  if (tid < n) L.off[tid] = excl;
-  if (tid == 0) L.off[n] = n_items;
-  __syncthreads();
-  TICK(1);
-  for (uint32_t x = tid; x < n_items; x += NTHREADS) {
-    int lo = 0, hi = n - 1;  // largest i with off[i] <= x
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L.off[mid] <= x) lo = mid; else hi = mid - 1; }
-    const int i = lo;
-    const uint32_t kk = x - L.off[i];
-    uint32_t c; int k; int child_fst = 0;
-    if (s.enabled) {
-      const uint2 arc = s.fst_arcs[L.a0[i] + kk];
-      if (arc.x == 0 || arc.x > (uint32_t)(C - 1)) continue;  // epsilon / label outside the alphabet: never matched
-      c = arc.x - 1;
-      child_fst = (int)arc.y;
-      k = L.pos[c];
-      if (k == 0xFFFF) continue;
-    } else {
-      k = (int)kk;
-      c = L.cls[k];
-    }
-    if ((int)c == p.blank) continue;
-    const float sci = L.score[cur][i];
-    const uint32_t chi = L.ch[cur][i];
-    const float lpc = L.lp[k];
-    if (full_beam && __fadd_rn(lpc, sci) < min_cutoff) continue;  // the `break` of :157-159 (beam is sorted by score)
-    float log_p = NEG;  // :199-207
-    if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
-    else log_p = __fadd_rn(lpc, sci);
-    uint32_t needs_lm = 0;
-    if (s.enabled) needs_lm = s.utf8 ? (is_scoring_boundary(s, al, S.pa, L.node[cur][i], c, c, probes) ? 1u : 0u) : ((int)c == al.space_id ? 1u : 0u);
-    const uint64_t ck = child_key(L.key[cur][i], c);
-    const int j = ht_find(L, ck);
-    if (j >= 0) {  // the child is a live prefix: one extension event per live prefix per step
-      L.ev_ext[j] = log_p;
-      L.ev_exti[j] = (uint32_t)i | (needs_lm << 31);
-    } else {
-      const int slot = atomicAdd(&sc[SC_M], 1);
-      if ((uint32_t)slot < S.cand_cap) {
-        const uint32_t piv = (uint32_t)i | ((uint32_t)k << 16) | (needs_lm << 31);
-        if ((uint32_t)slot < L.mcap) { L.lc_logp[slot] = log_p; L.lc_pi[slot] = piv; L.lc_fst[slot] = child_fst; }
-        else { S.c_logp[slot] = log_p; S.c_pi[slot] = piv; S.c_fst[slot] = child_fst; }
+      if ((int)c == p.blank) continue;
+      const float sci = L.score[cur][i];
+      const uint32_t chi = L.ch[cur][i];
+      const float lpc = lp[k];
+      if (full_beam && __fadd_rn(lpc, sci) < min_cutoff) continue;  // the `break` of :157-159 (beam is sorted by score)
+      float log_p = NEG;  // :199-207
+      if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
+      else log_p = __fadd_rn(lpc, sci);
+      uint32_t needs_lm = 0;
+      if (s.enabled) needs_lm = s.utf8 ? (is_scoring_boundary(s, al, S.pa, L.node[cur][i], c, c, probes) ? 1u : 0u) : ((int)c == al.space_id ? 1u : 0u);
+      const uint64_t ck = child_key(L.key[cur][i], c);
+      const int jj = ht_find(L, ck);
+      if (jj >= 0) {  // the child is a live prefix: one extension event per live prefix per step
+        L.ev_ext[jj] = log_p;
+        L.ev_exti[jj] = (uint32_t)i | (needs_lm << 31);
+      } else {
+        const int slot = atomicAdd(&sc[SC_M], 1);
+        if ((uint32_t)slot < S.cand_cap) {
+          const uint32_t piv = (uint32_t)i | ((uint32_t)k << 16) | (needs_lm << 31);
+          if ((uint32_t)slot < L.mcap) { L.lc_logp[slot] = log_p; L.lc_pi[slot] = piv; L.lc_fst[slot] = child_fst; }
+          else { S.c_logp[slot] = log_p; S.c_pi[slot] = piv; S.c_fst[slot] = child_fst; }
+        }
       }
     }
   }
@@ -670,7 +692,10 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   if ((uint32_t)m > S.cand_cap) { m = (int)S.cand_cap; if (tid == 0) sc[SC_ERR] |= 4; }
   TICK(2);
 
-  // ---- P3: language model on scoring boundaries (:209-243)
+  // ---- P3: language model on scoring boundaries (:209-243); meanwhile the next row's class log-probs; the hash is
+  // dead from here on and is cleared for the next beam
+  for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
+  if (next_row) prep_row(p, L, buf ^ 1, next_row, pre);
   if (s.enabled) {
     unsigned lmq = 0;
     for (int x = tid; x < m + n; x += NTHREADS) {
@@ -707,39 +732,42 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   TICK(3);
 
   // ---- P4: merge events of live prefixes in the reference's visiting order (class position, then beam index);
-  // selection keys of live prefixes and candidates
+  // selection keys of live prefixes and candidates.  Element e (live prefix e < n, else candidate e - n) belongs to
+  // thread e % NTHREADS; its first two keys stay in registers, further ones go to the HBM workspace.
   const int total = n + m;
-  uint64_t* keys = (total <= HTN) ? L.ht_key : S.sel_keys;  // the hash is dead from here on
+  uint64_t kreg0 = ~0ULL, kreg1 = ~0ULL;
   uint32_t hmin = 0xFFFFFFFFu, hmax = 0;
-  for (int j = tid; j < n; j += NTHREADS) {
-    const float e_self = L.ev_self[j], e_blank = L.ev_blank[j], e_ext = L.ev_ext[j];
-    const uint32_t ei = L.ev_exti[j] & 0x7FFFFFFFu;
-    float nb = NEG, bb = NEG;
-    uint32_t pend = 0xFFFFFFFEu;  // "no pending update" (previous_timesteps == nullptr)
-    const uint32_t chj = L.ch[cur][j];
-    const int kblank = L.pos[p.blank];
-    const int kself = chj == STT_ROOT_CH ? 0xFFFF : L.pos[chj];
-    const bool blank_first = kblank < kself;
-    if (blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
-    const bool ext_first = (int)ei < j;
-    if (ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = stt_log_sum_exp(nb, e_ext); }
-    if (!is_absent(e_self)) { if (nb < e_self) pend = 0xFFFFFFFEu; nb = stt_log_sum_exp(nb, e_self); }
-    if (!ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = stt_log_sum_exp(nb, e_ext); }
-    if (!blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
-    const float nscore = stt_log_sum_exp(bb, nb);  // iterate_to_vec, path_trie.cpp:170
-    L.ev_blank[j] = bb; L.ev_self[j] = nb; L.ev_ext[j] = nscore; L.ev_exti[j] = pend;
-    const uint64_t k = sel_key(nscore, chj, 0, (uint32_t)j);
-    keys[j] = k;
+  for (int e = tid, r = 0; e < total; e += NTHREADS, ++r) {
+    uint64_t k;
+    if (e < n) {
+      const int j = e;
+      const float e_self = L.ev_self[j], e_blank = L.ev_blank[j], e_ext = L.ev_ext[j];
+      const uint32_t ei = L.ev_exti[j] & 0x7FFFFFFFu;
+      float nb = NEG, bb = NEG;
+      uint32_t pend = 0xFFFFFFFEu;  // "no pending update" (previous_timesteps == nullptr)
+      const uint32_t chj = L.ch[cur][j];
+      const int kblank = L.pos[p.blank];
+      const int kself = chj == STT_ROOT_CH ? 0xFFFF : L.pos[chj];
+      const bool blank_first = kblank < kself;
+      if (blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
+      const bool ext_first = (int)ei < j;
+      if (ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = stt_log_sum_exp(nb, e_ext); }
+      if (!is_absent(e_self)) { if (nb < e_self) pend = 0xFFFFFFFEu; nb = stt_log_sum_exp(nb, e_self); }
+      if (!ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = stt_log_sum_exp(nb, e_ext); }
+      if (!blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
+      const float nscore = stt_log_sum_exp(bb, nb);  // iterate_to_vec, path_trie.cpp:170
+      L.ev_blank[j] = bb; L.ev_self[j] = nb; L.ev_ext[j] = nscore; L.ev_exti[j] = pend;
+      k = sel_key(nscore, chj, 0, (uint32_t)j);
+    } else {
+      const int x = e - n;
+      const uint32_t pi = CAND_PI(x);
+      k = sel_key(CAND_LOGP(x), (uint32_t)L.cls[(pi >> 16) & 0x7FFFu], 1, pi & 0xFFFFu);
+    }
+    if (r == 0) kreg0 = k; else if (r == 1) kreg1 = k; else S.sel_keys[e] = k;
     const uint32_t kh = (uint32_t)(k >> 32);
     hmin = kh < hmin ? kh : hmin; if (kh != NEG_HI) hmax = kh > hmax ? kh : hmax;
   }
-  for (int x = tid; x < m; x += NTHREADS) {
-    const uint32_t pi = CAND_PI(x);
-    const uint64_t k = sel_key(CAND_LOGP(x), (uint32_t)L.cls[(pi >> 16) & 0x7FFFu], 1, pi & 0xFFFFu);
-    keys[n + x] = k;
-    const uint32_t kh = (uint32_t)(k >> 32);
-    hmin = kh < hmin ? kh : hmin; if (kh != NEG_HI) hmax = kh > hmax ? kh : hmax;
-  }
+#define KEY_OF(e, r) ((r) == 0 ? kreg0 : (r) == 1 ? kreg1 : S.sel_keys[e])
   hmin = wave_min_u32(hmin); hmax = wave_max_u32(hmax);
   if (lane == 0) { atomicMin((unsigned int*)&sc[SC_KMIN], hmin); atomicMax((unsigned int*)&sc[SC_KMAX], hmax); }
   __syncthreads();
@@ -766,8 +794,8 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
     int need = keep, off = 0;
     uint32_t placed = 0;
     for (;;) {
-      for (int x = tid; x < total; x += NTHREADS) {
-        const uint64_t k0 = keys[x];
+      for (int e = tid, r = 0; e < total; e += NTHREADS, ++r) {
+        const uint64_t k0 = KEY_OF(e, r);
         const uint64_t k = REKEY(k0);
         if (k < base) continue;
         const uint64_t d = k - base;
@@ -784,8 +812,8 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
       __syncthreads();
       const uint32_t bt = (uint32_t)sc[SC_BT], bth = (uint32_t)sc[SC_BTH], btcum = (uint32_t)sc[SC_BTCUM];
       const bool last = (bth <= RCAP) || sh == 0;
-      for (int x = tid; x < total; x += NTHREADS) {
-        const uint64_t k0 = keys[x];
+      for (int e = tid, r = 0; e < total; e += NTHREADS, ++r) {
+        const uint64_t k0 = KEY_OF(e, r);
         const uint64_t k = REKEY(k0);
         if (k < base) continue;
         const uint64_t d = k - base;
@@ -795,7 +823,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
           const uint32_t seg0 = (uint32_t)off + L.cumb[b];
           const uint32_t len = L.cumb[b + 1] - L.cumb[b];
           const uint32_t at = seg0 + (atomicSub(&L.hist[b], 1u) - 1u);
-          L.skey[at] = k; L.ssrc[at] = (uint32_t)x; L.sseg[at] = seg0 | (len << 16);
+          L.skey[at] = k; L.ssrc[at] = (uint32_t)e; L.sseg[at] = seg0 | (len << 16);
         }
       }
       if (last) { placed = (uint32_t)off + btcum + bth; break; }
@@ -810,7 +838,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
     __syncthreads();
     TICK(5);
 
-    // rank inside the segment -> position r in the new beam; write the new beam entry (P6)
+    // rank inside the segment -> position r in the new beam; write the new beam entry (P6) and hash its key
     for (uint32_t q = tid; q < placed; q += NTHREADS) {
       const uint64_t k = L.skey[q];
       const uint32_t seg = L.sseg[q];
@@ -820,9 +848,11 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
       if ((int)r >= keep) continue;
       const uint32_t x = L.ssrc[q];
       uint32_t ts_new, pend;
+      uint64_t nkey;
       if ((int)x < n) {
         L.score[nxt][r] = L.ev_ext[x]; L.pb[nxt][r] = L.ev_blank[x]; L.pnb[nxt][r] = L.ev_self[x];
-        L.ch[nxt][r] = L.ch[cur][x]; L.node[nxt][r] = L.node[cur][x]; L.fst[nxt][r] = L.fst[cur][x]; L.key[nxt][r] = L.key[cur][x];
+        L.ch[nxt][r] = L.ch[cur][x]; L.node[nxt][r] = L.node[cur][x]; L.fst[nxt][r] = L.fst[cur][x];
+        nkey = L.key[cur][x];
         L.bnd[nxt][r] = L.bnd[cur][x];
         pend = L.ev_exti[x]; ts_new = L.ts[cur][x];
       } else {
@@ -833,7 +863,8 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
         const float lpv = CAND_LOGP(cx);
         const uint32_t pnode = L.node[cur][i];
         L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
-        L.ch[nxt][r] = c; L.fst[nxt][r] = ((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst[cx]; L.key[nxt][r] = child_key(L.key[cur][i], c);
+        L.ch[nxt][r] = c; L.fst[nxt][r] = ((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst[cx];
+        nkey = child_key(L.key[cur][i], c);
         uint32_t b = L.bnd[cur][i];
         if (s.enabled && !s.utf8 && (int)c == al.space_id) b = S.pq[pnode];  // the boundary entry scored in P3 (or earlier)
         L.bnd[nxt][r] = b;
@@ -843,6 +874,8 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
         pend = (NEG < lpv) ? L.ts[cur][i] : 0xFFFFFFFEu;  // :246-251 with log_prob_nb_cur == -inf
         ts_new = STT_ROOT_CH;                              // timesteps == nullptr
       }
+      L.key[nxt][r] = nkey;
+      ht_insert(L, nkey, (int)r);
       if (pend != 0xFFFFFFFEu) {  // path_trie.cpp:172-184
         const uint32_t slot = atomicAdd((uint32_t*)&sc[SC_TAN], 1u);
         if (slot < S.ta_cap) { S.ta[slot] = make_uint2(pend, (uint32_t)abs_t); ts_new = slot; }
@@ -851,9 +884,8 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
       L.ts[nxt][r] = ts_new;
     }
   }
-  __syncthreads();
-  TICK(6);
 #undef REKEY
+#undef KEY_OF
   if (tid == 0) {
     L.acc[0] += 1; L.acc[1] += (unsigned long long)m; L.acc[2] += (unsigned long long)sc[SC_LMQ]; L.acc[3] += (unsigned long long)(unsigned)sc[SC_PROBES];
   }
@@ -861,7 +893,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   cur = nxt;
   n = keep;
   __syncthreads();
-  TICK(7);
+  TICK(6);
 }
 
 __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScorer s, DevAlphabet al, DecStream* streams,
@@ -878,6 +910,8 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   int cur = 0;
   int start_expanding = S.start_expanding;
   int abs_t = S.abs_t;
+  const float* row = probs + ((size_t)blockIdx.x * p.t_max + frame_begin[blockIdx.x]) * p.C;
+  const float v0 = tid < p.C ? row[tid] : 0.0f;
   for (int i = tid; i < n; i += NTHREADS) {
     L.score[0][i] = S.score[i]; L.pb[0][i] = S.pb[i]; L.pnb[0][i] = S.pnb[i];
     L.ch[0][i] = S.ch[i]; L.node[0][i] = S.node[i]; L.ts[0][i] = S.ts[i]; L.fst[0][i] = S.fst[i]; L.key[0][i] = S.key[i];
@@ -887,14 +921,17 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
     uint8_t one = 0;
     if (c < al.n_labels) { const int b0 = c ? al.label_off[c - 1] : 0; if (al.label_off[c] - b0 == 1) one = al.label_bytes[b0]; }
     L.lab1[c] = one;
+    L.cls[c] = (uint16_t)c; L.pos[c] = (uint16_t)c;  // identity class order unless pruning re-sorts it every step
   }
+  for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
   if (tid == 0) { L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)S.pa_n; L.sc[SC_TAN] = (int)S.ta_n; L.sc[SC_BEN] = (int)S.be_n; }
   if (tid < 12) L.acc[tid] = 0;
+  prep_row(p, L, 0, row, v0);
   __syncthreads();
-  const float* row = probs + ((size_t)blockIdx.x * p.t_max + frame_begin[blockIdx.x]) * p.C;
-  float pre = 0.0f;
+  for (int i = tid; i < n; i += NTHREADS) ht_insert(L, L.key[0][i], i);
+  __syncthreads();
   for (int t = 0; t < nfr; ++t)
-    ctc_step(p, s, al, S, L, cur, n, start_expanding, abs_t, row + (size_t)t * p.C, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr, pre, t > 0);
+    ctc_step(p, s, al, S, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr);
   for (int i = tid; i < n; i += NTHREADS) {
     S.score[i] = L.score[cur][i]; S.pb[i] = L.pb[cur][i]; S.pnb[i] = L.pnb[cur][i];
     S.ch[i] = L.ch[cur][i]; S.node[i] = L.node[cur][i]; S.ts[i] = L.ts[cur][i]; S.fst[i] = L.fst[cur][i]; S.key[i] = L.key[cur][i];
