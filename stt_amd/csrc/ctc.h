@@ -85,7 +85,7 @@ struct DecStream {
   int n;                // live prefixes
   int abs_t;            // abs_time_step_
   int start_expanding;  // ctc_beam_search_decoder.cpp:125-132
-  int error;            // bit0: path arena full, bit1: time arena full, bit2: candidate workspace full
+  int error;            // bit0: path arena full, bit1: time arena full, bit2: candidate workspace full, bit3: scorer cache state lost
   uint32_t pa_n, ta_n, pa_cap, ta_cap;
   // beam arrays [beam_cap]
   float *score, *pb, *pnb;

@@ -27,6 +27,53 @@
 using sttm::stt_log_sum_exp;
 using sttm::stt_logf;
 
+// Every LDS pointer carries address space 3: the accesses compile to ds_read/ds_write/ds_add (32-bit addresses, LDS
+// counter only) instead of flat_* instructions, which resolve the aperture at run time and wait on both counters.
+#define LDS_AS __attribute__((address_space(3)))
+__device__ __forceinline__ uint32_t lds_add(LDS_AS uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int lds_add(LDS_AS int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lds_sub(LDS_AS uint32_t* p, uint32_t v) { return __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_or(LDS_AS int* p, int v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_min(LDS_AS uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_max(LDS_AS uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// returns the previous value (0 = the slot was empty and now holds `desired`)
+__device__ __forceinline__ uint64_t lds_cas0(LDS_AS uint64_t* p, uint64_t desired) {
+  uint64_t expected = 0;
+  __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return expected;
+}
+
+// The stream's HBM arrays as explicit global-memory (address space 1) pointers: global_load/global_store instead of
+// flat_*, so waiting for an LDS result does not also wait for the HBM reads in flight (flat ops count on both counters).
+#define GLB_AS __attribute__((address_space(1)))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct GStream {
+  GLB_AS uint64_t *pa, *ta;  // {parent (low word), character / timestep (high word)}
+  GLB_AS uint32_t* pq;
+  GLB_AS u32x4* be;          // BEntry = 4 x 16 bytes
+  GLB_AS float* c_logp; GLB_AS uint32_t* c_pi; GLB_AS int* c_fst; GLB_AS uint64_t* sel_keys;
+  const uint2* pa_generic;   // for the uncached scorer paths
+  uint32_t cand_cap, pa_cap, ta_cap, be_cap;
+};
+union BEntryBits { BEntry e; u32x4 q[4]; __device__ BEntryBits() {} };
+__device__ __forceinline__ BEntry load_be(const GStream& S, uint32_t idx) {
+  BEntryBits b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b.q[i] = S.be[(size_t)idx * 4 + i];
+  return b.e;
+}
+__device__ __forceinline__ void store_be(const GStream& S, uint32_t idx, const BEntry& e) {
+  BEntryBits b; b.e = e;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) S.be[(size_t)idx * 4 + i] = b.q[i];
+}
+__device__ __forceinline__ double load_be_raw(const GStream& S, uint32_t idx) {  // BEntry::raw is the first 8 bytes
+  const GLB_AS double* p = (const GLB_AS double*)(S.be + (size_t)idx * 4);
+  return *p;
+}
+__device__ __forceinline__ uint2 load_node(const GLB_AS uint64_t* a, uint32_t idx) { const uint64_t v = a[idx]; return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
+__device__ __forceinline__ void store_node(GLB_AS uint64_t* a, uint32_t idx, uint32_t x, uint32_t y) { a[idx] = (uint64_t)x | ((uint64_t)y << 32); }
+
 #define NTHREADS 1024
 #define ABSENT_BITS 0xFFFFFFFFu
 #define OOV_SCORE_D (-1000.0)  // scorer.h:16
@@ -289,7 +336,7 @@ __device__ bool is_scoring_boundary(const DevScorer& s, const DevAlphabet& al, c
 // the last `order` words from a null context (or all words from BeginSentence when there are fewer), and a KenLM state
 // holds at most order-1 words, so the state carried from the previous boundary is the state the reference rebuilds.
 // Appends a BEntry and records it in S.pq[node]; returns log_cond_prob + hot_boost.
-__device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al, const DecStream& S, const uint8_t* lab1, uint32_t* be_n, uint32_t node, uint32_t e_prev, unsigned& probes) {
+__device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al, const GStream& S, const LDS_AS uint8_t* lab1, LDS_AS uint32_t* be_n, uint32_t node, uint32_t e_prev, unsigned& probes) {
   // Walk back to the previous boundary collecting the word's UTF-8 bytes.  Labels arrive newest first, so shifting each
   // byte in from the low end leaves the word in little-endian order (first byte lowest): exactly the two 8-byte blocks
   // MurmurHash64A consumes.  Words longer than 16 bytes take the generic label-array path.
@@ -297,7 +344,7 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
   int nbytes = 0;
   bool overflow = false;
   for (uint32_t cur = node; cur != STT_ROOT_CH;) {
-    const uint2 pn = S.pa[cur];
+    const uint2 pn = load_node(S.pa, cur);
     ++probes;
     if (pn.y == (uint32_t)al.space_id || pn.y == STT_ROOT_CH) break;
     const uint8_t one = lab1[pn.y];  // LDS copy of single-byte labels (0 = multi-byte label: read it from HBM)
@@ -334,7 +381,7 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
     uint32_t labs[MAX_UNIT_LABELS];
     int nl = 0;
     for (uint32_t cur = node; cur != STT_ROOT_CH;) {
-      const uint2 pn = S.pa[cur];
+      const uint2 pn = load_node(S.pa, cur);
       ++probes;
       if (pn.y == (uint32_t)al.space_id || pn.y == STT_ROOT_CH) break;
       if (nl < MAX_UNIT_LABELS) labs[nl++] = pn.y;
@@ -343,7 +390,7 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
     h = hash_labels_reversed(al, labs, nl);
   }
   const uint32_t wi = vocab_index(s, h, probes);
-  const BEntry ep = S.be[e_prev];
+  const BEntry ep = load_be(S, e_prev);
   ++probes;
   BEntry en;
   const float prob = kenlm_full_score(s, ep.st, wi, en.st, probes);
@@ -360,7 +407,7 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
     while (k < s.order - 1 && e != 0 && e != STT_NONE) {  // entry 0 = root: no word
       hs[k++] = cur.hot_self;
       e = cur.prev;
-      if (e != 0 && e != STT_NONE) { cur = S.be[e]; ++probes; }
+      if (e != 0 && e != STT_NONE) { cur = load_be(S, e); ++probes; }
     }
     for (int i = k - 1; i >= 0; --i) hot_total = __fadd_rn(hot_total, hs[i]);  // oldest word first, like the reference's loop
     hot_total = __fadd_rn(hot_total, hot_self);
@@ -368,8 +415,8 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
   const double lcp = oov ? OOV_SCORE_D : __ddiv_rn((double)prob, (double)0.4342944819f);
   en.raw = __dadd_rn(lcp, (double)hot_total);
   en.prev = e_prev; en.pad = 0; en.hot_self = hot_self;
-  const uint32_t idx = atomicAdd(be_n, 1u);  // LDS copy of the arena fill (written back when the launch ends)
-  if (idx < S.be_cap) { S.be[idx] = en; S.pq[node] = idx; }
+  const uint32_t idx = lds_add(be_n, 1u);  // LDS copy of the arena fill (written back when the launch ends)
+  if (idx < S.be_cap) { store_be(S, idx, en); S.pq[node] = idx; }
   return en.raw;
 }
 
@@ -379,53 +426,69 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
 #define RCAP 128       // a threshold bucket with more members than this is subdivided instead of ranked pairwise
 #define HTN 2048       // LDS hash slots (>= 2 * STT_MAX_BEAM)
 
+// A double-buffered LDS array: buffer d starts `blk` bytes after buffer 0.  (An array of two pointers indexed with a
+// run-time `cur` would force the whole Lds struct into scratch memory and turn every beam access into a scratch load.)
+template <class T> struct DB {
+  LDS_AS T* p0; uint32_t blk;
+  __device__ __forceinline__ LDS_AS T* operator[](int d) const { return (LDS_AS T*)((LDS_AS unsigned char*)p0 + (uint32_t)d * blk); }
+};
 struct Lds {
-  float *score[2], *pb[2], *pnb[2];
-  uint32_t *ch[2], *node[2], *ts[2], *bnd[2];
-  int* fst[2];
-  uint64_t* key[2];
-  float *ev_self, *ev_blank, *ev_ext;  // reused as new pnb / new pb / new score in P4
-  uint32_t* ev_exti;                   // parent beam index | needs_lm << 31 ; reused as pending timestep parent
-  uint64_t* ht_key; uint16_t* ht_idx;  // path key -> beam index of the live prefixes (rebuilt whenever the beam is written)
-  float *pf[2], *lp[2], *lps;          // emissions and their logs (double buffered: the next row is prepared one step ahead); lps = by class position when pruning sorts
-  double* lbl;                         // [2] log((double)prob[blank])
-  uint16_t *cls, *pos;
-  uint8_t* lab1;                       // [C] the byte of every single-byte label (0 otherwise)
-  uint32_t *hist, *cumb;
-  uint64_t* skey; uint32_t *ssrc, *sseg;
-  uint32_t* wtot;
+  DB<float> score, pb, pnb;
+  DB<uint32_t> ch, node, ts, bnd;
+  DB<int> fst;
+  DB<uint32_t> a0; DB<uint16_t> an;    // out-arcs of the prefix's dictionary state: first arc, count (read when the beam is written)
+  DB<uint64_t> key;
+  LDS_AS float *ev_self, *ev_blank, *ev_ext;  // reused as new pnb / new pb / new score in P4
+  LDS_AS uint32_t* ev_exti;                   // parent beam index | needs_lm << 31 ; reused as pending timestep parent
+  LDS_AS uint64_t* ht_key; LDS_AS uint16_t* ht_idx;  // path key -> beam index of the live prefixes (rebuilt whenever the beam is written)
+  DB<float> pf, lp; LDS_AS float* lps;        // emissions and their logs (double buffered: the next row is prepared one step ahead); lps = by class position when pruning sorts
+  LDS_AS double* lbl;                         // [2] log((double)prob[blank])
+  LDS_AS uint16_t *cls, *pos;
+  LDS_AS uint8_t* lab1;                       // [C] the byte of every single-byte label (0 otherwise)
+  LDS_AS uint32_t *hist, *cumb;
+  LDS_AS uint64_t* skey; LDS_AS uint32_t *ssrc, *sseg;
+  LDS_AS uint32_t* wtot;
   // the first `mcap` candidates of a step live in LDS, the rest in the stream's HBM workspace
-  float* lc_logp; uint32_t* lc_pi; int* lc_fst; uint32_t mcap;
-  unsigned long long* acc;  // [0..3] stat counters, [4..11] phase cycles (accumulated in LDS, flushed when the launch ends)
-  int* sc;  // scalars
+  LDS_AS float* lc_logp; LDS_AS uint32_t* lc_pi; LDS_AS int* lc_fst; uint32_t mcap;
+  LDS_AS unsigned long long* acc;  // [0..3] stat counters, [4..11] phase cycles (accumulated in LDS, flushed when the launch ends)
+  LDS_AS int* sc;  // scalars
 };
 #define TICK(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); L.acc[4 + (k)] += now_ - tick_; tick_ = now_; } } while (0)
-enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_COUNT = 16 };
+enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_COUNT = 16 };
 #define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
 __host__ __device__ inline uint32_t pow2_ge(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
-__host__ __device__ inline size_t lds_carve(int beam, int C, Lds* l, unsigned char* base) {
-  const uint32_t cap = (uint32_t)((beam + 63) & ~63);
-  const uint32_t sn = cap + RCAP;
+// Layout for a beam capacity CAP (a compile-time constant: every array that only depends on CAP sits at a constant LDS
+// address, which the compiler folds into the ds_* instructions instead of keeping ~50 pointers alive in registers).
+// The class-count dependent arrays and the candidate staging area come last.
+template <int CAP>
+__host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, LDS_AS unsigned char* base, size_t& total) {
+  Lds L{};
+  Lds* l = &L;
+  constexpr uint32_t cap = CAP;
+  constexpr uint32_t sn = cap + RCAP;
+  constexpr bool arcs = cap <= 512;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
-  size_t offs[64]; int k = 0;
+  size_t offs[72]; int k = 0;
   for (int d = 0; d < 2; ++d) {
     offs[k++] = take(cap * 8);                                     // key
     for (int a = 0; a < 8; ++a) offs[k++] = take(cap * 4);         // score pb pnb ch node ts fst bnd
+    offs[k++] = take(arcs ? cap * 4 : 0); offs[k++] = take(arcs ? cap * 2 : 0);  // a0, an (wide beams read the FST instead)
   }
   for (int a = 0; a < 4; ++a) offs[k++] = take(cap * 4);           // events
   offs[k++] = take(HTN * 8); offs[k++] = take(HTN * 2);            // hash
-  for (int a = 0; a < 5; ++a) offs[k++] = take((size_t)C * 4);     // pf[2], lp[2], lps
-  offs[k++] = take(16);                                            // lbl[2]
-  offs[k++] = take((size_t)C * 2); offs[k++] = take((size_t)C * 2);
-  offs[k++] = take((size_t)C);
   offs[k++] = take(NBUCKET * 4); offs[k++] = take((NBUCKET + 1) * 4);
   offs[k++] = take(sn * 8); offs[k++] = take(sn * 4); offs[k++] = take(sn * 4);
   offs[k++] = take(64 * 4);
   offs[k++] = take(12 * 8);
   offs[k++] = take(SC_COUNT * 4);
+  offs[k++] = take(16);                                            // lbl[2]
+  // ---- class-count dependent from here on
+  for (int a = 0; a < 5; ++a) offs[k++] = take((size_t)C * 4);     // pf[2], lp[2], lps
+  offs[k++] = take((size_t)C * 2); offs[k++] = take((size_t)C * 2);
+  offs[k++] = take((size_t)C);
   // candidate staging: whatever fits under ~118 KiB (leaves room for a co-resident acoustic-model workgroup), at most 2048
   uint32_t mcap = 0;
   {
@@ -434,33 +497,48 @@ __host__ __device__ inline size_t lds_carve(int beam, int C, Lds* l, unsigned ch
   }
   const size_t o_lc = o;
   o += (size_t)mcap * 12;
-  if (l) {
+  {
     k = 0;
-    for (int d = 0; d < 2; ++d) {
-      l->key[d] = (uint64_t*)(base + offs[k++]);
-      l->score[d] = (float*)(base + offs[k++]); l->pb[d] = (float*)(base + offs[k++]); l->pnb[d] = (float*)(base + offs[k++]);
-      l->ch[d] = (uint32_t*)(base + offs[k++]); l->node[d] = (uint32_t*)(base + offs[k++]); l->ts[d] = (uint32_t*)(base + offs[k++]);
-      l->fst[d] = (int*)(base + offs[k++]); l->bnd[d] = (uint32_t*)(base + offs[k++]);
-    }
-    l->ev_self = (float*)(base + offs[k++]); l->ev_blank = (float*)(base + offs[k++]); l->ev_ext = (float*)(base + offs[k++]);
-    l->ev_exti = (uint32_t*)(base + offs[k++]);
-    l->ht_key = (uint64_t*)(base + offs[k++]); l->ht_idx = (uint16_t*)(base + offs[k++]);
-    l->pf[0] = (float*)(base + offs[k++]); l->pf[1] = (float*)(base + offs[k++]);
-    l->lp[0] = (float*)(base + offs[k++]); l->lp[1] = (float*)(base + offs[k++]); l->lps = (float*)(base + offs[k++]);
-    l->lbl = (double*)(base + offs[k++]);
-    l->cls = (uint16_t*)(base + offs[k++]); l->pos = (uint16_t*)(base + offs[k++]);
-    l->lab1 = (uint8_t*)(base + offs[k++]);
-    l->hist = (uint32_t*)(base + offs[k++]); l->cumb = (uint32_t*)(base + offs[k++]);
-    l->skey = (uint64_t*)(base + offs[k++]); l->ssrc = (uint32_t*)(base + offs[k++]); l->sseg = (uint32_t*)(base + offs[k++]);
-    l->wtot = (uint32_t*)(base + offs[k++]);
-    l->acc = (unsigned long long*)(base + offs[k++]);
-    l->sc = (int*)(base + offs[k++]);
+    const uint32_t blk = (uint32_t)(offs[11] - offs[0]);  // 11 arrays per buffer
+    auto db = [&](auto& m, size_t off, bool on) { using P = decltype(m.p0); m.p0 = on ? (P)(base + off) : (P) nullptr; m.blk = blk; };
+    db(l->key, offs[0], true);
+    db(l->score, offs[1], true); db(l->pb, offs[2], true); db(l->pnb, offs[3], true);
+    db(l->ch, offs[4], true); db(l->node, offs[5], true); db(l->ts, offs[6], true);
+    db(l->fst, offs[7], true); db(l->bnd, offs[8], true);
+    db(l->a0, offs[9], arcs); db(l->an, offs[10], arcs);
+    k = 22;
+    l->ev_self = (LDS_AS float*)(base + offs[k++]); l->ev_blank = (LDS_AS float*)(base + offs[k++]); l->ev_ext = (LDS_AS float*)(base + offs[k++]);
+    l->ev_exti = (LDS_AS uint32_t*)(base + offs[k++]);
+    l->ht_key = (LDS_AS uint64_t*)(base + offs[k++]); l->ht_idx = (LDS_AS uint16_t*)(base + offs[k++]);
+    l->hist = (LDS_AS uint32_t*)(base + offs[k++]); l->cumb = (LDS_AS uint32_t*)(base + offs[k++]);
+    l->skey = (LDS_AS uint64_t*)(base + offs[k++]); l->ssrc = (LDS_AS uint32_t*)(base + offs[k++]); l->sseg = (LDS_AS uint32_t*)(base + offs[k++]);
+    l->wtot = (LDS_AS uint32_t*)(base + offs[k++]);
+    l->acc = (LDS_AS unsigned long long*)(base + offs[k++]);
+    l->sc = (LDS_AS int*)(base + offs[k++]);
+    l->lbl = (LDS_AS double*)(base + offs[k++]);
+    l->pf.p0 = (LDS_AS float*)(base + offs[k]); l->pf.blk = (uint32_t)(offs[k + 1] - offs[k]); k += 2;
+    l->lp.p0 = (LDS_AS float*)(base + offs[k]); l->lp.blk = (uint32_t)(offs[k + 1] - offs[k]); k += 2;
+    l->lps = (LDS_AS float*)(base + offs[k++]);
+    l->cls = (LDS_AS uint16_t*)(base + offs[k++]); l->pos = (LDS_AS uint16_t*)(base + offs[k++]);
+    l->lab1 = (LDS_AS uint8_t*)(base + offs[k++]);
     l->mcap = mcap;
-    l->lc_logp = (float*)(base + o_lc); l->lc_pi = (uint32_t*)(base + o_lc + (size_t)mcap * 4); l->lc_fst = (int*)(base + o_lc + (size_t)mcap * 8);
+    l->lc_logp = (LDS_AS float*)(base + o_lc); l->lc_pi = (LDS_AS uint32_t*)(base + o_lc + (size_t)mcap * 4); l->lc_fst = (LDS_AS int*)(base + o_lc + (size_t)mcap * 8);
   }
-  return o;
+  total = o;
+  return L;
 }
-size_t ctc_next_lds_bytes(int beam, int C) { return lds_carve(beam, C, nullptr, nullptr); }
+inline int cap_bucket(int beam) { return beam <= 64 ? 64 : beam <= 128 ? 128 : beam <= 256 ? 256 : beam <= 512 ? 512 : 1024; }
+size_t ctc_next_lds_bytes(int beam, int C) {
+  size_t t = 0;
+  switch (cap_bucket(beam)) {
+    case 64: (void)lds_carve<64>(C, nullptr, t); break;
+    case 128: (void)lds_carve<128>(C, nullptr, t); break;
+    case 256: (void)lds_carve<256>(C, nullptr, t); break;
+    case 512: (void)lds_carve<512>(C, nullptr, t); break;
+    default: (void)lds_carve<1024>(C, nullptr, t); break;
+  }
+  return t;
+}
 
 __device__ __forceinline__ int ht_find(const Lds& L, uint64_t k) {
   uint32_t h = (uint32_t)(k >> 17) & (HTN - 1);
@@ -496,7 +574,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 }
 // Exclusive prefix sum of one value per thread over the workgroup (contains one __syncthreads; the caller separates
 // two calls by another barrier because `wtot` is reused).
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wtot, uint32_t& total) {
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, LDS_AS uint32_t* wtot, uint32_t& total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t inc = wave_incl_scan(v, lane);
   if (lane == 63) wtot[w] = inc;
@@ -526,8 +604,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 __device__ __forceinline__ void ht_insert(const Lds& L, uint64_t k, int idx) {
   uint32_t h = (uint32_t)(k >> 17) & (HTN - 1);
   for (;;) {
-    const unsigned long long old = atomicCAS((unsigned long long*)&L.ht_key[h], 0ULL, (unsigned long long)k);
-    if (old == 0ULL) { L.ht_idx[h] = (uint16_t)idx; break; }
+    if (lds_cas0(&L.ht_key[h], k) == 0ULL) { L.ht_idx[h] = (uint16_t)idx; break; }
     h = (h + 1) & (HTN - 1);
   }
 }
@@ -545,16 +622,44 @@ __device__ __forceinline__ void prep_row(const DecParams& p, const Lds& L, int b
   }
 }
 
+// Merge the <= 3 events of live prefix j in the reference's visiting order (class position, then beam index; :166-193,
+// :245-253) and leave the results in the event arrays: ev_blank = new log_prob_b, ev_self = new log_prob_nb,
+// ev_ext = new score (iterate_to_vec, path_trie.cpp:170), ev_exti = pending timestep parent.  Returns the new score.
+__device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, int cur, int j) {
+  const float NEG = STT_NEG_INF;
+  const float e_self = L.ev_self[j], e_blank = L.ev_blank[j], e_ext = L.ev_ext[j];
+  const uint32_t ei = L.ev_exti[j] & 0x7FFFFFFFu;
+  float nb = NEG, bb = NEG;
+  uint32_t pend = 0xFFFFFFFEu;  // "no pending update" (previous_timesteps == nullptr)
+  const uint32_t chj = L.ch[cur][j];
+  const int kblank = L.pos[p.blank];
+  const int kself = chj == STT_ROOT_CH ? 0xFFFF : L.pos[chj];
+  const bool blank_first = kblank < kself;
+  if (blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
+  const bool ext_first = (int)ei < j;
+  if (ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = stt_log_sum_exp(nb, e_ext); }
+  if (!is_absent(e_self)) { if (nb < e_self) pend = 0xFFFFFFFEu; nb = stt_log_sum_exp(nb, e_self); }
+  if (!ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = stt_log_sum_exp(nb, e_ext); }
+  if (!blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
+  const float nscore = stt_log_sum_exp(bb, nb);
+  L.ev_blank[j] = bb; L.ev_self[j] = nb; L.ev_ext[j] = nscore; L.ev_exti[j] = pend;
+  return nscore;
+}
+
 // `buf` holds this step's prepared emissions; `next_row` (or null) is prepared into buf^1 while the LM phase runs.
-__device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const DecStream& S, const Lds& L, int& cur, int& n,
+// MODE: 0 = no scorer, 1 = word-level scorer, 2 = utf8 (codepoint-level) scorer -- separate instantiations, so the
+// hot word-mode kernel does not carry the registers and code of the uncached codepoint paths.
+template <int MODE>
+__device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const GStream& S, const Lds& L, int& cur, int& n,
                          int& start_expanding, int& abs_t, int buf, const float* next_row) {
+  constexpr bool SC_ON = MODE != 0, SC_UTF8 = MODE == 2;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int C = p.C, beam = p.beam;
-  int* sc = L.sc;
+  LDS_AS int* sc = L.sc;
   const float NEG = STT_NEG_INF;
-  const float* pf = L.pf[buf];
-  float* lp = L.lp[buf];
+  const LDS_AS float* pf = L.pf[buf];
+  LDS_AS float* lp = L.lp[buf];
 
   unsigned long long tick_ = __builtin_readcyclecounter();
   float pre = 0.0f;
@@ -570,7 +675,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   // beam was written); class order / cut-off only when pruning is active
   for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
   L.hist[tid] = 0;
-  if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; }
+  if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; sc[SC_NQ] = 0; }
   const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
   int cutoff_len = C;
   if (sort_classes) {  // std::sort by probability, descending (ties: class index)
@@ -601,7 +706,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   }
   float min_cutoff = NEG;
   bool full_beam = false;
-  if (s.enabled) {  // :136-146 (the beam is kept in prefix_compare order, so no partial_sort is needed)
+  if (SC_ON) {  // :136-146 (the beam is kept in prefix_compare order, so no partial_sort is needed)
     const double mc = __dadd_rn(__dadd_rn((double)L.score[cur][n - 1], L.lbl[buf]), -fmax(0.0, s.beta));
     min_cutoff = (float)mc;
     full_beam = (n == beam);
@@ -613,6 +718,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   // (prefix, candidate label) -- with a dictionary only the out-arcs of the prefix's FST state can succeed
   // (path_trie.cpp:54-64), otherwise every kept class -- dealt to the lanes through a wave-local prefix sum.
   unsigned probes = 0;
+  const bool lm_queue = SC_ON && !SC_UTF8;  // word mode: <= 1 scored extension (the space) per prefix per step
   {
     uint32_t ppw = pow2_ge((uint32_t)((n + NWAVES - 1) / NWAVES));  // <= 64
     const int i0 = wave * (int)ppw + lane;
@@ -630,59 +736,76 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
           const int ks = L.pos[chi];
           if (ks != 0xFFFF) { const float lpc = lp[ks]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_self[i] = __fadd_rn(lpc, L.pnb[cur][i]); }
         }
-        if (s.enabled) {
-          const int st = L.fst[cur][i];
-          a0 = s.fst_state_pos[st];
-          cnt = s.fst_state_pos[st + 1] - a0;
-        } else {
-          cnt = (uint32_t)cutoff_len;
-        }
+        if (SC_ON) {
+          if (L.a0.p0) { a0 = L.a0[cur][i]; cnt = L.an[cur][i]; }
+          else { const int st = L.fst[cur][i]; a0 = s.fst_state_pos[st]; cnt = s.fst_state_pos[st + 1] - a0; }
+        } else cnt = (uint32_t)cutoff_len;
       }
     }
     const uint32_t inc = wave_incl_scan(cnt, lane);
     const uint32_t off = inc - cnt;
     const uint32_t n_items = __shfl(inc, 63);
-    for (uint32_t xb = 0; xb < n_items; xb += 64) {
-      const uint32_t x = xb + lane;
+    // Items are taken 64 at a time; the FST arc of the *next* item is fetched before the current one is processed,
+    // so the HBM/L2 latency of the arc read overlaps the LDS work of the previous item.
+    uint32_t j_n = 0, kk_n = 0; uint2 arc_n = make_uint2(0, 0); bool v_n = false;
+    {
+      const uint32_t x = lane;
       uint32_t j = 0;  // largest lane with off_j <= x (lanes with no items share their successor's offset)
       for (uint32_t step = ppw >> 1; step >= 1; step >>= 1) { const uint32_t v = __shfl(off, (int)(j + step)); if (v <= x) j += step; }
       const uint32_t offj = __shfl(off, (int)j), a0j = __shfl(a0, (int)j);
-      if (x >= n_items) continue;
-      const int i = wave * (int)ppw + (int)j;
-      const uint32_t kk = x - offj;
-      uint32_t c; int k; int child_fst = 0;
-      if (s.enabled) {
-        const uint2 arc = s.fst_arcs[a0j + kk];
-        if (arc.x == 0 || arc.x > (uint32_t)(C - 1)) continue;  // epsilon / label outside the alphabet: never matched
-        c = arc.x - 1;
-        child_fst = (int)arc.y;
-        k = L.pos[c];
-        if (k == 0xFFFF) continue;
-      } else {
-        k = (int)kk;
-        c = L.cls[k];
+      v_n = x < n_items; j_n = j; kk_n = x - offj;
+      if (v_n && SC_ON) arc_n = s.fst_arcs[a0j + kk_n];
+    }
+#pragma unroll 1
+    for (uint32_t xb = 0; xb < n_items; xb += 64) {
+      const uint32_t iju = j_n, kku = kk_n; const uint2 arc_c = arc_n; const bool vu = v_n;
+      if (xb + 64 < n_items) {  // uniform
+        const uint32_t x = xb + 64 + lane;
+        uint32_t j = 0;
+        for (uint32_t step = ppw >> 1; step >= 1; step >>= 1) { const uint32_t v = __shfl(off, (int)(j + step)); if (v <= x) j += step; }
+        const uint32_t offj = __shfl(off, (int)j), a0j = __shfl(a0, (int)j);
+        v_n = x < n_items; j_n = j; kk_n = x - offj;
+        if (v_n && SC_ON) arc_n = s.fst_arcs[a0j + kk_n];
       }
-      if ((int)c == p.blank) continue;
-      const float sci = L.score[cur][i];
-      const uint32_t chi = L.ch[cur][i];
-      const float lpc = lp[k];
-      if (full_beam && __fadd_rn(lpc, sci) < min_cutoff) continue;  // the `break` of :157-159 (beam is sorted by score)
-      float log_p = NEG;  // :199-207
-      if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
-      else log_p = __fadd_rn(lpc, sci);
-      uint32_t needs_lm = 0;
-      if (s.enabled) needs_lm = s.utf8 ? (is_scoring_boundary(s, al, S.pa, L.node[cur][i], c, c, probes) ? 1u : 0u) : ((int)c == al.space_id ? 1u : 0u);
-      const uint64_t ck = child_key(L.key[cur][i], c);
-      const int jj = ht_find(L, ck);
-      if (jj >= 0) {  // the child is a live prefix: one extension event per live prefix per step
-        L.ev_ext[jj] = log_p;
-        L.ev_exti[jj] = (uint32_t)i | (needs_lm << 31);
-      } else {
-        const int slot = atomicAdd(&sc[SC_M], 1);
-        if ((uint32_t)slot < S.cand_cap) {
-          const uint32_t piv = (uint32_t)i | ((uint32_t)k << 16) | (needs_lm << 31);
-          if ((uint32_t)slot < L.mcap) { L.lc_logp[slot] = log_p; L.lc_pi[slot] = piv; L.lc_fst[slot] = child_fst; }
-          else { S.c_logp[slot] = log_p; S.c_pi[slot] = piv; S.c_fst[slot] = child_fst; }
+      {
+        if (!vu) continue;
+        const int i = wave * (int)ppw + (int)iju;
+        uint32_t c; int k; int child_fst = 0;
+        if (SC_ON) {
+          const uint2 arc = arc_c;
+          if (arc.x == 0 || arc.x > (uint32_t)(C - 1)) continue;  // epsilon / label outside the alphabet: never matched
+          c = arc.x - 1;
+          child_fst = (int)arc.y;
+          k = L.pos[c];
+          if (k == 0xFFFF) continue;
+        } else {
+          k = (int)kku;
+          c = L.cls[k];
+        }
+        if ((int)c == p.blank) continue;
+        const float sci = L.score[cur][i];
+        const uint32_t chi = L.ch[cur][i];
+        const float lpc = lp[k];
+        if (full_beam && __fadd_rn(lpc, sci) < min_cutoff) continue;  // the `break` of :157-159 (beam is sorted by score)
+        float log_p = NEG;  // :199-207
+        if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
+        else log_p = __fadd_rn(lpc, sci);
+        uint32_t needs_lm = 0;
+        if (SC_ON) needs_lm = SC_UTF8 ? (is_scoring_boundary(s, al, S.pa_generic, L.node[cur][i], c, c, probes) ? 1u : 0u) : ((int)c == al.space_id ? 1u : 0u);
+        const uint64_t ck = child_key(L.key[cur][i], c);
+        const int jj = ht_find(L, ck);
+        if (jj >= 0) {  // the child is a live prefix: one extension event per live prefix per step
+          L.ev_ext[jj] = log_p;
+          L.ev_exti[jj] = (uint32_t)i | (needs_lm << 31);
+          if (needs_lm && lm_queue) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = 0x80000000u | (uint32_t)jj; }
+        } else {
+          const int slot = lds_add(&sc[SC_M], 1);
+          if ((uint32_t)slot < S.cand_cap) {
+            const uint32_t piv = (uint32_t)i | ((uint32_t)k << 16) | (needs_lm << 31);
+            if ((uint32_t)slot < L.mcap) { L.lc_logp[slot] = log_p; L.lc_pi[slot] = piv; L.lc_fst[slot] = child_fst; }
+            else { S.c_logp[slot] = log_p; S.c_pi[slot] = piv; S.c_fst[slot] = child_fst; }
+            if (needs_lm && lm_queue) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = (uint32_t)slot; }
+          }
         }
       }
     }
@@ -692,42 +815,62 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   if ((uint32_t)m > S.cand_cap) { m = (int)S.cand_cap; if (tid == 0) sc[SC_ERR] |= 4; }
   TICK(2);
 
-  // ---- P3: language model on scoring boundaries (:209-243); meanwhile the next row's class log-probs; the hash is
-  // dead from here on and is cleared for the next beam
+  // ---- P3: language model on scoring boundaries (:209-243).  Word mode: the few scored extensions of this step were
+  // queued by the expand phase and are taken by the *last* threads of the workgroup, while the first n threads already
+  // merge every live prefix that does not wait for a score.  Meanwhile the next row's class log-probs are prepared and
+  // the (now dead) hash is cleared for the next beam.
   for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
   if (next_row) prep_row(p, L, buf ^ 1, next_row, pre);
-  if (s.enabled) {
+  bool merged = false;
+  float my_score = NEG;
+  if (SC_ON) {
     unsigned lmq = 0;
-    for (int x = tid; x < m + n; x += NTHREADS) {
-      uint32_t pi; float lp0;
-      if (x < m) { pi = CAND_PI(x); if (!(pi >> 31)) continue; lp0 = CAND_LOGP(x); }
-      else { const int j = x - m; pi = L.ev_exti[j]; if (!(pi >> 31) || is_absent(L.ev_ext[j])) continue; lp0 = L.ev_ext[j]; }
-      const int i = (int)(pi & 0xFFFFu);
-      const uint32_t nodei = L.node[cur][i];
-      double raw;
-      if (!s.utf8) {
+    if (lm_queue) {
+      const int nq = sc[SC_NQ];
+      for (int q = NTHREADS - 1 - tid; q < nq; q += NTHREADS) {
+        const uint32_t ent = L.ssrc[q];
+        const bool live = (ent >> 31) != 0;
+        const int x = (int)(ent & 0x7FFFFFFFu);  // candidate slot, or live prefix index
+        uint32_t pi; float lp0;
+        if (!live) { pi = CAND_PI(x); lp0 = CAND_LOGP(x); } else { pi = L.ev_exti[x]; lp0 = L.ev_ext[x]; }
+        const int i = (int)(pi & 0xFFFFu);
+        const uint32_t nodei = L.node[cur][i];
         // word mode scores the prefix *before* the space (:211-216); the score depends only on that prefix, so it is
         // computed once per path node and kept (BEntry); later timesteps that retry "prefix + space" reuse it.
-        const uint32_t chi = L.ch[cur][i], bndi = L.bnd[cur][i];
-        if (bndi != STT_NONE && chi != STT_ROOT_CH && (int)chi != al.space_id) {
-          const uint32_t e = S.pq[nodei];
-          if (e != STT_NONE) raw = S.be[e].raw;
-          else { raw = lm_word_query_cached(s, al, S, L.lab1, (uint32_t*)&sc[SC_BEN], nodei, bndi, probes); ++lmq; }
-        } else {
-          raw = lm_score(s, al, S.pa, nodei, STT_ROOT_CH, true, probes); ++lmq;
+        // The root prefix (no word yet: the reference's n-gram is empty and scores 0) is entry 0, recorded in pq[0] when
+        // the stream is created; a prefix that itself ends in a space contributes the empty word, which the backward walk
+        // of lm_word_query_cached() produces by itself.  Entries cannot run out before path nodes do (one per node).
+        double raw;
+        const uint32_t e = S.pq[nodei];
+        if (e != STT_NONE) raw = load_be_raw(S, e);
+        else {
+          const uint32_t bndi = L.bnd[cur][i];
+          if (bndi == STT_NONE) { raw = 0.0; lds_or(&sc[SC_ERR], 8); }
+          else { raw = lm_word_query_cached(s, al, S, L.lab1, (LDS_AS uint32_t*)&sc[SC_BEN], nodei, bndi, probes); ++lmq; }
         }
-      } else {
-        const uint32_t first = (x < m) ? (uint32_t)L.cls[(pi >> 16) & 0x7FFFu] : L.ch[cur][x - m];  // score the *new* prefix
-        raw = lm_score(s, al, S.pa, nodei, first, true, probes); ++lmq;
+        const float lms = (float)__dmul_rn(raw, s.alpha);
+        float lpv = __fadd_rn(lp0, lms);                       // log_p += score;
+        lpv = (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
+        if (!live) { if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpv; else S.c_logp[x] = lpv; } else L.ev_ext[x] = lpv;
       }
-      const float lms = (float)__dmul_rn(raw, s.alpha);
-      float lpv = __fadd_rn(lp0, lms);                       // log_p += score;
-      lpv = (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
-      if (x < m) { if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpv; else S.c_logp[x] = lpv; } else L.ev_ext[x - m] = lpv;
+      if (tid < n && !((L.ev_exti[tid] >> 31) && !is_absent(L.ev_ext[tid]))) { my_score = merge_live(p, L, cur, tid); merged = true; }
+    } else {
+      for (int x = tid; x < m + n; x += NTHREADS) {
+        uint32_t pi; float lp0;
+        if (x < m) { pi = CAND_PI(x); if (!(pi >> 31)) continue; lp0 = CAND_LOGP(x); }
+        else { const int j = x - m; pi = L.ev_exti[j]; if (!(pi >> 31) || is_absent(L.ev_ext[j])) continue; lp0 = L.ev_ext[j]; }
+        const int i = (int)(pi & 0xFFFFu);
+        const uint32_t first = (x < m) ? (uint32_t)L.cls[(pi >> 16) & 0x7FFFu] : L.ch[cur][x - m];  // utf8 mode scores the *new* prefix
+        const double raw = lm_score(s, al, S.pa_generic, L.node[cur][i], first, true, probes); ++lmq;
+        const float lms = (float)__dmul_rn(raw, s.alpha);
+        float lpv = __fadd_rn(lp0, lms);
+        lpv = (float)__dadd_rn((double)lpv, s.beta);
+        if (x < m) { if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpv; else S.c_logp[x] = lpv; } else L.ev_ext[x - m] = lpv;
+      }
     }
-    if (lmq) atomicAdd(&sc[SC_LMQ], (int)lmq);
+    if (lmq) lds_add(&sc[SC_LMQ], (int)lmq);
   }
-  if (probes) atomicAdd(&sc[SC_PROBES], (int)probes);
+  if (probes) lds_add(&sc[SC_PROBES], (int)probes);
   __syncthreads();
   TICK(3);
 
@@ -739,25 +882,9 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   uint32_t hmin = 0xFFFFFFFFu, hmax = 0;
   for (int e = tid, r = 0; e < total; e += NTHREADS, ++r) {
     uint64_t k;
-    if (e < n) {
-      const int j = e;
-      const float e_self = L.ev_self[j], e_blank = L.ev_blank[j], e_ext = L.ev_ext[j];
-      const uint32_t ei = L.ev_exti[j] & 0x7FFFFFFFu;
-      float nb = NEG, bb = NEG;
-      uint32_t pend = 0xFFFFFFFEu;  // "no pending update" (previous_timesteps == nullptr)
-      const uint32_t chj = L.ch[cur][j];
-      const int kblank = L.pos[p.blank];
-      const int kself = chj == STT_ROOT_CH ? 0xFFFF : L.pos[chj];
-      const bool blank_first = kblank < kself;
-      if (blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
-      const bool ext_first = (int)ei < j;
-      if (ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = stt_log_sum_exp(nb, e_ext); }
-      if (!is_absent(e_self)) { if (nb < e_self) pend = 0xFFFFFFFEu; nb = stt_log_sum_exp(nb, e_self); }
-      if (!ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = stt_log_sum_exp(nb, e_ext); }
-      if (!blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
-      const float nscore = stt_log_sum_exp(bb, nb);  // iterate_to_vec, path_trie.cpp:170
-      L.ev_blank[j] = bb; L.ev_self[j] = nb; L.ev_ext[j] = nscore; L.ev_exti[j] = pend;
-      k = sel_key(nscore, chj, 0, (uint32_t)j);
+    if (e < n) {  // e == tid: either merged during the LM phase, or it waited for a score
+      const float nscore = merged ? my_score : merge_live(p, L, cur, e);
+      k = sel_key(nscore, L.ch[cur][e], 0, (uint32_t)e);
     } else {
       const int x = e - n;
       const uint32_t pi = CAND_PI(x);
@@ -769,7 +896,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   }
 #define KEY_OF(e, r) ((r) == 0 ? kreg0 : (r) == 1 ? kreg1 : S.sel_keys[e])
   hmin = wave_min_u32(hmin); hmax = wave_max_u32(hmax);
-  if (lane == 0) { atomicMin((unsigned int*)&sc[SC_KMIN], hmin); atomicMax((unsigned int*)&sc[SC_KMAX], hmax); }
+  if (lane == 0) { lds_min((LDS_AS uint32_t*)&sc[SC_KMIN], hmin); lds_max((LDS_AS uint32_t*)&sc[SC_KMAX], hmax); }
   __syncthreads();
   TICK(4);
 
@@ -800,7 +927,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
         if (k < base) continue;
         const uint64_t d = k - base;
         if (width_sh < 64 && (d >> width_sh) != 0) continue;
-        atomicAdd(&L.hist[(uint32_t)(d >> sh)], 1u);
+        lds_add(&L.hist[(uint32_t)(d >> sh)], 1u);
       }
       __syncthreads();
       const uint32_t h = L.hist[tid];
@@ -822,7 +949,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
         if (b < bt || (last && b == bt)) {
           const uint32_t seg0 = (uint32_t)off + L.cumb[b];
           const uint32_t len = L.cumb[b + 1] - L.cumb[b];
-          const uint32_t at = seg0 + (atomicSub(&L.hist[b], 1u) - 1u);
+          const uint32_t at = seg0 + (lds_sub(&L.hist[b], 1u) - 1u);
           L.skey[at] = k; L.ssrc[at] = (uint32_t)e; L.sseg[at] = seg0 | (len << 16);
         }
       }
@@ -852,6 +979,7 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
       if ((int)x < n) {
         L.score[nxt][r] = L.ev_ext[x]; L.pb[nxt][r] = L.ev_blank[x]; L.pnb[nxt][r] = L.ev_self[x];
         L.ch[nxt][r] = L.ch[cur][x]; L.node[nxt][r] = L.node[cur][x]; L.fst[nxt][r] = L.fst[cur][x];
+        if (L.a0.p0) { L.a0[nxt][r] = L.a0[cur][x]; L.an[nxt][r] = L.an[cur][x]; }
         nkey = L.key[cur][x];
         L.bnd[nxt][r] = L.bnd[cur][x];
         pend = L.ev_exti[x]; ts_new = L.ts[cur][x];
@@ -863,23 +991,25 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
         const float lpv = CAND_LOGP(cx);
         const uint32_t pnode = L.node[cur][i];
         L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
-        L.ch[nxt][r] = c; L.fst[nxt][r] = ((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst[cx];
+        const int cf = ((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst[cx];
+        L.ch[nxt][r] = c; L.fst[nxt][r] = cf;
+        if (SC_ON && L.a0.p0) { const uint32_t f0 = s.fst_state_pos[cf], f1 = s.fst_state_pos[cf + 1]; L.a0[nxt][r] = f0; L.an[nxt][r] = (uint16_t)(f1 - f0); }
         nkey = child_key(L.key[cur][i], c);
         uint32_t b = L.bnd[cur][i];
-        if (s.enabled && !s.utf8 && (int)c == al.space_id) b = S.pq[pnode];  // the boundary entry scored in P3 (or earlier)
+        if (SC_ON && !SC_UTF8 && (int)c == al.space_id) b = S.pq[pnode];  // the boundary entry scored in P3 (or earlier)
         L.bnd[nxt][r] = b;
-        const uint32_t slot = atomicAdd((uint32_t*)&sc[SC_PAN], 1u);
-        if (slot < S.pa_cap) { S.pa[slot] = make_uint2(pnode, c); S.pq[slot] = STT_NONE; L.node[nxt][r] = slot; }
-        else { L.node[nxt][r] = 0; atomicOr(&sc[SC_ERR], 1); }
+        const uint32_t slot = lds_add((LDS_AS uint32_t*)&sc[SC_PAN], 1u);
+        if (slot < S.pa_cap) { store_node(S.pa, slot, pnode, c); S.pq[slot] = STT_NONE; L.node[nxt][r] = slot; }
+        else { L.node[nxt][r] = 0; lds_or(&sc[SC_ERR], 1); }
         pend = (NEG < lpv) ? L.ts[cur][i] : 0xFFFFFFFEu;  // :246-251 with log_prob_nb_cur == -inf
         ts_new = STT_ROOT_CH;                              // timesteps == nullptr
       }
       L.key[nxt][r] = nkey;
       ht_insert(L, nkey, (int)r);
       if (pend != 0xFFFFFFFEu) {  // path_trie.cpp:172-184
-        const uint32_t slot = atomicAdd((uint32_t*)&sc[SC_TAN], 1u);
-        if (slot < S.ta_cap) { S.ta[slot] = make_uint2(pend, (uint32_t)abs_t); ts_new = slot; }
-        else atomicOr(&sc[SC_ERR], 2);
+        const uint32_t slot = lds_add((LDS_AS uint32_t*)&sc[SC_TAN], 1u);
+        if (slot < S.ta_cap) { store_node(S.ta, slot, pend, (uint32_t)abs_t); ts_new = slot; }
+        else lds_or(&sc[SC_ERR], 2);
       }
       L.ts[nxt][r] = ts_new;
     }
@@ -896,26 +1026,37 @@ __device__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphab
   TICK(6);
 }
 
+template <int MODE, int CAP>
 __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScorer s, DevAlphabet al, DecStream* streams,
                                                             const float* probs, const int* frame_begin, const int* frame_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Lds L;
-  lds_carve(p.beam, p.C, &L, smem);
+  size_t lds_total;
+  const Lds L = lds_carve<CAP>(p.C, (LDS_AS unsigned char*)smem, lds_total);
   DecStream& G = streams[blockIdx.x];
-  const DecStream S = G;  // pointers and capacities in registers: no pointer-chasing through the stream table
   const int nfr = frame_count[blockIdx.x];
   if (nfr <= 0) return;
+  // the stream's pointers and capacities, read once into registers (field by field: a struct copy indexed in a loop would
+  // live in scratch memory)
+  GStream GS;
+  GS.pa = (GLB_AS uint64_t*)G.pa; GS.ta = (GLB_AS uint64_t*)G.ta; GS.pq = (GLB_AS uint32_t*)G.pq; GS.be = (GLB_AS u32x4*)G.be;
+  GS.c_logp = (GLB_AS float*)G.c_logp; GS.c_pi = (GLB_AS uint32_t*)G.c_pi; GS.c_fst = (GLB_AS int*)G.c_fst; GS.sel_keys = (GLB_AS uint64_t*)G.sel_keys;
+  GS.pa_generic = G.pa; GS.cand_cap = G.cand_cap; GS.pa_cap = G.pa_cap; GS.ta_cap = G.ta_cap; GS.be_cap = G.be_cap;
+  GLB_AS float* g_score = (GLB_AS float*)G.score; GLB_AS float* g_pb = (GLB_AS float*)G.pb; GLB_AS float* g_pnb = (GLB_AS float*)G.pnb;
+  GLB_AS uint32_t* g_ch = (GLB_AS uint32_t*)G.ch; GLB_AS uint32_t* g_node = (GLB_AS uint32_t*)G.node; GLB_AS uint32_t* g_ts = (GLB_AS uint32_t*)G.ts;
+  GLB_AS int* g_fst = (GLB_AS int*)G.fst; GLB_AS uint64_t* g_key = (GLB_AS uint64_t*)G.key; GLB_AS uint32_t* g_bnd = (GLB_AS uint32_t*)G.bnd;
+  constexpr bool SC_ON = MODE != 0;
   const int tid = threadIdx.x;
-  int n = S.n;
+  int n = G.n;
   int cur = 0;
-  int start_expanding = S.start_expanding;
-  int abs_t = S.abs_t;
+  int start_expanding = G.start_expanding;
+  int abs_t = G.abs_t;
   const float* row = probs + ((size_t)blockIdx.x * p.t_max + frame_begin[blockIdx.x]) * p.C;
   const float v0 = tid < p.C ? row[tid] : 0.0f;
   for (int i = tid; i < n; i += NTHREADS) {
-    L.score[0][i] = S.score[i]; L.pb[0][i] = S.pb[i]; L.pnb[0][i] = S.pnb[i];
-    L.ch[0][i] = S.ch[i]; L.node[0][i] = S.node[i]; L.ts[0][i] = S.ts[i]; L.fst[0][i] = S.fst[i]; L.key[0][i] = S.key[i];
-    L.bnd[0][i] = S.bnd[i];
+    L.score[0][i] = g_score[i]; L.pb[0][i] = g_pb[i]; L.pnb[0][i] = g_pnb[i];
+    L.ch[0][i] = g_ch[i]; L.node[0][i] = g_node[i]; L.ts[0][i] = g_ts[i]; const int st = g_fst[i]; L.fst[0][i] = st; L.key[0][i] = g_key[i];
+    L.bnd[0][i] = g_bnd[i];
+    if (SC_ON && L.a0.p0) { const uint32_t f0 = s.fst_state_pos[st], f1 = s.fst_state_pos[st + 1]; L.a0[0][i] = f0; L.an[0][i] = (uint16_t)(f1 - f0); }
   }
   for (int c = tid; c < p.C; c += NTHREADS) {
     uint8_t one = 0;
@@ -924,24 +1065,26 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
     L.cls[c] = (uint16_t)c; L.pos[c] = (uint16_t)c;  // identity class order unless pruning re-sorts it every step
   }
   for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
-  if (tid == 0) { L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)S.pa_n; L.sc[SC_TAN] = (int)S.ta_n; L.sc[SC_BEN] = (int)S.be_n; }
+  if (tid == 0) { L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
   if (tid < 12) L.acc[tid] = 0;
   prep_row(p, L, 0, row, v0);
   __syncthreads();
   for (int i = tid; i < n; i += NTHREADS) ht_insert(L, L.key[0][i], i);
   __syncthreads();
   for (int t = 0; t < nfr; ++t)
-    ctc_step(p, s, al, S, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr);
+    ctc_step<MODE>(p, s, al, GS, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr);
   for (int i = tid; i < n; i += NTHREADS) {
-    S.score[i] = L.score[cur][i]; S.pb[i] = L.pb[cur][i]; S.pnb[i] = L.pnb[cur][i];
-    S.ch[i] = L.ch[cur][i]; S.node[i] = L.node[cur][i]; S.ts[i] = L.ts[cur][i]; S.fst[i] = L.fst[cur][i]; S.key[i] = L.key[cur][i];
-    S.bnd[i] = L.bnd[cur][i];
+    g_score[i] = L.score[cur][i]; g_pb[i] = L.pb[cur][i]; g_pnb[i] = L.pnb[cur][i];
+    g_ch[i] = L.ch[cur][i]; g_node[i] = L.node[cur][i]; g_ts[i] = L.ts[cur][i]; g_fst[i] = L.fst[cur][i]; g_key[i] = L.key[cur][i];
+    g_bnd[i] = L.bnd[cur][i];
   }
   if (tid == 0) {
-    G.n = n; G.start_expanding = start_expanding; G.abs_t = abs_t; G.error = S.error | L.sc[SC_ERR];
+    G.n = n; G.start_expanding = start_expanding; G.abs_t = abs_t; G.error |= L.sc[SC_ERR];
     G.pa_n = (uint32_t)L.sc[SC_PAN]; G.ta_n = (uint32_t)L.sc[SC_TAN]; G.be_n = (uint32_t)L.sc[SC_BEN];
-    for (int k = 0; k < 4; ++k) G.stat[k] = S.stat[k] + L.acc[k];
-    for (int k = 0; k < 8; ++k) G.phase[k] = S.phase[k] + L.acc[4 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) G.stat[k] += L.acc[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) G.phase[k] += L.acc[4 + k];
   }
 }
 
@@ -1008,7 +1151,7 @@ __global__ void ctc_init_kernel(DecStream* streams, int n_streams, int fst_start
   S.score[0] = 0.0f; S.pb[0] = 0.0f; S.pnb[0] = STT_NEG_INF; S.ch[0] = STT_ROOT_CH; S.node[0] = 0; S.ts[0] = 0;
   S.fst[0] = fst_start; S.key[0] = 0x5151515151515151ULL; S.bnd[0] = 0;
   S.pa[0] = make_uint2(STT_ROOT_CH, STT_ROOT_CH); S.ta[0] = make_uint2(STT_ROOT_CH, 0);
-  S.pq[0] = STT_NONE;
+  S.pq[0] = 0;  // scoring "root, then a word boundary" = entry 0 (raw 0: get_log_cond_prob of an empty n-gram)
   BEntry e{};  // boundary entry 0: the empty prefix, KenLM BeginSentence state (lm/model.cc:115-124)
   e.raw = 0.0; e.prev = STT_NONE; e.oov_hist = 0; e.pad = 0; e.hot_self = 0.0f;
   e.st.words[0] = bos_index; e.st.backoff[0] = bos_backoff; e.st.length = 1;
@@ -1025,13 +1168,24 @@ void launch_ctc_init(DecStream* streams, int n_streams, const DevScorer* sc, hip
 // ------------------------------------------------------------------------------------ launchers
 void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
                      const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st) {
-  const size_t lds = lds_carve(p.beam, p.C, nullptr, nullptr);
-  static size_t configured = 0;
-  if (lds > configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_next_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = lds;
+  const size_t lds = ctc_next_lds_bytes(p.beam, p.C);
+  const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : 1);
+  const int cb = cap_bucket(p.beam);
+  const int ci = cb == 64 ? 0 : cb == 128 ? 1 : cb == 256 ? 2 : cb == 512 ? 3 : 4;
+  static size_t configured[3][5] = {};
+#define STT_CTC_CASE(M, CI, CAPV)                                                                                            \
+  if (mode == M && ci == CI) {                                                                                               \
+    if (lds > configured[M][CI]) {                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_next_kernel<M, CAPV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      configured[M][CI] = lds;                                                                                               \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((ctc_next_kernel<M, CAPV>), dim3(n_streams), dim3(NTHREADS), lds, st, p, s, al, streams, probs, frame_begin, frame_count); \
+    return;                                                                                                                  \
   }
-  hipLaunchKernelGGL(ctc_next_kernel, dim3(n_streams), dim3(NTHREADS), lds, st, p, s, al, streams, probs, frame_begin, frame_count);
+#define STT_CTC_MODE(M) STT_CTC_CASE(M, 0, 64) STT_CTC_CASE(M, 1, 128) STT_CTC_CASE(M, 2, 256) STT_CTC_CASE(M, 3, 512) STT_CTC_CASE(M, 4, 1024)
+  STT_CTC_MODE(0) STT_CTC_MODE(1) STT_CTC_MODE(2)
+#undef STT_CTC_MODE
+#undef STT_CTC_CASE
 }
 void launch_ctc_decode(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const DecStream* streams, int n_streams,
                        const DecodeOut& out, hipStream_t st) {

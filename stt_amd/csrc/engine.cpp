@@ -131,8 +131,8 @@ static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Per-stream slab: [fixed: beam arrays + per-step candidate workspace][path arena][time arena][pq][boundary entries].
 // Arena capacity covers `expected_frames` timesteps (each step appends at most beam path nodes and beam time nodes);
-// boundary entries (one per scored word end) are far rarer than nodes: a quarter of the node capacity, and the kernel
-// falls back to uncached scoring if that ever runs out.
+// boundary entries (one per scored word end) are far rarer than nodes but capped by them, so the same capacity is reserved
+// (address space only: HBM pages the kernel never touches cost nothing).
 namespace {
 struct SlabLayout {
   size_t fixed, o_pa, o_ta, o_pq, o_be, per;
@@ -140,7 +140,7 @@ struct SlabLayout {
 };
 SlabLayout slab_layout(size_t fixed, uint32_t arena) {
   SlabLayout l{};
-  l.fixed = fixed; l.arena = arena; l.be_cap = arena / 4 + 64;
+  l.fixed = fixed; l.arena = arena; l.be_cap = arena;  // at most one entry per path node
   l.o_pa = fixed; l.o_ta = l.o_pa + al256((size_t)arena * 8); l.o_pq = l.o_ta + al256((size_t)arena * 8);
   l.o_be = l.o_pq + al256((size_t)arena * 4); l.per = l.o_be + al256((size_t)l.be_cap * sizeof(BEntry));
   return l;
