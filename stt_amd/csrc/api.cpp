@@ -133,9 +133,15 @@ int create_stream(ModelState* aCtx, StreamingState** retval, bool keep_emissions
 // ---- batch path: every utterance goes through exactly the arithmetic of STT_SpeechToText ---------------------
 // Groups of <= 64 utterances.  Within a group the acoustic model runs in time-chunks on `stream` and the beam search of
 // chunk k runs on `stream_dec` while chunk k+1 is being computed (the search only occupies one workgroup per utterance).
+// Chunk schedule: a short first chunk so the beam search starts early, then chunks of STT_AMD_CHUNK (default 32) frames.
 int batch_chunk_frames() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("STT_AMD_CHUNK"); v = e ? atoi(e) : 32; if (v < 1) v = 1 << 30; }
+  return v;
+}
+int batch_first_chunk_frames() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("STT_AMD_CHUNK0"); v = e ? atoi(e) : 16; if (v < 1) v = 1 << 30; }
   return v;
 }
 std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio, unsigned stride, const unsigned* sizes, unsigned B, unsigned num_results) {
@@ -149,8 +155,10 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
     std::vector<int> hn(Bg), nfr;
     int t_max = 1;
     for (int b = 0; b < Bg; ++b) { hn[b] = (int)sizes[g0 + b]; t_max = std::max(t_max, n_frames_for(m->g, hn[b])); }
-    const int Tc = std::min(batch_chunk_frames(), t_max);
-    const int n_chunks = (t_max + Tc - 1) / Tc;
+    std::vector<int> cb;  // chunk boundaries
+    for (int t = 0, k = 0; t < t_max; ++k) { cb.push_back(t); t += (k == 0) ? std::min(batch_first_chunk_frames(), batch_chunk_frames()) : batch_chunk_frames(); }
+    cb.push_back(t_max);
+    const int n_chunks = (int)cb.size() - 1;
     mark(m, 0);
     m->run_mfcc(d_audio + (size_t)g0 * stride, hn.data(), Bg, (int)stride, t_max, nfr);
     // decoder streams + per-chunk frame tables (begin, count per utterance), all enqueued on `stream`
@@ -159,15 +167,15 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
     std::vector<int> tab((size_t)2 * n_chunks * Bg);
     for (int k = 0; k < n_chunks; ++k)
       for (int b = 0; b < Bg; ++b) {
-        tab[(size_t)(2 * k) * Bg + b] = k * Tc;
-        tab[(size_t)(2 * k + 1) * Bg + b] = std::max(0, std::min(Tc, nfr[b] - k * Tc));
+        tab[(size_t)(2 * k) * Bg + b] = cb[k];
+        tab[(size_t)(2 * k + 1) * Bg + b] = std::max(0, std::min(cb[k + 1], nfr[b]) - cb[k]);
       }
     m->ws_fbegin.upload(tab.data(), tab.size() * 4, m->stream);
     DecParams p{};
     p.C = m->g.n_classes; p.blank = p.C - 1; p.beam = db.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = t_max;
     DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
     for (int k = 0; k < n_chunks; ++k) {
-      const int t0 = k * Tc, T = std::min(Tc, t_max - t0);
+      const int t0 = cb[k], T = cb[k + 1] - cb[k];
       m->run_acoustic_chunk(m->ws_feats.as<float>(), m->ws_nframes.as<int>(), Bg, t_max, t0, T);  // marks 1, 2, 3
       mark(m, -1);
       hipEvent_t ev = m->ev_chunk[k % 2];  // an event may be re-recorded once the wait on it has been enqueued

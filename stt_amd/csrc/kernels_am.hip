@@ -280,17 +280,47 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-  for (int s = 0; s < ksteps; ++s) {
-    uint4 w0 = wp[(size_t)(s * 2 + 0) * 64];
-    uint4 w1 = wp[(size_t)(s * 2 + 1) * 64];
-    f16x8 fa0 = *reinterpret_cast<f16x8*>(&w0), fa1 = *reinterpret_cast<f16x8*>(&w1);
+  // k-steps are taken four at a time with the next group's weight and h fragments already in flight (double buffered in
+  // registers: one wave per SIMD, so the register file is ours): the kernel is bound by L2/HBM latency, not by MFMA issue.
+  constexpr int G = 4;
+  if (ksteps % (2 * G) == 0) {
+    uint4 wa[G][2], ha[G][NT], wb[G][2], hb[G][NT];
+#define LSTM_LOAD(W, Hh, s0)                                                                      \
+  _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                 \
+    W[g][0] = wp[(size_t)(((s0) + g) * 2 + 0) * 64];                                              \
+    W[g][1] = wp[(size_t)(((s0) + g) * 2 + 1) * 64];                                              \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) Hh[g][j] = hp[(size_t)(((s0) + g) * NT + j) * 64]; \
+  }
+#define LSTM_MMA(W, Hh)                                                                           \
+  _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                 \
+    const f16x8 fa0 = *reinterpret_cast<f16x8*>(&W[g][0]), fa1 = *reinterpret_cast<f16x8*>(&W[g][1]); \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                              \
+      const f16x8 fb = *reinterpret_cast<f16x8*>(&Hh[g][j]);                                      \
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb, acc[0][j], 0, 0, 0);            \
+      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb, acc[1][j], 0, 0, 0);            \
+    }                                                                                             \
+  }
+    LSTM_LOAD(wa, ha, 0);
+    for (int s0 = 0; s0 < ksteps; s0 += 2 * G) {
+      LSTM_LOAD(wb, hb, s0 + G);
+      LSTM_MMA(wa, ha);
+      if (s0 + 2 * G < ksteps) { LSTM_LOAD(wa, ha, s0 + 2 * G); }
+      LSTM_MMA(wb, hb);
+    }
+#undef LSTM_LOAD
+#undef LSTM_MMA
+  } else {
+    for (int s = 0; s < ksteps; ++s) {
+      uint4 w0 = wp[(size_t)(s * 2 + 0) * 64];
+      uint4 w1 = wp[(size_t)(s * 2 + 1) * 64];
+      f16x8 fa0 = *reinterpret_cast<f16x8*>(&w0), fa1 = *reinterpret_cast<f16x8*>(&w1);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      uint4 hv = hp[(size_t)(s * NT + j) * 64];
-      f16x8 fb = *reinterpret_cast<f16x8*>(&hv);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb, acc[1][j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) {
+        uint4 hv = hp[(size_t)(s * NT + j) * 64];
+        f16x8 fb = *reinterpret_cast<f16x8*>(&hv);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb, acc[1][j], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
