@@ -40,6 +40,9 @@ struct DevBitPacked {
   uint64_t word_mask, next_mask;
   const uint64_t* off_begin;  // ArrayBhiksha offsets (null for DontBhiksha)
   uint32_t off_count;
+  const uint32_t* off_hint;   // off_hint[i >> hint_shift] = upper_bound(offsets, (i >> hint_shift) << hint_shift) - 1 (built at load)
+  uint32_t hint_shift;
+  uint64_t max_word;          // upper bound of the word field (KenLM's max_vocab), for the interpolation search
   uint8_t word_bits, total_bits, quant_bits, next_bits;
 };
 

@@ -118,30 +118,44 @@ __device__ __forceinline__ uint32_t vocab_index(const DevScorer& s, uint64_t h, 
     slot = (slot + 1) & s.vtab_mask;
   }
 }
-__device__ bool find_bitpacked(const DevBitPacked& bp, uint64_t begin, uint64_t end, uint64_t key, uint64_t& at, unsigned& probes) {
-  while (begin < end) {
-    const uint64_t mid = begin + (end - begin) / 2;
-    const uint64_t v = read_int57(bp.base, mid * bp.total_bits, bp.word_mask);
+// FindBitPacked (lm/trie.cc:32-36) = BoundedSortedUniformFind (util/sorted_uniform.hh:64-84) with the integer pivot of
+// Pivot32/Pivot64 (:26-40): interpolation search over the word field, about log log n probes for KenLM's near-uniform
+// word ids.  Keys are unique within [begin, end), so any correct search returns the same position.
+__device__ __forceinline__ bool find_bitpacked(const DevBitPacked& bp, uint64_t begin, uint64_t end, uint64_t key, uint64_t& at, unsigned& probes) {
+  int64_t before_it = (int64_t)begin - 1, after_it = (int64_t)end;
+  uint64_t before_v = 0, after_v = bp.max_word;
+  while (after_it - before_it > 1) {
+    const uint64_t width = (uint64_t)(after_it - before_it - 1);
+    const uint64_t off = key - before_v, range = after_v - before_v;
+    // word ids are 32-bit (lm::WordIndex) and a range never holds 2^32 entries, so the 64-bit product cannot overflow;
+    // the guard only keeps a corrupt file from running away (plain bisection then)
+    const uint64_t step = (off <= 0xFFFFFFFFull && width <= 0xFFFFFFFFull) ? (off * width) / (range + 1) : width / 2;
+    const int64_t pivot = before_it + 1 + (int64_t)step;
+    const uint64_t v = read_int57(bp.base, (uint64_t)pivot * bp.total_bits, bp.word_mask);
     ++probes;
-    if (v < key) begin = mid + 1; else if (v > key) end = mid; else { at = mid; return true; }
+    if (v < key) { before_it = pivot; before_v = v; }
+    else if (v > key) { after_it = pivot; after_v = v; }
+    else { at = (uint64_t)pivot; return true; }
   }
   return false;
 }
-__device__ void read_next(const DevBitPacked& m, uint64_t bit_offset, uint64_t index, KNode& out, unsigned& probes) {
+__device__ __forceinline__ void read_next(const DevBitPacked& m, uint64_t bit_offset, uint64_t index, KNode& out, unsigned& probes) {
   if (!m.off_begin) {
     out.begin = read_int57(m.base, bit_offset, m.next_mask);
     out.end = read_int57(m.base, bit_offset + m.total_bits, m.next_mask);
     probes += 2;
     return;
   }
-  uint32_t lo = 0, hi = m.off_count;  // upper_bound(offsets, index) - 1
-  while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; ++probes; if (m.off_begin[mid] <= index) lo = mid + 1; else hi = mid; }
-  const uint32_t bi = lo - 1;
+  // ArrayBhiksha::ReadNext (lm/bhiksha.hh:76-95): bi = upper_bound(offsets, index) - 1, found from the hint table
+  const uint64_t lo = read_int57(m.base, bit_offset, m.next_mask), hi = read_int57(m.base, bit_offset + m.total_bits, m.next_mask);
+  uint32_t bi = m.off_hint[index >> m.hint_shift];
+  ++probes;
+  while (bi + 1 < m.off_count && m.off_begin[bi + 1] <= index) { ++bi; ++probes; }
   uint32_t ei = bi + 1;
   while (ei < m.off_count && m.off_begin[ei] <= index + 1) { ++ei; ++probes; }
   --ei;
-  out.begin = ((uint64_t)bi << m.next_bits) | read_int57(m.base, bit_offset, m.next_mask);
-  out.end = ((uint64_t)ei << m.next_bits) | read_int57(m.base, bit_offset + m.total_bits, m.next_mask);
+  out.begin = ((uint64_t)bi << m.next_bits) | lo;
+  out.end = ((uint64_t)ei << m.next_bits) | hi;
   probes += 2;
 }
 __device__ bool lookup_middle(const DevScorer& s, int om2, uint32_t word, KNode& node, bool& independent_left, float& prob, float& backoff, unsigned& probes) {
@@ -331,18 +345,40 @@ __device__ bool is_scoring_boundary(const DevScorer& s, const DevAlphabet& al, c
 }
 
 // ------------------------------------------------------------------------------------ word-mode scorer cache
-// Score "prefix X, then a word boundary" for a live word-mode prefix X whose last label is neither space nor root,
-// given the cached KenLM state of the previous boundary (entry e_prev).  Equivalent to lm_score(): the reference scores
-// the last `order` words from a null context (or all words from BeginSentence when there are fewer), and a KenLM state
-// holds at most order-1 words, so the state carried from the previous boundary is the state the reference rebuilds.
-// Appends a BEntry and records it in S.pq[node]; returns log_cond_prob + hot_boost.
-__device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al, const GStream& S, const LDS_AS uint8_t* lab1, LDS_AS uint32_t* be_n, uint32_t node, uint32_t e_prev, unsigned& probes) {
-  // Walk back to the previous boundary collecting the word's UTF-8 bytes.  Labels arrive newest first, so shifting each
-  // byte in from the low end leaves the word in little-endian order (first byte lowest): exactly the two 8-byte blocks
-  // MurmurHash64A consumes.  Words longer than 16 bytes take the generic label-array path.
-  uint64_t lo = 0, hi = 0;
+__device__ __forceinline__ int word_nbytes(uint64_t lo, uint64_t hi) {
+  if (hi) return 8 + (64 - __clzll((long long)hi) + 7) / 8;
+  return lo ? (64 - __clzll((long long)lo) + 7) / 8 : 0;
+}
+// append one byte to a packed word (all ones = overflow, sticky)
+__device__ __forceinline__ void word_push(uint64_t& lo, uint64_t& hi, uint8_t b) {
+  if ((lo & hi) == ~0ULL) return;
+  const int n = word_nbytes(lo, hi);
+  if (n < 8) lo |= (uint64_t)b << (8 * n);
+  else if (n < 16) hi |= (uint64_t)b << (8 * (n - 8));
+  else { lo = ~0ULL; hi = ~0ULL; }
+}
+// MurmurHash64A (seed 0) of a word of nbytes <= 16 bytes packed first-byte-lowest in (lo, hi)
+__device__ __forceinline__ uint64_t murmur_packed(uint64_t lo, uint64_t hi, int nbytes) {
+  const uint64_t m = 0xc6a4a7935bd1e995ULL;
+  const int r = 47;
+  uint64_t h = 0 ^ ((uint64_t)nbytes * m);
+  if (nbytes >= 8) {
+    uint64_t k = lo;
+    k *= m; k ^= k >> r; k *= m;
+    h ^= k; h *= m;
+    if (nbytes == 16) { k = hi; k *= m; k ^= k >> r; k *= m; h ^= k; h *= m; }
+    else if (nbytes > 8) { h ^= hi; h *= m; }
+  } else if (nbytes > 0) {
+    h ^= lo; h *= m;
+  }
+  h ^= h >> r; h *= m; h ^= h >> r;
+  return h;
+}
+// Walk back from `node` to the previous word boundary collecting the word's bytes (newest label first: shifting each
+// byte in from the low end leaves the word first-byte-lowest).  More than 16 bytes -> all ones.
+__device__ __forceinline__ void word_walk(const DevAlphabet& al, const GStream& S, const LDS_AS uint8_t* lab1, uint32_t node, uint64_t& lo, uint64_t& hi, unsigned& probes) {
+  lo = 0; hi = 0;
   int nbytes = 0;
-  bool overflow = false;
   for (uint32_t cur = node; cur != STT_ROOT_CH;) {
     const uint2 pn = load_node(S.pa, cur);
     ++probes;
@@ -351,32 +387,33 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
     if (one) {
       hi = (hi << 8) | (lo >> 56);
       lo = (lo << 8) | (uint64_t)one;
-      if (++nbytes > 16) overflow = true;
+      ++nbytes;
     } else {
       const int b0 = pn.y ? al.label_off[pn.y - 1] : 0, b1 = al.label_off[pn.y];
       for (int b = b1 - 1; b >= b0; --b) {
         hi = (hi << 8) | (lo >> 56);
         lo = (lo << 8) | (uint64_t)al.label_bytes[b];
-        if (++nbytes > 16) overflow = true;
+        ++nbytes;
       }
     }
     cur = pn.x;
   }
+  if (nbytes > 16) { lo = ~0ULL; hi = ~0ULL; }
+}
+
+// Score "prefix X, then a word boundary" for a live word-mode prefix X whose last label is neither space nor root,
+// given the cached KenLM state of the previous boundary (entry e_prev).  Equivalent to lm_score(): the reference scores
+// the last `order` words from a null context (or all words from BeginSentence when there are fewer), and a KenLM state
+// holds at most order-1 words, so the state carried from the previous boundary is the state the reference rebuilds.
+// Appends a BEntry and records it in S.pq[node]; returns log_cond_prob + hot_boost.
+__device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al, const GStream& S, const LDS_AS uint8_t* lab1, LDS_AS uint32_t* be_n, uint32_t node, uint32_t e_prev,
+                                       bool have_word, uint64_t lo, uint64_t hi, uint32_t& out_entry, unsigned& probes) {
+  // The word's bytes come from the beam state (have_word) or from a walk back to the previous boundary; words longer than
+  // 16 bytes take the generic label-array path.
+  if (!have_word) word_walk(al, S, lab1, node, lo, hi, probes);
   uint64_t h;
-  if (!overflow) {
-    const uint64_t m = 0xc6a4a7935bd1e995ULL;
-    const int r = 47;
-    h = 0 ^ ((uint64_t)nbytes * m);
-    if (nbytes >= 8) {
-      uint64_t k = lo;
-      k *= m; k ^= k >> r; k *= m;
-      h ^= k; h *= m;
-      if (nbytes == 16) { k = hi; k *= m; k ^= k >> r; k *= m; h ^= k; h *= m; }
-      else if (nbytes > 8) { h ^= hi; h *= m; }
-    } else if (nbytes > 0) {
-      h ^= lo; h *= m;
-    }
-    h ^= h >> r; h *= m; h ^= h >> r;
+  if ((lo & hi) != ~0ULL) {
+    h = murmur_packed(lo, hi, word_nbytes(lo, hi));
   } else {
     uint32_t labs[MAX_UNIT_LABELS];
     int nl = 0;
@@ -416,7 +453,8 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
   en.raw = __dadd_rn(lcp, (double)hot_total);
   en.prev = e_prev; en.pad = 0; en.hot_self = hot_self;
   const uint32_t idx = lds_add(be_n, 1u);  // LDS copy of the arena fill (written back when the launch ends)
-  if (idx < S.be_cap) { store_be(S, idx, en); S.pq[node] = idx; }
+  out_entry = STT_NONE;
+  if (idx < S.be_cap) { store_be(S, idx, en); S.pq[node] = idx; out_entry = idx; }
   return en.raw;
 }
 
@@ -438,6 +476,9 @@ struct Lds {
   DB<int> fst;
   DB<uint32_t> a0; DB<uint16_t> an;    // out-arcs of the prefix's dictionary state: first arc, count (read when the beam is written)
   DB<uint64_t> key;
+  // word mode, narrow beams: the UTF-8 bytes of the prefix's current (unfinished) word, first byte lowest (wlo = bytes
+  // 0..7, whi = 8..15; all ones = longer than 16 bytes), and the BEntry of "prefix + boundary" once scored (STT_NONE before)
+  DB<uint64_t> wlo, whi; DB<uint32_t> pqe;
   LDS_AS float *ev_self, *ev_blank, *ev_ext;  // reused as new pnb / new pb / new score in P4
   LDS_AS uint32_t* ev_exti;                   // parent beam index | needs_lm << 31 ; reused as pending timestep parent
   LDS_AS uint64_t* ht_key; LDS_AS uint16_t* ht_idx;  // path key -> beam index of the live prefixes (rebuilt whenever the beam is written)
@@ -476,6 +517,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
     offs[k++] = take(cap * 8);                                     // key
     for (int a = 0; a < 8; ++a) offs[k++] = take(cap * 4);         // score pb pnb ch node ts fst bnd
     offs[k++] = take(arcs ? cap * 4 : 0); offs[k++] = take(arcs ? cap * 2 : 0);  // a0, an (wide beams read the FST instead)
+    offs[k++] = take(arcs ? cap * 8 : 0); offs[k++] = take(arcs ? cap * 8 : 0); offs[k++] = take(arcs ? cap * 4 : 0);  // wlo, whi, pqe
   }
   for (int a = 0; a < 4; ++a) offs[k++] = take(cap * 4);           // events
   offs[k++] = take(HTN * 8); offs[k++] = take(HTN * 2);            // hash
@@ -489,24 +531,25 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   for (int a = 0; a < 5; ++a) offs[k++] = take((size_t)C * 4);     // pf[2], lp[2], lps
   offs[k++] = take((size_t)C * 2); offs[k++] = take((size_t)C * 2);
   offs[k++] = take((size_t)C);
-  // candidate staging: whatever fits under ~118 KiB (leaves room for a co-resident acoustic-model workgroup), at most 2048
+  // candidate staging: whatever fits under 126 KiB (leaves 34 KiB for a co-resident LSTM workgroup), at most 2048
   uint32_t mcap = 0;
   {
-    const size_t budget = 118 * 1024;
+    const size_t budget = 126 * 1024;
     if (o + 256 * 12 <= budget) { mcap = (uint32_t)((budget - o) / 12) & ~63u; if (mcap > 2048) mcap = 2048; }
   }
   const size_t o_lc = o;
   o += (size_t)mcap * 12;
   {
     k = 0;
-    const uint32_t blk = (uint32_t)(offs[11] - offs[0]);  // 11 arrays per buffer
+    const uint32_t blk = (uint32_t)(offs[14] - offs[0]);  // 14 arrays per buffer
     auto db = [&](auto& m, size_t off, bool on) { using P = decltype(m.p0); m.p0 = on ? (P)(base + off) : (P) nullptr; m.blk = blk; };
     db(l->key, offs[0], true);
     db(l->score, offs[1], true); db(l->pb, offs[2], true); db(l->pnb, offs[3], true);
     db(l->ch, offs[4], true); db(l->node, offs[5], true); db(l->ts, offs[6], true);
     db(l->fst, offs[7], true); db(l->bnd, offs[8], true);
     db(l->a0, offs[9], arcs); db(l->an, offs[10], arcs);
-    k = 22;
+    db(l->wlo, offs[11], arcs); db(l->whi, offs[12], arcs); db(l->pqe, offs[13], arcs);
+    k = 28;
     l->ev_self = (LDS_AS float*)(base + offs[k++]); l->ev_blank = (LDS_AS float*)(base + offs[k++]); l->ev_ext = (LDS_AS float*)(base + offs[k++]);
     l->ev_exti = (LDS_AS uint32_t*)(base + offs[k++]);
     l->ht_key = (LDS_AS uint64_t*)(base + offs[k++]); l->ht_idx = (LDS_AS uint16_t*)(base + offs[k++]);
@@ -841,12 +884,19 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         // the stream is created; a prefix that itself ends in a space contributes the empty word, which the backward walk
         // of lm_word_query_cached() produces by itself.  Entries cannot run out before path nodes do (one per node).
         double raw;
-        const uint32_t e = S.pq[nodei];
+        const bool in_lds = L.pqe.p0 != nullptr;
+        const uint32_t e = in_lds ? L.pqe[cur][i] : S.pq[nodei];
         if (e != STT_NONE) raw = load_be_raw(S, e);
         else {
           const uint32_t bndi = L.bnd[cur][i];
           if (bndi == STT_NONE) { raw = 0.0; lds_or(&sc[SC_ERR], 8); }
-          else { raw = lm_word_query_cached(s, al, S, L.lab1, (LDS_AS uint32_t*)&sc[SC_BEN], nodei, bndi, probes); ++lmq; }
+          else {
+            uint32_t ne;
+            raw = lm_word_query_cached(s, al, S, L.lab1, (LDS_AS uint32_t*)&sc[SC_BEN], nodei, bndi, in_lds, in_lds ? L.wlo[cur][i] : 0ULL,
+                                       in_lds ? L.whi[cur][i] : 0ULL, ne, probes);
+            if (in_lds) L.pqe[cur][i] = ne;
+            ++lmq;
+          }
         }
         const float lms = (float)__dmul_rn(raw, s.alpha);
         float lpv = __fadd_rn(lp0, lms);                       // log_p += score;
@@ -982,6 +1032,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         if (L.a0.p0) { L.a0[nxt][r] = L.a0[cur][x]; L.an[nxt][r] = L.an[cur][x]; }
         nkey = L.key[cur][x];
         L.bnd[nxt][r] = L.bnd[cur][x];
+        if (MODE == 1 && L.pqe.p0) { L.wlo[nxt][r] = L.wlo[cur][x]; L.whi[nxt][r] = L.whi[cur][x]; L.pqe[nxt][r] = L.pqe[cur][x]; }
         pend = L.ev_exti[x]; ts_new = L.ts[cur][x];
       } else {
         const int cx = (int)x - n;
@@ -996,8 +1047,18 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         if (SC_ON && L.a0.p0) { const uint32_t f0 = s.fst_state_pos[cf], f1 = s.fst_state_pos[cf + 1]; L.a0[nxt][r] = f0; L.an[nxt][r] = (uint16_t)(f1 - f0); }
         nkey = child_key(L.key[cur][i], c);
         uint32_t b = L.bnd[cur][i];
-        if (SC_ON && !SC_UTF8 && (int)c == al.space_id) b = S.pq[pnode];  // the boundary entry scored in P3 (or earlier)
+        if (MODE == 1 && (int)c == al.space_id) b = L.pqe.p0 ? L.pqe[cur][i] : S.pq[pnode];  // the boundary entry scored in P3 (or earlier)
         L.bnd[nxt][r] = b;
+        if (MODE == 1 && L.pqe.p0) {
+          uint64_t lo = 0, hi = 0;
+          if ((int)c != al.space_id) {
+            lo = L.wlo[cur][i]; hi = L.whi[cur][i];
+            const uint8_t one = L.lab1[c];
+            if (one) word_push(lo, hi, one);
+            else { const int b0 = c ? al.label_off[c - 1] : 0, b1 = al.label_off[c]; for (int bb = b0; bb < b1; ++bb) word_push(lo, hi, al.label_bytes[bb]); }
+          }
+          L.wlo[nxt][r] = lo; L.whi[nxt][r] = hi; L.pqe[nxt][r] = STT_NONE;
+        }
         const uint32_t slot = lds_add((LDS_AS uint32_t*)&sc[SC_PAN], 1u);
         if (slot < S.pa_cap) { store_node(S.pa, slot, pnode, c); S.pq[slot] = STT_NONE; L.node[nxt][r] = slot; }
         else { L.node[nxt][r] = 0; lds_or(&sc[SC_ERR], 1); }
@@ -1069,6 +1130,15 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   if (tid < 12) L.acc[tid] = 0;
   prep_row(p, L, 0, row, v0);
   __syncthreads();
+  if (MODE == 1 && L.pqe.p0) {
+    unsigned pr = 0;
+    for (int i = tid; i < n; i += NTHREADS) {
+      const uint32_t nd = L.node[0][i];
+      uint64_t lo, hi;
+      word_walk(al, GS, L.lab1, nd, lo, hi, pr);
+      L.wlo[0][i] = lo; L.whi[0][i] = hi; L.pqe[0][i] = GS.pq[nd];
+    }
+  }
   for (int i = tid; i < n; i += NTHREADS) ht_insert(L, L.key[0][i], i);
   __syncthreads();
   for (int t = 0; t < nfr; ++t)

@@ -73,7 +73,7 @@ class ScorerDev {
 
  private:
   int Parse(const uint8_t* buf, size_t len);
-  DevBuf blob_, fst_pos_, fst_arcs_, vtab_;
+  DevBuf blob_, fst_pos_, fst_arcs_, vtab_, hint_;
 };
 
 // ---------------------------------------------------------------------------------------------

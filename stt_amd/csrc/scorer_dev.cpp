@@ -73,7 +73,7 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len) {
   if (len < 108 + 8 * (size_t)ord) return STT_ERR_SCORER_INVALID_LM;
   for (int i = 0; i < ord; ++i) counts[i] = rd64(buf + 108 + 8 * i);
 
-  struct BP { uint64_t base_off; uint8_t word_bits, total_bits, quant_bits, next_bits; uint64_t off_begin_off; uint32_t off_count; };
+  struct BP { uint64_t base_off; uint8_t word_bits, total_bits, quant_bits, next_bits; uint64_t off_begin_off; uint32_t off_count; uint64_t entries; };
   BP mid[STT_KENLM_MAX_ORDER - 2]{}; BP lon{};
   uint64_t off = align8(108 + 8 * (uint64_t)ord);
   if (off + 8 > len) return STT_ERR_SCORER_INVALID_LM;
@@ -106,7 +106,7 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len) {
       const uint64_t array_count = (max_next >> (required - chop)) + 1;
       bh_size = 8 * (1 + array_count) + 7;
       inline_bits = required - chop;
-      m.off_begin_off = align8(off) + 8; m.off_count = (uint32_t)array_count;
+      m.off_begin_off = align8(off) + 8; m.off_count = (uint32_t)array_count; m.entries = entries;
     } else {
       inline_bits = required_bits(max_next);
     }
@@ -194,12 +194,39 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len) {
     ds.qprob[i] = quant && qprob_off[i] ? reinterpret_cast<const float*>(d + qprob_off[i]) : nullptr;
     ds.qbackoff[i] = quant && qback_off[i] ? reinterpret_cast<const float*>(d + qback_off[i]) : nullptr;
   }
+  // Bhiksha hint tables: the offsets array is sorted; a coarse direct-index table replaces KenLM's std::upper_bound over it
+  // (lm/bhiksha.hh:76-95) by one read plus a short forward scan.  Same result, fewer dependent HBM reads.
+  std::vector<uint32_t> hints;
+  size_t hint_off[STT_KENLM_MAX_ORDER - 2] = {};
+  uint32_t hint_shift[STT_KENLM_MAX_ORDER - 2] = {};
+  for (int i = 0; i < ord - 2; ++i) {
+    if (!mid[i].off_begin_off) continue;
+    const uint64_t* offs = reinterpret_cast<const uint64_t*>(buf + mid[i].off_begin_off);
+    const uint32_t cnt = mid[i].off_count;
+    const uint64_t entries = mid[i].entries + 2;
+    uint32_t sh = 0;
+    while (((entries >> sh) > 4ull * cnt + 1024) && sh < 40) ++sh;  // about four table slots per offset
+    hint_off[i] = hints.size(); hint_shift[i] = sh;
+    const uint64_t slots = (entries >> sh) + 2;
+    uint32_t pos = 0;  // upper_bound(offs, v) - 1 for increasing v
+    for (uint64_t j = 0; j < slots; ++j) {
+      const uint64_t v = j << sh;
+      while (pos + 1 < cnt && offs[pos + 1] <= v) ++pos;
+      hints.push_back(pos);
+    }
+  }
+  if (hints.empty()) hints.push_back(0);
+  hint_.upload(hints.data(), hints.size() * 4);
   auto fill = [&](DevBitPacked& o2, const BP& b2) {
     o2.base = d + b2.base_off; o2.word_bits = b2.word_bits; o2.total_bits = b2.total_bits; o2.quant_bits = b2.quant_bits; o2.next_bits = b2.next_bits;
     o2.word_mask = (1ULL << b2.word_bits) - 1; o2.next_mask = (1ULL << b2.next_bits) - 1;
     o2.off_begin = b2.off_begin_off ? reinterpret_cast<const uint64_t*>(d + b2.off_begin_off) : nullptr; o2.off_count = b2.off_count;
+    o2.off_hint = nullptr; o2.hint_shift = 0; o2.max_word = counts[0];
   };
-  for (int i = 0; i < ord - 2; ++i) fill(ds.middle[i], mid[i]);
+  for (int i = 0; i < ord - 2; ++i) {
+    fill(ds.middle[i], mid[i]);
+    if (mid[i].off_begin_off) { ds.middle[i].off_hint = hint_.as<uint32_t>() + hint_off[i]; ds.middle[i].hint_shift = hint_shift[i]; }
+  }
   fill(ds.longest, lon);
   ds.prob_bits = prob_bits; ds.backoff_bits = backoff_bits;
   ds.prob_mask = (1u << prob_bits) - 1; ds.backoff_mask = (1u << backoff_bits) - 1;
