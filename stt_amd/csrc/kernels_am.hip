@@ -280,6 +280,22 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // operands of the cell update, fetched now so that their latency hides behind the k-loop
+  constexpr int CU_ITEMS = NT * 16 * 8, CU_ITERS = (CU_ITEMS + 255) / 256;
+  const int B = a.batch;
+  float xv[CU_ITERS][4], cv[CU_ITERS];
+#pragma unroll
+  for (int it = 0; it < CU_ITERS; ++it) {
+    const int p = tid + it * 256;
+    const int b = p >> 3, u = p & 7;
+    xv[it][0] = xv[it][1] = xv[it][2] = xv[it][3] = 0.0f; cv[it] = 0.0f;
+    if (p < CU_ITEMS && b < B) {
+      const int unit = wg * 8 + u;
+      const float* xp = a.xproj + ((size_t)a.t * B + b) * (4 * H) + unit;
+      xv[it][0] = xp[0]; xv[it][1] = xp[H]; xv[it][2] = xp[2 * H]; xv[it][3] = xp[3 * H];
+      cv[it] = a.c[(size_t)b * H + unit];
+    }
+  }
   // k-steps are taken four at a time with the next group's weight and h fragments already in flight (double buffered in
   // registers: one wave per SIMD, so the register file is ours): the kernel is bound by L2/HBM latency, not by MFMA issue.
   constexpr int G = 4;
@@ -329,8 +345,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
     for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&red[q][i][j][lane][0]) = acc[i][j];
   __syncthreads();
   // cell update: (unit u in 0..7, batch row b): gate row r = g*8+u lives in tile r>>4, lane group (r&15)>>2, reg r&3
-  const int B = a.batch;
-  for (int p = tid; p < NT * 16 * 8; p += 256) {
+  // (the x-projection and cell-state operands were fetched before the k-loop: xv/cv)
+#pragma unroll
+  for (int it = 0; it < CU_ITERS; ++it) {
+    const int p = tid + it * 256;
+    if (p >= CU_ITEMS) break;
     const int b = p >> 3, u = p & 7;
     float z[4];
 #pragma unroll
@@ -344,11 +363,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
     float hval = 0.0f;
     if (b < B) {
       const int unit = wg * 8 + u;
-      const float* xp = a.xproj + ((size_t)a.t * B + b) * (4 * H) + unit;
-      const float zi = z[0] + xp[0], zj = z[1] + xp[H], zf = z[2] + xp[2 * H], zo = z[3] + xp[3 * H];
-      float* cptr = a.c + (size_t)b * H + unit;
-      const float cn = sigmoidf_(zf) * (*cptr) + sigmoidf_(zi) * tanhf_(zj);
-      *cptr = cn;
+      const float zi = z[0] + xv[it][0], zj = z[1] + xv[it][1], zf = z[2] + xv[it][2], zo = z[3] + xv[it][3];
+      const float cn = sigmoidf_(zf) * cv[it] + sigmoidf_(zi) * tanhf_(zj);
+      a.c[(size_t)b * H + unit] = cn;
       hval = sigmoidf_(zo) * tanhf_(cn);
       if (a.h_f32) a.h_f32[(size_t)b * H + unit] = hval;
     }
