@@ -7,8 +7,10 @@
 metric   audio-seconds per wall-second (RTF x), whole job, audio already resident in HBM when the clock starts
 step     one pass of the hot path (MFCC -> dense x3 -> LSTM-2048 -> dense x2 -> softmax -> CTC beam search + KenLM/FST scorer)
          over one batch per GPU; configs[1]: 64 synthetic 5 s 16 kHz utterances, English geometry, beam 500, scorer
-weights  seeded random init of the reference architecture (no checkpoint exists offline); scorer = the reference's
-         data/smoke_test/pruned_lm.scorer fixture (a huge-vocabulary scorer needs the packaging tool)
+weights  seeded random init of the reference architecture (no checkpoint exists offline); scorer = a synthetic
+         huge-vocabulary package written at start-up by stt_amd/tools (500 k pseudo-words, order 5, 30 M n-grams, KenLM
+         `-a 255 -q 8 trie` layout = the release recipe of doc/LANGUAGE_MODEL.rst:52-62; no corpus or lmplz offline).
+         --scorer fixture switches to the reference's small data/smoke_test/pruned_lm.scorer.
 scaling  weak: every rank decodes its own 64 utterances; one RCCL gather of the transcripts per step
 
 One JSON line on rank 0, including `roofline` (dominant kernel, algorithmic bytes / measured HIP-event time on the
@@ -29,6 +31,8 @@ FIX = os.path.join(ROOT, "tests", "golden", "fixtures")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 H, C, BEAM, BATCH, SECONDS = 2048, 29, 500, 64, 5.0
+SCORER_PATH = os.path.join(FIX, "pruned_lm.scorer")
+SCORER_DESC = "pruned_lm.scorer fixture (quant-array-trie order 4)"
 
 
 def cpu_baseline(model_weights, audio, probs_gpu, n_utts):
@@ -44,14 +48,14 @@ def cpu_baseline(model_weights, audio, probs_gpu, n_utts):
     t1 = time.perf_counter()
     if ref.available():
         A = ref.Alphabet(os.path.join(FIX, "alphabet.txt"))
-        S = ref.Scorer(os.path.join(FIX, "pruned_lm.scorer"), A)
+        S = ref.Scorer(SCORER_PATH, A)
         p = np.stack([probs_gpu[i] for i in range(n_utts)]).astype(np.float64)
         ref.decode_batch(p, [p.shape[1]] * n_utts, A, BEAM, cores, S)
         dec = "reference ctc_beam_search_decoder_batch (oracle/_ref), %d threads" % cores
     else:
         from oracle import port
         labels, space = port.parse_alphabet_file(os.path.join(FIX, "alphabet.txt"))
-        P = port.Scorer(os.path.join(FIX, "pruned_lm.scorer"))
+        P = port.Scorer(SCORER_PATH)
         for i in range(n_utts):
             d = port.Decoder(labels, space, BEAM, P); d.next(probs_gpu[i]); d.decode(1)
         dec = "C port decoder, 1 thread"
@@ -68,6 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scorer", default="synthetic", choices=["synthetic", "fixture"])
     args = ap.parse_args()
 
     import torch
@@ -93,7 +98,20 @@ def main():
         path = os.path.join(d, "english_synth.sttw")
         modelfile.write_model(path, weights, synth.ENGLISH_LABELS, beam_width=BEAM)
         model = Model(path)
-    model.enableExternalScorer(os.path.join(FIX, "pruned_lm.scorer"))
+    global SCORER_PATH, SCORER_DESC
+    scorer_dir = None
+    if args.scorer == "synthetic":
+        from stt_amd import scorertools
+        scorer_dir = tempfile.TemporaryDirectory()
+        lm, vocab = os.path.join(scorer_dir.name, "lm.binary"), os.path.join(scorer_dir.name, "vocab.txt")
+        SCORER_PATH = os.path.join(scorer_dir.name, "synthetic_500k.scorer")
+        t_s = time.perf_counter()
+        scorertools.synth_lm(lm, vocab, words=500000, order=5, seed=7, avg={2: 24, 3: 1.2, 4: 0.7, 5: 0.5})
+        scorertools.generate_scorer_package(lm, vocab, SCORER_PATH, alphabet=os.path.join(FIX, "alphabet.txt"),
+                                            default_alpha=0.931289039105002, default_beta=1.1834137581510284)   # doc/LANGUAGE_MODEL.rst:80-81
+        SCORER_DESC = ("synthetic huge-vocabulary scorer (500 k words, order 5, quant-array-trie `-a 255 -q 8`, %.0f MB, built in %.0f s)"
+                       % (os.path.getsize(SCORER_PATH) / 1e6, time.perf_counter() - t_s))
+    model.enableExternalScorer(SCORER_PATH)
 
     n = int(SECONDS * 16000)
     audio = [synth.synth_audio(n, seed=1000 * rank + i) for i in range(BATCH)]
@@ -159,7 +177,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16 (MFMA operands, f32 accumulate/state; decoder f32+f64)", "data": "synthetic",
             "config": {"workload": "configs[1]: batch=64 synthetic 5 s 16 kHz utterances per GPU, English geometry (n_hidden 2048, 29 classes), "
-                                   "beam_width=500, KenLM scorer = pruned_lm.scorer fixture (quant-array-trie order 4)",
+                                   "beam_width=500, KenLM scorer = " + SCORER_DESC,
                        "global_batch": world * BATCH, "parallelism": "dp%d (utterance shards, RCCL transcript gather)" % world},
             "p50_utterance_latency_ms": 1e3 * elapsed / args.steps,   # a batch completes together: submit -> transcripts on host
             "stage_ms_per_step": {k: v / K for k, v in stage.items() if k.endswith("_ms")},

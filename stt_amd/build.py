@@ -48,7 +48,22 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    build_tools(force=force, verbose=verbose)
     return LIB
+
+
+TOOLS_SRC = os.path.join(HERE, "tools", "scorer_tools.cpp")
+TOOLS_BIN = os.path.join(HERE, "lib", "stt_scorer_tools")
+
+
+def build_tools(force=False, verbose=True):
+    """Host-only scorer packaging tool (generate_scorer_package restated + synthetic LM writer)."""
+    if force or _newer(TOOLS_SRC, TOOLS_BIN):
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-o", TOOLS_BIN, TOOLS_SRC]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return TOOLS_BIN
 
 
 if __name__ == "__main__":

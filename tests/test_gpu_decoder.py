@@ -140,3 +140,39 @@ def test_decoder_streams_are_independent_and_chunking_is_exact(models, port, eng
             d2.next(p[k:k + 16])
         a, b, c = canon(together[i]), canon(d1.decode(10)[0]), canon(d2.decode(10)[0])
         assert a == b == c, i
+
+
+def test_decoder_with_synthetic_order5_scorer(models, port, english, fix, tmp_path):
+    """A scorer written by stt_amd/tools (synthetic order-5 quantised array trie, 3000 pseudo-words, words up to 15 letters):
+    exercises every trie level, the Bhiksha hint table, the interpolation search and the 16-byte word registers."""
+    from stt_amd import scorertools
+    labels, space = english
+    lm, vocab_p, pkg = str(tmp_path / "lm.binary"), str(tmp_path / "vocab.txt"), str(tmp_path / "synth.scorer")
+    scorertools.synth_lm(lm, vocab_p, words=3000, order=5, seed=5)
+    scorertools.generate_scorer_package(lm, vocab_p, pkg, alphabet=os.path.join(fix, "alphabet.txt"), default_alpha=0.9, default_beta=1.2)
+    vocab = open(vocab_p).read().split()
+    P = port.Scorer(pkg)
+    m = _mk(tmp_path, synth.ENGLISH_LABELS, 500, "synth_lm")
+    m.enableExternalScorer(pkg)
+    rng = np.random.RandomState(321)
+    for it in range(5):
+        sent = " ".join(rng.choice(vocab, size=rng.randint(2, 7)))
+        lab = [0 if ch == " " else (27 if ch == "'" else ord(ch) - ord("a") + 1) for ch in sent]
+        p = synth.peaky_emissions(lab, 30 + 5 * len(lab), 29, 28, seed=40 + it, noise=[0.02, 0.1, 0.3, 0.6, 1.0][it])
+        for beam in (64, 500, 1024):
+            hot = {vocab[3]: 2.5, vocab[10]: -1.0} if it == 2 else None
+            dp = port.Decoder(labels, space, beam, P, hot_words=hot); dp.next(p)
+            if hot:
+                for wd, b in hot.items():
+                    m.addHotWord(wd, b)
+            d = m.createDecoder(1, beam); d.next(p)
+            if hot:
+                m.clearHotWords()
+            gs, gb, gnb, gch = d.raw_beam(0)
+            ps, pb, pnb, pch, _ = dp.raw_beam()
+            tag = "it%d beam%d" % (it, beam)
+            assert len(gs) == len(ps) and np.array_equal(gs.view(np.uint32), ps.view(np.uint32)), tag
+            assert np.array_equal(gch, pch), tag
+            n = min(beam, 20)
+            assert canon(d.decode(n)[0]) == canon(dp.decode(n)), tag
+            assert d.stats()["error"] == 0
