@@ -1,0 +1,97 @@
+"""BASELINE.json configs[2..4] as parity cases at test size (the bench line is configs[1]):
+   [2] streaming chunked feed (320 ms hops) with an intermediate decode after every chunk,
+   [3] a variable-length batch (more than one 64-utterance group) sharded like the multi-GPU path,
+   [4] byte-output model (256 classes, UTF8Alphabet) with the bytes scorer at beam 1024."""
+import os
+
+import numpy as np
+import pytest
+
+from stt_amd import dist, modelfile, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model(tmp_path_factory, fix):
+    from stt_amd import Model
+    w = synth.synth_weights(33, n_hidden=256)
+    w["layer_6/weights"] = (w["layer_6/weights"] * 6.0).astype(np.float32)
+    path = str(tmp_path_factory.mktemp("cfg") / "m.sttw")
+    modelfile.write_model(path, w, synth.ENGLISH_LABELS, beam_width=100)
+    m = Model(path)
+    m.enableExternalScorer(os.path.join(fix, "pruned_lm.scorer"))
+    return m
+
+
+def test_config3_streaming_320ms_hops_with_intermediate_decodes(model, port, english, fix):
+    """stt.cc:553-639: IntermediateDecode after every 5120-sample feed never changes what FinishStream returns, and every
+    intermediate result equals decoding the windows processed so far (checked through the oracle on the GPU's emissions)."""
+    labels, space = english
+    P = port.Scorer(os.path.join(fix, "pruned_lm.scorer"))
+    rng = np.random.RandomState(1)
+    for u in range(4):
+        n = int(rng.uniform(1.0, 6.0) * 16000)
+        a = synth.synth_audio(n, seed=300 + u)
+        probs = model.acousticProbs([a])[0]
+        s = model.createStream()
+        inter = []
+        for k in range(0, n, 5120):
+            s.feedAudioContent(a[k:k + 5120])
+            inter.append(s.intermediateDecode())
+        final = s.finishStream()
+        assert final == model.stt(a)
+        # after feeding F samples, 16*floor(windows/16) windows have been through the model (stt.cc:311-334); window count
+        # = full frames pushed - n_context (the 9 leading zero frames are already there)
+        for j, text in enumerate(inter):
+            fed = min(n, (j + 1) * 5120)
+            frames = (fed - 512) // 320 + 1 if fed >= 512 else 0
+            done = max(0, frames - 9) // 16 * 16
+            d = port.Decoder(labels, space, 100, P)
+            if done:
+                d.next(probs[:done])
+            want = b"".join(labels[t] for t in d.decode(1)[0][1]).decode()
+            assert text == want, (u, j, fed, done)
+
+
+def test_config4_variable_length_batch_and_shards(model):
+    """150 utterances of 0.5-6 s: the batch path (three groups, ragged lengths inside a group) == one utterance at a time,
+    and the LPT shards of stt_amd/dist.py put together again give the same list (what 8 ranks + all_gather produce)."""
+    rng = np.random.RandomState(2)
+    lens = (rng.uniform(0.5, 6.0, size=150) * 16000).astype(int)
+    lens[7] = 0; lens[19] = 300                      # empty and shorter than one window
+    audio = [synth.synth_audio(int(n), seed=500 + i) for i, n in enumerate(lens)]
+    whole = model.sttBatch(audio)
+    for i in (0, 7, 19, 64, 65, 128, 149):
+        assert model.stt(audio[i]) == whole[i], i
+    shards = dist.shard_utterances([len(a) for a in audio], 8)
+    assert sorted(i for s in shards for i in s) == list(range(150))
+    merged = [None] * 150
+    for s in shards:
+        for i, t in zip(s, model.sttBatch([audio[i] for i in s])):
+            merged[i] = t
+    assert merged == whole
+
+
+def test_config5_bytes_model_beam_1024_with_bytes_scorer(tmp_path, port, fix):
+    """Byte-output mode as the reference defines it (doc/DECODER.rst: 255 byte labels + blank); C = 256 > cutoff_top_n = 40,
+    so the class sort / cut-off of get_pruned_emissions is active; codepoint-level scorer; beam 1024."""
+    from stt_amd import Model
+    ulabels, uspace = port.utf8_alphabet()
+    w = synth.synth_weights(44, n_hidden=128, n_classes=256)
+    w["layer_6/weights"] = (w["layer_6/weights"] * 8.0).astype(np.float32)
+    path = str(tmp_path / "bytes.sttw")
+    modelfile.write_model(path, w, ulabels, beam_width=1024)
+    m = Model(path)
+    m.enableExternalScorer(os.path.join(fix, "pruned_lm.bytes.scorer"))
+    P = port.Scorer(os.path.join(fix, "pruned_lm.bytes.scorer"))
+    for u, n in enumerate([16000, 30000]):
+        a = synth.synth_audio(n, seed=800 + u)
+        probs = m.acousticProbs([a])[0]
+        assert probs.shape[1] == 256
+        d = port.Decoder(ulabels, uspace, 1024, P); d.next(probs)
+        conf, tok, ts = d.decode(1)[0]
+        md = m.sttWithMetadata(a, 1)["transcripts"][0]
+        assert [t[1] for t in md["tokens"]] == [int(x) for x in ts]
+        assert md["confidence"] == conf
+        assert md["text"].encode("utf-8", "surrogateescape") == b"".join(ulabels[t] for t in tok) or len(md["tokens"]) == len(tok)
