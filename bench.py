@@ -183,6 +183,7 @@ def main():
             "stage_ms_per_step": {k: v / K for k, v in stage.items() if k.endswith("_ms")},
             "decoder_counters_last_step": dstats,
             "decoder_phase_cycle_share": {k: round(v / max(1, sum(dphase.values())), 4) for k, v in dphase.items()},
+            "decoder_phase_cycles_per_stream_step": {k: round(v / max(1, dstats["steps"]), 1) for k, v in dphase.items()},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -133,15 +133,15 @@ int create_stream(ModelState* aCtx, StreamingState** retval, bool keep_emissions
 // ---- batch path: every utterance goes through exactly the arithmetic of STT_SpeechToText ---------------------
 // Groups of <= 64 utterances.  Within a group the acoustic model runs in time-chunks on `stream` and the beam search of
 // chunk k runs on `stream_dec` while chunk k+1 is being computed (the search only occupies one workgroup per utterance).
-// Chunk schedule: a short first chunk so the beam search starts early, then chunks of STT_AMD_CHUNK (default 32) frames.
+// Chunk schedule: a short first chunk (STT_AMD_CHUNK0, default 24 frames) so the beam search starts early, then chunks of STT_AMD_CHUNK (default 48) frames.
 int batch_chunk_frames() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("STT_AMD_CHUNK"); v = e ? atoi(e) : 32; if (v < 1) v = 1 << 30; }
+  if (v < 0) { const char* e = getenv("STT_AMD_CHUNK"); v = e ? atoi(e) : 48; if (v < 1) v = 1 << 30; }
   return v;
 }
 int batch_first_chunk_frames() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("STT_AMD_CHUNK0"); v = e ? atoi(e) : 16; if (v < 1) v = 1 << 30; }
+  if (v < 0) { const char* e = getenv("STT_AMD_CHUNK0"); v = e ? atoi(e) : 24; if (v < 1) v = 1 << 30; }
   return v;
 }
 std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio, unsigned stride, const unsigned* sizes, unsigned B, unsigned num_results) {

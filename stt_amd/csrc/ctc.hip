@@ -487,6 +487,7 @@ struct Lds {
   LDS_AS uint16_t *cls, *pos;
   LDS_AS uint8_t* lab1;                       // [C] the byte of every single-byte label (0 otherwise)
   LDS_AS uint32_t *hist, *cumb;
+  LDS_AS uint8_t* own; uint32_t own_cap;     // expand: per-wave table item -> owning lane (aliases skey/sseg/cumb, idle in that phase)
   LDS_AS uint64_t* skey; LDS_AS uint32_t *ssrc, *sseg;
   LDS_AS uint32_t* wtot;
   // the first `mcap` candidates of a step live in LDS, the rest in the stream's HBM workspace
@@ -521,8 +522,11 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   }
   for (int a = 0; a < 4; ++a) offs[k++] = take(cap * 4);           // events
   offs[k++] = take(HTN * 8); offs[k++] = take(HTN * 2);            // hash
-  offs[k++] = take(NBUCKET * 4); offs[k++] = take((NBUCKET + 1) * 4);
-  offs[k++] = take(sn * 8); offs[k++] = take(sn * 4); offs[k++] = take(sn * 4);
+  offs[k++] = take(NBUCKET * 4);                                   // hist
+  offs[k++] = take(sn * 4);                                        // ssrc
+  const size_t o_own = o;                                          // skey | sseg | cumb double as the expand phase's item-owner tables
+  offs[k++] = take(sn * 8); offs[k++] = take(sn * 4); offs[k++] = take((NBUCKET + 1) * 4);
+  const uint32_t own_cap = (uint32_t)((o - o_own) / NWAVES) & ~3u;
   offs[k++] = take(64 * 4);
   offs[k++] = take(12 * 8);
   offs[k++] = take(SC_COUNT * 4);
@@ -553,8 +557,10 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
     l->ev_self = (LDS_AS float*)(base + offs[k++]); l->ev_blank = (LDS_AS float*)(base + offs[k++]); l->ev_ext = (LDS_AS float*)(base + offs[k++]);
     l->ev_exti = (LDS_AS uint32_t*)(base + offs[k++]);
     l->ht_key = (LDS_AS uint64_t*)(base + offs[k++]); l->ht_idx = (LDS_AS uint16_t*)(base + offs[k++]);
-    l->hist = (LDS_AS uint32_t*)(base + offs[k++]); l->cumb = (LDS_AS uint32_t*)(base + offs[k++]);
-    l->skey = (LDS_AS uint64_t*)(base + offs[k++]); l->ssrc = (LDS_AS uint32_t*)(base + offs[k++]); l->sseg = (LDS_AS uint32_t*)(base + offs[k++]);
+    l->hist = (LDS_AS uint32_t*)(base + offs[k++]);
+    l->ssrc = (LDS_AS uint32_t*)(base + offs[k++]);
+    l->skey = (LDS_AS uint64_t*)(base + offs[k++]); l->sseg = (LDS_AS uint32_t*)(base + offs[k++]); l->cumb = (LDS_AS uint32_t*)(base + offs[k++]);
+    l->own = (LDS_AS uint8_t*)(base + o_own); l->own_cap = own_cap;
     l->wtot = (LDS_AS uint32_t*)(base + offs[k++]);
     l->acc = (LDS_AS unsigned long long*)(base + offs[k++]);
     l->sc = (LDS_AS int*)(base + offs[k++]);
@@ -757,14 +763,14 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   __syncthreads();
   TICK(0);
 
-  // ---- P2: expand.  Wave w owns prefixes [w*ppw, (w+1)*ppw): blank / repeat events per prefix, then one work item per
+  // ---- P2: expand.  Wave w owns prefixes w, w+16, w+32, ...: blank / repeat events per prefix, then one work item per
   // (prefix, candidate label) -- with a dictionary only the out-arcs of the prefix's FST state can succeed
   // (path_trie.cpp:54-64), otherwise every kept class -- dealt to the lanes through a wave-local prefix sum.
   unsigned probes = 0;
   const bool lm_queue = SC_ON && !SC_UTF8;  // word mode: <= 1 scored extension (the space) per prefix per step
   {
     uint32_t ppw = pow2_ge((uint32_t)((n + NWAVES - 1) / NWAVES));  // <= 64
-    const int i0 = wave * (int)ppw + lane;
+    const int i0 = lane * NWAVES + wave;  // interleaved: the beam is sorted by score and good prefixes survive the cut-off for more labels, so every wave gets its share of them
     uint32_t cnt = 0, a0 = 0;
     if (lane < (int)ppw && i0 < n) {
       const int i = i0;
@@ -788,31 +794,44 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     const uint32_t inc = wave_incl_scan(cnt, lane);
     const uint32_t off = inc - cnt;
     const uint32_t n_items = __shfl(inc, 63);
-    // Items are taken 64 at a time; the FST arc of the *next* item is fetched before the current one is processed,
-    // so the HBM/L2 latency of the arc read overlaps the LDS work of the previous item.
-    uint32_t j_n = 0, kk_n = 0; uint2 arc_n = make_uint2(0, 0); bool v_n = false;
-    {
-      const uint32_t x = lane;
-      uint32_t j = 0;  // largest lane with off_j <= x (lanes with no items share their successor's offset)
-      for (uint32_t step = ppw >> 1; step >= 1; step >>= 1) { const uint32_t v = __shfl(off, (int)(j + step)); if (v <= x) j += step; }
-      const uint32_t offj = __shfl(off, (int)j), a0j = __shfl(a0, (int)j);
-      v_n = x < n_items; j_n = j; kk_n = x - offj;
-      if (v_n && SC_ON) arc_n = s.fst_arcs[a0j + kk_n];
+    // Items are taken 64 at a time; the FST arcs of the next two rounds are already in flight while a round is processed,
+    // so the HBM/L2 latency of the arc reads overlaps the LDS work of the earlier items.
+    // item -> owning lane: a per-wave byte table filled by the owners (one LDS read per item) when the wave's items fit,
+    // else a binary search over the lanes' offsets with shuffles
+    const bool use_tab = n_items <= L.own_cap;  // wave-uniform
+    LDS_AS uint8_t* own = L.own + (uint32_t)wave * L.own_cap;
+    if (use_tab) {
+      for (uint32_t kk = 0; kk < cnt; ++kk) own[off + kk] = (uint8_t)lane;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
+#define EXPAND_LOCATE(X, J, KK, V, ARC)                                                                         \
+    {                                                                                                             \
+      const uint32_t x_ = (X);                                                                                    \
+      uint32_t j_ = 0; /* largest lane with off_j <= x (lanes with no items share their successor's offset) */    \
+      if (use_tab) j_ = x_ < n_items ? (uint32_t)own[x_] : 0u;                                                    \
+      else for (uint32_t step = ppw >> 1; step >= 1; step >>= 1) { const uint32_t v_ = __shfl(off, (int)(j_ + step)); if (v_ <= x_) j_ += step; } \
+      const uint32_t offj_ = __shfl(off, (int)j_), a0j_ = __shfl(a0, (int)j_);                                    \
+      V = x_ < n_items; J = j_; KK = x_ - offj_;                                                                  \
+      ARC = make_uint2(0, 0);                                                                                     \
+      if (V && SC_ON) ARC = s.fst_arcs[a0j_ + KK];                                                                \
+    }
+    TICK(1);
+    uint32_t j_0 = 0, kk_0 = 0, j_1 = 0, kk_1 = 0, j_2 = 0, kk_2 = 0;
+    uint2 arc_0 = make_uint2(0, 0), arc_1 = arc_0, arc_2 = arc_0;
+    bool v_0 = false, v_1 = false, v_2 = false;
+    if (n_items > 0) EXPAND_LOCATE(lane, j_0, kk_0, v_0, arc_0)
+    if (n_items > 64) EXPAND_LOCATE(64 + lane, j_1, kk_1, v_1, arc_1)
 #pragma unroll 1
     for (uint32_t xb = 0; xb < n_items; xb += 64) {
-      const uint32_t iju = j_n, kku = kk_n; const uint2 arc_c = arc_n; const bool vu = v_n;
-      if (xb + 64 < n_items) {  // uniform
-        const uint32_t x = xb + 64 + lane;
-        uint32_t j = 0;
-        for (uint32_t step = ppw >> 1; step >= 1; step >>= 1) { const uint32_t v = __shfl(off, (int)(j + step)); if (v <= x) j += step; }
-        const uint32_t offj = __shfl(off, (int)j), a0j = __shfl(a0, (int)j);
-        v_n = x < n_items; j_n = j; kk_n = x - offj;
-        if (v_n && SC_ON) arc_n = s.fst_arcs[a0j + kk_n];
-      }
+      if (xb + 128 < n_items) EXPAND_LOCATE(xb + 128 + lane, j_2, kk_2, v_2, arc_2)  // uniform condition
+      const uint32_t iju = j_0, kku = kk_0; const uint2 arc_c = arc_0; const bool vu = v_0;
+      j_0 = j_1; kk_0 = kk_1; arc_0 = arc_1; v_0 = v_1;
+      j_1 = j_2; kk_1 = kk_2; arc_1 = arc_2; v_1 = v_2;
+      v_2 = false;
       {
         if (!vu) continue;
-        const int i = wave * (int)ppw + (int)iju;
+        const int i = (int)iju * NWAVES + wave;
         uint32_t c; int k; int child_fst = 0;
         if (SC_ON) {
           const uint2 arc = arc_c;
@@ -853,6 +872,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       }
     }
   }
+#undef EXPAND_LOCATE
   __syncthreads();
   int m = sc[SC_M];
   if ((uint32_t)m > S.cand_cap) { m = (int)S.cand_cap; if (tid == 0) sc[SC_ERR] |= 4; }
