@@ -168,8 +168,20 @@ def main():
         }
         dom = max(kernels, key=lambda k: kernels[k]["share_ms"])
         ach = kernels[dom]["bytes"] / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and
+        # WRITE_SIZE cannot share a pass, and counters are never collected inside a timed run); bytes per batch, like `achieved`
+        traffic, traffic_note = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            key = [k for k in pmc if k.startswith(dom.split("<")[0])][0]
+            e = pmc[key]
+            wide = dom.startswith("lstm")   # 16 B/lane coalesced streams: FETCH_SIZE reads 1/2 on gfx950 (MI355X_MICROARCH.md, HBM)
+            traffic = (e["fetch_kb_per_launch"] * (2.0 if wide else 1.0) + e["write_kb_per_launch"]) * 1024.0 * (e["launches_per_batch"] if not wide else 1.0)
+            traffic_note = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE (separate passes, profiles/r01_pmc_per_kernel.csv), bytes per %s" % ("launch" if wide else "batch (%d chunk launches)" % round(e["launches_per_batch"]))
+        except Exception:
+            pass
         roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": None,
+                    "traffic": traffic, "traffic_note": traffic_note,
                     "all": {k: {"GB/s": v["bytes"] / (v["avg_ms"] * 1e-3) / 1e9, "avg_ms": v["avg_ms"], "ms_per_step": v["share_ms"]}
                             for k, v in kernels.items()}}
         res = {
