@@ -54,12 +54,21 @@ def build(force=False, verbose=True):
 
 TOOLS_SRC = os.path.join(HERE, "tools", "scorer_tools.cpp")
 TOOLS_BIN = os.path.join(HERE, "lib", "stt_scorer_tools")
+CLIENT_SRC = os.path.join(HERE, "tools", "stt_client.cpp")
+CLIENT_BIN = os.path.join(HERE, "lib", "stt")
 
 
 def build_tools(force=False, verbose=True):
     """Host-only scorer packaging tool (generate_scorer_package restated + synthetic LM writer)."""
     if force or _newer(TOOLS_SRC, TOOLS_BIN):
         cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-o", TOOLS_BIN, TOOLS_SRC]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    # the `stt` command-line client: plain C++ on include/coqui-stt.h + include/stt_amd.h, linked against libstt.so
+    if os.path.exists(LIB) and (force or _newer(CLIENT_SRC, CLIENT_BIN) or _newer(LIB, CLIENT_BIN)):
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-o", CLIENT_BIN, CLIENT_SRC, "-L" + os.path.dirname(LIB), "-lstt",
+               "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
