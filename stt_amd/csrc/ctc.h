@@ -70,6 +70,7 @@ struct DevScorer {
   int fst_start;
   const uint32_t* fst_state_pos;
   const uint2* fst_arcs;
+  const uint8_t* fst_has_space;  // word mode: state has an out-arc for the space label (a word may end here)
   // hot words (murmur hashes of the words)
   int n_hot;
   const uint64_t* hot_hash;

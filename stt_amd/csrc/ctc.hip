@@ -487,6 +487,7 @@ struct Lds {
   LDS_AS uint16_t *cls, *pos;
   LDS_AS uint8_t* lab1;                       // [C] the byte of every single-byte label (0 otherwise)
   LDS_AS uint32_t *hist, *cumb;
+  LDS_AS uint16_t* lmw;                      // the LM wave's list of prefixes to score this step
   LDS_AS uint8_t* own; uint32_t own_cap;     // expand: per-wave table item -> owning lane (aliases skey/sseg/cumb, idle in that phase)
   LDS_AS uint64_t* skey; LDS_AS uint32_t *ssrc, *sseg;
   LDS_AS uint32_t* wtot;
@@ -528,6 +529,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   offs[k++] = take(sn * 8); offs[k++] = take(sn * 4); offs[k++] = take((NBUCKET + 1) * 4);
   const uint32_t own_cap = (uint32_t)((o - o_own) / NWAVES) & ~3u;
   offs[k++] = take(64 * 4);
+  offs[k++] = take(cap * 2);                                       // lmw
   offs[k++] = take(12 * 8);
   offs[k++] = take(SC_COUNT * 4);
   offs[k++] = take(16);                                            // lbl[2]
@@ -562,6 +564,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
     l->skey = (LDS_AS uint64_t*)(base + offs[k++]); l->sseg = (LDS_AS uint32_t*)(base + offs[k++]); l->cumb = (LDS_AS uint32_t*)(base + offs[k++]);
     l->own = (LDS_AS uint8_t*)(base + o_own); l->own_cap = own_cap;
     l->wtot = (LDS_AS uint32_t*)(base + offs[k++]);
+    l->lmw = (LDS_AS uint16_t*)(base + offs[k++]);
     l->acc = (LDS_AS unsigned long long*)(base + offs[k++]);
     l->sc = (LDS_AS int*)(base + offs[k++]);
     l->lbl = (LDS_AS double*)(base + offs[k++]);
@@ -768,9 +771,44 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   // (path_trie.cpp:54-64), otherwise every kept class -- dealt to the lanes through a wave-local prefix sum.
   unsigned probes = 0;
   const bool lm_queue = SC_ON && !SC_UTF8;  // word mode: <= 1 scored extension (the space) per prefix per step
-  {
-    uint32_t ppw = pow2_ge((uint32_t)((n + NWAVES - 1) / NWAVES));  // <= 64
-    const int i0 = lane * NWAVES + wave;  // interleaved: the beam is sorted by score and good prefixes survive the cut-off for more labels, so every wave gets its share of them
+  // Word mode, narrow beams: the last wave takes no prefixes.  It finds the prefixes whose "prefix + space" extension will
+  // need a language-model score this step (same tests as the expand items: a word may end here, not yet scored, survives
+  // the cut-off) and runs those queries *now*, so their dependent HBM reads overlap the expand work of the other waves
+  // instead of sitting between two barriers.  P3 then finds the entry in pqe and only reads its score.
+  const bool lm_wave = MODE == 1 && L.pqe.p0 != nullptr && n > NWAVES;
+  const int nw_exp = lm_wave ? NWAVES - 1 : NWAVES;
+  if (lm_wave && wave == NWAVES - 1) {
+    const int ksp = L.pos[al.space_id];
+    unsigned lmq = 0;
+    if (ksp != 0xFFFF) {
+      const float lpsp = lp[ksp];
+      uint32_t n_need = 0;
+      for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        bool need = false;
+        if (i < n) {
+          const float sci = L.score[cur][i];
+          need = (L.an[cur][i] >> 15) && L.pqe[cur][i] == STT_NONE && L.bnd[cur][i] != STT_NONE && sci != NEG &&
+                 !(full_beam && __fadd_rn(lpsp, sci) < min_cutoff);
+        }
+        const uint64_t mask = __ballot(need);
+        if (need) L.lmw[n_need + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        n_need += (uint32_t)__popcll(mask);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t q = lane; q < n_need; q += 64) {
+        const int i = (int)L.lmw[q];
+        uint32_t ne;
+        (void)lm_word_query_cached(s, al, S, L.lab1, (LDS_AS uint32_t*)&sc[SC_BEN], L.node[cur][i], L.bnd[cur][i], true, L.wlo[cur][i], L.whi[cur][i], ne, probes);
+        L.pqe[cur][i] = ne;
+        ++lmq;
+      }
+    }
+    if (lmq) lds_add(&sc[SC_LMQ], (int)lmq);
+  } else {
+    uint32_t ppw = pow2_ge((uint32_t)((n + nw_exp - 1) / nw_exp));  // <= 64 (n <= 64 * 15 when the last wave is set aside: beams <= 512)
+    const int i0 = lane * nw_exp + wave;  // interleaved: the beam is sorted by score and good prefixes survive the cut-off for more labels, so every wave gets its share of them
     uint32_t cnt = 0, a0 = 0;
     if (lane < (int)ppw && i0 < n) {
       const int i = i0;
@@ -786,7 +824,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
           if (ks != 0xFFFF) { const float lpc = lp[ks]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_self[i] = __fadd_rn(lpc, L.pnb[cur][i]); }
         }
         if (SC_ON) {
-          if (L.a0.p0) { a0 = L.a0[cur][i]; cnt = L.an[cur][i]; }
+          if (L.a0.p0) { a0 = L.a0[cur][i]; cnt = L.an[cur][i] & 0x7FFFu; }
           else { const int st = L.fst[cur][i]; a0 = s.fst_state_pos[st]; cnt = s.fst_state_pos[st + 1] - a0; }
         } else cnt = (uint32_t)cutoff_len;
       }
@@ -831,7 +869,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       v_2 = false;
       {
         if (!vu) continue;
-        const int i = (int)iju * NWAVES + wave;
+        const int i = (int)iju * nw_exp + wave;
         uint32_t c; int k; int child_fst = 0;
         if (SC_ON) {
           const uint2 arc = arc_c;
@@ -1064,7 +1102,11 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
         const int cf = ((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst[cx];
         L.ch[nxt][r] = c; L.fst[nxt][r] = cf;
-        if (SC_ON && L.a0.p0) { const uint32_t f0 = s.fst_state_pos[cf], f1 = s.fst_state_pos[cf + 1]; L.a0[nxt][r] = f0; L.an[nxt][r] = (uint16_t)(f1 - f0); }
+        if (SC_ON && L.a0.p0) {  // arc range of the child's dictionary state; top bit: a word may end here (space arc)
+          const uint32_t f0 = s.fst_state_pos[cf], f1 = s.fst_state_pos[cf + 1];
+          const uint32_t sp = MODE == 1 ? (uint32_t)s.fst_has_space[cf] : 0u;
+          L.a0[nxt][r] = f0; L.an[nxt][r] = (uint16_t)((f1 - f0) | (sp << 15));
+        }
         nkey = child_key(L.key[cur][i], c);
         uint32_t b = L.bnd[cur][i];
         if (MODE == 1 && (int)c == al.space_id) b = L.pqe.p0 ? L.pqe[cur][i] : S.pq[pnode];  // the boundary entry scored in P3 (or earlier)
@@ -1137,7 +1179,11 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
     L.score[0][i] = g_score[i]; L.pb[0][i] = g_pb[i]; L.pnb[0][i] = g_pnb[i];
     L.ch[0][i] = g_ch[i]; L.node[0][i] = g_node[i]; L.ts[0][i] = g_ts[i]; const int st = g_fst[i]; L.fst[0][i] = st; L.key[0][i] = g_key[i];
     L.bnd[0][i] = g_bnd[i];
-    if (SC_ON && L.a0.p0) { const uint32_t f0 = s.fst_state_pos[st], f1 = s.fst_state_pos[st + 1]; L.a0[0][i] = f0; L.an[0][i] = (uint16_t)(f1 - f0); }
+    if (SC_ON && L.a0.p0) {
+      const uint32_t f0 = s.fst_state_pos[st], f1 = s.fst_state_pos[st + 1];
+      const uint32_t sp = MODE == 1 ? (uint32_t)s.fst_has_space[st] : 0u;
+      L.a0[0][i] = f0; L.an[0][i] = (uint16_t)((f1 - f0) | (sp << 15));
+    }
   }
   for (int c = tid; c < p.C; c += NTHREADS) {
     uint8_t one = 0;

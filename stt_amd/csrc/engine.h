@@ -72,8 +72,8 @@ class ScorerDev {
   uint64_t blob_bytes = 0;
 
  private:
-  int Parse(const uint8_t* buf, size_t len);
-  DevBuf blob_, fst_pos_, fst_arcs_, vtab_, hint_;
+  int Parse(const uint8_t* buf, size_t len, int space_label);
+  DevBuf blob_, fst_pos_, fst_arcs_, fst_space_, vtab_, hint_;
 };
 
 // ---------------------------------------------------------------------------------------------

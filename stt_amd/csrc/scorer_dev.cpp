@@ -56,11 +56,11 @@ int ScorerDev::LoadFile(const std::string& path, const Alphabet& alphabet) {
   return LoadBuffer(data.data(), data.size(), alphabet);
 }
 
-int ScorerDev::LoadBuffer(const char* data, size_t len, const Alphabet&) {
-  return Parse(reinterpret_cast<const uint8_t*>(data), len);
+int ScorerDev::LoadBuffer(const char* data, size_t len, const Alphabet& alphabet) {
+  return Parse(reinterpret_cast<const uint8_t*>(data), len, alphabet.GetSpaceLabel());
 }
 
-int ScorerDev::Parse(const uint8_t* buf, size_t len) {
+int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label) {
   static const char kMagic[] = "mmap lm http://kheafield.com/code format version 5\n";
   if (len < 88 + 20 || memcmp(buf, kMagic, sizeof(kMagic)) != 0) return STT_ERR_SCORER_INVALID_LM;
   const uint8_t* fp = buf + 88;  // FixedWidthParameters after the 88-byte Sanity block
@@ -150,6 +150,7 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len) {
   std::vector<uint32_t> pos((size_t)nstates + 1);
   std::vector<uint8_t> fin((size_t)nstates);
   std::vector<uint2> arcv((size_t)narcs);
+  std::vector<uint8_t> has_space((size_t)nstates + 1, 0);
   for (int64_t s = 0; s < nstates; ++s) fin[s] = !(rdf(states + 20 * s) == INFINITY);  // Final(s) != TropicalWeight::Zero()
   uint32_t w = 0;
   for (int64_t s = 0; s < nstates; ++s) {
@@ -162,6 +163,7 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len) {
       const uint32_t next = rd32(A + 12);
       if (next >= (uint64_t)nstates) return STT_ERR_SCORER_INVALID_TRIE;
       arcv[w++] = make_uint2(rd32(A), fin[next] ? (uint32_t)fst_start : next);
+      if (space_label >= 0 && (int64_t)rd32(A) == (int64_t)space_label + 1) has_space[s] = 1;
     }
   }
   pos[nstates] = w;
@@ -183,6 +185,7 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len) {
   fst_pos_.upload(pos.data(), pos.size() * 4);
   vtab_.upload(vtab.data(), vtab.size() * sizeof(DevVocabSlot));
   fst_arcs_.upload(arcv.data(), arcv.size() * sizeof(uint2));
+  fst_space_.upload(has_space.data(), has_space.size());
   const uint8_t* d = blob_.as<uint8_t>();
   DevScorer ds{};
   ds.enabled = 1; ds.order = ord; ds.quant = quant; ds.utf8 = utf8;
@@ -240,7 +243,7 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len) {
     ds.bos_backoff = rdf(buf + unigram_off + 16 * (uint64_t)idx + 4);
   }
   ds.fst_start = (int)fst_start;
-  ds.fst_state_pos = fst_pos_.as<uint32_t>(); ds.fst_arcs = fst_arcs_.as<uint2>();
+  ds.fst_state_pos = fst_pos_.as<uint32_t>(); ds.fst_arcs = fst_arcs_.as<uint2>(); ds.fst_has_space = fst_space_.as<uint8_t>();
   dev = ds;
   is_utf8 = utf8; order = ord; blob_bytes = lm_end;
   return STT_ERR_OK;
