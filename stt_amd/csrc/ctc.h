@@ -33,7 +33,9 @@ struct __attribute__((aligned(16))) BEntry {
 };
 #define STT_NONE 0xFFFFFFFFu
 
-struct DevVocabSlot { uint64_t hash; uint32_t index; uint32_t used; };
+// One slot of the vocabulary table; carries a copy of the word's unigram record (lm/trie.hh UnigramValue: prob, backoff,
+// next) so that a query's first trie level costs no further read.  begin/end are valid when DevScorer::uni_in_vtab.
+struct DevVocabSlot { uint64_t hash; uint32_t index; uint32_t used; float prob, backoff; uint32_t begin, end; };
 
 struct DevBitPacked {
   const uint8_t* base;
@@ -56,6 +58,7 @@ struct DevScorer {
   uint64_t vocab_n;
   const DevVocabSlot* vtab;    // open-addressing table over the same hashes (built at load): 1-2 probes instead of log2(n)
   uint32_t vtab_mask;
+  int uni_in_vtab;             // the slots' unigram copies are usable (bigram count < 2^32)
   const uint8_t* unigram;
   const float* qprob[STT_KENLM_MAX_ORDER];
   const float* qbackoff[STT_KENLM_MAX_ORDER];

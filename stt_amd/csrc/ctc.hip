@@ -187,17 +187,35 @@ __device__ bool lookup_longest(const DevScorer& s, uint32_t word, const KNode& n
   ++probes;
   return true;
 }
+// vocabulary lookup that also hands back the slot (the word's unigram record rides along in it)
+__device__ __forceinline__ uint32_t vocab_slot(const DevScorer& s, uint64_t h, DevVocabSlot& out, unsigned& probes) {
+  uint32_t slot = (uint32_t)h & s.vtab_mask;
+  for (;;) {
+    const DevVocabSlot e = s.vtab[slot];
+    ++probes;
+    if (!e.used) { out = e; return 0; }
+    if (e.hash == h) { out = e; return e.index; }
+    slot = (slot + 1) & s.vtab_mask;
+  }
+}
+
 // GenericModel::FullScore (model.cc:170-176) = ScoreExceptBackoff (:285-310) + ResumeScore (:312-338).
 // Written with compile-time indices only (fully unrolled over KENLM_MAX_ORDER) so that both states stay in registers.
-__device__ __forceinline__ float kenlm_full_score(const DevScorer& s, const KState& in, uint32_t new_word, KState& out, unsigned& probes) {
+__device__ __forceinline__ float kenlm_full_score(const DevScorer& s, const KState& in, uint32_t new_word, KState& out, unsigned& probes,
+                                                  const DevVocabSlot* uni = nullptr) {
   KNode node;
-  const uint8_t* u = s.unigram + 16 * (uint64_t)new_word;
-  const uint64_t pb = ld64u(u);  // {float prob, float backoff, uint64 next}; the three loads are independent
-  node.begin = ld64u(u + 8);
-  node.end = ld64u(u + 24);
-  float prob = __uint_as_float((uint32_t)pb);
-  out.backoff[0] = __uint_as_float((uint32_t)(pb >> 32));
-  probes += 2;
+  float prob;
+  if (uni) {  // unigram record copied into the vocabulary slot at load time
+    prob = uni->prob; out.backoff[0] = uni->backoff; node.begin = uni->begin; node.end = uni->end;
+  } else {
+    const uint8_t* u = s.unigram + 16 * (uint64_t)new_word;
+    const uint64_t pb = ld64u(u);  // {float prob, float backoff, uint64 next}; the three loads are independent
+    node.begin = ld64u(u + 8);
+    node.end = ld64u(u + 24);
+    prob = __uint_as_float((uint32_t)pb);
+    out.backoff[0] = __uint_as_float((uint32_t)(pb >> 32));
+    probes += 2;
+  }
   bool independent_left = (node.begin == node.end);
   int nl = 1;
   int out_len = has_extension(out.backoff[0]) ? 1 : 0;
@@ -426,11 +444,12 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
     }
     h = hash_labels_reversed(al, labs, nl);
   }
-  const uint32_t wi = vocab_index(s, h, probes);
-  const BEntry ep = load_be(S, e_prev);
+  const BEntry ep = load_be(S, e_prev);  // issued before the vocabulary probe: the two reads are independent
   ++probes;
+  DevVocabSlot vs;
+  const uint32_t wi = vocab_slot(s, h, vs, probes);
   BEntry en;
-  const float prob = kenlm_full_score(s, ep.st, wi, en.st, probes);
+  const float prob = kenlm_full_score(s, ep.st, wi, en.st, probes, (wi != 0 && s.uni_in_vtab) ? &vs : nullptr);
   en.oov_hist = (uint16_t)((ep.oov_hist << 1) | (wi == 0 ? 1u : 0u));
   const bool oov = (en.oov_hist & ((1u << s.order) - 1u)) != 0;  // this word + the order-1 before it
   float hot_self = 0.0f, hot_total = 0.0f;
@@ -478,7 +497,7 @@ struct Lds {
   DB<uint64_t> key;
   // word mode, narrow beams: the UTF-8 bytes of the prefix's current (unfinished) word, first byte lowest (wlo = bytes
   // 0..7, whi = 8..15; all ones = longer than 16 bytes), and the BEntry of "prefix + boundary" once scored (STT_NONE before)
-  DB<uint64_t> wlo, whi; DB<uint32_t> pqe;
+  DB<uint64_t> wlo, whi; DB<uint32_t> pqe; DB<float> pqs;  // pqs = (float)(raw score * alpha) of entry pqe
   LDS_AS float *ev_self, *ev_blank, *ev_ext;  // reused as new pnb / new pb / new score in P4
   LDS_AS uint32_t* ev_exti;                   // parent beam index | needs_lm << 31 ; reused as pending timestep parent
   LDS_AS uint64_t* ht_key; LDS_AS uint16_t* ht_idx;  // path key -> beam index of the live prefixes (rebuilt whenever the beam is written)
@@ -520,6 +539,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
     for (int a = 0; a < 8; ++a) offs[k++] = take(cap * 4);         // score pb pnb ch node ts fst bnd
     offs[k++] = take(arcs ? cap * 4 : 0); offs[k++] = take(arcs ? cap * 2 : 0);  // a0, an (wide beams read the FST instead)
     offs[k++] = take(arcs ? cap * 8 : 0); offs[k++] = take(arcs ? cap * 8 : 0); offs[k++] = take(arcs ? cap * 4 : 0);  // wlo, whi, pqe
+    offs[k++] = take(arcs ? cap * 4 : 0);                                                                              // pqs
   }
   for (int a = 0; a < 4; ++a) offs[k++] = take(cap * 4);           // events
   offs[k++] = take(HTN * 8); offs[k++] = take(HTN * 2);            // hash
@@ -547,15 +567,15 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   o += (size_t)mcap * 12;
   {
     k = 0;
-    const uint32_t blk = (uint32_t)(offs[14] - offs[0]);  // 14 arrays per buffer
+    const uint32_t blk = (uint32_t)(offs[15] - offs[0]);  // 15 arrays per buffer
     auto db = [&](auto& m, size_t off, bool on) { using P = decltype(m.p0); m.p0 = on ? (P)(base + off) : (P) nullptr; m.blk = blk; };
     db(l->key, offs[0], true);
     db(l->score, offs[1], true); db(l->pb, offs[2], true); db(l->pnb, offs[3], true);
     db(l->ch, offs[4], true); db(l->node, offs[5], true); db(l->ts, offs[6], true);
     db(l->fst, offs[7], true); db(l->bnd, offs[8], true);
     db(l->a0, offs[9], arcs); db(l->an, offs[10], arcs);
-    db(l->wlo, offs[11], arcs); db(l->whi, offs[12], arcs); db(l->pqe, offs[13], arcs);
-    k = 28;
+    db(l->wlo, offs[11], arcs); db(l->whi, offs[12], arcs); db(l->pqe, offs[13], arcs); db(l->pqs, offs[14], arcs);
+    k = 30;
     l->ev_self = (LDS_AS float*)(base + offs[k++]); l->ev_blank = (LDS_AS float*)(base + offs[k++]); l->ev_ext = (LDS_AS float*)(base + offs[k++]);
     l->ev_exti = (LDS_AS uint32_t*)(base + offs[k++]);
     l->ht_key = (LDS_AS uint64_t*)(base + offs[k++]); l->ht_idx = (LDS_AS uint16_t*)(base + offs[k++]);
@@ -778,6 +798,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   const bool lm_wave = MODE == 1 && L.pqe.p0 != nullptr && n > NWAVES;
   const int nw_exp = lm_wave ? NWAVES - 1 : NWAVES;
   if (lm_wave && wave == NWAVES - 1) {
+    __builtin_amdgcn_s_setprio(3);  // the chain of dependent reads is the critical path of the phase: issue it first
     const int ksp = L.pos[al.space_id];
     unsigned lmq = 0;
     if (ksp != 0xFFFF) {
@@ -800,12 +821,13 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       for (uint32_t q = lane; q < n_need; q += 64) {
         const int i = (int)L.lmw[q];
         uint32_t ne;
-        (void)lm_word_query_cached(s, al, S, L.lab1, (LDS_AS uint32_t*)&sc[SC_BEN], L.node[cur][i], L.bnd[cur][i], true, L.wlo[cur][i], L.whi[cur][i], ne, probes);
-        L.pqe[cur][i] = ne;
+        const double raw = lm_word_query_cached(s, al, S, L.lab1, (LDS_AS uint32_t*)&sc[SC_BEN], L.node[cur][i], L.bnd[cur][i], true, L.wlo[cur][i], L.whi[cur][i], ne, probes);
+        L.pqe[cur][i] = ne; L.pqs[cur][i] = (float)__dmul_rn(raw, s.alpha);
         ++lmq;
       }
     }
     if (lmq) lds_add(&sc[SC_LMQ], (int)lmq);
+    __builtin_amdgcn_s_setprio(0);
   } else {
     uint32_t ppw = pow2_ge((uint32_t)((n + nw_exp - 1) / nw_exp));  // <= 64 (n <= 64 * 15 when the last wave is set aside: beams <= 512)
     const int i0 = lane * nw_exp + wave;  // interleaved: the beam is sorted by score and good prefixes survive the cut-off for more labels, so every wave gets its share of them
@@ -941,10 +963,13 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         // The root prefix (no word yet: the reference's n-gram is empty and scores 0) is entry 0, recorded in pq[0] when
         // the stream is created; a prefix that itself ends in a space contributes the empty word, which the backward walk
         // of lm_word_query_cached() produces by itself.  Entries cannot run out before path nodes do (one per node).
-        double raw;
+        double raw = 0.0;
+        float lms_cached = 0.0f;
         const bool in_lds = L.pqe.p0 != nullptr;
         const uint32_t e = in_lds ? L.pqe[cur][i] : S.pq[nodei];
-        if (e != STT_NONE) raw = load_be_raw(S, e);
+        const bool cached_f = in_lds && e != STT_NONE;  // scored earlier (or by the LM wave during expand): alpha-scaled score is in LDS
+        if (cached_f) lms_cached = L.pqs[cur][i];
+        else if (e != STT_NONE) raw = load_be_raw(S, e);
         else {
           const uint32_t bndi = L.bnd[cur][i];
           if (bndi == STT_NONE) { raw = 0.0; lds_or(&sc[SC_ERR], 8); }
@@ -952,11 +977,11 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
             uint32_t ne;
             raw = lm_word_query_cached(s, al, S, L.lab1, (LDS_AS uint32_t*)&sc[SC_BEN], nodei, bndi, in_lds, in_lds ? L.wlo[cur][i] : 0ULL,
                                        in_lds ? L.whi[cur][i] : 0ULL, ne, probes);
-            if (in_lds) L.pqe[cur][i] = ne;
+            if (in_lds) { L.pqe[cur][i] = ne; L.pqs[cur][i] = (float)__dmul_rn(raw, s.alpha); }
             ++lmq;
           }
         }
-        const float lms = (float)__dmul_rn(raw, s.alpha);
+        const float lms = cached_f ? lms_cached : (float)__dmul_rn(raw, s.alpha);
         float lpv = __fadd_rn(lp0, lms);                       // log_p += score;
         lpv = (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
         if (!live) { if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpv; else S.c_logp[x] = lpv; } else L.ev_ext[x] = lpv;
@@ -1090,7 +1115,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         if (L.a0.p0) { L.a0[nxt][r] = L.a0[cur][x]; L.an[nxt][r] = L.an[cur][x]; }
         nkey = L.key[cur][x];
         L.bnd[nxt][r] = L.bnd[cur][x];
-        if (MODE == 1 && L.pqe.p0) { L.wlo[nxt][r] = L.wlo[cur][x]; L.whi[nxt][r] = L.whi[cur][x]; L.pqe[nxt][r] = L.pqe[cur][x]; }
+        if (MODE == 1 && L.pqe.p0) { L.wlo[nxt][r] = L.wlo[cur][x]; L.whi[nxt][r] = L.whi[cur][x]; L.pqe[nxt][r] = L.pqe[cur][x]; L.pqs[nxt][r] = L.pqs[cur][x]; }
         pend = L.ev_exti[x]; ts_new = L.ts[cur][x];
       } else {
         const int cx = (int)x - n;
@@ -1202,7 +1227,9 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
       const uint32_t nd = L.node[0][i];
       uint64_t lo, hi;
       word_walk(al, GS, L.lab1, nd, lo, hi, pr);
-      L.wlo[0][i] = lo; L.whi[0][i] = hi; L.pqe[0][i] = GS.pq[nd];
+      const uint32_t e0 = GS.pq[nd];
+      L.wlo[0][i] = lo; L.whi[0][i] = hi; L.pqe[0][i] = e0;
+      L.pqs[0][i] = e0 != STT_NONE ? (float)__dmul_rn(load_be_raw(GS, e0), s.alpha) : 0.0f;
     }
   }
   for (int i = tid; i < n; i += NTHREADS) ht_insert(L, L.key[0][i], i);

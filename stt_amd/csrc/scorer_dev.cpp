@@ -93,6 +93,7 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label) {
   }
   const uint64_t unigram_off = off;
   off += (counts[0] + 2) * 16;
+  if (off > len) return STT_ERR_SCORER_INVALID_LM;
   uint8_t cfg_bhiksha = 0;
   if (array && ord > 2) { if (off + 2 > len) return STT_ERR_SCORER_INVALID_LM; cfg_bhiksha = buf[off + 1]; }
   const uint8_t middle_quant_bits = quant ? (uint8_t)(prob_bits + backoff_bits) : 63;
@@ -171,18 +172,25 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label) {
   // ---- vocabulary hash table over KenLM's sorted hash array (index = position + 1, vocab.hh:72-83)
   uint32_t vt_n = 16;
   while ((uint64_t)vt_n < 2 * vocab_n + 2) vt_n <<= 1;
-  std::vector<DevVocabSlot> vtab(vt_n, DevVocabSlot{0, 0, 0});
+  std::vector<DevVocabSlot> vtab(vt_n, DevVocabSlot{0, 0, 0, 0.f, 0.f, 0, 0});
+  const bool uni_ok = ord >= 2 && counts[1] < 0xFFFFFFFFull;
   if (vocab_off + 8 * vocab_n > len) return STT_ERR_SCORER_INVALID_LM;
   for (uint64_t i = 0; i < vocab_n; ++i) {
     const uint64_t h = rd64(buf + vocab_off + 8 * i);
     uint32_t slot = (uint32_t)h & (vt_n - 1);
     while (vtab[slot].used) slot = (slot + 1) & (vt_n - 1);
-    vtab[slot] = DevVocabSlot{h, (uint32_t)(i + 1), 1};
+    vtab[slot] = DevVocabSlot{h, (uint32_t)(i + 1), 1, 0.f, 0.f, 0, 0};
   }
 
   // ---- upload
   blob_.upload(buf, lm_end + 16);  // +16: the 64-bit bit-packed reads may touch up to 8 bytes past the last record
   fst_pos_.upload(pos.data(), pos.size() * 4);
+  for (auto& e : vtab) {
+    if (!e.used) continue;
+    const uint8_t* u = buf + unigram_off + 16 * (uint64_t)e.index;
+    e.prob = rdf(u); e.backoff = rdf(u + 4);
+    e.begin = (uint32_t)rd64(u + 8); e.end = (uint32_t)rd64(u + 24);
+  }
   vtab_.upload(vtab.data(), vtab.size() * sizeof(DevVocabSlot));
   fst_arcs_.upload(arcv.data(), arcv.size() * sizeof(uint2));
   fst_space_.upload(has_space.data(), has_space.size());
@@ -191,7 +199,7 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label) {
   ds.enabled = 1; ds.order = ord; ds.quant = quant; ds.utf8 = utf8;
   ds.alpha = (double)(float)a; ds.beta = (double)(float)b;  // Scorer::reset_params(float, float)
   ds.vocab = reinterpret_cast<const uint64_t*>(d + vocab_off); ds.vocab_n = vocab_n;
-  ds.vtab = vtab_.as<DevVocabSlot>(); ds.vtab_mask = vt_n - 1;
+  ds.vtab = vtab_.as<DevVocabSlot>(); ds.vtab_mask = vt_n - 1; ds.uni_in_vtab = uni_ok ? 1 : 0;
   ds.unigram = d + unigram_off;
   for (int i = 0; i < STT_KENLM_MAX_ORDER; ++i) {
     ds.qprob[i] = quant && qprob_off[i] ? reinterpret_cast<const float*>(d + qprob_off[i]) : nullptr;
