@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scorer", default="synthetic", choices=["synthetic", "fixture"])
+    ap.add_argument("--no-profile", action="store_true", help="experiment: no HIP-event stage timing inside the timed region")
     args = ap.parse_args()
 
     import torch
@@ -126,7 +127,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    model.setProfiling(True)
+    model.setProfiling(not args.no_profile)
     stage = {}
     if dist is not None:
         dist.barrier()
@@ -149,7 +150,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if rank == 0:
+    if rank == 0 and args.no_profile:
+        print(json.dumps({"experiment": "no-profile", "ms_per_step": 1e3 * elapsed / args.steps, "value": world * BATCH * SECONDS * args.steps / elapsed}))
+    elif rank == 0:
         audio_s = world * BATCH * SECONDS * args.steps
         K = args.steps
         T = 250

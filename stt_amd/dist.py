@@ -22,33 +22,38 @@ def shard_utterances(lengths, world_size):
 
 
 def gather_transcripts(texts, device=None, group=None):
-    """All ranks call this with their local list of str; every rank returns the list of all ranks' lists (rank order)."""
+    """All ranks call this with their local list of str; every rank returns the list of all ranks' lists (rank order).
+
+    Two collectives: all_gather of the packed size, then all_gather of one padded uint8 record per rank
+    ([int32 n][int32 byte length x n][utf-8 bytes ...]).  The record is packed on the host and moved with a single copy
+    each way: the exchange is latency-bound (a few KB), so the number of device round trips is what matters."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return [list(texts)]
     world = dist.get_world_size(group)
     enc = [t.encode("utf-8") for t in texts]
-    lens = torch.tensor([len(e) for e in enc] or [0], dtype=torch.int32, device=device)
-    meta = torch.tensor([len(enc), int(lens.max().item()) if len(enc) else 0], dtype=torch.int32, device=device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
-    n_max = max(int(m[0]) for m in metas)
-    l_max = max(1, max(int(m[1]) for m in metas))
-    lens_p = torch.zeros(max(1, n_max), dtype=torch.int32, device=device)
-    lens_p[:len(enc)] = lens[:len(enc)]
-    buf = torch.zeros((max(1, n_max), l_max), dtype=torch.uint8, device=device)
-    for i, e in enumerate(enc):
-        if e:
-            buf[i, :len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).to(buf.device)
-    all_lens = [torch.zeros_like(lens_p) for _ in range(world)]
-    all_buf = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(all_lens, lens_p, group=group)
-    dist.all_gather(all_buf, buf, group=group)
+    head = np.array([len(enc)] + [len(e) for e in enc], dtype=np.int32)
+    rec = np.concatenate([head.view(np.uint8), np.frombuffer(b"".join(enc), dtype=np.uint8)])
+    size = torch.tensor([rec.size], dtype=torch.int64, device=device)
+    sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, size, group=group)
+    cap = int(sizes.max().item())
+    buf = np.zeros(cap, dtype=np.uint8)
+    buf[:rec.size] = rec
+    mine = torch.from_numpy(buf).to(device) if device is not None else torch.from_numpy(buf)
+    allb = torch.zeros(world * cap, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(allb, mine, group=group)
+    flat = allb.cpu().numpy().reshape(world, cap)
     out = []
     for r in range(world):
-        n = int(metas[r][0])
-        ls = all_lens[r].cpu().numpy()
-        b = all_buf[r].cpu().numpy()
-        out.append([bytes(b[i, :ls[i]]).decode("utf-8", "replace") for i in range(n)])
+        row = flat[r]
+        n = int(row[:4].view(np.int32)[0])
+        lens = row[4:4 + 4 * n].view(np.int32)
+        off = 4 + 4 * n
+        items = []
+        for ln in lens:
+            items.append(bytes(row[off:off + int(ln)]).decode("utf-8", "replace"))
+            off += int(ln)
+        out.append(items)
     return out
