@@ -78,11 +78,13 @@ static void acoustic_rows(ModelState& m, const _Float16* d_x1, int B, int T, flo
   // layer 5, layer 6, softmax (deepspeech_model.py:241-252, 357)
   d.wt = m.w5t.as<_Float16>(); d.x = m.ws_hall.as<_Float16>(); d.bias = m.b5.as<float>(); d.y = m.ws_b.p; d.N = H; d.K = H; d.ldx = H; d.ldy = H;
   launch_dense(d, DENSE_EPI_RELU_F16, stream);
-  d.wt = m.w6t.as<_Float16>(); d.x = m.ws_b.as<_Float16>(); d.bias = m.b6.as<float>(); d.y = m.ws_logits.p; d.N = g.c_pad(); d.ldy = g.c_pad();
-  launch_dense(d, DENSE_EPI_BIAS_F32, stream);
-  SoftmaxArgs s{};
-  s.logits = m.ws_logits.as<float>(); s.probs = d_probs_out; s.M = M; s.C = C; s.ldl = g.c_pad(); s.batch = B; s.t_max = probs_t_max;
-  launch_softmax(s, stream);
+  if (!launch_logits_softmax(m.ws_b.as<_Float16>(), m.w6t.as<_Float16>(), m.b6.as<float>(), d_probs_out, M, H, C, B, probs_t_max, stream)) {
+    d.wt = m.w6t.as<_Float16>(); d.x = m.ws_b.as<_Float16>(); d.bias = m.b6.as<float>(); d.y = m.ws_logits.p; d.N = g.c_pad(); d.ldy = g.c_pad();
+    launch_dense(d, DENSE_EPI_BIAS_F32, stream);
+    SoftmaxArgs s{};
+    s.logits = m.ws_logits.as<float>(); s.probs = d_probs_out; s.M = M; s.C = C; s.ldl = g.c_pad(); s.batch = B; s.t_max = probs_t_max;
+    launch_softmax(s, stream);
+  }
 }
 
 void ModelState::run_acoustic_rows(const _Float16* d_x1, int B, int T, float* d_c, float* d_h, bool carry_in, float* d_probs_out, int probs_t_max) {

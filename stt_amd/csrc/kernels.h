@@ -62,4 +62,7 @@ int lstm_nt_for_batch(int B);
 void launch_lstm_step(const LstmArgs& a, int NT, hipStream_t st);
 void launch_pack_h(const float* h, void* hp, int B, int H, int NT, hipStream_t st);
 void launch_softmax(const SoftmaxArgs& a, hipStream_t st);
+// fused output layer + softmax for C <= 256 (returns false if the shape is not covered: caller uses dense + softmax)
+bool launch_logits_softmax(const _Float16* x, const _Float16* wt, const float* bias, float* probs, int M, int K, int C, int batch, int t_max,
+                           hipStream_t st);
 void launch_window_rows(const float* frames, _Float16* x1, int rows, int n_input, int kw, int kp, hipStream_t st);

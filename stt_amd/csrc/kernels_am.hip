@@ -424,6 +424,79 @@ __global__ void softmax_kernel(SoftmaxArgs a) {
   for (int c = 0; c < a.C; ++c) o[c] = expf(l[c] - mx) * inv;
 }
 
+// =============================================================================================
+// Output layer + softmax fused (deepspeech_model.py:250-252, 357): probs = softmax(x . W6 + b6).
+// The output layer is a *skinny* GEMM (N = 29 classes for English): with 128x128 tiles it occupied
+// 24 workgroups for a whole K = 2048 sweep.  Here one workgroup takes 16 rows of x and ALL classes
+// (CT tiles of 16): its 4 waves split K, operands go straight from L2 into MFMA fragments (x rows
+// and W6^T rows are both K-contiguous), partial sums meet in LDS, and 16 threads per row finish the
+// softmax.  M/16 workgroups (192 for a 48-frame chunk of 64 utterances).
+// =============================================================================================
+template <int CT>
+__global__ __launch_bounds__(256) void logits_softmax_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ wt, const float* __restrict__ bias,
+                                                              float* __restrict__ probs, int M, int K, int C, int batch, int t_max) {
+  __shared__ __attribute__((aligned(16))) float red[4][CT][64][4];
+  __shared__ float lg[16][CT * 16 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+  const int m0 = blockIdx.x * 16;
+  const int kq = K / 4;  // this wave's K range
+  int row = m0 + (lane & 15);
+  if (row >= M) row = M - 1;
+  const _Float16* xp = x + (size_t)row * K + q * kq + (lane >> 4) * 8;
+  const _Float16* wp = wt + (size_t)(lane & 15) * K + q * kq + (lane >> 4) * 8;
+  f32x4 acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int k = 0; k < kq; k += 32) {
+    const f16x8 fb = *reinterpret_cast<const f16x8*>(xp + k);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const f16x8 fa = *reinterpret_cast<const f16x8*>(wp + (size_t)c * 16 * K + k);
+      acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc[c], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) *reinterpret_cast<f32x4*>(&red[q][c][lane][0]) = acc[c];
+  __syncthreads();
+  // logits: lane group g = lane >> 4 holds classes g*4 .. g*4+3 of tile c for batch row (lane & 15)
+  for (int e = tid; e < CT * 64; e += 256) {
+    const int c = e >> 6, l = e & 63;
+    const int r = l & 15, cls0 = c * 16 + (l >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      lg[r][cls0 + j] = red[0][c][l][j] + red[1][c][l][j] + red[2][c][l][j] + red[3][c][l][j] + bias[cls0 + j];
+  }
+  __syncthreads();
+  // softmax: 16 threads per row
+  const int r = tid >> 4, t16 = tid & 15;
+  float mx = -3.0e38f;
+  for (int c = t16; c < C; c += 16) mx = fmaxf(mx, lg[r][c]);
+#pragma unroll
+  for (int d = 8; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+  float sum = 0.f;
+  for (int c = t16; c < C; c += 16) { const float e = expf(lg[r][c] - mx); lg[r][c] = e; sum += e; }
+#pragma unroll
+  for (int d = 8; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 16);
+  const int m = m0 + r;
+  if (m < M) {
+    const int t = m / batch, b = m - t * batch;
+    float* o = probs + ((size_t)b * t_max + t) * C;
+    const float inv = 1.0f / sum;
+    for (int c = t16; c < C; c += 16) o[c] = lg[r][c] * inv;
+  }
+}
+bool launch_logits_softmax(const _Float16* x, const _Float16* wt, const float* bias, float* probs, int M, int K, int C, int batch, int t_max, hipStream_t st) {
+  if (K % 128 != 0 || C > 256) return false;  // wider output layers take the generic dense + softmax path
+  const dim3 grid((M + 15) / 16), block(256);
+  const int ct = (C + 15) / 16;
+  if (ct <= 2) hipLaunchKernelGGL(logits_softmax_kernel<2>, grid, block, 0, st, x, wt, bias, probs, M, K, C, batch, t_max);
+  else if (ct <= 4) hipLaunchKernelGGL(logits_softmax_kernel<4>, grid, block, 0, st, x, wt, bias, probs, M, K, C, batch, t_max);
+  else if (ct <= 8) hipLaunchKernelGGL(logits_softmax_kernel<8>, grid, block, 0, st, x, wt, bias, probs, M, K, C, batch, t_max);
+  else hipLaunchKernelGGL(logits_softmax_kernel<16>, grid, block, 0, st, x, wt, bias, probs, M, K, C, batch, t_max);
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
