@@ -507,6 +507,7 @@ struct Lds {
   LDS_AS uint8_t* lab1;                       // [C] the byte of every single-byte label (0 otherwise)
   LDS_AS uint32_t *hist, *cumb;
   LDS_AS uint16_t* lmw;                      // the LM wave's list of prefixes to score this step
+  LDS_AS uint64_t* exp_tab; LDS_AS double* log_tab;  // sttmath.h tables (32 x u64, 32 x f64)
   LDS_AS uint8_t* own; uint32_t own_cap;     // expand: per-wave table item -> owning lane (aliases skey/sseg/cumb, idle in that phase)
   LDS_AS uint64_t* skey; LDS_AS uint32_t *ssrc, *sseg;
   LDS_AS uint32_t* wtot;
@@ -550,6 +551,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   const uint32_t own_cap = (uint32_t)((o - o_own) / NWAVES) & ~3u;
   offs[k++] = take(64 * 4);
   offs[k++] = take(cap * 2);                                       // lmw
+  offs[k++] = take(32 * 8); offs[k++] = take(32 * 8);              // exp / log tables
   offs[k++] = take(12 * 8);
   offs[k++] = take(SC_COUNT * 4);
   offs[k++] = take(16);                                            // lbl[2]
@@ -585,6 +587,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
     l->own = (LDS_AS uint8_t*)(base + o_own); l->own_cap = own_cap;
     l->wtot = (LDS_AS uint32_t*)(base + offs[k++]);
     l->lmw = (LDS_AS uint16_t*)(base + offs[k++]);
+    l->exp_tab = (LDS_AS uint64_t*)(base + offs[k++]); l->log_tab = (LDS_AS double*)(base + offs[k++]);
     l->acc = (LDS_AS unsigned long long*)(base + offs[k++]);
     l->sc = (LDS_AS int*)(base + offs[k++]);
     l->lbl = (LDS_AS double*)(base + offs[k++]);
@@ -689,7 +692,7 @@ __device__ __forceinline__ void prep_row(const DecParams& p, const Lds& L, int b
   for (int c = tid; c < p.C; c += NTHREADS) {
     const float x = (c == tid) ? v : row[c];
     L.pf[buf][c] = x;
-    L.lp[buf][c] = stt_logf(__fadd_rn(x, STT_FLT_MIN));
+    L.lp[buf][c] = sttm::stt_logf_t(__fadd_rn(x, STT_FLT_MIN), L.log_tab);
     if (c == p.blank) L.lbl[buf] = log((double)x);
   }
 }
@@ -699,6 +702,7 @@ __device__ __forceinline__ void prep_row(const DecParams& p, const Lds& L, int b
 // ev_ext = new score (iterate_to_vec, path_trie.cpp:170), ev_exti = pending timestep parent.  Returns the new score.
 __device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, int cur, int j) {
   const float NEG = STT_NEG_INF;
+#define LSE(x, y) sttm::stt_log_sum_exp_t((x), (y), L.exp_tab, L.log_tab)
   const float e_self = L.ev_self[j], e_blank = L.ev_blank[j], e_ext = L.ev_ext[j];
   const uint32_t ei = L.ev_exti[j] & 0x7FFFFFFFu;
   float nb = NEG, bb = NEG;
@@ -707,14 +711,15 @@ __device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, in
   const int kblank = L.pos[p.blank];
   const int kself = chj == STT_ROOT_CH ? 0xFFFF : L.pos[chj];
   const bool blank_first = kblank < kself;
-  if (blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
+  if (blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = LSE(bb, e_blank); }
   const bool ext_first = (int)ei < j;
-  if (ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = stt_log_sum_exp(nb, e_ext); }
-  if (!is_absent(e_self)) { if (nb < e_self) pend = 0xFFFFFFFEu; nb = stt_log_sum_exp(nb, e_self); }
-  if (!ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = stt_log_sum_exp(nb, e_ext); }
-  if (!blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = stt_log_sum_exp(bb, e_blank); }
-  const float nscore = stt_log_sum_exp(bb, nb);
+  if (ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = LSE(nb, e_ext); }
+  if (!is_absent(e_self)) { if (nb < e_self) pend = 0xFFFFFFFEu; nb = LSE(nb, e_self); }
+  if (!ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = LSE(nb, e_ext); }
+  if (!blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = LSE(bb, e_blank); }
+  const float nscore = LSE(bb, nb);
   L.ev_blank[j] = bb; L.ev_self[j] = nb; L.ev_ext[j] = nscore; L.ev_exti[j] = pend;
+#undef LSE
   return nscore;
 }
 
@@ -1217,8 +1222,10 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
     L.cls[c] = (uint16_t)c; L.pos[c] = (uint16_t)c;  // identity class order unless pruning re-sorts it every step
   }
   for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
+  if (tid < 32) { L.exp_tab[tid] = sttm::kExp2Tab[tid]; L.log_tab[tid] = sttm::kLogfTab[tid >> 1][tid & 1]; }
   if (tid == 0) { L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
   if (tid < 12) L.acc[tid] = 0;
+  __syncthreads();  // the math tables must be in place before the first row is prepared
   prep_row(p, L, 0, row, v0);
   __syncthreads();
   if (MODE == 1 && L.pqe.p0) {

@@ -40,7 +40,10 @@ __device__ __constant__ const double kLogfTab[16][2] = {
 
 // All double arithmetic below is written with explicit __dmul_rn/__dadd_rn/__fma_rn so the
 // compiler can neither contract nor reassociate it.
-__device__ __forceinline__ float stt_expf(float x) {
+// The table arguments let a kernel keep its own copy of the two tables in LDS (a data-dependent read of __constant__
+// memory is a vector load through the cache hierarchy; the search kernel evaluates these on its critical path).
+template <class ExpTab>
+__device__ __forceinline__ float stt_expf_t(float x, ExpTab exp2_tab) {
   const double N = 32.0;
   const double C0 = 0x1.c6af84b912394p-5 / N / N / N, C1 = 0x1.ebfce50fac4f3p-3 / N / N, C2 = 0x1.62e42ff0c52d6p-1 / N;
   const double SHIFT = 0x1.8p+52, InvLn2N = 0x1.71547652b82fep+0 * N;
@@ -58,7 +61,7 @@ __device__ __forceinline__ float stt_expf(float x) {
   const uint64_t ki = (uint64_t)__double_as_longlong(kd);
   kd = __dadd_rn(kd, -SHIFT);
   const double r = __fma_rn(InvLn2N, xd, -kd);
-  uint64_t t = kExp2Tab[ki & 31];
+  uint64_t t = exp2_tab[ki & 31];
   t += ki << 47;
   const double s = __longlong_as_double((long long)t);
   const double z2 = __dadd_rn(__dmul_rn(C0, r), C1);
@@ -69,7 +72,11 @@ __device__ __forceinline__ float stt_expf(float x) {
   return (float)y;
 }
 
-__device__ __forceinline__ float stt_logf(float x) {
+__device__ __forceinline__ float stt_expf(float x) { return stt_expf_t(x, kExp2Tab); }
+
+// log_tab: 16 x {invc, logc} doubles, flat [32]
+template <class LogTab>
+__device__ __forceinline__ float stt_logf_t(float x, LogTab log_tab) {
   const double Ln2 = 0x1.62e42fefa39efp-1;
   const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
   uint32_t ix = __float_as_uint(x);
@@ -85,7 +92,7 @@ __device__ __forceinline__ float stt_logf(float x) {
   const int i = (tmp >> 19) & 15;
   const int k = (int32_t)tmp >> 23;
   const uint32_t iz = ix - (tmp & 0xff800000u);
-  const double invc = kLogfTab[i][0], logc = kLogfTab[i][1];
+  const double invc = log_tab[2 * i], logc = log_tab[2 * i + 1];
   const double z = (double)__uint_as_float(iz);
   const double r = __dadd_rn(__dmul_rn(z, invc), -1.0);
   const double y0 = __dadd_rn(logc, __dmul_rn((double)k, Ln2));
@@ -96,12 +103,19 @@ __device__ __forceinline__ float stt_logf(float x) {
   return (float)y;
 }
 
-// log_sum_exp<float>, decoder_utils.h:46-53
-__device__ __forceinline__ float stt_log_sum_exp(float x, float y) {
+__device__ __forceinline__ float stt_logf(float x) { return stt_logf_t(x, &kLogfTab[0][0]); }
+
+// log_sum_exp<float>, decoder_utils.h:46-53: log(exp(x - max) + exp(y - max)) + max.  The larger operand contributes
+// exp(+0.0f), which glibc's expf returns as exactly 1.0f, so only the smaller one is evaluated (float addition commutes).
+template <class ExpTab, class LogTab>
+__device__ __forceinline__ float stt_log_sum_exp_t(float x, float y, ExpTab exp2_tab, LogTab log_tab) {
   if (x <= STT_NEG_INF) return y;
   if (y <= STT_NEG_INF) return x;
   const float xmax = (x < y) ? y : x;  // std::max
-  return __fadd_rn(stt_logf(__fadd_rn(stt_expf(__fadd_rn(x, -xmax)), stt_expf(__fadd_rn(y, -xmax)))), xmax);
+  const float xmin = (x < y) ? x : y;
+  const float e = stt_expf_t(__fadd_rn(xmin, -xmax), exp2_tab);
+  return __fadd_rn(stt_logf_t(__fadd_rn(1.0f, e), log_tab), xmax);
 }
+__device__ __forceinline__ float stt_log_sum_exp(float x, float y) { return stt_log_sum_exp_t(x, y, kExp2Tab, &kLogfTab[0][0]); }
 
 }  // namespace sttm
