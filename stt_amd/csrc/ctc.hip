@@ -471,9 +471,11 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
   const double lcp = oov ? OOV_SCORE_D : __ddiv_rn((double)prob, (double)0.4342944819f);
   en.raw = __dadd_rn(lcp, (double)hot_total);
   en.prev = e_prev; en.pad = 0; en.hot_self = hot_self;
-  const uint32_t idx = lds_add(be_n, 1u);  // LDS copy of the arena fill (written back when the launch ends)
   out_entry = STT_NONE;
-  if (idx < S.be_cap) { store_be(S, idx, en); S.pq[node] = idx; out_entry = idx; }
+  if (be_n) {  // (null: a read-only caller -- DecoderState::decode -- only wants the value)
+    const uint32_t idx = lds_add(be_n, 1u);  // LDS copy of the arena fill (written back when the launch ends)
+    if (idx < S.be_cap) { store_be(S, idx, en); S.pq[node] = idx; out_entry = idx; }
+  }
   return en.raw;
 }
 
@@ -622,23 +624,6 @@ __device__ __forceinline__ int ht_find(const Lds& L, uint64_t k) {
     if (v == k) return (int)L.ht_idx[h];
     if (v == 0) return -1;
     h = (h + 1) & (HTN - 1);
-  }
-}
-
-// in-LDS bitonic sort of (key, src) pairs, ascending by key; n must be a power of two
-__device__ void bitonic_sort(uint64_t* key, uint32_t* src, uint32_t n) {
-  for (uint32_t k = 2; k <= n; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t ixj = i ^ j;
-        if (ixj > i) {
-          const uint64_t a = key[i], b = key[ixj];
-          const bool up = ((i & k) == 0);
-          if ((a > b) == up) { key[i] = b; key[ixj] = a; const uint32_t t = src[i]; src[i] = src[ixj]; src[ixj] = t; }
-        }
-      }
-      __syncthreads();
-    }
   }
 }
 
@@ -1265,13 +1250,24 @@ __global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevSc
   __shared__ uint64_t skey[STT_MAX_BEAM];
   __shared__ uint32_t ssrc[STT_MAX_BEAM];
   __shared__ float sscore[STT_MAX_BEAM];
+  __shared__ uint8_t lab1[256];
   const DecStream& S = streams[blockIdx.x];
   const int tid = threadIdx.x;
   const int n = S.n;
   const uint32_t sortn = pow2_ge((uint32_t)(n > 0 ? n : 1));
   unsigned probes = 0;
+  GStream GS;
+  GS.pa = (GLB_AS uint64_t*)S.pa; GS.ta = (GLB_AS uint64_t*)S.ta; GS.pq = (GLB_AS uint32_t*)S.pq; GS.be = (GLB_AS u32x4*)S.be;
+  GS.c_logp = nullptr; GS.c_pi = nullptr; GS.c_fst = nullptr; GS.sel_keys = nullptr;
+  GS.pa_generic = S.pa; GS.cand_cap = 0; GS.pa_cap = S.pa_cap; GS.ta_cap = S.ta_cap; GS.be_cap = S.be_cap;
+  if (tid < 256) {  // single-byte labels (the word walk reads them); labels >= 256 are looked up in HBM
+    uint8_t one = 0;
+    if (tid < al.n_labels) { const int b0 = tid ? al.label_off[tid - 1] : 0; if (al.label_off[tid] - b0 == 1) one = al.label_bytes[b0]; }
+    lab1[tid] = one;
+  }
+  __syncthreads();
   for (uint32_t i = tid; i < sortn; i += NTHREADS) {
-    if ((int)i >= n) { skey[i] = ~0ULL; ssrc[i] = 0; continue; }
+    if ((int)i >= n) { skey[i] = ~0ULL; continue; }
     float sc = S.score[i];
     if (s.enabled && (int)i < p.beam) {
       const uint32_t node = S.node[i], chi = S.ch[i];
@@ -1283,17 +1279,35 @@ __global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevSc
         do_score = (par != STT_ROOT_CH) && !((int)chi == al.space_id);
       }
       if (do_score) {
-        float v = (float)__dmul_rn(lm_score(s, al, S.pa, node, STT_ROOT_CH, false, probes), s.alpha);  // :293-297, no hot-word boost here
+        // :293-297, no hot-word boost here.  Word mode without hot words: the value is exactly the cached score of
+        // "this prefix, then a word boundary" (or one FullScore from the cached state of the previous boundary).
+        double lcp;
+        const uint32_t bndi = S.bnd[i];
+        if (!s.utf8 && s.n_hot == 0 && bndi != STT_NONE && al.n_labels <= 256) {
+          const uint32_t e = S.pq[node];
+          if (e != STT_NONE) lcp = load_be_raw(GS, e);
+          else { uint32_t ne; lcp = lm_word_query_cached(s, al, GS, (const LDS_AS uint8_t*)lab1, (LDS_AS uint32_t*)nullptr, node, bndi, false, 0ULL, 0ULL, ne, probes); }
+        } else {
+          lcp = lm_score(s, al, S.pa, node, STT_ROOT_CH, false, probes);
+        }
+        float v = (float)__dmul_rn(lcp, s.alpha);
         v = (float)__dadd_rn((double)v, s.beta);
         sc = __fadd_rn(sc, v);
       }
     }
     sscore[i] = sc;
     skey[i] = sel_key(sc, S.ch[i], 0, i);
-    ssrc[i] = i;
   }
   __syncthreads();
-  bitonic_sort(skey, ssrc, sortn);
+  // order by key: keys are unique, so a prefix's rank is the number of smaller keys (one pass over LDS instead of the
+  // ~45 barrier-separated stages of a bitonic sort)
+  for (int i = tid; i < n; i += NTHREADS) {
+    const uint64_t k = skey[i];
+    int r = 0;
+    for (int j = 0; j < n; ++j) r += skey[j] < k ? 1 : 0;
+    ssrc[r] = (uint32_t)i;
+  }
+  __syncthreads();
   const int nret = n < out.num_results ? n : out.num_results;
   if (tid == 0) out.n_results[blockIdx.x] = nret;
   for (int r = tid; r < nret; r += NTHREADS) {
