@@ -189,7 +189,7 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
     HIP_CHECK(hipEventRecord(m->ev_chunk[2], m->stream_dec));
     HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_chunk[2], 0));
     mark(m, 5);
-    auto outs = decode_streams(*m, db, m->scorer_, m->hot_words_, num_results, 4096);  // synchronises `stream`
+    auto outs = decode_streams(*m, db, m->scorer_, m->hot_words_, num_results, t_max + 1);  // a token needs its own timestep: <= t_max tokens; synchronises `stream`
     mark(m, -1);
     if (pr.on) {
       HIP_CHECK(hipStreamSynchronize(m->stream));

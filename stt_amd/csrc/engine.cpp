@@ -362,6 +362,6 @@ void StreamingState::processReady(bool flush_partial, bool final_flush) {
 }
 
 std::vector<Output> StreamingState::decode(unsigned num_results) const {
-  auto r = decode_streams(*model_, dec, scorer_, hot_words_, num_results, 4096);
+  auto r = decode_streams(*model_, dec, scorer_, hot_words_, num_results, std::max(1, windows_done_) + 1);  // <= one token per processed window
   return r.empty() ? std::vector<Output>() : r[0];
 }
