@@ -1310,20 +1310,31 @@ __global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevSc
   __syncthreads();
   const int nret = n < out.num_results ? n : out.num_results;
   if (tid == 0) out.n_results[blockIdx.x] = nret;
-  for (int r = tid; r < nret; r += NTHREADS) {
+  // Back-tracking is a pointer chase through the arenas (one dependent HBM read per token), so each result gets two threads
+  // -- tokens and timesteps -- and each chain is walked ONCE: entry k from the end goes to ring slot k % max_len and the
+  // host puts the list the right way round (token j of len sits in slot (len-1-j) % max_len).
+  for (int q = tid; q < 2 * nret; q += NTHREADS) {
+    const int r = q >> 1;
     const uint32_t i = ssrc[r];
     const size_t ob = ((size_t)blockIdx.x * out.num_results + r);
-    int len = 0;
-    for (uint32_t x = S.node[i]; x != STT_ROOT_CH && S.pa[x].y != STT_ROOT_CH; x = S.pa[x].x) ++len;
-    int tl = 0;
-    for (uint32_t x = S.ts[i]; x != STT_ROOT_CH && x != 0; x = S.ta[x].x) ++tl;
-    const int wl = len < out.max_len ? len : out.max_len;
-    out.lens[ob] = len;
-    out.confidence[ob] = (double)sscore[i];
-    int j = len;
-    for (uint32_t x = S.node[i]; x != STT_ROOT_CH && S.pa[x].y != STT_ROOT_CH; x = S.pa[x].x) { --j; if (j < wl) out.tokens[ob * out.max_len + j] = S.pa[x].y; }
-    j = tl;
-    for (uint32_t x = S.ts[i]; x != STT_ROOT_CH && x != 0; x = S.ta[x].x) { --j; const int jj = j - (tl - len); if (jj >= 0 && jj < wl) out.timesteps[ob * out.max_len + jj] = S.ta[x].y; }
+    if ((q & 1) == 0) {
+      int k = 0;
+      for (uint32_t x = S.node[i]; x != STT_ROOT_CH;) {
+        const uint2 pn = load_node(GS.pa, x);
+        if (pn.y == STT_ROOT_CH) break;
+        out.tokens[ob * out.max_len + (k % out.max_len)] = pn.y;
+        ++k; x = pn.x;
+      }
+      out.lens[ob] = k;
+      out.confidence[ob] = (double)sscore[i];
+    } else {
+      int k = 0;
+      for (uint32_t x = S.ts[i]; x != STT_ROOT_CH && x != 0;) {
+        const uint2 tn = load_node(GS.ta, x);
+        out.timesteps[ob * out.max_len + (k % out.max_len)] = tn.y;
+        ++k; x = tn.x;
+      }
+    }
   }
 }
 

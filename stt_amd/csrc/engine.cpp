@@ -254,8 +254,14 @@ std::vector<std::vector<Output>> decode_streams(const ModelState& mc, const Deco
       const size_t ob = (size_t)i * nr + r;
       const int len = std::min(lens[ob], max_len);
       ou.confidence = conf[ob];
-      ou.tokens.assign(tok.begin() + ob * max_len, tok.begin() + ob * max_len + len);
-      ou.timesteps.assign(ts.begin() + ob * max_len, ts.begin() + ob * max_len + len);
+      // the kernel walked each chain once, newest entry first, into ring slot k % max_len; the (oldest) `len` kept
+      // entries come back in order here: entry j is k = total-1-j
+      const int total = lens[ob];
+      ou.tokens.resize(len); ou.timesteps.resize(len);
+      for (int j = 0; j < len; ++j) {
+        const size_t slot = ob * max_len + (size_t)((total - 1 - j) % max_len);
+        ou.tokens[j] = tok[slot]; ou.timesteps[j] = ts[slot];
+      }
       out[i].push_back(std::move(ou));
     }
   }
