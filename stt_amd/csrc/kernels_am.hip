@@ -447,7 +447,6 @@ __global__ __launch_bounds__(256) void logits_softmax_kernel(const _Float16* __r
   f32x4 acc[CT];
 #pragma unroll
   for (int c = 0; c < CT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
   for (int k = 0; k < kq; k += 32) {
     const f16x8 fb = *reinterpret_cast<const f16x8*>(xp + k);
 #pragma unroll

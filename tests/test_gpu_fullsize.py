@@ -51,3 +51,31 @@ def test_fullsize_acoustic_tolerance(big):
     got = model.acousticProbs([a])[0]
     want = am_ref.utterance_probs(a, w, weight_round=np.float16)
     assert np.abs(got - want).max() < 3e-3, np.abs(got - want).max()
+
+
+def test_fullsize_huge_vocab_scorer_against_the_real_reference_decoder(big, ref, port, english, fix, tmp_path):
+    """configs[1] with a scorer of the bench's kind (synthetic, 50 k words here to keep the test short, order 5, quantised array
+    trie written by stt_amd/tools): GPU transcripts == the REAL reference decoder (oracle/_ref) on the GPU's own emissions."""
+    from stt_amd import scorertools
+    model, w = big
+    lm, vocab, pkg = str(tmp_path / "lm.binary"), str(tmp_path / "vocab.txt"), str(tmp_path / "synth50k.scorer")
+    scorertools.synth_lm(lm, vocab, words=50000, order=5, seed=11, avg={2: 12, 3: 1.0, 4: 0.6, 5: 0.5})
+    scorertools.generate_scorer_package(lm, vocab, pkg, alphabet=os.path.join(fix, "alphabet.txt"),
+                                        default_alpha=0.931289039105002, default_beta=1.1834137581510284)
+    model.enableExternalScorer(pkg)
+    try:
+        audio = [synth.synth_audio(80000, seed=2000 + i) for i in range(64)]
+        got = model.sttBatch(audio)
+        pick = (0, 31, 63)
+        probs = model.acousticProbs([audio[i] for i in pick])
+        A = ref.Alphabet(os.path.join(fix, "alphabet.txt"))
+        S = ref.Scorer(pkg, A)
+        for k, i in enumerate(pick):
+            d = ref.Decoder(A, 500, S)
+            d.next(probs[k].astype(np.float64))
+            conf, tok, ts = d.decode(1)[0]
+            assert A.decode(tok).decode() == got[i], i
+            md = model.sttWithMetadata(audio[i], 1)["transcripts"][0]
+            assert md["confidence"] == conf and [t[1] for t in md["tokens"]] == [int(x) for x in ts], i
+    finally:
+        model.enableExternalScorer(os.path.join(fix, "pruned_lm.scorer"))
