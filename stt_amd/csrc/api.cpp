@@ -144,62 +144,131 @@ int batch_first_chunk_frames() {
   if (v < 0) { const char* e = getenv("STT_AMD_CHUNK0"); v = e ? atoi(e) : 24; if (v < 1) v = 1 << 30; }
   return v;
 }
+// Enqueue everything one group needs, on both streams, without waiting for anything: features + acoustic chunks on
+// `stream`, the beam search of every chunk + the final ranking + the copy of the results to page-locked memory on
+// `stream_dec`, then the slot's `done` event.
+void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t* d_audio, unsigned stride, const unsigned* sizes,
+                         const std::vector<unsigned>& idx, unsigned num_results, const DevScorer& ds) {
+  const int Bg = (int)idx.size();
+  int t_max = 1;
+  for (int b = 0; b < Bg; ++b) t_max = std::max(t_max, n_frames_for(m->g, (int)sizes[idx[b]]));
+  std::vector<int> cb;  // chunk boundaries
+  for (int t = 0, k = 0; t < t_max; ++k) { cb.push_back(t); t += (k == 0) ? std::min(batch_first_chunk_frames(), batch_chunk_frames()) : batch_chunk_frames(); }
+  cb.push_back(t_max);
+  const int n_chunks = (int)cb.size() - 1;
+  // small integer tables in one page-locked block: [n_samples | n_frames | audio row | per chunk: begin, count]
+  const size_t n_ints = (size_t)(3 + 2 * n_chunks) * Bg;
+  sl.h_ints.reserve(n_ints * 4); sl.ints.reserve(n_ints * 4);
+  int* hi = sl.h_ints.as<int>();
+  int *h_ns = hi, *h_nf = hi + Bg, *h_row = hi + 2 * Bg, *h_tab = hi + 3 * Bg;
+  for (int b = 0; b < Bg; ++b) { h_ns[b] = (int)sizes[idx[b]]; h_nf[b] = n_frames_for(m->g, h_ns[b]); h_row[b] = (int)idx[b]; }
+  for (int k = 0; k < n_chunks; ++k)
+    for (int b = 0; b < Bg; ++b) {
+      h_tab[(size_t)(2 * k) * Bg + b] = cb[k];
+      h_tab[(size_t)(2 * k + 1) * Bg + b] = std::max(0, std::min(cb[k + 1], h_nf[b]) - cb[k]);
+    }
+  HIP_CHECK(hipMemcpyAsync(sl.ints.p, hi, n_ints * 4, hipMemcpyHostToDevice, m->stream));
+  const int* d_ns = sl.ints.as<int>(); const int* d_nf = d_ns + Bg; const int* d_row = d_ns + 2 * Bg; const int* d_tab = d_ns + 3 * Bg;
+  sl.Bg = Bg; sl.t_max = t_max; sl.idx = idx;
+  // features
+  mark(m, 0);
+  m->ws_feats.reserve((size_t)Bg * t_max * m->g.n_input * 4);
+  MfccArgs fa = m->mfcc_args();
+  fa.audio = d_audio; fa.rows = d_row; fa.n_samples = d_ns; fa.n_frames = d_nf;
+  fa.feats = m->ws_feats.as<float>(); fa.n_max = (int)stride; fa.t_max = t_max;
+  launch_mfcc(fa, Bg * t_max, m->stream);
+  // decoder streams of the group
+  m->decoder_create(sl.dec, Bg, (int)m->beam_width_, t_max, m->scorer_, &sl.h_table);
+  sl.probs.reserve((size_t)Bg * t_max * m->g.n_classes * 4);
+  DecParams p{};
+  p.C = m->g.n_classes; p.blank = p.C - 1; p.beam = sl.dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = t_max;
+  for (int k = 0; k < n_chunks; ++k) {
+    m->run_acoustic_chunk(m->ws_feats.as<float>(), d_nf, Bg, t_max, cb[k], cb[k + 1] - cb[k], sl.probs.as<float>());  // marks 1, 2, 3
+    mark(m, -1);
+    hipEvent_t ev = m->ev_chunk[k % 2];  // an event may be re-recorded once the wait on it has been enqueued
+    HIP_CHECK(hipEventRecord(ev, m->stream));
+    HIP_CHECK(hipStreamWaitEvent(m->stream_dec, ev, 0));
+    mark_on(m, 4, 1);
+    const int* fb = d_tab + (size_t)(2 * k) * Bg;
+    launch_ctc_next(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, sl.probs.as<float>(), fb, fb + Bg, m->stream_dec);
+    mark_on(m, -1, 1);
+  }
+  // ranking + back-tracking, results to page-locked memory (a token needs its own timestep: <= t_max tokens)
+  const int nr = (int)std::max(1u, std::min<unsigned>(num_results, (unsigned)sl.dec.beam));
+  const int max_len = t_max + 1;
+  sl.nr = nr; sl.max_len = max_len;
+  const size_t n_tok = (size_t)Bg * nr * max_len;
+  sl.out_tok.reserve(n_tok * 4); sl.out_ts.reserve(n_tok * 4); sl.out_len.reserve((size_t)Bg * nr * 4); sl.out_conf.reserve((size_t)Bg * nr * 8); sl.out_n.reserve((size_t)Bg * 4);
+  sl.h_tok.reserve(n_tok * 4); sl.h_ts.reserve(n_tok * 4); sl.h_len.reserve((size_t)Bg * nr * 4); sl.h_conf.reserve((size_t)Bg * nr * 8); sl.h_n.reserve((size_t)Bg * 4);
+  DecodeOut o{};
+  o.tokens = sl.out_tok.as<uint32_t>(); o.timesteps = sl.out_ts.as<uint32_t>(); o.lens = sl.out_len.as<int>();
+  o.confidence = sl.out_conf.as<double>(); o.n_results = sl.out_n.as<int>(); o.num_results = nr; o.max_len = max_len;
+  mark_on(m, 5, 1);
+  launch_ctc_decode(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, o, m->stream_dec);
+  HIP_CHECK(hipMemcpyAsync(sl.h_tok.p, o.tokens, n_tok * 4, hipMemcpyDeviceToHost, m->stream_dec));
+  HIP_CHECK(hipMemcpyAsync(sl.h_ts.p, o.timesteps, n_tok * 4, hipMemcpyDeviceToHost, m->stream_dec));
+  HIP_CHECK(hipMemcpyAsync(sl.h_len.p, o.lens, (size_t)Bg * nr * 4, hipMemcpyDeviceToHost, m->stream_dec));
+  HIP_CHECK(hipMemcpyAsync(sl.h_conf.p, o.confidence, (size_t)Bg * nr * 8, hipMemcpyDeviceToHost, m->stream_dec));
+  HIP_CHECK(hipMemcpyAsync(sl.h_n.p, o.n_results, (size_t)Bg * 4, hipMemcpyDeviceToHost, m->stream_dec));
+  mark_on(m, -1, 1);
+  HIP_CHECK(hipEventRecord(sl.done, m->stream_dec));
+}
+
+// Wait for a group and turn its page-locked result block into Output lists (scattered to the caller's utterance order).
+void batch_collect_group(ModelState* m, ModelState::GroupSlot& sl, std::vector<std::vector<Output>>& all, Prof& pr) {
+  HIP_CHECK(hipEventSynchronize(sl.done));
+  const uint32_t* tok = sl.h_tok.as<uint32_t>(); const uint32_t* ts = sl.h_ts.as<uint32_t>();
+  const int* lens = sl.h_len.as<int>(); const double* conf = sl.h_conf.as<double>(); const int* nres = sl.h_n.as<int>();
+  for (int i = 0; i < sl.Bg; ++i) {
+    std::vector<Output>& dst = all[sl.idx[i]];
+    for (int r = 0; r < nres[i]; ++r) {
+      Output ou;
+      const size_t ob = (size_t)i * sl.nr + r;
+      const int total = lens[ob], len = std::min(total, sl.max_len);
+      ou.confidence = conf[ob];
+      ou.tokens.resize(len); ou.timesteps.resize(len);
+      for (int j = 0; j < len; ++j) {  // ring slots of the single-pass back-tracking (ctc_decode_kernel)
+        const size_t slot = ob * sl.max_len + (size_t)((total - 1 - j) % sl.max_len);
+        ou.tokens[j] = tok[slot]; ou.timesteps[j] = ts[slot];
+      }
+      dst.push_back(std::move(ou));
+    }
+  }
+  if (pr.on) {
+    pr.ms[6] += (float)sl.t_max; pr.ms[7] += (float)sl.t_max * sl.Bg;
+    std::vector<DecStream> tb(sl.Bg);
+    HIP_CHECK(hipMemcpy(tb.data(), sl.dec.table.p, sizeof(DecStream) * sl.Bg, hipMemcpyDeviceToHost));
+    for (auto& S : tb) { for (int k = 0; k < 4; ++k) pr.dec_stats[k] += S.stat[k]; for (int k = 0; k < 8; ++k) pr.dec_phase[k] += S.phase[k]; }
+  }
+}
+
+// Utterances are taken longest first in groups of 64 (length-homogeneous groups: the LSTM runs every group to its longest
+// member), two groups in flight (see ModelState::GroupSlot).
 std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio, unsigned stride, const unsigned* sizes, unsigned B, unsigned num_results) {
-  std::vector<std::vector<Output>> all;
+  std::vector<std::vector<Output>> all(B);
   HIP_CHECK(hipSetDevice(m->device));
   Prof& pr = prof_of(m);
   if (pr.on) { for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; prof_reset(pr); }
-  if (!m->ev_chunk[0]) for (auto& e : m->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (unsigned g0 = 0; g0 < B; g0 += 64) {
-    const int Bg = (int)std::min(64u, B - g0);
-    std::vector<int> hn(Bg), nfr;
-    int t_max = 1;
-    for (int b = 0; b < Bg; ++b) { hn[b] = (int)sizes[g0 + b]; t_max = std::max(t_max, n_frames_for(m->g, hn[b])); }
-    std::vector<int> cb;  // chunk boundaries
-    for (int t = 0, k = 0; t < t_max; ++k) { cb.push_back(t); t += (k == 0) ? std::min(batch_first_chunk_frames(), batch_chunk_frames()) : batch_chunk_frames(); }
-    cb.push_back(t_max);
-    const int n_chunks = (int)cb.size() - 1;
-    mark(m, 0);
-    m->run_mfcc(d_audio + (size_t)g0 * stride, hn.data(), Bg, (int)stride, t_max, nfr);
-    // decoder streams + per-chunk frame tables (begin, count per utterance), all enqueued on `stream`
-    DecoderBatch& db = m->batch_dec_;  // slab and table stay allocated between calls (grow-only)
-    m->decoder_create(db, Bg, (int)m->beam_width_, t_max, m->scorer_);
-    std::vector<int> tab((size_t)2 * n_chunks * Bg);
-    for (int k = 0; k < n_chunks; ++k)
-      for (int b = 0; b < Bg; ++b) {
-        tab[(size_t)(2 * k) * Bg + b] = cb[k];
-        tab[(size_t)(2 * k + 1) * Bg + b] = std::max(0, std::min(cb[k + 1], nfr[b]) - cb[k]);
-      }
-    m->ws_fbegin.upload(tab.data(), tab.size() * 4, m->stream);
-    DecParams p{};
-    p.C = m->g.n_classes; p.blank = p.C - 1; p.beam = db.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = t_max;
-    DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
-    for (int k = 0; k < n_chunks; ++k) {
-      const int t0 = cb[k], T = cb[k + 1] - cb[k];
-      m->run_acoustic_chunk(m->ws_feats.as<float>(), m->ws_nframes.as<int>(), Bg, t_max, t0, T);  // marks 1, 2, 3
-      mark(m, -1);
-      hipEvent_t ev = m->ev_chunk[k % 2];  // an event may be re-recorded once the wait on it has been enqueued
-      HIP_CHECK(hipEventRecord(ev, m->stream));
-      HIP_CHECK(hipStreamWaitEvent(m->stream_dec, ev, 0));
-      mark_on(m, 4, 1);
-      const int* fb = m->ws_fbegin.as<int>() + (size_t)(2 * k) * Bg;
-      launch_ctc_next(p, ds, m->dev_alphabet, db.table.as<DecStream>(), Bg, m->ws_probs.as<float>(), fb, fb + Bg, m->stream_dec);
-      mark_on(m, -1, 1);
-    }
-    HIP_CHECK(hipEventRecord(m->ev_chunk[2], m->stream_dec));
-    HIP_CHECK(hipStreamWaitEvent(m->stream, m->ev_chunk[2], 0));
-    mark(m, 5);
-    auto outs = decode_streams(*m, db, m->scorer_, m->hot_words_, num_results, t_max + 1);  // a token needs its own timestep: <= t_max tokens; synchronises `stream`
-    mark(m, -1);
-    if (pr.on) {
-      HIP_CHECK(hipStreamSynchronize(m->stream));
-      prof_collect(pr);
-      pr.ms[6] += (float)t_max; pr.ms[7] += (float)t_max * Bg;
-      std::vector<DecStream> tb(Bg);
-      HIP_CHECK(hipMemcpy(tb.data(), db.table.p, sizeof(DecStream) * Bg, hipMemcpyDeviceToHost));
-      for (auto& S : tb) { for (int k = 0; k < 4; ++k) pr.dec_stats[k] += S.stat[k]; for (int k = 0; k < 8; ++k) pr.dec_phase[k] += S.phase[k]; }
-    }
-    for (auto& o : outs) all.push_back(std::move(o));
+  if (!m->ev_chunk[0]) {
+    for (auto& e : m->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& sl : m->slots_) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  }
+  std::vector<unsigned> order(B);
+  for (unsigned i = 0; i < B; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return sizes[x] > sizes[y]; });
+  const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
+  int pending = -1, gi = 0;
+  for (unsigned g0 = 0; g0 < B; g0 += 64, ++gi) {
+    const std::vector<unsigned> idx(order.begin() + g0, order.begin() + std::min(B, g0 + 64));
+    batch_enqueue_group(m, m->slots_[gi & 1], d_audio, stride, sizes, idx, num_results, ds);
+    if (pending >= 0) batch_collect_group(m, m->slots_[pending & 1], all, pr);
+    pending = gi;
+  }
+  if (pending >= 0) batch_collect_group(m, m->slots_[pending & 1], all, pr);
+  if (pr.on) {
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream_dec));
+    prof_collect(pr);
   }
   return all;
 }

@@ -102,16 +102,15 @@ void ModelState::run_acoustic(const float* d_feats, const int* d_nframes, int B,
   run_acoustic_rows(ws_x1.as<_Float16>(), B, t_max, d_c, d_h, carry_in, ws_probs.as<float>(), t_max);
 }
 
-void ModelState::run_acoustic_chunk(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T) {
+void ModelState::run_acoustic_chunk(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs) {
   const int M = T * B;
   ws_x1.reserve((size_t)M * g.k1_pad() * 2);
-  ws_probs.reserve((size_t)B * t_max * g.n_classes * 4);
   ContextArgs c{};
   c.feats = d_feats; c.n_frames = d_nframes; c.x1 = ws_x1.as<_Float16>();
   c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = g.k1_pad(); c.t0 = t0;
   launch_context(c, M, stream);
   // probs[b][t0 + t][:]: the softmax writes row (t, b) at probs + ((b*t_max + t)*C), so offsetting the base by t0*C lands it
-  acoustic_rows(*this, ws_x1.as<_Float16>(), B, T, nullptr, nullptr, t0 == 0 ? 0 : 2, t0, ws_probs.as<float>() + (size_t)t0 * g.n_classes, t_max);
+  acoustic_rows(*this, ws_x1.as<_Float16>(), B, T, nullptr, nullptr, t0 == 0 ? 0 : 2, t0, d_probs + (size_t)t0 * g.n_classes, t_max);
 }
 
 // ------------------------------------------------------------------------------------------- decoder state
@@ -153,7 +152,7 @@ void point_arenas(DecStream& S, uint8_t* base, const SlabLayout& l) {
 }
 }  // namespace
 
-void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc) {
+void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc, PinnedBuf* staging) {
   const int C = g.n_classes;
   if (beam < 1 || beam > STT_MAX_BEAM) throw std::runtime_error("beam width must be in [1, 1024]");
   db.n_streams = n_streams; db.beam = beam; db.C = C;
@@ -180,7 +179,14 @@ void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int e
     point_arenas(S, base + l.per * i, l);
     S.cand_cap = cand_cap;
   }
-  db.table.upload(db.host.data(), sizeof(DecStream) * n_streams, stream);
+  if (staging) {
+    staging->reserve(sizeof(DecStream) * n_streams);
+    memcpy(staging->p, db.host.data(), sizeof(DecStream) * n_streams);
+    db.table.reserve(sizeof(DecStream) * n_streams);
+    HIP_CHECK(hipMemcpyAsync(db.table.p, staging->p, sizeof(DecStream) * n_streams, hipMemcpyHostToDevice, stream));
+  } else {
+    db.table.upload(db.host.data(), sizeof(DecStream) * n_streams, stream);
+  }
   launch_ctc_init(db.table.as<DecStream>(), n_streams, sc ? &sc->dev : nullptr, stream);
 }
 

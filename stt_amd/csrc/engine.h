@@ -39,6 +39,18 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Page-locked host memory (grow-only): source / destination of copies that must not block the host.
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  void reserve(size_t bytes);
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 // ---------------------------------------------------------------------------------------------
 class Alphabet {
  public:
@@ -120,8 +132,19 @@ struct ModelState {
   DevBuf ws_audio, ws_nsamp, ws_nframes, ws_feats, ws_x1, ws_a, ws_b, ws_xproj, ws_hall, ws_logits, ws_probs;
   DevBuf ws_c, ws_hp0, ws_hp1, ws_hf32, ws_fbegin, ws_fcount;
   DevBuf ws_out_tok, ws_out_ts, ws_out_len, ws_out_conf, ws_out_n, ws_hot_hash, ws_hot_boost;
-  DecoderBatch batch_dec_;  // decoder streams of the STTX_SpeechToTextBatch* path, reused across calls
-  hipEvent_t ev_chunk[3] = {};  // chunk hand-over acoustic stream -> decoder stream (2, alternating) and back (1)
+  // The batch path works on two 64-utterance groups at a time: while the beam search of group g finishes on `stream_dec`,
+  // the acoustic model of group g+1 already runs on `stream`, and the host unpacks group g-1.  Everything a group owns
+  // beyond the acoustic stream's scratch buffers lives in its slot.
+  struct GroupSlot {
+    DecoderBatch dec;
+    DevBuf probs, ints, out_tok, out_ts, out_len, out_conf, out_n;
+    PinnedBuf h_ints, h_table, h_tok, h_ts, h_len, h_conf, h_n;
+    hipEvent_t done = nullptr;
+    int Bg = 0, nr = 0, max_len = 0, t_max = 0;
+    std::vector<unsigned> idx;  // caller's utterance index of every stream of the group
+  };
+  GroupSlot slots_[2];
+  hipEvent_t ev_chunk[2] = {};  // chunk hand-over acoustic stream -> decoder stream (alternating)
 
   ~ModelState();
   int InitFromBuffer(const char* buf, size_t len);  // STT_ERR_* code
@@ -136,11 +159,12 @@ struct ModelState {
   void run_acoustic_rows(const _Float16* d_x1, int B, int T, float* d_c, float* d_h, bool carry_in, float* d_probs_out, int probs_t_max);
   // one time-chunk [t0, t0+T) of a batch: context rows from feats, then the layers; the LSTM state continues from the
   // previous chunk (internal buffers) unless t0 == 0
-  void run_acoustic_chunk(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T);
+  void run_acoustic_chunk(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs);
 
   // ---- decoder ----
   DevScorer current_scorer(std::shared_ptr<ScorerDev> sc, const std::map<std::string, float>& hot, DevBuf& hh, DevBuf& hb) const;
-  void decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc);
+  // `staging`: page-locked room for the stream table; the upload then does not wait for the stream (batch path)
+  void decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc, PinnedBuf* staging = nullptr);
   void decoder_reserve(DecoderBatch& db, const std::vector<int>& more_frames);
 };
 

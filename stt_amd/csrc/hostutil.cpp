@@ -20,6 +20,13 @@ void DevBuf::reserve(size_t bytes, bool keep, hipStream_t st) {
   p = np;
   cap = ncap;
 }
+void PinnedBuf::reserve(size_t bytes) {
+  if (bytes <= cap && p) return;
+  if (p) HIP_CHECK(hipHostFree(p));
+  p = nullptr;
+  cap = bytes + bytes / 4 + 256;
+  HIP_CHECK(hipHostMalloc(&p, cap, hipHostMallocDefault));
+}
 void DevBuf::upload(const void* src, size_t bytes, hipStream_t st) {
   reserve(bytes ? bytes : 1);
   if (bytes) {

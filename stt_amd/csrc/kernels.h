@@ -6,7 +6,8 @@
 
 // ---- features -----------------------------------------------------------------------------------
 struct MfccArgs {
-  const int16_t* audio;    // [B][n_max]
+  const int16_t* audio;    // [rows][n_max]
+  const int* rows;         // [B] row of utterance b in `audio` (null: row b)
   const int* n_samples;    // [B]
   const int* n_frames;     // [B]
   float* feats;            // [B][t_max][n_coef]

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccArgs a) {
     if (threadIdx.x < a.n_coef) out[threadIdx.x] = 0.0f;
     return;
   }
-  const int16_t* au = a.audio + (size_t)b * a.n_max;
+  const int16_t* au = a.audio + (size_t)(a.rows ? a.rows[b] : b) * a.n_max;
   const int tid = threadIdx.x;
   for (int i = tid; i < 512; i += 256) {
     const int s = f * a.win_step + i;

@@ -71,6 +71,7 @@ ModelState::~ModelState() {
   if (stream) (void)hipStreamDestroy(stream);
   if (stream_dec) (void)hipStreamDestroy(stream_dec);
   for (auto& e : ev_chunk) if (e) (void)hipEventDestroy(e);
+  for (auto& sl : slots_) if (sl.done) (void)hipEventDestroy(sl.done);
 }
 
 int ModelState::InitFromBuffer(const char* buf, size_t len) {
