@@ -24,7 +24,7 @@ struct Prof {
   bool on = false;
   std::vector<hipEvent_t> pool;
   size_t used = 0;
-  std::vector<std::pair<int, hipEvent_t>> marks[2];  // [0] = acoustic stream, [1] = decoder stream
+  std::vector<std::pair<int, hipEvent_t>> marks[3];  // [0] = acoustic stream, [1], [2] = the two groups' search streams
   float ms[8] = {};
   unsigned long long dec_stats[4] = {};
   unsigned long long dec_phase[8] = {};
@@ -32,16 +32,16 @@ struct Prof {
 std::unordered_map<ModelState*, Prof> g_prof;
 
 Prof& prof_of(ModelState* m) { return g_prof[m]; }
-void mark_on(ModelState* m, int id, int which) {
+void mark_on(ModelState* m, int id, int which, hipStream_t st) {
   Prof& p = prof_of(m);
   if (!p.on) return;
   if (p.used == p.pool.size()) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); p.pool.push_back(e); }
   hipEvent_t e = p.pool[p.used++];
-  HIP_CHECK(hipEventRecord(e, which ? m->stream_dec : m->stream));
+  HIP_CHECK(hipEventRecord(e, st));
   p.marks[which].push_back({id, e});
 }
-void mark(ModelState* m, int id) { mark_on(m, id, 0); }
-void prof_reset(Prof& p) { p.used = 0; p.marks[0].clear(); p.marks[1].clear(); }
+void mark(ModelState* m, int id) { mark_on(m, id, 0, m->stream); }
+void prof_reset(Prof& p) { p.used = 0; for (auto& mk : p.marks) mk.clear(); }
 void prof_collect(Prof& p) {  // both streams must be idle
   for (auto& mk : p.marks)
     for (size_t i = 0; i + 1 < mk.size(); ++i) {
@@ -150,6 +150,7 @@ int batch_first_chunk_frames() {
 void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t* d_audio, unsigned stride, const unsigned* sizes,
                          const std::vector<unsigned>& idx, unsigned num_results, const DevScorer& ds) {
   const int Bg = (int)idx.size();
+  const int which = (&sl == &m->slots_[0]) ? 1 : 2;  // profiling mark list of this group's search stream
   int t_max = 1;
   for (int b = 0; b < Bg; ++b) t_max = std::max(t_max, n_frames_for(m->g, (int)sizes[idx[b]]));
   std::vector<int> cb;  // chunk boundaries
@@ -187,11 +188,11 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
     mark(m, -1);
     hipEvent_t ev = m->ev_chunk[k % 2];  // an event may be re-recorded once the wait on it has been enqueued
     HIP_CHECK(hipEventRecord(ev, m->stream));
-    HIP_CHECK(hipStreamWaitEvent(m->stream_dec, ev, 0));
-    mark_on(m, 4, 1);
+    HIP_CHECK(hipStreamWaitEvent(sl.stream_dec, ev, 0));
+    mark_on(m, 4, which, sl.stream_dec);
     const int* fb = d_tab + (size_t)(2 * k) * Bg;
-    launch_ctc_next(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, sl.probs.as<float>(), fb, fb + Bg, m->stream_dec);
-    mark_on(m, -1, 1);
+    launch_ctc_next(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, sl.probs.as<float>(), fb, fb + Bg, sl.stream_dec);
+    mark_on(m, -1, which, sl.stream_dec);
   }
   // ranking + back-tracking, results to page-locked memory (a token needs its own timestep: <= t_max tokens)
   const int nr = (int)std::max(1u, std::min<unsigned>(num_results, (unsigned)sl.dec.beam));
@@ -203,15 +204,15 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
   DecodeOut o{};
   o.tokens = sl.out_tok.as<uint32_t>(); o.timesteps = sl.out_ts.as<uint32_t>(); o.lens = sl.out_len.as<int>();
   o.confidence = sl.out_conf.as<double>(); o.n_results = sl.out_n.as<int>(); o.num_results = nr; o.max_len = max_len;
-  mark_on(m, 5, 1);
-  launch_ctc_decode(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, o, m->stream_dec);
-  HIP_CHECK(hipMemcpyAsync(sl.h_tok.p, o.tokens, n_tok * 4, hipMemcpyDeviceToHost, m->stream_dec));
-  HIP_CHECK(hipMemcpyAsync(sl.h_ts.p, o.timesteps, n_tok * 4, hipMemcpyDeviceToHost, m->stream_dec));
-  HIP_CHECK(hipMemcpyAsync(sl.h_len.p, o.lens, (size_t)Bg * nr * 4, hipMemcpyDeviceToHost, m->stream_dec));
-  HIP_CHECK(hipMemcpyAsync(sl.h_conf.p, o.confidence, (size_t)Bg * nr * 8, hipMemcpyDeviceToHost, m->stream_dec));
-  HIP_CHECK(hipMemcpyAsync(sl.h_n.p, o.n_results, (size_t)Bg * 4, hipMemcpyDeviceToHost, m->stream_dec));
-  mark_on(m, -1, 1);
-  HIP_CHECK(hipEventRecord(sl.done, m->stream_dec));
+  mark_on(m, 5, which, sl.stream_dec);
+  launch_ctc_decode(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, o, sl.stream_dec);
+  HIP_CHECK(hipMemcpyAsync(sl.h_tok.p, o.tokens, n_tok * 4, hipMemcpyDeviceToHost, sl.stream_dec));
+  HIP_CHECK(hipMemcpyAsync(sl.h_ts.p, o.timesteps, n_tok * 4, hipMemcpyDeviceToHost, sl.stream_dec));
+  HIP_CHECK(hipMemcpyAsync(sl.h_len.p, o.lens, (size_t)Bg * nr * 4, hipMemcpyDeviceToHost, sl.stream_dec));
+  HIP_CHECK(hipMemcpyAsync(sl.h_conf.p, o.confidence, (size_t)Bg * nr * 8, hipMemcpyDeviceToHost, sl.stream_dec));
+  HIP_CHECK(hipMemcpyAsync(sl.h_n.p, o.n_results, (size_t)Bg * 4, hipMemcpyDeviceToHost, sl.stream_dec));
+  mark_on(m, -1, which, sl.stream_dec);
+  HIP_CHECK(hipEventRecord(sl.done, sl.stream_dec));
 }
 
 // Wait for a group and turn its page-locked result block into Output lists (scattered to the caller's utterance order).
@@ -252,6 +253,8 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
   if (!m->ev_chunk[0]) {
     for (auto& e : m->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& sl : m->slots_) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    m->slots_[0].stream_dec = m->stream_dec;
+    HIP_CHECK(hipStreamCreateWithFlags(&m->slots_[1].stream_dec, hipStreamNonBlocking));
   }
   std::vector<unsigned> order(B);
   for (unsigned i = 0; i < B; ++i) order[i] = i;
@@ -267,7 +270,7 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
   if (pending >= 0) batch_collect_group(m, m->slots_[pending & 1], all, pr);
   if (pr.on) {
     HIP_CHECK(hipStreamSynchronize(m->stream));
-    HIP_CHECK(hipStreamSynchronize(m->stream_dec));
+    for (auto& sl : m->slots_) HIP_CHECK(hipStreamSynchronize(sl.stream_dec));
     prof_collect(pr);
   }
   return all;

@@ -140,6 +140,7 @@ struct ModelState {
     DevBuf probs, ints, out_tok, out_ts, out_len, out_conf, out_n;
     PinnedBuf h_ints, h_table, h_tok, h_ts, h_len, h_conf, h_n;
     hipEvent_t done = nullptr;
+    hipStream_t stream_dec = nullptr;  // the group's search stream (slot 0: ModelState::stream_dec, slot 1: its own)
     int Bg = 0, nr = 0, max_len = 0, t_max = 0;
     std::vector<unsigned> idx;  // caller's utterance index of every stream of the group
   };
