@@ -89,6 +89,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        from stt_amd import dist as _sd
+        _sd.assume_equal_batches()      # weak scaling: every rank decodes BATCH utterances -> the gather is one collective
 
     from stt_amd import Model, modelfile, native, synth
     from stt_amd import dist as sdist

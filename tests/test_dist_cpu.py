@@ -20,8 +20,13 @@ lengths = [16000 * (1 + (7 * i) %% 15) for i in range(23)]
 shards = sdist.shard_utterances(lengths, 2)
 mine = ["utt%%d-len%%d-é" %% (i, lengths[i]) if i %% 5 else "" for i in shards[rank]]
 allr = sdist.gather_transcripts(mine, device=torch.device("cpu"))
+# equal batches declared (bench.py's weak scaling): single collective; one long transcript forces the second round
+sdist.assume_equal_batches()
+eq = ["r%%d-%%d" %% (rank, i) for i in range(7)]
+eq[3] = "x" * (5000 if rank == 1 else 3)
+alleq = sdist.gather_transcripts(eq, device=torch.device("cpu"), bytes_per_utterance=16)
 if rank == 0:
-    print(json.dumps({"shards": shards, "all": allr}))
+    print(json.dumps({"shards": shards, "all": allr, "eq": alleq}))
 dist.destroy_process_group()
 '''
 
@@ -54,6 +59,9 @@ def test_gather_transcripts_two_ranks_gloo(tmp_path):
     for rank in range(2):
         want = ["utt%d-len%d-é" % (i, lengths[i]) if i % 5 else "" for i in res["shards"][rank]]
         assert res["all"][rank] == want
+        weq = ["r%d-%d" % (rank, i) for i in range(7)]
+        weq[3] = "x" * (5000 if rank == 1 else 3)
+        assert res["eq"][rank] == weq
 
 
 def test_gather_without_process_group_is_identity():
