@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -265,7 +266,9 @@ __device__ __forceinline__ float tanhf_(float x) {
   return copysignf(t, x);
 }
 
-template <int NT>
+// PF: double-buffered register prefetch of the weight / h fragments (256 VGPRs, fastest when the kernel has the chip to itself)
+// or the plain loop (<= 128 VGPRs: up to four workgroups per CU, which packs better next to the search kernel's workgroups).
+template <int NT, bool PF>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   __shared__ __attribute__((aligned(16))) float red[4][2][NT][64][4];
   __shared__ __attribute__((aligned(16))) _Float16 hout[NT * 16][8];
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   // k-steps are taken four at a time with the next group's weight and h fragments already in flight (double buffered in
   // registers: one wave per SIMD, so the register file is ours): the kernel is bound by L2/HBM latency, not by MFMA issue.
   constexpr int G = 4;
-  if (ksteps % (2 * G) == 0) {
+  if (PF && ksteps % (2 * G) == 0) {
     uint4 wa[G][2], ha[G][NT], wb[G][2], hb[G][NT];
 #define LSTM_LOAD(W, Hh, s0)                                                                      \
   _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                 \
@@ -381,9 +384,10 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
     if (b < B) *reinterpret_cast<uint4*>(a.h_all + ((size_t)a.t * B + b) * H + k0) = v;
   }
 }
-template __global__ void lstm_step_kernel<1>(LstmArgs);
-template __global__ void lstm_step_kernel<2>(LstmArgs);
-template __global__ void lstm_step_kernel<4>(LstmArgs);
+template __global__ void lstm_step_kernel<1, true>(LstmArgs);
+template __global__ void lstm_step_kernel<2, true>(LstmArgs);
+template __global__ void lstm_step_kernel<4, true>(LstmArgs);
+template __global__ void lstm_step_kernel<4, false>(LstmArgs);
 
 // h (f32 [B][H]) -> fragment-ordered f16 hp (used once per chunk to seed the recurrence from a carried state)
 __global__ void pack_h_kernel(const float* h, _Float16* hp, int B, int H, int NT) {
@@ -515,10 +519,14 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
 int lstm_nt_for_batch(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : -1; }  // 64 rows per launch (LDS reduce buffer 32 KiB)
 void launch_lstm_step(const LstmArgs& a, int NT, hipStream_t st) {
   const dim3 grid(a.n_hidden / 8), block(256);
+  static const bool pf = []() { const char* e = getenv("STT_AMD_LSTM_PREFETCH"); return !(e && e[0] == '0'); }();
   switch (NT) {
-    case 1: hipLaunchKernelGGL(lstm_step_kernel<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(lstm_step_kernel<2>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(lstm_step_kernel<4>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((lstm_step_kernel<1, true>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((lstm_step_kernel<2, true>), grid, block, 0, st, a); break;
+    default:
+      if (pf) hipLaunchKernelGGL((lstm_step_kernel<4, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((lstm_step_kernel<4, false>), grid, block, 0, st, a);
+      break;
   }
 }
 void launch_pack_h(const float* h, void* hp, int B, int H, int NT, hipStream_t st) {
