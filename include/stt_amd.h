@@ -46,6 +46,19 @@ STTX_EXPORT char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* a
 STTX_EXPORT void STTX_FreeStrings(char** aStrings, unsigned int aCount);
 STTX_EXPORT void STTX_FreeMetadataArray(Metadata** aMetadata, unsigned int aCount);
 
+/* ---- many streams at once (serving) -------------------------------------------------------------
+ * The reference API advances one stream per call (stt.cc:553-639).  A server with many live streams calls these instead:
+ * the semantics per stream are exactly those of STT_FeedAudioContent / STT_IntermediateDecode / STT_FinishStream, but the
+ * windows that become ready in ANY of the streams go through the acoustic model and the beam search as one batch.
+ * All streams must belong to the same model; streams that differ in beam width, scorer or hot words (captured at creation)
+ * are processed one by one. */
+STTX_EXPORT void STTX_FeedAudioContentBatch(StreamingState* const* aStreams, const short* const* aBuffers, const unsigned int* aBufferSizes,
+                                           unsigned int aCount);
+/* aCount malloc'd strings (free with STTX_FreeStrings), or NULL on error. */
+STTX_EXPORT char** STTX_IntermediateDecodeBatch(StreamingState* const* aStreams, unsigned int aCount);
+/* Like STT_FinishStream on every stream: the streams are destroyed. */
+STTX_EXPORT char** STTX_FinishStreamBatch(StreamingState* const* aStreams, unsigned int aCount);
+
 /* Per-stage GPU time of the last batch call, measured with HIP events on the engine's own stream.
  * aMs receives up to aCap floats: [0] features, [1] dense layers 1-3 + x-projection, [2] LSTM recurrence,
  * [3] layers 5-6 + softmax, [4] decoder next, [5] decoder decode + D2H, [6] LSTM launches, [7] timesteps. */

@@ -408,6 +408,52 @@ Metadata* STT_IntermediateDecodeWithMetadataFlushBuffers(StreamingState* aSctx, 
   return r;
 }
 void STT_FreeStream(StreamingState* aSctx) { delete aSctx; }
+// ---- many streams per call (stt_amd.h)
+static char** strings_of(const ModelState* m, const std::vector<std::vector<Output>>& outs) {
+  char** r = (char**)malloc(sizeof(char*) * std::max<size_t>(1, outs.size()));
+  for (size_t i = 0; i < outs.size(); ++i) {
+    const std::string t = outs[i].empty() ? std::string() : m->alphabet_.Decode(outs[i][0].tokens.data(), (int)outs[i][0].tokens.size());
+    r[i] = strdup(t.c_str());
+  }
+  return r;
+}
+void STTX_FeedAudioContentBatch(StreamingState* const* aStreams, const short* const* aBuffers, const unsigned int* aBufferSizes, unsigned int aCount) {
+  guarded([&]() {
+    if (!aCount) return 0;
+    std::vector<StreamingState*> ss(aStreams, aStreams + aCount);
+    HIP_CHECK(hipSetDevice(ss[0]->model_->device));
+    if (streams_batchable(ss)) streams_feed_batch(ss, aBuffers, aBufferSizes);
+    else for (unsigned i = 0; i < aCount; ++i) ss[i]->feedAudioContent(aBuffers[i], aBufferSizes[i]);
+    return 0;
+  }, 0);
+}
+char** STTX_IntermediateDecodeBatch(StreamingState* const* aStreams, unsigned int aCount) {
+  char** r = nullptr;
+  guarded([&]() {
+    if (!aCount) return 0;
+    std::vector<StreamingState*> ss(aStreams, aStreams + aCount);
+    HIP_CHECK(hipSetDevice(ss[0]->model_->device));
+    if (streams_batchable(ss)) r = strings_of(ss[0]->model_, streams_decode_batch(ss, 1));
+    else { r = (char**)malloc(sizeof(char*) * aCount); for (unsigned i = 0; i < aCount; ++i) r[i] = decode_string(ss[i]); }
+    return 0;
+  }, 0);
+  return r;
+}
+char** STTX_FinishStreamBatch(StreamingState* const* aStreams, unsigned int aCount) {
+  char** r = nullptr;
+  guarded([&]() {
+    if (!aCount) return 0;
+    std::vector<StreamingState*> ss(aStreams, aStreams + aCount);
+    HIP_CHECK(hipSetDevice(ss[0]->model_->device));
+    if (streams_batchable(ss)) { streams_flush_batch(ss, true); r = strings_of(ss[0]->model_, streams_decode_batch(ss, 1)); }
+    else { r = (char**)malloc(sizeof(char*) * aCount); for (unsigned i = 0; i < aCount; ++i) { ss[i]->flushBuffers(true); r[i] = decode_string(ss[i]); } }
+    return 0;
+  }, 0);
+  for (unsigned i = 0; i < aCount; ++i) STT_FreeStream(aStreams[i]);
+  return r;
+}
+
+
 char* STT_FinishStream(StreamingState* aSctx) {
   char* r = nullptr;
   guarded([&]() { aSctx->flushBuffers(true); r = decode_string(aSctx); return 0; }, 0);

@@ -139,3 +139,6 @@ void launch_ctc_decode(const DecParams& p, const DevScorer& s, const DevAlphabet
                        const DecodeOut& out, hipStream_t st);
 size_t ctc_next_lds_bytes(int beam, int C);
 void launch_ctc_init(DecStream* streams, int n_streams, const DevScorer* scorer_or_null, hipStream_t st);
+// batched streaming: every stream owns a one-entry table; a launch over many of them works on a gathered copy
+void launch_gather_streams(const DecStream* const* src, DecStream* dst, int n, hipStream_t st);
+void launch_scatter_streams(DecStream* const* dst, const DecStream* src, int n, hipStream_t st);

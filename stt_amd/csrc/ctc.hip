@@ -1360,6 +1360,29 @@ void launch_ctc_init(DecStream* streams, int n_streams, const DevScorer* sc, hip
                      sc ? sc->bos_index : 0u, sc ? sc->bos_backoff : 0.0f);
 }
 
+__global__ void gather_streams_kernel(const DecStream* const* src, DecStream* dst, int n) {
+  constexpr int W = sizeof(DecStream) / 4;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * W) return;
+  const int i = idx / W, w = idx - i * W;
+  reinterpret_cast<uint32_t*>(dst + i)[w] = reinterpret_cast<const uint32_t*>(src[i])[w];
+}
+__global__ void scatter_streams_kernel(DecStream* const* dst, const DecStream* src, int n) {
+  constexpr int W = sizeof(DecStream) / 4;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * W) return;
+  const int i = idx / W, w = idx - i * W;
+  reinterpret_cast<uint32_t*>(dst[i])[w] = reinterpret_cast<const uint32_t*>(src + i)[w];
+}
+void launch_gather_streams(const DecStream* const* src, DecStream* dst, int n, hipStream_t st) {
+  const int total = n * (int)(sizeof(DecStream) / 4);
+  hipLaunchKernelGGL(gather_streams_kernel, dim3((total + 255) / 256), dim3(256), 0, st, src, dst, n);
+}
+void launch_scatter_streams(DecStream* const* dst, const DecStream* src, int n, hipStream_t st) {
+  const int total = n * (int)(sizeof(DecStream) / 4);
+  hipLaunchKernelGGL(scatter_streams_kernel, dim3((total + 255) / 256), dim3(256), 0, st, dst, src, n);
+}
+
 // ------------------------------------------------------------------------------------ launchers
 void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
                      const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st) {

@@ -233,17 +233,21 @@ void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_
 std::vector<std::vector<Output>> decode_streams(const ModelState& mc, const DecoderBatch& db, std::shared_ptr<ScorerDev> sc,
                                                 const std::map<std::string, float>& hot, unsigned num_results, int max_len) {
   ModelState& m = const_cast<ModelState&>(mc);  // workspaces only
-  const int n = db.n_streams;
-  const int nr = (int)std::max(1u, std::min<unsigned>(num_results, (unsigned)db.beam));
+  return decode_table(m, db.table.as<DecStream>(), db.n_streams, db.beam, db.C, sc, hot, num_results, max_len);
+}
+
+std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_table, int n, int beam, int C, std::shared_ptr<ScorerDev> sc,
+                                              const std::map<std::string, float>& hot, unsigned num_results, int max_len) {
+  const int nr = (int)std::max(1u, std::min<unsigned>(num_results, (unsigned)beam));
   m.ws_out_tok.reserve((size_t)n * nr * max_len * 4); m.ws_out_ts.reserve((size_t)n * nr * max_len * 4);
   m.ws_out_len.reserve((size_t)n * nr * 4); m.ws_out_conf.reserve((size_t)n * nr * 8); m.ws_out_n.reserve((size_t)n * 4);
   DecodeOut o{};
   o.tokens = m.ws_out_tok.as<uint32_t>(); o.timesteps = m.ws_out_ts.as<uint32_t>(); o.lens = m.ws_out_len.as<int>();
   o.confidence = m.ws_out_conf.as<double>(); o.n_results = m.ws_out_n.as<int>(); o.num_results = nr; o.max_len = max_len;
   DecParams p{};
-  p.C = db.C; p.blank = db.C - 1; p.beam = db.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = 0;
+  p.C = C; p.blank = C - 1; p.beam = beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = 0;
   DevScorer ds = m.current_scorer(sc, hot, m.ws_hot_hash, m.ws_hot_boost);
-  launch_ctc_decode(p, ds, m.dev_alphabet, db.table.as<DecStream>(), n, o, m.stream);
+  launch_ctc_decode(p, ds, m.dev_alphabet, d_table, n, o, m.stream);
   std::vector<uint32_t> tok((size_t)n * nr * max_len), ts((size_t)n * nr * max_len);
   std::vector<int> lens((size_t)n * nr), nres(n);
   std::vector<double> conf((size_t)n * nr);
@@ -359,7 +363,7 @@ void StreamingState::processReady(bool flush_partial, bool final_flush) {
       probs_.assign(pr.begin(), pr.end());
     }
     // decoder_state_.next(inputs, n_frames, num_classes)
-    m.decoder_reserve(dec, std::vector<int>{take});
+    reserveArena(take);
     DecParams p{};
     p.C = C; p.blank = C - 1; p.beam = dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = T;  // stt.cc:539-540
     const int fb[2] = {0, take};
@@ -371,6 +375,180 @@ void StreamingState::processReady(bool flush_partial, bool final_flush) {
     launch_ctc_next(p, ds, m.dev_alphabet, dec.table.as<DecStream>(), 1, m.ws_probs.as<float>(), m.ws_fbegin.as<int>(), m.ws_fcount.as<int>(), m.stream);
     windows_done_ += take;
   }
+}
+
+// Room for `take` more timesteps in the arenas.  The exact fill lives on the device; a host-side bound (every step appends
+// at most beam nodes) avoids reading it back on every chunk.
+void StreamingState::reserveArena(int take) {
+  const uint32_t add = (uint32_t)(take + 1) * (uint32_t)dec.beam + 2;
+  if (arena_bound_ + add > dec.host[0].pa_cap) {
+    model_->decoder_reserve(dec, std::vector<int>{take});  // reads the table back, grows the slab if needed
+    arena_bound_ = std::max(dec.host[0].pa_n, dec.host[0].ta_n);
+  }
+  arena_bound_ += (uint32_t)take * (uint32_t)dec.beam;
+}
+
+// ------------------------------------------------------------------------------------------- batched streaming
+bool streams_batchable(const std::vector<StreamingState*>& ss) {
+  if (ss.empty()) return false;
+  const StreamingState* a = ss[0];
+  for (const StreamingState* s : ss)
+    if (!s || s->model_ != a->model_ || s->beam_width_ != a->beam_width_ || s->scorer_ != a->scorer_ || s->hot_words_ != a->hot_words_ || s->keep_emissions_)
+      return false;
+  for (size_t i = 0; i < ss.size(); ++i)
+    for (size_t j = i + 1; j < ss.size(); ++j)
+      if (ss[i] == ss[j]) return false;
+  return true;
+}
+
+namespace {
+// runs every batch of n_steps windows that is ready in any of the streams (and the partial ones when flushing)
+void streams_process(const std::vector<StreamingState*>& ss, bool flush_partial) {
+  ModelState& m = *ss[0]->model_;
+  const Geometry& g = m.g;
+  const int H = g.n_hidden, C = g.n_classes, kp = g.k1_pad(), kw = g.n_in1(), T = g.n_steps;
+  DevScorer ds = m.current_scorer(ss[0]->scorer_, ss[0]->hot_words_, ss[0]->hot_hash, ss[0]->hot_boost);
+  for (;;) {
+    std::vector<StreamingState*> R;
+    std::vector<int> takes;
+    for (StreamingState* s : ss) {
+      const int ready = std::max(0, s->frames_ - 2 * g.n_context) - s->windows_done_;
+      const int take = ready >= T ? T : ((flush_partial && ready > 0) ? ready : 0);
+      if (take) { R.push_back(s); takes.push_back(take); }
+    }
+    if (R.empty()) break;
+    for (size_t g0 = 0; g0 < R.size(); g0 += 64) {
+      const int B = (int)std::min<size_t>(64, R.size() - g0);
+      for (int b = 0; b < B; ++b) {
+        StreamingState* s = R[g0 + b];
+        s->d_c.reserve((size_t)H * 4); s->d_h.reserve((size_t)H * 4);
+        s->reserveArena(takes[g0 + b]);
+      }
+      // one page-locked table: [frames ptr | c ptr | h ptr | stream-table ptr] (8 bytes each) then [win_off | take | zero] ints, then valid bytes
+      const size_t n_ptr = (size_t)4 * B, bytes = n_ptr * 8 + (size_t)3 * B * 4 + B;
+      m.sb_htab.reserve(bytes); m.sb_tab.reserve(bytes);
+      uint8_t* hb = m.sb_htab.as<uint8_t>();
+      void** hp = reinterpret_cast<void**>(hb);
+      int* hi = reinterpret_cast<int*>(hb + n_ptr * 8);
+      uint8_t* hv = hb + n_ptr * 8 + (size_t)3 * B * 4;
+      for (int b = 0; b < B; ++b) {
+        StreamingState* s = R[g0 + b];
+        hp[b] = s->d_frames.p; hp[B + b] = s->d_c.p; hp[2 * B + b] = s->d_h.p; hp[3 * B + b] = s->dec.table.p;
+        hi[b] = s->windows_done_; hi[B + b] = takes[g0 + b]; hi[2 * B + b] = 0;
+        hv[b] = s->state_nonzero ? 1 : 0;
+      }
+      HIP_CHECK(hipMemcpyAsync(m.sb_tab.p, hb, bytes, hipMemcpyHostToDevice, m.stream));
+      uint8_t* db = m.sb_tab.as<uint8_t>();
+      const float* const* d_frames = reinterpret_cast<const float* const*>(db);
+      float* const* d_cp = reinterpret_cast<float* const*>(db + (size_t)B * 8);
+      float* const* d_hp = reinterpret_cast<float* const*>(db + (size_t)2 * B * 8);
+      DecStream* const* d_tp = reinterpret_cast<DecStream* const*>(db + (size_t)3 * B * 8);
+      const int* d_int = reinterpret_cast<const int*>(db + n_ptr * 8);
+      const unsigned char* d_valid = db + n_ptr * 8 + (size_t)3 * B * 4;
+      m.ws_x1.reserve((size_t)T * B * kp * 2);
+      launch_window_rows_batch(d_frames, d_int, d_int + B, m.ws_x1.as<_Float16>(), B, T, g.n_input, kw, kp, m.stream);
+      m.sb_c.reserve((size_t)B * H * 4); m.sb_h.reserve((size_t)B * H * 4);
+      launch_gather_rows(d_cp, d_valid, m.sb_c.as<float>(), B, H, m.stream);
+      launch_gather_rows(d_hp, d_valid, m.sb_h.as<float>(), B, H, m.stream);
+      m.ws_probs.reserve((size_t)B * T * C * 4);
+      m.run_acoustic_rows(m.ws_x1.as<_Float16>(), B, T, m.sb_c.as<float>(), m.sb_h.as<float>(), true, m.ws_probs.as<float>(), T);
+      launch_scatter_rows(d_cp, m.sb_c.as<float>(), B, H, m.stream);
+      launch_scatter_rows(d_hp, m.sb_h.as<float>(), B, H, m.stream);
+      m.sb_table.reserve(sizeof(DecStream) * B);
+      launch_gather_streams(d_tp, m.sb_table.as<DecStream>(), B, m.stream);
+      DecParams p{};
+      p.C = C; p.blank = C - 1; p.beam = R[g0]->dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = T;  // stt.cc:539-540
+      launch_ctc_next(p, ds, m.dev_alphabet, m.sb_table.as<DecStream>(), B, m.ws_probs.as<float>(), d_int + 2 * B, d_int + B, m.stream);
+      launch_scatter_streams(d_tp, m.sb_table.as<DecStream>(), B, m.stream);
+      HIP_CHECK(hipStreamSynchronize(m.stream));  // the page-locked table is reused by the next group
+      for (int b = 0; b < B; ++b) { R[g0 + b]->windows_done_ += takes[g0 + b]; R[g0 + b]->state_nonzero = true; }
+    }
+  }
+}
+
+// MFCC of the new windows of every stream in one launch, written straight behind each stream's frame list
+void streams_push_frames(const std::vector<StreamingState*>& ss, const std::vector<std::vector<int16_t>>& spans, const std::vector<int>& n_frames) {
+  ModelState& m = *ss[0]->model_;
+  const Geometry& g = m.g;
+  const int n = (int)ss.size();
+  int max_span = 1, max_w = 0;
+  for (int i = 0; i < n; ++i) { max_span = std::max(max_span, (int)spans[i].size()); max_w = std::max(max_w, n_frames[i]); }
+  if (max_w == 0) return;
+  for (int i = 0; i < n; ++i) {
+    StreamingState* s = ss[i];
+    const int need = s->frames_ + n_frames[i];
+    if (need > s->frames_cap) { s->frames_cap = std::max(need * 2, 256); s->d_frames.reserve((size_t)s->frames_cap * g.n_input * 4, true, m.stream); }
+  }
+  m.sb_haudio.reserve((size_t)n * max_span * 2); m.sb_audio.reserve((size_t)n * max_span * 2);
+  int16_t* ha = m.sb_haudio.as<int16_t>();
+  memset(ha, 0, (size_t)n * max_span * 2);
+  for (int i = 0; i < n; ++i) if (!spans[i].empty()) memcpy(ha + (size_t)i * max_span, spans[i].data(), spans[i].size() * 2);
+  HIP_CHECK(hipMemcpyAsync(m.sb_audio.p, ha, (size_t)n * max_span * 2, hipMemcpyHostToDevice, m.stream));
+  const size_t bytes = (size_t)n * 8 + (size_t)2 * n * 4;
+  m.sb_htab.reserve(bytes); m.sb_tab.reserve(bytes);
+  uint8_t* hb = m.sb_htab.as<uint8_t>();
+  void** hp = reinterpret_cast<void**>(hb);
+  int* hi = reinterpret_cast<int*>(hb + (size_t)n * 8);
+  for (int i = 0; i < n; ++i) {
+    hp[i] = ss[i]->d_frames.as<float>() + (size_t)ss[i]->frames_ * g.n_input;
+    hi[i] = (int)spans[i].size(); hi[n + i] = n_frames[i];
+  }
+  HIP_CHECK(hipMemcpyAsync(m.sb_tab.p, hb, bytes, hipMemcpyHostToDevice, m.stream));
+  MfccArgs a = m.mfcc_args();
+  a.audio = m.sb_audio.as<int16_t>(); a.n_max = max_span; a.t_max = max_w;
+  a.feats = nullptr; a.feats_ptrs = reinterpret_cast<float* const*>(m.sb_tab.p);
+  a.n_samples = reinterpret_cast<const int*>(m.sb_tab.as<uint8_t>() + (size_t)n * 8); a.n_frames = a.n_samples + n;
+  launch_mfcc(a, n * max_w, m.stream);
+  HIP_CHECK(hipStreamSynchronize(m.stream));  // page-locked staging is reused by the next call
+  for (int i = 0; i < n; ++i) ss[i]->frames_ += n_frames[i];
+}
+}  // namespace
+
+void streams_feed_batch(const std::vector<StreamingState*>& ss, const short* const* buffers, const unsigned int* sizes) {
+  const Geometry& g = ss[0]->model_->g;
+  const int n = (int)ss.size();
+  std::vector<std::vector<int16_t>> spans(n);
+  std::vector<int> nf(n, 0);
+  for (int i = 0; i < n; ++i) {  // the window arithmetic of StreamingState::feedAudioContent, per stream
+    StreamingState* s = ss[i];
+    std::vector<int16_t> all(s->audio_buffer_);
+    all.insert(all.end(), buffers[i], buffers[i] + sizes[i]);
+    const int len = (int)all.size();
+    const int W = len >= g.win_len ? (len - g.win_len) / g.win_step + 1 : 0;
+    if (W > 0) {
+      spans[i].assign(all.begin(), all.begin() + (size_t)(W - 1) * g.win_step + g.win_len);
+      s->audio_buffer_.assign(all.begin() + (size_t)W * g.win_step, all.end());
+      nf[i] = W;
+    } else {
+      s->audio_buffer_.swap(all);
+    }
+  }
+  streams_push_frames(ss, spans, nf);
+  streams_process(ss, false);
+}
+
+void streams_flush_batch(const std::vector<StreamingState*>& ss, bool addZeroMfccVectors) {
+  const int n = (int)ss.size();
+  std::vector<std::vector<int16_t>> spans(n);
+  std::vector<int> nf(n, 1);
+  for (int i = 0; i < n; ++i) spans[i] = ss[i]->audio_buffer_;  // stt.cc:236-254: the partial window as is (zero padded)
+  streams_push_frames(ss, spans, nf);
+  if (addZeroMfccVectors) for (StreamingState* s : ss) s->pushZeroFrames(s->model_->g.n_context);
+  streams_process(ss, true);
+}
+
+std::vector<std::vector<Output>> streams_decode_batch(const std::vector<StreamingState*>& ss, unsigned num_results) {
+  ModelState& m = *ss[0]->model_;
+  const int n = (int)ss.size();
+  const size_t bytes = (size_t)n * 8;
+  m.sb_htab.reserve(bytes); m.sb_tab.reserve(bytes);
+  void** hp = m.sb_htab.as<void*>();
+  int max_len = 2;
+  for (int i = 0; i < n; ++i) { hp[i] = ss[i]->dec.table.p; max_len = std::max(max_len, ss[i]->windows_done_ + 1); }
+  HIP_CHECK(hipMemcpyAsync(m.sb_tab.p, hp, bytes, hipMemcpyHostToDevice, m.stream));
+  m.sb_table.reserve(sizeof(DecStream) * n);
+  launch_gather_streams(reinterpret_cast<const DecStream* const*>(m.sb_tab.p), m.sb_table.as<DecStream>(), n, m.stream);
+  return decode_table(m, m.sb_table.as<DecStream>(), n, ss[0]->dec.beam, ss[0]->dec.C, ss[0]->scorer_, ss[0]->hot_words_, num_results, max_len);
 }
 
 std::vector<Output> StreamingState::decode(unsigned num_results) const {

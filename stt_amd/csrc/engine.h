@@ -145,6 +145,9 @@ struct ModelState {
     std::vector<unsigned> idx;  // caller's utterance index of every stream of the group
   };
   GroupSlot slots_[2];
+  // scratch of the batched streaming calls (STTX_FeedAudioContentBatch & co.)
+  DevBuf sb_audio, sb_tab, sb_c, sb_h, sb_table;
+  PinnedBuf sb_haudio, sb_htab;
   hipEvent_t ev_chunk[2] = {};  // chunk hand-over acoustic stream -> decoder stream (alternating)
 
   ~ModelState();
@@ -189,6 +192,7 @@ struct StreamingState {
   DevBuf d_c, d_h;                            // LSTM state [H] f32
   bool state_nonzero = false;
   DecoderBatch dec;                           // one stream
+  uint32_t arena_bound_ = 2;                  // host-side upper bound of the arena fill (each step appends <= beam nodes)
   DevBuf hot_hash, hot_boost;
   std::vector<double> probs_;                 // emissions of the last processed batch (keep_emissions_)
 
@@ -197,11 +201,21 @@ struct StreamingState {
   void pushFrames(const int16_t* d_audio_span_host, int n_samples_span, int n_new_frames);
   void pushZeroFrames(int n);
   void processReady(bool flush_partial, bool final_flush);
+  void reserveArena(int take);
   std::vector<Output> decode(unsigned num_results) const;
 };
 
 std::vector<std::vector<Output>> decode_streams(const ModelState& m, const DecoderBatch& db, std::shared_ptr<ScorerDev> sc,
                                                 const std::map<std::string, float>& hot, unsigned num_results, int max_len);
+std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_table, int n, int beam, int C, std::shared_ptr<ScorerDev> sc,
+                                              const std::map<std::string, float>& hot, unsigned num_results, int max_len);
+// Many streams of one model at once (same beam width, scorer and hot words; otherwise the callers fall back to one by one):
+// what STT_FeedAudioContent / STT_IntermediateDecode / flushBuffers do, with the ready windows of all streams pushed through
+// the acoustic model and the beam search as one batch.
+bool streams_batchable(const std::vector<StreamingState*>& ss);
+void streams_feed_batch(const std::vector<StreamingState*>& ss, const short* const* buffers, const unsigned int* sizes);
+void streams_flush_batch(const std::vector<StreamingState*>& ss, bool addZeroMfccVectors);
+std::vector<std::vector<Output>> streams_decode_batch(const std::vector<StreamingState*>& ss, unsigned num_results);
 int n_frames_for(const Geometry& g, int n_samples);
 void stt_prof_mark(ModelState* m, int i);  // HIP-event marks for STTX_GetStageTimes (api.cpp)
 void pack_lstm_recurrent_host(const float* kernel /*[2H][4H]*/, int H, _Float16* out);

@@ -11,6 +11,7 @@ struct MfccArgs {
   const int* n_samples;    // [B]
   const int* n_frames;     // [B]
   float* feats;            // [B][t_max][n_coef]
+  float* const* feats_ptrs;  // optional: per-utterance output base (frames of utterance b go to feats_ptrs[b] + f*n_coef; frames >= n_frames[b] are not written)
   int n_max, t_max;
   int win_len, win_step, n_coef, n_mel;
   const double* window;    // [win_len]
@@ -67,3 +68,9 @@ void launch_softmax(const SoftmaxArgs& a, hipStream_t st);
 bool launch_logits_softmax(const _Float16* x, const _Float16* wt, const float* bias, float* probs, int M, int K, int C, int batch, int t_max,
                            hipStream_t st);
 void launch_window_rows(const float* frames, _Float16* x1, int rows, int n_input, int kw, int kp, hipStream_t st);
+// batched streaming: window t of stream b = frames_ptrs[b][(win_off[b] + t) * n_input ...], rows t >= take[b] are zero; row = t*B + b
+void launch_window_rows_batch(const float* const* frames_ptrs, const int* win_off, const int* take, _Float16* x1, int B, int T, int n_input, int kw, int kp,
+                              hipStream_t st);
+// LSTM state of stream b <-> row b of a [B][H] matrix (src null or valid[b] == 0: zeros)
+void launch_gather_rows(const float* const* src, const unsigned char* valid, float* dst, int B, int H, hipStream_t st);
+void launch_scatter_rows(float* const* dst, const float* src, int B, int H, hipStream_t st);

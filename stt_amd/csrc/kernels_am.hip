@@ -41,9 +41,9 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccArgs a) {
   const int f = frame - b * a.t_max;
   const int n = a.n_samples[b];
   const int nf = a.n_frames[b];
-  float* out = a.feats + ((size_t)b * a.t_max + f) * a.n_coef;
-  if (f >= nf) {  // beyond the utterance: defined zeros (never consumed)
-    if (threadIdx.x < a.n_coef) out[threadIdx.x] = 0.0f;
+  float* out = a.feats_ptrs ? a.feats_ptrs[b] + (size_t)f * a.n_coef : a.feats + ((size_t)b * a.t_max + f) * a.n_coef;
+  if (f >= nf) {  // beyond the utterance: defined zeros (never consumed); per-stream outputs end at n_frames
+    if (!a.feats_ptrs && threadIdx.x < a.n_coef) out[threadIdx.x] = 0.0f;
     return;
   }
   const int16_t* au = a.audio + (size_t)(a.rows ? a.rows[b] : b) * a.n_max;
@@ -406,6 +406,39 @@ __global__ void window_rows_kernel(const float* frames, _Float16* x1, int rows, 
   if (idx >= rows * kp) return;
   const int t = idx / kp, k = idx - t * kp;
   x1[idx] = (_Float16)(k < kw ? frames[(size_t)t * n_input + k] : 0.0f);
+}
+__global__ void window_rows_batch_kernel(const float* const* frames_ptrs, const int* win_off, const int* take, _Float16* x1, int B, int T, int n_input, int kw, int kp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * B * kp) return;
+  const int row = idx / kp, k = idx - row * kp;
+  const int t = row / B, b = row - t * B;
+  float v = 0.0f;
+  if (k < kw && t < take[b]) v = frames_ptrs[b][(size_t)(win_off[b] + t) * n_input + k];
+  x1[idx] = (_Float16)v;
+}
+void launch_window_rows_batch(const float* const* frames_ptrs, const int* win_off, const int* take, _Float16* x1, int B, int T, int n_input, int kw, int kp,
+                              hipStream_t st) {
+  const int n = T * B * kp;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(window_rows_batch_kernel, dim3((n + 255) / 256), dim3(256), 0, st, frames_ptrs, win_off, take, x1, B, T, n_input, kw, kp);
+}
+__global__ void gather_rows_kernel(const float* const* src, const unsigned char* valid, float* dst, int B, int H) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * H) return;
+  const int b = idx / H, k = idx - b * H;
+  dst[idx] = (valid[b] && src[b]) ? src[b][k] : 0.0f;
+}
+__global__ void scatter_rows_kernel(float* const* dst, const float* src, int B, int H) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * H) return;
+  const int b = idx / H, k = idx - b * H;
+  dst[b][k] = src[idx];
+}
+void launch_gather_rows(const float* const* src, const unsigned char* valid, float* dst, int B, int H, hipStream_t st) {
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, src, valid, dst, B, H);
+}
+void launch_scatter_rows(float* const* dst, const float* src, int B, int H, hipStream_t st) {
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, dst, src, B, H);
 }
 void launch_window_rows(const float* frames, _Float16* x1, int rows, int n_input, int kw, int kp, hipStream_t st) {
   const int n = rows * kp;

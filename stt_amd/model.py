@@ -223,6 +223,43 @@ class Model(object):
         return Decoder(self, n_streams, beam_width or self.beamWidth(), cutoff_prob, cutoff_top_n)
 
 
+def _stream_ptrs(streams):
+    for st in streams:
+        st._check()
+    return (C.c_void_p * len(streams))(*[st._impl for st in streams])
+
+
+def feedAudioContentBatch(streams, audio_buffers):
+    """STTX_FeedAudioContentBatch: stream i receives audio_buffers[i]; the ready windows of all streams run as one batch."""
+    arrs = [np.ascontiguousarray(a, dtype=np.int16) for a in audio_buffers]
+    n = len(streams)
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data if a.size else 0 for a in arrs])
+    sizes = (C.c_uint * n)(*[a.shape[0] for a in arrs])
+    native.lib().STTX_FeedAudioContentBatch(_stream_ptrs(streams), ptrs, sizes, n)
+
+
+def intermediateDecodeBatch(streams):
+    n = len(streams)
+    r = native.lib().STTX_IntermediateDecodeBatch(_stream_ptrs(streams), n)
+    if not r:
+        raise RuntimeError("STTX_IntermediateDecodeBatch failed")
+    out = [C.string_at(r[i]).decode("utf-8", "replace") for i in range(n)]
+    native.lib().STTX_FreeStrings(r, n)
+    return out
+
+
+def finishStreamBatch(streams):
+    n = len(streams)
+    r = native.lib().STTX_FinishStreamBatch(_stream_ptrs(streams), n)
+    for st in streams:
+        st._impl = None   # destroyed by the call, like STT_FinishStream
+    if not r:
+        raise RuntimeError("STTX_FinishStreamBatch failed")
+    out = [C.string_at(r[i]).decode("utf-8", "replace") for i in range(n)]
+    native.lib().STTX_FreeStrings(r, n)
+    return out
+
+
 class Stream(object):
     """native_client/python/__init__.py:223-384"""
 

@@ -95,3 +95,38 @@ def test_config5_bytes_model_beam_1024_with_bytes_scorer(tmp_path, port, fix):
         assert [t[1] for t in md["tokens"]] == [int(x) for x in ts]
         assert md["confidence"] == conf
         assert md["text"].encode("utf-8", "surrogateescape") == b"".join(ulabels[t] for t in tok) or len(md["tokens"]) == len(tok)
+
+
+def test_config3_many_streams_batched_equal_one_by_one(model):
+    """STTX_FeedAudioContentBatch / IntermediateDecodeBatch / FinishStreamBatch: 70 live streams (more than one 64-group) of
+    different lengths, fed in 320 ms hops together == each stream fed alone through coqui-stt.h (every intermediate result
+    and the final one)."""
+    from stt_amd import model as M
+    rng = np.random.RandomState(3)
+    lens = (rng.uniform(0.2, 4.0, size=70) * 16000).astype(int)
+    lens[5] = 100; lens[9] = 5120 * 3                                      # shorter than a window; exact multiple of the hop
+    audio = [synth.synth_audio(int(n), seed=900 + i) for i, n in enumerate(lens)]
+    # one by one (reference API)
+    want_inter, want_final = [], []
+    for a in audio:
+        s = model.createStream()
+        inter = []
+        for k in range(0, len(a), 5120):
+            s.feedAudioContent(a[k:k + 5120]); inter.append(s.intermediateDecode())
+        want_inter.append(inter); want_final.append(s.finishStream())
+    # all together
+    streams = [model.createStream() for _ in audio]
+    got_inter = [[] for _ in audio]
+    k = 0
+    live = list(range(len(audio)))
+    while live:
+        M.feedAudioContentBatch([streams[i] for i in live], [audio[i][k:k + 5120] for i in live])
+        for i, t in zip(live, M.intermediateDecodeBatch([streams[i] for i in live])):
+            got_inter[i].append(t)
+        k += 5120
+        live = [i for i in live if k < len(audio[i])]
+    got_final = M.finishStreamBatch(streams)
+    assert got_final == want_final
+    assert got_inter == want_inter
+    with pytest.raises(RuntimeError):
+        streams[0].intermediateDecode()                                    # destroyed by the batch finish
