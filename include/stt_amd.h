@@ -99,6 +99,24 @@ STTX_EXPORT int STTX_DecoderBeam(const STTX_Decoder* aDec, unsigned int aStream,
 STTX_EXPORT int STTX_DecoderStats(const STTX_Decoder* aDec, unsigned long long* aOut4);
 STTX_EXPORT void STTX_DecoderFree(STTX_Decoder* aDec);
 
+/* ---- model files (host only, no GPU needed) ---------------------------------------------------- */
+/* STT_CreateModel accepts two containers: the reference's `.tflite` export (float or hybrid int8; read without TensorFlow
+ * Lite, replaces TFLiteModelState::init, native_client/tflitemodelstate.cc:161-338) and this engine's raw container
+ * (stt_amd/modelfile.py).  These two calls parse a model image the same way STT_CreateModel does and hand out what was
+ * found; `python -m stt_amd.convert` builds the .tflite -> .sttw converter on them. */
+typedef struct STTX_ModelInfo {
+  int n_input, n_context, n_hidden, n_classes, n_steps, sample_rate, win_len, win_step, beam_width;
+  float relu_clip;
+  unsigned int alphabet_bytes;
+  int is_tflite;
+} STTX_ModelInfo;
+STTX_EXPORT int STTX_InspectModel(const char* aModelBuffer, unsigned int aBufferSize, STTX_ModelInfo* aInfo);
+/* aIndex 0..11: layer_1/weights, layer_1/bias, layer_2/weights, layer_2/bias, layer_3/weights, layer_3/bias, lstm/kernel,
+ * lstm/bias, layer_5/weights, layer_5/bias, layer_6/weights, layer_6/bias as f32 (matrices [inputs][outputs]); 12: the
+ * serialised alphabet.  Writes min(size, aCapBytes) bytes to aOut (may be NULL) and the full size to *aBytes. */
+STTX_EXPORT int STTX_ReadModelTensor(const char* aModelBuffer, unsigned int aBufferSize, int aIndex, void* aOut,
+                                    unsigned long long aCapBytes, unsigned long long* aBytes);
+
 /* ---- kernel-level test hooks ------------------------------------------------------------------ */
 /* y = epi(x[M][K] . w[K][N] + bias): runs the MFMA dense kernel (f16 operands, f32 accumulate).  aEpilogue 0 = clipped
  * ReLU (y rounded to f16, returned as f32), 1 = bias only (f32). */

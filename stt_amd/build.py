@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libstt.so")
-SOURCES = ["kernels_am.hip", "ctc.hip", "hostutil.cpp", "scorer_dev.cpp", "model.cpp", "engine.cpp", "api.cpp"]
+SOURCES = ["kernels_am.hip", "ctc.hip", "hostutil.cpp", "scorer_dev.cpp", "model.cpp", "tflite_reader.cpp", "engine.cpp", "api.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "hip", "-Wno-unused-result"]
 
 

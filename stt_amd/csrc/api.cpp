@@ -798,6 +798,32 @@ int STTX_TestMath(int aOp, const float* aA, const float* aB, float* aOut, unsign
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_RUN_SESS);
 }
+int STTX_InspectModel(const char* aModelBuffer, unsigned int aBufferSize, STTX_ModelInfo* aInfo) {
+  if (!aModelBuffer || !aInfo) return STT_ERR_FAIL_CREATE_MODEL;
+  ModelTensors storage; ModelView v; std::string err;
+  int rc = STT_ERR_FAIL_CREATE_MODEL;
+  try { rc = parse_model_file(aModelBuffer, aBufferSize, storage, v, err); } catch (const std::exception& e) { err = e.what(); }
+  if (rc != STT_ERR_OK) { std::cerr << err << std::endl; return rc; }
+  const Geometry& g = v.g;
+  *aInfo = STTX_ModelInfo{g.n_input, g.n_context, g.n_hidden, g.n_classes, g.n_steps, g.sample_rate, g.win_len, g.win_step, g.beam_width,
+                          g.relu_clip, (unsigned)v.alphabet_bytes, looks_like_tflite(aModelBuffer, aBufferSize) ? 1 : 0};
+  return STT_ERR_OK;
+}
+
+int STTX_ReadModelTensor(const char* aModelBuffer, unsigned int aBufferSize, int aIndex, void* aOut, unsigned long long aCapBytes,
+                         unsigned long long* aBytes) {
+  if (!aModelBuffer || aIndex < 0 || aIndex > 12) return STT_ERR_FAIL_CREATE_MODEL;
+  ModelTensors storage; ModelView v; std::string err;
+  int rc = STT_ERR_FAIL_CREATE_MODEL;
+  try { rc = parse_model_file(aModelBuffer, aBufferSize, storage, v, err); } catch (const std::exception& e) { err = e.what(); }
+  if (rc != STT_ERR_OK) { std::cerr << err << std::endl; return rc; }
+  const void* src = aIndex == 12 ? (const void*)v.alphabet : (const void*)v.t[aIndex];
+  const unsigned long long n = aIndex == 12 ? v.alphabet_bytes : v.count[aIndex] * 4ull;
+  if (aBytes) *aBytes = n;
+  if (aOut && src) memcpy(aOut, src, (size_t)std::min(n, aCapBytes));
+  return STT_ERR_OK;
+}
+
 int STTX_PackLstmRecurrent(const float* aKernel, int aHidden, unsigned short* aOut) {
   if (aHidden % 128) return STT_ERR_INVALID_SHAPE;
   pack_lstm_recurrent_host(aKernel, aHidden, reinterpret_cast<_Float16*>(aOut));

@@ -98,6 +98,25 @@ struct Geometry {
   int c_pad() const { return (n_classes + 127) / 128 * 128; }
 };
 
+// What a model file yields, whichever container it came in (model.cpp: "STTAMDW1"; tflite_reader.cpp: ".tflite"):
+// geometry, the serialised alphabet and the twelve f32 tensors, matrices as [inputs][outputs] (checkpoint orientation).
+struct ModelTensors {
+  Geometry g;
+  std::string alphabet;
+  std::vector<float> l1w, l1b, l2w, l2b, l3w, l3b, lk, lb, l5w, l5b, l6w, l6b;
+};
+bool looks_like_tflite(const char* buf, size_t len);
+int read_tflite_model(const char* buf, size_t len, ModelTensors& out, std::string& err);  // STT_ERR_* code
+// Host-only parse of either container: pointers into `buf` (STTAMDW1) or into `storage` (.tflite).
+struct ModelView {
+  Geometry g;
+  const char* alphabet = nullptr;
+  size_t alphabet_bytes = 0;
+  const float* t[12] = {};  // l1w l1b l2w l2b l3w l3b lk lb l5w l5b l6w l6b
+  size_t count[12] = {};
+};
+int parse_model_file(const char* buf, size_t len, ModelTensors& storage, ModelView& view, std::string& err);
+
 struct StreamingState;
 
 // Decoder states of a batch of streams (device arrays + host mirror of the pointer table).

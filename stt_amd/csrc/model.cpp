@@ -13,9 +13,10 @@
 //     layer_1/weights [n_input*(2*n_context+1)][H], layer_1/bias [H], layer_2/weights [H][H], layer_2/bias,
 //     layer_3/weights [H][H], layer_3/bias, lstm/kernel [2H][4H] (rows x then h; columns i|j|f|o), lstm/bias [4H],
 //     layer_5/weights [H][H], layer_5/bias, layer_6/weights [H][C], layer_6/bias [C]
-// The released .tflite files (hybrid int8) are SURVEY.md 8f rank 1 ("next"); this container carries the
-// same tensors in f32.
+// `.tflite` exports of the reference (float or hybrid int8) are recognised by their file identifier and read by
+// tflite_reader.cpp into the same twelve tensors.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -75,31 +76,62 @@ ModelState::~ModelState() {
   if (slots_[1].stream_dec) (void)hipStreamDestroy(slots_[1].stream_dec);
 }
 
+int parse_model_file(const char* buf, size_t len, ModelTensors& tfl, ModelView& v, std::string& err) {
+  Geometry& g = v.g;
+  if (looks_like_tflite(buf, len)) {
+    const int rc = read_tflite_model(buf, len, tfl, err);
+    if (rc != STT_ERR_OK) return rc;
+    g = tfl.g;
+    v.alphabet = tfl.alphabet.data(); v.alphabet_bytes = tfl.alphabet.size();
+    const std::vector<float>* src[12] = {&tfl.l1w, &tfl.l1b, &tfl.l2w, &tfl.l2b, &tfl.l3w, &tfl.l3b, &tfl.lk, &tfl.lb, &tfl.l5w, &tfl.l5b, &tfl.l6w, &tfl.l6b};
+    for (int i = 0; i < 12; ++i) { v.t[i] = src[i]->data(); v.count[i] = src[i]->size(); }
+  } else {
+    if (len < sizeof(SttwHeader)) { err = "model file too short"; return STT_ERR_FAIL_READ_PROTOBUF; }
+    SttwHeader h;
+    memcpy(&h, buf, sizeof(h));
+    if (memcmp(h.magic, "STTAMDW1", 8) != 0) { err = "unknown model file format (neither STTAMDW1 nor TFL3)"; return STT_ERR_FAIL_READ_PROTOBUF; }
+    if (h.version != 1) { err = "unsupported container version"; return STT_ERR_MODEL_INCOMPATIBLE; }
+    g.n_input = h.n_input; g.n_context = h.n_context; g.n_hidden = h.n_hidden; g.n_classes = h.n_classes; g.n_steps = h.n_steps;
+    g.sample_rate = h.sample_rate; g.win_len = h.win_len; g.win_step = h.win_step; g.beam_width = h.beam_width; g.relu_clip = h.relu_clip;
+    size_t off = sizeof(SttwHeader);
+    if (off + h.alphabet_bytes > len) { err = "alphabet runs past the end of the file"; return STT_ERR_INVALID_ALPHABET; }
+    v.alphabet = buf + off; v.alphabet_bytes = h.alphabet_bytes;
+    off += (h.alphabet_bytes + 7) & ~(size_t)7;
+    const size_t H = g.n_hidden, C = g.n_classes, K1 = g.n_in1();
+    const size_t cnt[12] = {K1 * H, H, H * H, H, H * H, H, 2 * H * 4 * H, 4 * H, H * H, H, H * C, C};
+    size_t n_f32 = 0;
+    for (size_t c : cnt) n_f32 += c;
+    if (H == 0 || H > 65536 || C > 65536 || off + n_f32 * 4 > len) { err = "tensor data runs past the end of the file"; return STT_ERR_INVALID_SHAPE; }
+    const float* f = reinterpret_cast<const float*>(buf + off);
+    for (int i = 0; i < 12; ++i) { v.t[i] = f; v.count[i] = cnt[i]; f += cnt[i]; }
+  }
+  const int H = g.n_hidden, C = g.n_classes;
+  if (H % 128 != 0 || H < 128 || C < 2 || C > 1024 || g.win_len > 512 || g.win_len < 2 || g.win_step < 1 || g.n_input > 64 || g.n_input < 1 ||
+      g.n_steps < 1 || g.n_context < 0 || g.beam_width < 1) {
+    err = "model geometry outside what the engine supports";
+    return STT_ERR_INVALID_SHAPE;
+  }
+  return STT_ERR_OK;
+}
+
 int ModelState::InitFromBuffer(const char* buf, size_t len) {
-  if (len < sizeof(SttwHeader)) return STT_ERR_FAIL_READ_PROTOBUF;
-  SttwHeader h;
-  memcpy(&h, buf, sizeof(h));
-  if (memcmp(h.magic, "STTAMDW1", 8) != 0) return STT_ERR_FAIL_READ_PROTOBUF;
-  if (h.version != 1) return STT_ERR_MODEL_INCOMPATIBLE;
-  g.n_input = h.n_input; g.n_context = h.n_context; g.n_hidden = h.n_hidden; g.n_classes = h.n_classes; g.n_steps = h.n_steps;
-  g.sample_rate = h.sample_rate; g.win_len = h.win_len; g.win_step = h.win_step; g.beam_width = h.beam_width; g.relu_clip = h.relu_clip;
-  beam_width_ = h.beam_width;
+  ModelTensors storage;
+  ModelView v;
+  std::string err;
+  const int rc = parse_model_file(buf, len, storage, v, err);
+  if (rc != STT_ERR_OK) { fprintf(stderr, "%s\n", err.c_str()); return rc; }
+  g = v.g;
+  if (alphabet_.Deserialize(v.alphabet, (int)v.alphabet_bytes) != 0) return STT_ERR_INVALID_ALPHABET;
+  if ((int)alphabet_.GetSize() + 1 != g.n_classes) {  // tflitemodelstate.cc:319-329
+    fprintf(stderr, "Error: Alphabet size does not match loaded model: alphabet has size %d, but model has %d classes in its output. "
+                    "Make sure you're passing an alphabet file with the same size as the one used for training.\n",
+            (int)alphabet_.GetSize(), g.n_classes - 1);
+    return STT_ERR_INVALID_ALPHABET;
+  }
+  const float *l1w = v.t[0], *l1b = v.t[1], *l2w = v.t[2], *l2b = v.t[3], *l3w = v.t[4], *l3b = v.t[5], *lk = v.t[6], *lb = v.t[7],
+              *l5w = v.t[8], *l5b = v.t[9], *l6w = v.t[10], *l6b = v.t[11];
+  beam_width_ = g.beam_width;
   const int H = g.n_hidden, C = g.n_classes, K1 = g.n_in1();
-  if (H % 128 != 0 || H < 128 || C < 2 || C > 1024 || g.win_len > 512 || g.n_input > 64 || g.n_steps < 1) return STT_ERR_INVALID_SHAPE;
-  size_t off = sizeof(SttwHeader);
-  if (off + h.alphabet_bytes > len) return STT_ERR_INVALID_ALPHABET;
-  if (alphabet_.Deserialize(buf + off, (int)h.alphabet_bytes) != 0) return STT_ERR_INVALID_ALPHABET;
-  if ((int)alphabet_.GetSize() + 1 != C) return STT_ERR_INVALID_ALPHABET;  // tflitemodelstate.cc:319-329
-  off += (h.alphabet_bytes + 7) & ~(size_t)7;
-  const size_t n_f32 = (size_t)K1 * H + H + 2 * ((size_t)H * H + H) + (size_t)2 * H * 4 * H + 4 * H + (size_t)H * H + H + (size_t)H * C + C;
-  if (off + n_f32 * 4 > len) return STT_ERR_INVALID_SHAPE;
-  const float* f = reinterpret_cast<const float*>(buf + off);
-  const float* l1w = f; f += (size_t)K1 * H; const float* l1b = f; f += H;
-  const float* l2w = f; f += (size_t)H * H; const float* l2b = f; f += H;
-  const float* l3w = f; f += (size_t)H * H; const float* l3b = f; f += H;
-  const float* lk = f; f += (size_t)2 * H * 4 * H; const float* lb = f; f += 4 * H;
-  const float* l5w = f; f += (size_t)H * H; const float* l5b = f; f += H;
-  const float* l6w = f; f += (size_t)H * C; const float* l6b = f; f += C;
 
   HIP_CHECK(hipSetDevice(device));
   // Optional CU partition (experiment, STT_AMD_CUMASK=<n>): the decoder stream gets the first n mask bits, the acoustic

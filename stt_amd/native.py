@@ -24,6 +24,12 @@ class AcousticModelEmissions(C.Structure):
                 ("emissions", C.POINTER(C.c_double))]
 
 
+class ModelInfo(C.Structure):  # STTX_ModelInfo, include/stt_amd.h
+    _fields_ = [(n, C.c_int) for n in ("n_input", "n_context", "n_hidden", "n_classes", "n_steps", "sample_rate", "win_len",
+                                       "win_step", "beam_width")] + [("relu_clip", C.c_float), ("alphabet_bytes", C.c_uint),
+                                                                      ("is_tflite", C.c_int)]
+
+
 class Metadata(C.Structure):
     _fields_ = [("transcripts", C.POINTER(CandidateTranscript)), ("num_transcripts", C.c_uint),
                 ("emissions", C.POINTER(AcousticModelEmissions))]
@@ -45,6 +51,7 @@ STT_AMD_H = [
     "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
     "STTX_DecoderStats", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
+    "STTX_InspectModel", "STTX_ReadModelTensor",
 ]
 
 _lib = None
@@ -118,6 +125,8 @@ def lib():
         "STTX_TestDense": (ci, [ci, ci, ci, vp, vp, vp, cf, ci, vp]),
         "STTX_TestMath": (ci, [ci, vp, vp, vp, cu]),
         "STTX_PackLstmRecurrent": (ci, [vp, ci, vp]),
+        "STTX_InspectModel": (ci, [vp, cu, pp(ModelInfo)]),
+        "STTX_ReadModelTensor": (ci, [vp, cu, ci, vp, C.c_ulonglong, pp(C.c_ulonglong)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
