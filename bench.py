@@ -145,6 +145,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dstats = model.decoderStats()
+    model.setProfiling(2)            # one extra, untimed step with the search kernel's phase cycle counters on
+    step()
     dphase = model.decoderPhaseCycles()
     model.setProfiling(False)
     if dist is not None:

@@ -61,7 +61,9 @@ STTX_EXPORT char** STTX_FinishStreamBatch(StreamingState* const* aStreams, unsig
 
 /* Per-stage GPU time of the last batch call, measured with HIP events on the engine's own stream.
  * aMs receives up to aCap floats: [0] features, [1] dense layers 1-3 + x-projection, [2] LSTM recurrence,
- * [3] layers 5-6 + softmax, [4] decoder next, [5] decoder decode + D2H, [6] LSTM launches, [7] timesteps. */
+ * [3] layers 5-6 + softmax, [4] decoder next, [5] decoder decode + D2H, [6] LSTM launches, [7] timesteps.
+ * aEnable: 0 = off, 1 = stage events + decoder counters, 2 = also the search kernel's per-phase shader-cycle
+ * counters (STTX_GetDecoderPhaseCycles; they cost a few percent of the search kernel, so not inside timed runs). */
 STTX_EXPORT int STTX_SetProfiling(ModelState* aCtx, int aEnable);
 STTX_EXPORT int STTX_GetStageTimes(ModelState* aCtx, float* aMs, int aCap);
 /* Decoder counters accumulated over the last batch call: steps, candidates, lm queries, lm memory probes. */

@@ -22,6 +22,7 @@ const char* kVersion = "1.4.0";  // training/coqui_stt_training/VERSION of the r
 // 1 dense layers 1-3 + x-projection, 2 LSTM recurrence, 3 layers 5-6 + softmax, 4 decoder next, 5 decoder decode + D2H.
 struct Prof {
   bool on = false;
+  bool phase_cycles = false;  // level 2: also the search kernel's per-phase cycle counters
   std::vector<hipEvent_t> pool;
   size_t used = 0;
   std::vector<std::pair<int, hipEvent_t>> marks[3];  // [0] = acoustic stream, [1], [2] = the two groups' search streams
@@ -183,6 +184,7 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
   sl.probs.reserve((size_t)Bg * t_max * m->g.n_classes * 4);
   DecParams p{};
   p.C = m->g.n_classes; p.blank = p.C - 1; p.beam = sl.dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = t_max;
+  p.phase_cycles = prof_of(m).phase_cycles ? 1 : 0;
   for (int k = 0; k < n_chunks; ++k) {
     m->run_acoustic_chunk(m->ws_feats.as<float>(), d_nf, Bg, t_max, cb[k], cb[k + 1] - cb[k], sl.probs.as<float>());  // marks 1, 2, 3
     mark(m, -1);
@@ -579,7 +581,11 @@ void STTX_FreeMetadataArray(Metadata** aMetadata, unsigned int aCount) {
   for (unsigned i = 0; i < aCount; ++i) STT_FreeMetadata(aMetadata[i]);
   free(aMetadata);
 }
-int STTX_SetProfiling(ModelState* aCtx, int aEnable) { prof_of(aCtx).on = aEnable != 0; return STT_ERR_OK; }
+int STTX_SetProfiling(ModelState* aCtx, int aEnable) {
+  Prof& p = prof_of(aCtx);
+  p.on = aEnable != 0; p.phase_cycles = aEnable >= 2;
+  return STT_ERR_OK;
+}
 int STTX_GetStageTimes(ModelState* aCtx, float* aMs, int aCap) {
   Prof& p = prof_of(aCtx);
   for (int i = 0; i < aCap && i < 8; ++i) aMs[i] = p.ms[i];

@@ -122,6 +122,7 @@ struct DecParams {
   int C, blank, beam, cutoff_top_n;
   double cutoff_prob;
   int t_max;  // row stride of probs in frames
+  int phase_cycles;  // accumulate shader cycles per phase into DecStream::phase (profiling level 2)
 };
 
 struct DecodeOut {

@@ -518,7 +518,8 @@ struct Lds {
   LDS_AS unsigned long long* acc;  // [0..3] stat counters, [4..11] phase cycles (accumulated in LDS, flushed when the launch ends)
   LDS_AS int* sc;  // scalars
 };
-#define TICK(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); L.acc[4 + (k)] += now_ - tick_; tick_ = now_; } } while (0)
+// phase cycle counters (s_memtime is a scalar memory operation with a wait: only on request, DecParams::phase_cycles)
+#define TICK(k) do { if (p.phase_cycles && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); L.acc[4 + (k)] += now_ - tick_; tick_ = now_; } } while (0)
 enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_COUNT = 16 };
 #define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
@@ -690,18 +691,25 @@ __device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, in
 #define LSE(x, y) sttm::stt_log_sum_exp_t((x), (y), L.exp_tab, L.log_tab)
   const float e_self = L.ev_self[j], e_blank = L.ev_blank[j], e_ext = L.ev_ext[j];
   const uint32_t ei = L.ev_exti[j] & 0x7FFFFFFFu;
-  float nb = NEG, bb = NEG;
-  uint32_t pend = 0xFFFFFFFEu;  // "no pending update" (previous_timesteps == nullptr)
+  const uint32_t NOUP = 0xFFFFFFFEu;  // "no pending update" (previous_timesteps == nullptr)
   const uint32_t chj = L.ch[cur][j];
   const int kblank = L.pos[p.blank];
   const int kself = chj == STT_ROOT_CH ? 0xFFFF : L.pos[chj];
   const bool blank_first = kblank < kself;
-  if (blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = LSE(bb, e_blank); }
   const bool ext_first = (int)ei < j;
-  if (ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = LSE(nb, e_ext); }
-  if (!is_absent(e_self)) { if (nb < e_self) pend = 0xFFFFFFFEu; nb = LSE(nb, e_self); }
-  if (!ext_first && !is_absent(e_ext)) { if (nb < e_ext) pend = L.ts[cur][ei]; nb = LSE(nb, e_ext); }
-  if (!blank_first && !is_absent(e_blank)) { if (nb < e_blank) pend = 0xFFFFFFFEu; bb = LSE(bb, e_blank); }
+  const uint32_t ts_ext = L.ts[cur][ei];  // (ei == 0 when there is no extension event: a harmless read)
+  // The visiting order is [blank if blank_first] [ext if ext_first] self [ext if !ext_first] [blank if !blank_first].
+  // log_prob_b collects at most one event and log_prob_nb at most two, and log_sum_exp(-inf, y) returns y itself, so the
+  // whole merge needs two real log_sum_exp evaluations: nb = lse(first, second) and score = lse(b, nb).  (Written with one
+  // call site each: six inlined copies behind divergent branches made every wave walk through most of them.)
+  const float a1 = ext_first ? e_ext : e_self, a2 = ext_first ? e_self : e_ext;
+  const uint32_t p1 = ext_first ? ts_ext : NOUP, p2 = ext_first ? NOUP : ts_ext;
+  float nb = NEG;
+  uint32_t pend = NOUP;  // a blank visited first compares against nb == -inf and leaves pend == NOUP: no effect
+  if (!is_absent(a1)) { if (nb < a1) pend = p1; nb = a1; }
+  if (!is_absent(a2)) { if (nb < a2) pend = p2; nb = LSE(nb, a2); }
+  if (!blank_first && !is_absent(e_blank) && nb < e_blank) pend = NOUP;
+  const float bb = is_absent(e_blank) ? NEG : e_blank;
   const float nscore = LSE(bb, nb);
   L.ev_blank[j] = bb; L.ev_self[j] = nb; L.ev_ext[j] = nscore; L.ev_exti[j] = pend;
 #undef LSE
@@ -723,7 +731,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   const LDS_AS float* pf = L.pf[buf];
   LDS_AS float* lp = L.lp[buf];
 
-  unsigned long long tick_ = __builtin_readcyclecounter();
+  unsigned long long tick_ = p.phase_cycles ? __builtin_readcyclecounter() : 0ull;
   float pre = 0.0f;
   if (next_row && tid < C) pre = next_row[tid];  // consumed in P3
   if ((double)pf[p.blank] < 0.999) start_expanding = 1;  // :125-132 (uniform: every thread reads the same value)

@@ -123,16 +123,28 @@ __global__ __launch_bounds__(256) void context_kernel(ContextArgs a) {
 // The MFMA "A" operand is the weight tile (rows = output features), "B" is the activation tile
 // (columns = rows of X), so every lane ends up with 4 *consecutive output features* of one X row
 // and stores them with one 8-byte (f16) or 16-byte (f32) store.
+//
+// Staging: both operand tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no staging registers,
+// no ds_write pass), double buffered: the DMA of K-tile t+1 is in flight while tile t feeds the
+// MFMAs, one barrier per K-tile.  The LDS image of a tile is [128 rows][8 slots of 16 B]; a DMA
+// instruction writes wave-base + lane*16, i.e. 8 consecutive rows per wave-instruction, so the
+// bank-conflict swizzle sits on the *source* side: slot s of row r holds K-chunk s ^ (r & 7)
+// (still one 128-byte line per row), and a fragment read of chunk c goes to slot c ^ (r & 7).
+// For the 16-lane groups that a ds_read_b128 is serviced in, the rows r..r+15 at one chunk then
+// cover all 64 banks exactly once.
 // =============================================================================================
 #define GT_BM 128
 #define GT_BN 128
 #define GT_BK 64
-#define GT_LDS_STRIDE 72  // halfs per LDS row: 64 + 8 pad => ds_read_b128 of 16 rows is conflict-free
+#define GT_TILE_BYTES (128 * GT_BK * 2)  // one operand tile: 16 KiB
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(1))) const void gvoid_c;
 
 template <int EPI>
 __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
-  __shared__ __attribute__((aligned(16))) _Float16 lw[GT_BN * GT_LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) _Float16 lx[GT_BM * GT_LDS_STRIDE];
+  __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[4 * GT_TILE_BYTES];  // [buffer][W | X]
+  lds_u8* const lds = (lds_u8*)lds_raw;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -159,70 +171,64 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // staging: 1024 16-byte chunks per tile, 4 per thread; chunk q -> row q>>3, 8-half column group q&7
-  uint4 rw0, rw1, rw2, rw3, rx0, rx1, rx2, rx3;
-  const _Float16* WT = a.wt;
-  const _Float16* X = a.x;
-  const int srow = tid >> 3, scg = (tid & 7) * 8;  // this thread's chunk: rows srow + 32*i
-  const _Float16* wsrc = WT + (size_t)(n0 + srow) * K + scg;
-  const size_t wstep = (size_t)32 * K;
-  size_t xoff[4];
+  // DMA sources: chunk q = i*256 + tid of a tile is LDS bytes [16q, 16q+16) = row q>>3, slot q&7 = K-chunk (q&7) ^ (row&7)
+  const int srow = tid >> 3;                       // rows srow + 32*i
+  const int schunk = (tid & 7) ^ (srow & 7);       // (32*i does not change row & 7)
+  const _Float16* wsrc[4];
+  const _Float16* xsrc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    wsrc[i] = a.wt + (size_t)(n0 + srow + 32 * i) * K + schunk * 8;
     int mr = m0 + srow + 32 * i;
     mr = mr < a.M ? mr : a.M - 1;
-    xoff[i] = (size_t)mr * a.ldx + scg;
+    xsrc[i] = a.x + (size_t)mr * a.ldx + schunk * 8;
   }
-#define GLOAD(k0)                                                          \
-  do {                                                                     \
-    rw0 = *reinterpret_cast<const uint4*>(wsrc + (k0));                    \
-    rw1 = *reinterpret_cast<const uint4*>(wsrc + wstep + (k0));            \
-    rw2 = *reinterpret_cast<const uint4*>(wsrc + 2 * wstep + (k0));        \
-    rw3 = *reinterpret_cast<const uint4*>(wsrc + 3 * wstep + (k0));        \
-    rx0 = *reinterpret_cast<const uint4*>(X + xoff[0] + (k0));             \
-    rx1 = *reinterpret_cast<const uint4*>(X + xoff[1] + (k0));             \
-    rx2 = *reinterpret_cast<const uint4*>(X + xoff[2] + (k0));             \
-    rx3 = *reinterpret_cast<const uint4*>(X + xoff[3] + (k0));             \
+  const unsigned wave_off = (unsigned)wave * 64 * 16;  // this wave's 1 KiB piece inside each 4 KiB (256-chunk) group
+#define STAGE(buf, k0)                                                                                                   \
+  do {                                                                                                                   \
+    lds_u8* const bw_ = lds + (buf) * 2 * GT_TILE_BYTES + wave_off;                                                      \
+    lds_u8* const bx_ = bw_ + GT_TILE_BYTES;                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                      \
+      __builtin_amdgcn_global_load_lds((gvoid_c*)(wsrc[i] + (k0)), (__attribute__((address_space(3))) void*)(bw_ + i * 4096), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((gvoid_c*)(xsrc[i] + (k0)), (__attribute__((address_space(3))) void*)(bx_ + i * 4096), 16, 0, 0); \
+    }                                                                                                                    \
   } while (0)
-#define LSTORE()                                                                                  \
-  do {                                                                                            \
-    *reinterpret_cast<uint4*>(lw + (srow + 0) * GT_LDS_STRIDE + scg) = rw0;                        \
-    *reinterpret_cast<uint4*>(lw + (srow + 32) * GT_LDS_STRIDE + scg) = rw1;                       \
-    *reinterpret_cast<uint4*>(lw + (srow + 64) * GT_LDS_STRIDE + scg) = rw2;                       \
-    *reinterpret_cast<uint4*>(lw + (srow + 96) * GT_LDS_STRIDE + scg) = rw3;                       \
-    *reinterpret_cast<uint4*>(lx + (srow + 0) * GT_LDS_STRIDE + scg) = rx0;                        \
-    *reinterpret_cast<uint4*>(lx + (srow + 32) * GT_LDS_STRIDE + scg) = rx1;                       \
-    *reinterpret_cast<uint4*>(lx + (srow + 64) * GT_LDS_STRIDE + scg) = rx2;                       \
-    *reinterpret_cast<uint4*>(lx + (srow + 96) * GT_LDS_STRIDE + scg) = rx3;                       \
-  } while (0)
+
+  // fragment read offsets (bytes inside an operand tile): row * 128 + ((chunk ^ (row & 7)) << 4), chunk = ks*4 + (lane>>4)
+  const int frow = lane & 15, fq = lane >> 4;
+  unsigned offw[4], offx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rw = wn * 64 + i * 16 + frow, rx = wm * 64 + i * 16 + frow;
+    offw[i] = (unsigned)rw * 128u + (unsigned)((fq ^ (rw & 7)) << 4);
+    offx[i] = (unsigned)rx * 128u + (unsigned)((fq ^ (rx & 7)) << 4);
+  }
   const int nk = K / GT_BK;
-  GLOAD(0);
-  LSTORE();
-  __syncthreads();
+  STAGE(0, 0);
+  __syncthreads();  // (waits for the DMA: vmcnt(0) + barrier)
+  int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) GLOAD((kt + 1) * GT_BK);
+    if (kt + 1 < nk) STAGE(cur ^ 1, (kt + 1) * GT_BK);
+    const lds_u8* const bw = lds + cur * 2 * GT_TILE_BYTES;
+    const lds_u8* const bx = bw + GT_TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       f16x8 fa[4], fb[4];
-      const int kof = ks * 32 + (lane >> 4) * 8;
+      // chunk ks*4 + fq: the slot index flips bit 2 for ks = 1 -> byte offset ^ 64
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const f16x8*>(lw + (wn * 64 + i * 16 + (lane & 15)) * GT_LDS_STRIDE + kof);
-        fb[i] = *reinterpret_cast<const f16x8*>(lx + (wm * 64 + i * 16 + (lane & 15)) * GT_LDS_STRIDE + kof);
+        fa[i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(bw + (offw[i] ^ (unsigned)(ks << 6)));
+        fb[i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(bx + (offx[i] ^ (unsigned)(ks << 6)));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      LSTORE();
-      __syncthreads();
-    }
+    __syncthreads();  // tile kt+1 has landed; every wave is done reading tile kt (its buffer is restaged next iteration)
+    cur ^= 1;
   }
-#undef GLOAD
-#undef LSTORE
+#undef STAGE
   // epilogue: lane holds features n = nb + (lane>>4)*4 + 0..3 of X row m = mb + (lane&15)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

@@ -162,8 +162,9 @@ class Model(object):
         native.lib().STTX_FreeStrings(r, B)
         return out
 
-    def setProfiling(self, on):
-        native.lib().STTX_SetProfiling(self._impl, int(on))
+    def setProfiling(self, level):
+        """0/False = off, 1/True = stage events + decoder counters, 2 = also the search kernel's phase cycle counters."""
+        native.lib().STTX_SetProfiling(self._impl, int(level))
 
     def stageTimes(self):
         ms = (C.c_float * 8)()
