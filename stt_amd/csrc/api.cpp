@@ -185,6 +185,9 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
   DecParams p{};
   p.C = m->g.n_classes; p.blank = p.C - 1; p.beam = sl.dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = t_max;
   p.phase_cycles = prof_of(m).phase_cycles ? 1 : 0;
+  int max_chunk = 1;
+  for (int k = 0; k < n_chunks; ++k) max_chunk = std::max(max_chunk, cb[k + 1] - cb[k]);
+  sl.wide.reserve(ctc_wide_ws_bytes(p.beam, p.C, Bg, max_chunk));
   for (int k = 0; k < n_chunks; ++k) {
     m->run_acoustic_chunk(m->ws_feats.as<float>(), d_nf, Bg, t_max, cb[k], cb[k + 1] - cb[k], sl.probs.as<float>());  // marks 1, 2, 3
     mark(m, -1);
@@ -193,7 +196,7 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
     HIP_CHECK(hipStreamWaitEvent(sl.stream_dec, ev, 0));
     mark_on(m, 4, which, sl.stream_dec);
     const int* fb = d_tab + (size_t)(2 * k) * Bg;
-    launch_ctc_next(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, sl.probs.as<float>(), fb, fb + Bg, sl.stream_dec);
+    launch_ctc_next(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, sl.probs.as<float>(), fb, fb + Bg, sl.stream_dec, max_chunk, sl.wide.p);
     mark_on(m, -1, which, sl.stream_dec);
   }
   // ranking + back-tracking, results to page-locked memory (a token needs its own timestep: <= t_max tokens)
@@ -680,7 +683,7 @@ struct STTX_Decoder {
   std::map<std::string, float> hot;
   DecoderBatch db;
   DecParams p;
-  DevBuf probs, fbegin, fcount, hh, hb;
+  DevBuf probs, fbegin, fcount, hh, hb, wide;
 };
 int STTX_DecoderCreate(ModelState* m, unsigned int aNumStreams, unsigned int aBeamWidth, double aCutoffProb, unsigned int aCutoffTopN, STTX_Decoder** retval) {
   *retval = nullptr;
@@ -708,7 +711,11 @@ int STTX_DecoderNext(STTX_Decoder* d, const float* aProbs, unsigned int aStride,
     d->fcount.upload(more.data(), n * 4, m->stream);
     d->p.t_max = (int)aStride;
     DevScorer ds = m->current_scorer(d->scorer, d->hot, d->hh, d->hb);
-    launch_ctc_next(d->p, ds, m->dev_alphabet, d->db.table.as<DecStream>(), n, d->probs.as<float>(), d->fbegin.as<int>(), d->fcount.as<int>(), m->stream);
+    int max_frames = 1;
+    for (int i = 0; i < n; ++i) max_frames = std::max(max_frames, more[i]);
+    d->wide.reserve(ctc_wide_ws_bytes(d->p.beam, d->p.C, n, max_frames));
+    launch_ctc_next(d->p, ds, m->dev_alphabet, d->db.table.as<DecStream>(), n, d->probs.as<float>(), d->fbegin.as<int>(), d->fcount.as<int>(), m->stream,
+                    max_frames, d->wide.p);
     HIP_CHECK(hipStreamSynchronize(m->stream));
     HIP_CHECK(hipGetLastError());
     return (int)STT_ERR_OK;

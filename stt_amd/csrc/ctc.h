@@ -123,6 +123,10 @@ struct DecParams {
   double cutoff_prob;
   int t_max;  // row stride of probs in frames
   int phase_cycles;  // accumulate shader cycles per phase into DecStream::phase (profiling level 2)
+  // wide alphabets (ctc_is_wide): per-row records prepared by ctc_wide_rows_kernel; filled in by launch_ctc_next
+  const unsigned char* wide_rows;
+  unsigned long long wide_stride;
+  int wide_max_frames;
 };
 
 struct DecodeOut {
@@ -134,8 +138,16 @@ struct DecodeOut {
   int num_results, max_len;
 };
 
+// `max_frames` = upper bound of frame_count[]; `wide_ws` = ctc_wide_ws_bytes(...) bytes of device memory when
+// ctc_is_wide(p.beam, p.C) (may be null otherwise).
 void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
-                     const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st);
+                     const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st,
+                     int max_frames = 0, void* wide_ws = nullptr);
+bool ctc_is_wide(int beam, int C);
+size_t ctc_wide_row_bytes(int C);
+inline size_t ctc_wide_ws_bytes(int beam, int C, int n_streams, int max_frames) {
+  return ctc_is_wide(beam, C) ? (size_t)n_streams * (size_t)max_frames * ctc_wide_row_bytes(C) : 0;
+}
 void launch_ctc_decode(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const DecStream* streams, int n_streams,
                        const DecodeOut& out, hipStream_t st);
 size_t ctc_next_lds_bytes(int beam, int C);

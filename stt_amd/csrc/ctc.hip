@@ -20,6 +20,8 @@
 // reference; ties the reference leaves to libstdc++ are broken by (live-before-new, beam index).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "ctc.h"
 #include "sttmath.h"
@@ -401,7 +403,7 @@ __device__ __forceinline__ void word_walk(const DevAlphabet& al, const GStream& 
     const uint2 pn = load_node(S.pa, cur);
     ++probes;
     if (pn.y == (uint32_t)al.space_id || pn.y == STT_ROOT_CH) break;
-    const uint8_t one = lab1[pn.y];  // LDS copy of single-byte labels (0 = multi-byte label: read it from HBM)
+    const uint8_t one = lab1 ? lab1[pn.y] : (uint8_t)0;  // LDS copy of single-byte labels (0 / no table = read the label from HBM)
     if (one) {
       hi = (hi << 8) | (lo >> 56);
       lo = (lo << 8) | (uint64_t)one;
@@ -479,6 +481,97 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
   return en.raw;
 }
 
+__host__ __device__ inline uint32_t pow2_ge(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+// ------------------------------------------------------------------------------------ wide alphabets
+// The per-class arrays of a timestep (log-probs, class order, class -> position) live in LDS for ordinary alphabets.  A
+// 6000-label alphabet at beam 1024 does not fit (the beam state alone takes ~148 KiB), so for wide alphabets
+// a separate, row-parallel kernel prepares one record per emission row in HBM -- get_pruned_emissions
+// (ctc_beam_search_decoder.cpp:328-358) for all rows of the chunk at once -- and the search kernel reads the few entries it
+// needs (blank, repeated label, the labels on the dictionary arcs) through L2.
+//   record = { WideRowHdr | float lpc[C] : log(p + FLT_MIN) by class | u16 pos[C2] : class -> position (0xFFFF = cut off)
+//              | u16 cls[C2] : position -> class },  C2 = C rounded up to even
+struct WideRowHdr { int cutoff_len; float pblank; double lbl; };
+__host__ __device__ inline size_t wide_off_pos(int C) { return sizeof(WideRowHdr) + (size_t)C * 4; }
+__host__ __device__ inline size_t wide_off_cls(int C) { return wide_off_pos(C) + (size_t)((C + 1) & ~1) * 2; }
+size_t ctc_wide_row_bytes(int C) { return (wide_off_cls(C) + (size_t)((C + 1) & ~1) * 2 + 15) & ~(size_t)15; }
+struct WRow { const GLB_AS float* lpc; const GLB_AS uint16_t* pos; const GLB_AS uint16_t* cls; };
+__device__ __forceinline__ const WideRowHdr* wide_hdr(const DecParams& p, int stream, int t) {
+  return reinterpret_cast<const WideRowHdr*>(p.wide_rows + ((size_t)stream * p.wide_max_frames + t) * p.wide_stride);
+}
+__device__ __forceinline__ WRow wide_row(const DecParams& p, int stream, int t) {
+  const unsigned char* r = p.wide_rows + ((size_t)stream * p.wide_max_frames + t) * p.wide_stride;
+  WRow w;
+  w.lpc = (const GLB_AS float*)(r + sizeof(WideRowHdr));
+  w.pos = (const GLB_AS uint16_t*)(r + wide_off_pos(p.C));
+  w.cls = (const GLB_AS uint16_t*)(r + wide_off_cls(p.C));
+  return w;
+}
+
+#define WIDE_SORT_N 8192  // = STT_MAX_CLASSES: keys of one row in LDS
+// One 1024-thread workgroup per (stream, frame of the chunk).
+__global__ __launch_bounds__(1024) void ctc_wide_rows_kernel(DecParams p, const float* probs, const int* frame_begin, const int* frame_count) {
+  __shared__ uint64_t keys[WIDE_SORT_N];
+  __shared__ double log_tab[32];
+  __shared__ int s_cut;
+  const int s = blockIdx.x / p.wide_max_frames, tt = blockIdx.x - s * p.wide_max_frames;
+  if (tt >= frame_count[s]) return;
+  const int tid = threadIdx.x, C = p.C;
+  const float* row = probs + ((size_t)s * p.t_max + frame_begin[s] + tt) * C;
+  unsigned char* rec = const_cast<unsigned char*>(p.wide_rows) + ((size_t)s * p.wide_max_frames + tt) * p.wide_stride;
+  float* lpc = reinterpret_cast<float*>(rec + sizeof(WideRowHdr));
+  uint16_t* pos = reinterpret_cast<uint16_t*>(rec + wide_off_pos(C));
+  uint16_t* cls = reinterpret_cast<uint16_t*>(rec + wide_off_cls(C));
+  if (tid < 32) log_tab[tid] = sttm::kLogfTab[tid >> 1][tid & 1];
+  __syncthreads();
+  const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
+  const uint32_t n2 = pow2_ge((uint32_t)C);
+  for (uint32_t i = tid; i < n2; i += 1024) {
+    uint64_t k = ~0ULL;
+    if ((int)i < C) {
+      const float v = row[i];
+      lpc[i] = sttm::stt_logf_t(__fadd_rn(v, STT_FLT_MIN), log_tab);
+      // ascending key == (probability descending, class index ascending): std::sort by pair_comp_second_rev, ties by index
+      uint32_t u = (v == 0.0f) ? 0u : __float_as_uint(v);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      k = ((uint64_t)(~u) << 32) | (uint64_t)i;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  if (sort_classes) {
+    for (uint32_t k = 2; k <= n2; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = tid; i < n2; i += 1024) {
+          const uint32_t ixj = i ^ j;
+          if (ixj > i) {
+            const uint64_t a = keys[i], b = keys[ixj];
+            if ((a > b) == ((i & k) == 0)) { keys[i] = b; keys[ixj] = a; }
+          }
+        }
+        __syncthreads();
+      }
+  }
+  if (tid == 0) {
+    int cl = C;
+    if (sort_classes && p.cutoff_prob < 1.0) {  // :342-350
+      double cum = 0.0; cl = 0;
+      for (int i = 0; i < C; ++i) { cum = __dadd_rn(cum, (double)row[(uint32_t)keys[i]]); cl += 1; if (cum >= p.cutoff_prob || cl >= p.cutoff_top_n) break; }
+    }
+    s_cut = cl;
+    WideRowHdr h;
+    h.cutoff_len = cl; h.pblank = row[p.blank]; h.lbl = log((double)row[p.blank]);
+    *reinterpret_cast<WideRowHdr*>(rec) = h;
+  }
+  __syncthreads();
+  const int cl = s_cut;
+  for (int k = tid; k < C; k += 1024) {
+    const uint32_t c = (uint32_t)keys[k];
+    cls[k] = (uint16_t)c;
+    pos[c] = k < cl ? (uint16_t)k : (uint16_t)0xFFFF;
+  }
+}
+
 // ------------------------------------------------------------------------------------ LDS layout
 #define NWAVES (NTHREADS / 64)
 #define NBUCKET 1024   // selection histogram bins (one per thread)
@@ -523,7 +616,6 @@ struct Lds {
 enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_COUNT = 16 };
 #define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
-__host__ __device__ inline uint32_t pow2_ge(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
 // Layout for a beam capacity CAP (a compile-time constant: every array that only depends on CAP sits at a constant LDS
 // address, which the compiler folds into the ds_* instructions instead of keeping ~50 pointers alive in registers).
@@ -606,6 +698,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   return L;
 }
 inline int cap_bucket(int beam) { return beam <= 64 ? 64 : beam <= 128 ? 128 : beam <= 256 ? 256 : beam <= 512 ? 512 : 1024; }
+// LDS bytes of the search kernel with the class arrays of a C-class alphabet in LDS (C = 0: wide mode, none)
 size_t ctc_next_lds_bytes(int beam, int C) {
   size_t t = 0;
   switch (cap_bucket(beam)) {
@@ -617,6 +710,10 @@ size_t ctc_next_lds_bytes(int beam, int C) {
   }
   return t;
 }
+
+#define STT_LDS_MAX (160 * 1024)
+// Wide mode when the class arrays do not fit next to the beam state (or the in-kernel class sort would dominate a step).
+bool ctc_is_wide(int beam, int C) { return C > 1024 || ctc_next_lds_bytes(beam, C) > (size_t)STT_LDS_MAX; }
 
 __device__ __forceinline__ int ht_find(const Lds& L, uint64_t k) {
   uint32_t h = (uint32_t)(k >> 17) & (HTN - 1);
@@ -686,15 +783,16 @@ __device__ __forceinline__ void prep_row(const DecParams& p, const Lds& L, int b
 // Merge the <= 3 events of live prefix j in the reference's visiting order (class position, then beam index; :166-193,
 // :245-253) and leave the results in the event arrays: ev_blank = new log_prob_b, ev_self = new log_prob_nb,
 // ev_ext = new score (iterate_to_vec, path_trie.cpp:170), ev_exti = pending timestep parent.  Returns the new score.
-__device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, int cur, int j) {
+template <bool WIDE>
+__device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, const WRow& W, int cur, int j) {
   const float NEG = STT_NEG_INF;
 #define LSE(x, y) sttm::stt_log_sum_exp_t((x), (y), L.exp_tab, L.log_tab)
   const float e_self = L.ev_self[j], e_blank = L.ev_blank[j], e_ext = L.ev_ext[j];
   const uint32_t ei = L.ev_exti[j] & 0x7FFFFFFFu;
   const uint32_t NOUP = 0xFFFFFFFEu;  // "no pending update" (previous_timesteps == nullptr)
   const uint32_t chj = L.ch[cur][j];
-  const int kblank = L.pos[p.blank];
-  const int kself = chj == STT_ROOT_CH ? 0xFFFF : L.pos[chj];
+  const int kblank = WIDE ? (int)W.pos[p.blank] : (int)L.pos[p.blank];
+  const int kself = chj == STT_ROOT_CH ? 0xFFFF : (WIDE ? (int)W.pos[chj] : (int)L.pos[chj]);
   const bool blank_first = kblank < kself;
   const bool ext_first = (int)ei < j;
   const uint32_t ts_ext = L.ts[cur][ei];  // (ei == 0 when there is no extension event: a harmless read)
@@ -719,10 +817,18 @@ __device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, in
 // `buf` holds this step's prepared emissions; `next_row` (or null) is prepared into buf^1 while the LM phase runs.
 // MODE: 0 = no scorer, 1 = word-level scorer, 2 = utf8 (codepoint-level) scorer -- separate instantiations, so the
 // hot word-mode kernel does not carry the registers and code of the uncached codepoint paths.
-template <int MODE>
+// WIDE: the class arrays of the row come from the HBM record `t_local` of this stream (see "wide alphabets" above).
+template <int MODE, bool WIDE>
 __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const GStream& S, const Lds& L, int& cur, int& n,
-                         int& start_expanding, int& abs_t, int buf, const float* next_row) {
+                         int& start_expanding, int& abs_t, int buf, const float* next_row, int t_local) {
   constexpr bool SC_ON = MODE != 0, SC_UTF8 = MODE == 2;
+  WRow W{};
+  WideRowHdr wh{};
+  if (WIDE) { W = wide_row(p, (int)blockIdx.x, t_local); wh = *wide_hdr(p, (int)blockIdx.x, t_local); }
+#define POS_OF(c) (WIDE ? (int)W.pos[c] : (int)L.pos[c])
+#define CLS_AT(k) (WIDE ? (uint32_t)W.cls[k] : (uint32_t)L.cls[k])
+#define LP_AT(k, c) (WIDE ? W.lpc[c] : lp[k])
+  const LDS_AS uint8_t* const lab1 = WIDE ? (const LDS_AS uint8_t*)nullptr : (const LDS_AS uint8_t*)L.lab1;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int C = p.C, beam = p.beam;
@@ -733,10 +839,10 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
 
   unsigned long long tick_ = p.phase_cycles ? __builtin_readcyclecounter() : 0ull;
   float pre = 0.0f;
-  if (next_row && tid < C) pre = next_row[tid];  // consumed in P3
-  if ((double)pf[p.blank] < 0.999) start_expanding = 1;  // :125-132 (uniform: every thread reads the same value)
+  if (!WIDE && next_row && tid < C) pre = next_row[tid];  // consumed in P3
+  if ((double)(WIDE ? wh.pblank : pf[p.blank]) < 0.999) start_expanding = 1;  // :125-132 (uniform: every thread reads the same value)
   if (!start_expanding) {
-    if (next_row) prep_row(p, L, buf ^ 1, next_row, pre);
+    if (!WIDE && next_row) prep_row(p, L, buf ^ 1, next_row, pre);
     abs_t++;
     __syncthreads();
     return;
@@ -747,8 +853,8 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   L.hist[tid] = 0;
   if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; sc[SC_NQ] = 0; }
   const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
-  int cutoff_len = C;
-  if (sort_classes) {  // std::sort by probability, descending (ties: class index)
+  int cutoff_len = WIDE ? wh.cutoff_len : C;
+  if (!WIDE && sort_classes) {  // std::sort by probability, descending (ties: class index)
     for (int c = tid; c < C; c += NTHREADS) {
       const float v = pf[c];
       int rank = 0;
@@ -777,7 +883,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   float min_cutoff = NEG;
   bool full_beam = false;
   if (SC_ON) {  // :136-146 (the beam is kept in prefix_compare order, so no partial_sort is needed)
-    const double mc = __dadd_rn(__dadd_rn((double)L.score[cur][n - 1], L.lbl[buf]), -fmax(0.0, s.beta));
+    const double mc = __dadd_rn(__dadd_rn((double)L.score[cur][n - 1], WIDE ? wh.lbl : L.lbl[buf]), -fmax(0.0, s.beta));
     min_cutoff = (float)mc;
     full_beam = (n == beam);
   }
@@ -797,10 +903,10 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   const int nw_exp = lm_wave ? NWAVES - 1 : NWAVES;
   if (lm_wave && wave == NWAVES - 1) {
     __builtin_amdgcn_s_setprio(3);  // the chain of dependent reads is the critical path of the phase: issue it first
-    const int ksp = L.pos[al.space_id];
+    const int ksp = POS_OF(al.space_id);
     unsigned lmq = 0;
     if (ksp != 0xFFFF) {
-      const float lpsp = lp[ksp];
+      const float lpsp = LP_AT(ksp, al.space_id);
       uint32_t n_need = 0;
       for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
@@ -819,7 +925,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       for (uint32_t q = lane; q < n_need; q += 64) {
         const int i = (int)L.lmw[q];
         uint32_t ne;
-        const double raw = lm_word_query_cached(s, al, S, L.lab1, (LDS_AS uint32_t*)&sc[SC_BEN], L.node[cur][i], L.bnd[cur][i], true, L.wlo[cur][i], L.whi[cur][i], ne, probes);
+        const double raw = lm_word_query_cached(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], L.node[cur][i], L.bnd[cur][i], true, L.wlo[cur][i], L.whi[cur][i], ne, probes);
         L.pqe[cur][i] = ne; L.pqs[cur][i] = (float)__dmul_rn(raw, s.alpha);
         ++lmq;
       }
@@ -836,12 +942,12 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       if (sci != NEG) {  // :160-162
         const uint32_t chi = L.ch[cur][i];
         {  // blank, :166-179
-          const int kb = L.pos[p.blank];
-          if (kb != 0xFFFF) { const float lpc = lp[kb]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_blank[i] = __fadd_rn(lpc, sci); }
+          const int kb = POS_OF(p.blank);
+          if (kb != 0xFFFF) { const float lpc = LP_AT(kb, p.blank); if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_blank[i] = __fadd_rn(lpc, sci); }
         }
         if (chi != STT_ROOT_CH) {  // repeated character, :182-193
-          const int ks = L.pos[chi];
-          if (ks != 0xFFFF) { const float lpc = lp[ks]; if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_self[i] = __fadd_rn(lpc, L.pnb[cur][i]); }
+          const int ks = POS_OF(chi);
+          if (ks != 0xFFFF) { const float lpc = LP_AT(ks, chi); if (!(full_beam && __fadd_rn(lpc, sci) < min_cutoff)) L.ev_self[i] = __fadd_rn(lpc, L.pnb[cur][i]); }
         }
         if (SC_ON) {
           if (L.a0.p0) { a0 = L.a0[cur][i]; cnt = L.an[cur][i] & 0x7FFFu; }
@@ -896,16 +1002,16 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
           if (arc.x == 0 || arc.x > (uint32_t)(C - 1)) continue;  // epsilon / label outside the alphabet: never matched
           c = arc.x - 1;
           child_fst = (int)arc.y;
-          k = L.pos[c];
+          k = POS_OF(c);
           if (k == 0xFFFF) continue;
         } else {
           k = (int)kku;
-          c = L.cls[k];
+          c = CLS_AT(k);
         }
         if ((int)c == p.blank) continue;
         const float sci = L.score[cur][i];
         const uint32_t chi = L.ch[cur][i];
-        const float lpc = lp[k];
+        const float lpc = LP_AT(k, c);
         if (full_beam && __fadd_rn(lpc, sci) < min_cutoff) continue;  // the `break` of :157-159 (beam is sorted by score)
         float log_p = NEG;  // :199-207
         if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
@@ -941,7 +1047,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   // merge every live prefix that does not wait for a score.  Meanwhile the next row's class log-probs are prepared and
   // the (now dead) hash is cleared for the next beam.
   for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
-  if (next_row) prep_row(p, L, buf ^ 1, next_row, pre);
+  if (!WIDE && next_row) prep_row(p, L, buf ^ 1, next_row, pre);
   bool merged = false;
   float my_score = NEG;
   if (SC_ON) {
@@ -973,7 +1079,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
           if (bndi == STT_NONE) { raw = 0.0; lds_or(&sc[SC_ERR], 8); }
           else {
             uint32_t ne;
-            raw = lm_word_query_cached(s, al, S, L.lab1, (LDS_AS uint32_t*)&sc[SC_BEN], nodei, bndi, in_lds, in_lds ? L.wlo[cur][i] : 0ULL,
+            raw = lm_word_query_cached(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], nodei, bndi, in_lds, in_lds ? L.wlo[cur][i] : 0ULL,
                                        in_lds ? L.whi[cur][i] : 0ULL, ne, probes);
             if (in_lds) { L.pqe[cur][i] = ne; L.pqs[cur][i] = (float)__dmul_rn(raw, s.alpha); }
             ++lmq;
@@ -984,14 +1090,14 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         lpv = (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
         if (!live) { if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpv; else S.c_logp[x] = lpv; } else L.ev_ext[x] = lpv;
       }
-      if (tid < n && !((L.ev_exti[tid] >> 31) && !is_absent(L.ev_ext[tid]))) { my_score = merge_live(p, L, cur, tid); merged = true; }
+      if (tid < n && !((L.ev_exti[tid] >> 31) && !is_absent(L.ev_ext[tid]))) { my_score = merge_live<WIDE>(p, L, W, cur, tid); merged = true; }
     } else {
       for (int x = tid; x < m + n; x += NTHREADS) {
         uint32_t pi; float lp0;
         if (x < m) { pi = CAND_PI(x); if (!(pi >> 31)) continue; lp0 = CAND_LOGP(x); }
         else { const int j = x - m; pi = L.ev_exti[j]; if (!(pi >> 31) || is_absent(L.ev_ext[j])) continue; lp0 = L.ev_ext[j]; }
         const int i = (int)(pi & 0xFFFFu);
-        const uint32_t first = (x < m) ? (uint32_t)L.cls[(pi >> 16) & 0x7FFFu] : L.ch[cur][x - m];  // utf8 mode scores the *new* prefix
+        const uint32_t first = (x < m) ? CLS_AT((pi >> 16) & 0x7FFFu) : L.ch[cur][x - m];  // utf8 mode scores the *new* prefix
         const double raw = lm_score(s, al, S.pa_generic, L.node[cur][i], first, true, probes); ++lmq;
         const float lms = (float)__dmul_rn(raw, s.alpha);
         float lpv = __fadd_rn(lp0, lms);
@@ -1014,12 +1120,12 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   for (int e = tid, r = 0; e < total; e += NTHREADS, ++r) {
     uint64_t k;
     if (e < n) {  // e == tid: either merged during the LM phase, or it waited for a score
-      const float nscore = merged ? my_score : merge_live(p, L, cur, e);
+      const float nscore = merged ? my_score : merge_live<WIDE>(p, L, W, cur, e);
       k = sel_key(nscore, L.ch[cur][e], 0, (uint32_t)e);
     } else {
       const int x = e - n;
       const uint32_t pi = CAND_PI(x);
-      k = sel_key(CAND_LOGP(x), (uint32_t)L.cls[(pi >> 16) & 0x7FFFu], 1, pi & 0xFFFFu);
+      k = sel_key(CAND_LOGP(x), CLS_AT((pi >> 16) & 0x7FFFu), 1, pi & 0xFFFFu);
     }
     if (r == 0) kreg0 = k; else if (r == 1) kreg1 = k; else S.sel_keys[e] = k;
     const uint32_t kh = (uint32_t)(k >> 32);
@@ -1119,7 +1225,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         const int cx = (int)x - n;
         const uint32_t pi = CAND_PI(cx);
         const int i = (int)(pi & 0xFFFFu);
-        const uint32_t c = (uint32_t)L.cls[(pi >> 16) & 0x7FFFu];
+        const uint32_t c = CLS_AT((pi >> 16) & 0x7FFFu);
         const float lpv = CAND_LOGP(cx);
         const uint32_t pnode = L.node[cur][i];
         L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
@@ -1138,7 +1244,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
           uint64_t lo = 0, hi = 0;
           if ((int)c != al.space_id) {
             lo = L.wlo[cur][i]; hi = L.whi[cur][i];
-            const uint8_t one = L.lab1[c];
+            const uint8_t one = lab1 ? lab1[c] : (uint8_t)0;
             if (one) word_push(lo, hi, one);
             else { const int b0 = c ? al.label_off[c - 1] : 0, b1 = al.label_off[c]; for (int bb = b0; bb < b1; ++bb) word_push(lo, hi, al.label_bytes[bb]); }
           }
@@ -1162,6 +1268,9 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   }
 #undef REKEY
 #undef KEY_OF
+#undef POS_OF
+#undef CLS_AT
+#undef LP_AT
   if (tid == 0) {
     L.acc[0] += 1; L.acc[1] += (unsigned long long)m; L.acc[2] += (unsigned long long)sc[SC_LMQ]; L.acc[3] += (unsigned long long)(unsigned)sc[SC_PROBES];
   }
@@ -1172,12 +1281,12 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   TICK(6);
 }
 
-template <int MODE, int CAP>
+template <int MODE, int CAP, bool WIDE>
 __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScorer s, DevAlphabet al, DecStream* streams,
                                                             const float* probs, const int* frame_begin, const int* frame_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   size_t lds_total;
-  const Lds L = lds_carve<CAP>(p.C, (LDS_AS unsigned char*)smem, lds_total);
+  const Lds L = lds_carve<CAP>(WIDE ? 0 : p.C, (LDS_AS unsigned char*)smem, lds_total);
   DecStream& G = streams[blockIdx.x];
   const int nfr = frame_count[blockIdx.x];
   if (nfr <= 0) return;
@@ -1197,7 +1306,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   int start_expanding = G.start_expanding;
   int abs_t = G.abs_t;
   const float* row = probs + ((size_t)blockIdx.x * p.t_max + frame_begin[blockIdx.x]) * p.C;
-  const float v0 = tid < p.C ? row[tid] : 0.0f;
+  const float v0 = (!WIDE && tid < p.C) ? row[tid] : 0.0f;
   for (int i = tid; i < n; i += NTHREADS) {
     L.score[0][i] = g_score[i]; L.pb[0][i] = g_pb[i]; L.pnb[0][i] = g_pnb[i];
     L.ch[0][i] = g_ch[i]; L.node[0][i] = g_node[i]; L.ts[0][i] = g_ts[i]; const int st = g_fst[i]; L.fst[0][i] = st; L.key[0][i] = g_key[i];
@@ -1208,7 +1317,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
       L.a0[0][i] = f0; L.an[0][i] = (uint16_t)((f1 - f0) | (sp << 15));
     }
   }
-  for (int c = tid; c < p.C; c += NTHREADS) {
+  for (int c = tid; !WIDE && c < p.C; c += NTHREADS) {
     uint8_t one = 0;
     if (c < al.n_labels) { const int b0 = c ? al.label_off[c - 1] : 0; if (al.label_off[c] - b0 == 1) one = al.label_bytes[b0]; }
     L.lab1[c] = one;
@@ -1219,14 +1328,15 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   if (tid == 0) { L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
   if (tid < 12) L.acc[tid] = 0;
   __syncthreads();  // the math tables must be in place before the first row is prepared
-  prep_row(p, L, 0, row, v0);
+  if (!WIDE) prep_row(p, L, 0, row, v0);
   __syncthreads();
+  const LDS_AS uint8_t* const lab1 = WIDE ? (const LDS_AS uint8_t*)nullptr : (const LDS_AS uint8_t*)L.lab1;
   if (MODE == 1 && L.pqe.p0) {
     unsigned pr = 0;
     for (int i = tid; i < n; i += NTHREADS) {
       const uint32_t nd = L.node[0][i];
       uint64_t lo, hi;
-      word_walk(al, GS, L.lab1, nd, lo, hi, pr);
+      word_walk(al, GS, lab1, nd, lo, hi, pr);
       const uint32_t e0 = GS.pq[nd];
       L.wlo[0][i] = lo; L.whi[0][i] = hi; L.pqe[0][i] = e0;
       L.pqs[0][i] = e0 != STT_NONE ? (float)__dmul_rn(load_be_raw(GS, e0), s.alpha) : 0.0f;
@@ -1235,7 +1345,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   for (int i = tid; i < n; i += NTHREADS) ht_insert(L, L.key[0][i], i);
   __syncthreads();
   for (int t = 0; t < nfr; ++t)
-    ctc_step<MODE>(p, s, al, GS, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr);
+    ctc_step<MODE, WIDE>(p, s, al, GS, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr, t);
   for (int i = tid; i < n; i += NTHREADS) {
     g_score[i] = L.score[cur][i]; g_pb[i] = L.pb[cur][i]; g_pnb[i] = L.pnb[cur][i];
     g_ch[i] = L.ch[cur][i]; g_node[i] = L.node[cur][i]; g_ts[i] = L.ts[cur][i]; g_fst[i] = L.fst[cur][i]; g_key[i] = L.key[cur][i];
@@ -1392,24 +1502,33 @@ void launch_scatter_streams(DecStream* const* dst, const DecStream* src, int n, 
 }
 
 // ------------------------------------------------------------------------------------ launchers
-void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
-                     const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st) {
-  const size_t lds = ctc_next_lds_bytes(p.beam, p.C);
+void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
+                     const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st, int max_frames, void* wide_ws) {
+  DecParams p = p_in;
+  const bool wide = ctc_is_wide(p.beam, p.C);
+  p.wide_rows = nullptr; p.wide_stride = 0; p.wide_max_frames = 0;
+  if (wide) {
+    if (!wide_ws || max_frames <= 0 || p.C > STT_MAX_CLASSES) { fprintf(stderr, "stt_amd: launch_ctc_next: wide alphabet without a row workspace\n"); abort(); }
+    p.wide_rows = (const unsigned char*)wide_ws; p.wide_stride = ctc_wide_row_bytes(p.C); p.wide_max_frames = max_frames;
+    hipLaunchKernelGGL(ctc_wide_rows_kernel, dim3(n_streams * max_frames), dim3(1024), 0, st, p, probs, frame_begin, frame_count);
+  }
+  const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : p.C);
   const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : 1);
   const int cb = cap_bucket(p.beam);
   const int ci = cb == 64 ? 0 : cb == 128 ? 1 : cb == 256 ? 2 : cb == 512 ? 3 : 4;
-  static size_t configured[3][5] = {};
-#define STT_CTC_CASE(M, CI, CAPV)                                                                                            \
-  if (mode == M && ci == CI) {                                                                                               \
-    if (lds > configured[M][CI]) {                                                                                           \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_next_kernel<M, CAPV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      configured[M][CI] = lds;                                                                                               \
+  static size_t configured[2][3][5] = {};
+#define STT_CTC_CASE(M, CI, CAPV, W)                                                                                         \
+  if (mode == M && ci == CI && wide == W) {                                                                                  \
+    if (lds > configured[W][M][CI]) {                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_next_kernel<M, CAPV, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      configured[W][M][CI] = lds;                                                                                            \
     }                                                                                                                        \
-    hipLaunchKernelGGL((ctc_next_kernel<M, CAPV>), dim3(n_streams), dim3(NTHREADS), lds, st, p, s, al, streams, probs, frame_begin, frame_count); \
+    hipLaunchKernelGGL((ctc_next_kernel<M, CAPV, W>), dim3(n_streams), dim3(NTHREADS), lds, st, p, s, al, streams, probs, frame_begin, frame_count); \
     return;                                                                                                                  \
   }
-#define STT_CTC_MODE(M) STT_CTC_CASE(M, 0, 64) STT_CTC_CASE(M, 1, 128) STT_CTC_CASE(M, 2, 256) STT_CTC_CASE(M, 3, 512) STT_CTC_CASE(M, 4, 1024)
-  STT_CTC_MODE(0) STT_CTC_MODE(1) STT_CTC_MODE(2)
+#define STT_CTC_MODE(M, W) STT_CTC_CASE(M, 0, 64, W) STT_CTC_CASE(M, 1, 128, W) STT_CTC_CASE(M, 2, 256, W) STT_CTC_CASE(M, 3, 512, W) STT_CTC_CASE(M, 4, 1024, W)
+  STT_CTC_MODE(0, false) STT_CTC_MODE(1, false) STT_CTC_MODE(2, false)
+  STT_CTC_MODE(0, true) STT_CTC_MODE(1, true) STT_CTC_MODE(2, true)
 #undef STT_CTC_MODE
 #undef STT_CTC_CASE
 }

@@ -372,7 +372,9 @@ void StreamingState::processReady(bool flush_partial, bool final_flush) {
     HIP_CHECK(hipMemcpyAsync(m.ws_fcount.p, &fb[1], 4, hipMemcpyHostToDevice, m.stream));
     HIP_CHECK(hipStreamSynchronize(m.stream));
     DevScorer ds = m.current_scorer(scorer_, hot_words_, hot_hash, hot_boost);
-    launch_ctc_next(p, ds, m.dev_alphabet, dec.table.as<DecStream>(), 1, m.ws_probs.as<float>(), m.ws_fbegin.as<int>(), m.ws_fcount.as<int>(), m.stream);
+    m.ws_wide.reserve(ctc_wide_ws_bytes(p.beam, C, 1, take));
+    launch_ctc_next(p, ds, m.dev_alphabet, dec.table.as<DecStream>(), 1, m.ws_probs.as<float>(), m.ws_fbegin.as<int>(), m.ws_fcount.as<int>(), m.stream,
+                    take, m.ws_wide.p);
     windows_done_ += take;
   }
 }
@@ -458,7 +460,8 @@ void streams_process(const std::vector<StreamingState*>& ss, bool flush_partial)
       launch_gather_streams(d_tp, m.sb_table.as<DecStream>(), B, m.stream);
       DecParams p{};
       p.C = C; p.blank = C - 1; p.beam = R[g0]->dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = T;  // stt.cc:539-540
-      launch_ctc_next(p, ds, m.dev_alphabet, m.sb_table.as<DecStream>(), B, m.ws_probs.as<float>(), d_int + 2 * B, d_int + B, m.stream);
+      m.ws_wide.reserve(ctc_wide_ws_bytes(p.beam, C, B, T));
+      launch_ctc_next(p, ds, m.dev_alphabet, m.sb_table.as<DecStream>(), B, m.ws_probs.as<float>(), d_int + 2 * B, d_int + B, m.stream, T, m.ws_wide.p);
       launch_scatter_streams(d_tp, m.sb_table.as<DecStream>(), B, m.stream);
       HIP_CHECK(hipStreamSynchronize(m.stream));  // the page-locked table is reused by the next group
       for (int b = 0; b < B; ++b) { R[g0 + b]->windows_done_ += takes[g0 + b]; R[g0 + b]->state_nonzero = true; }

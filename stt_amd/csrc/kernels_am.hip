@@ -452,19 +452,26 @@ void launch_window_rows(const float* frames, _Float16* x1, int rows, int n_input
   hipLaunchKernelGGL(window_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, frames, x1, rows, n_input, kw, kp);
 }
 
-// softmax over the first C of ldl logits per row (deepspeech_model.py:357); row m = t*B+b -> probs[b][t][:]
-__global__ void softmax_kernel(SoftmaxArgs a) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+// softmax over the first C of ldl logits per row (deepspeech_model.py:357); row m = t*B+b -> probs[b][t][:].
+// Output layers wider than the fused kernel handles (C > 256, e.g. a 6000-label alphabet): one wave per row, the
+// row read and written with consecutive lanes on consecutive classes.
+__global__ __launch_bounds__(256) void softmax_kernel(SoftmaxArgs a) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (m >= a.M) return;
   const float* l = a.logits + (size_t)m * a.ldl;
   const int t = m / a.batch, b = m - t * a.batch;
-  float mx = l[0];
-  for (int c = 1; c < a.C; ++c) mx = fmaxf(mx, l[c]);
+  float mx = -3.0e38f;
+  for (int c = lane; c < a.C; c += 64) mx = fmaxf(mx, l[c]);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
   float s = 0.f;
-  for (int c = 0; c < a.C; ++c) s += expf(l[c] - mx);
+  for (int c = lane; c < a.C; c += 64) s += expf(l[c] - mx);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
   float* o = a.probs + ((size_t)b * a.t_max + t) * a.C;
   const float inv = 1.0f / s;
-  for (int c = 0; c < a.C; ++c) o[c] = expf(l[c] - mx) * inv;
+  for (int c = lane; c < a.C; c += 64) o[c] = expf(l[c] - mx) * inv;
 }
 
 // =============================================================================================
@@ -573,5 +580,5 @@ void launch_pack_h(const float* h, void* hp, int B, int H, int NT, hipStream_t s
   hipLaunchKernelGGL(pack_h_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h, reinterpret_cast<_Float16*>(hp), B, H, NT);
 }
 void launch_softmax(const SoftmaxArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(softmax_kernel, dim3((a.M + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(softmax_kernel, dim3((a.M + 3) / 4), dim3(256), 0, st, a);
 }

@@ -106,7 +106,7 @@ int parse_model_file(const char* buf, size_t len, ModelTensors& tfl, ModelView& 
     for (int i = 0; i < 12; ++i) { v.t[i] = f; v.count[i] = cnt[i]; f += cnt[i]; }
   }
   const int H = g.n_hidden, C = g.n_classes;
-  if (H % 128 != 0 || H < 128 || C < 2 || C > 1024 || g.win_len > 512 || g.win_len < 2 || g.win_step < 1 || g.n_input > 64 || g.n_input < 1 ||
+  if (H % 128 != 0 || H < 128 || C < 2 || C > STT_MAX_CLASSES || g.win_len > 512 || g.win_len < 2 || g.win_step < 1 || g.n_input > 64 || g.n_input < 1 ||
       g.n_steps < 1 || g.n_context < 0 || g.beam_width < 1) {
     err = "model geometry outside what the engine supports";
     return STT_ERR_INVALID_SHAPE;
@@ -126,6 +126,10 @@ int ModelState::InitFromBuffer(const char* buf, size_t len) {
     fprintf(stderr, "Error: Alphabet size does not match loaded model: alphabet has size %d, but model has %d classes in its output. "
                     "Make sure you're passing an alphabet file with the same size as the one used for training.\n",
             (int)alphabet_.GetSize(), g.n_classes - 1);
+    return STT_ERR_INVALID_ALPHABET;
+  }
+  if (g.n_classes > STT_MAX_CLASSES) {
+    fprintf(stderr, "Error: %d output classes; the beam search handles alphabets of up to %d labels.\n", g.n_classes, STT_MAX_CLASSES - 1);
     return STT_ERR_INVALID_ALPHABET;
   }
   const float *l1w = v.t[0], *l1b = v.t[1], *l2w = v.t[2], *l2b = v.t[3], *l3w = v.t[4], *l3b = v.t[5], *lk = v.t[6], *lb = v.t[7],
