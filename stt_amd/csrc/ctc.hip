@@ -725,9 +725,25 @@ __device__ __forceinline__ int ht_find(const Lds& L, uint64_t k) {
   }
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) v += t; }
+// Wave-level scans and reductions on the DPP network (row shifts inside the 16-lane rows, then row_bcast:15 / :31 across
+// rows): a handful of VALU cycles per step, where __shfl_up / __shfl_xor go through the LDS crossbar (ds_bpermute, one
+// LDS round trip per step -- six per scan, on the critical path of a phase).  A lane whose DPP source is outside its row
+// (or whose row is masked off) keeps `identity`.
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+#define WAVE_SCAN_STEPS(OP, IDENT)                                                                                        \
+  { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, DPP_ROW_SHR(1), 0xF, 0xF, false); v = OP(v, t); } \
+  { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, DPP_ROW_SHR(2), 0xF, 0xF, false); v = OP(v, t); } \
+  { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, DPP_ROW_SHR(4), 0xF, 0xF, false); v = OP(v, t); } \
+  { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, DPP_ROW_SHR(8), 0xF, 0xF, false); v = OP(v, t); } \
+  { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, DPP_ROW_BCAST15, 0xA, 0xF, false); v = OP(v, t); } \
+  { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, DPP_ROW_BCAST31, 0xC, 0xF, false); v = OP(v, t); }
+#define OP_ADD(a, b) ((a) + (b))
+#define OP_MIN(a, b) ((b) < (a) ? (b) : (a))
+#define OP_MAX(a, b) ((b) > (a) ? (b) : (a))
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
+  WAVE_SCAN_STEPS(OP_ADD, 0u)
   return v;
 }
 // Exclusive prefix sum of one value per thread over the workgroup (contains one __syncthreads; the caller separates
@@ -739,19 +755,18 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, LDS_AS uint32_t*
   __syncthreads();
   const uint32_t t = lane < NWAVES ? wtot[lane] : 0u;
   const uint32_t tinc = wave_incl_scan(t, lane);
-  const uint32_t wbase = __shfl(tinc, w > 0 ? w - 1 : 0);
-  total = __shfl(tinc, NWAVES - 1);
+  const int wu = __builtin_amdgcn_readfirstlane(w);  // (wave-uniform by construction; now the compiler knows it too)
+  const uint32_t wbase = (uint32_t)__builtin_amdgcn_readlane((int)tinc, wu > 0 ? wu - 1 : 0);
+  total = (uint32_t)__builtin_amdgcn_readlane((int)tinc, NWAVES - 1);
   return (w > 0 ? wbase : 0u) + inc - v;
 }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) { const uint32_t t = __shfl_xor(v, d); v = t < v ? t : v; }
-  return v;
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {  // the same value in every lane
+  WAVE_SCAN_STEPS(OP_MIN, 0xFFFFFFFFu)
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) { const uint32_t t = __shfl_xor(v, d); v = t > v ? t : v; }
-  return v;
+  WAVE_SCAN_STEPS(OP_MAX, 0u)
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 #define CAND_PI(x) (((uint32_t)(x) < L.mcap) ? L.lc_pi[x] : S.c_pi[x])
@@ -957,7 +972,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     }
     const uint32_t inc = wave_incl_scan(cnt, lane);
     const uint32_t off = inc - cnt;
-    const uint32_t n_items = __shfl(inc, 63);
+    const uint32_t n_items = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     // Items are taken 64 at a time; the FST arcs of the next two rounds are already in flight while a round is processed,
     // so the HBM/L2 latency of the arc reads overlaps the LDS work of the earlier items.
     // item -> owning lane: a per-wave byte table filled by the owners (one LDS read per item) when the wave's items fit,
