@@ -114,7 +114,8 @@ struct DecStream {
   uint32_t cand_cap;
   // statistics (DESIGN.md roofline accounting): steps, candidates, lm queries, lm memory probes
   unsigned long long stat[4];
-  // shader cycles (s_memtime, thread 0) per phase: P0 emissions, P1 hash, P2 expand, P3 LM, P4 merge, P5a select, P5b sort, P6 write
+  // shader cycles (s_memtime, thread 0; profiling level 2) per phase: [0] setup, [1] expand: events, [2] expand: items, [3] LM
+  // queue + early merges, [4] merge + keys, [5] select, [6] rank + write, [7] the LM wave's own time (runs beside [1]+[2])
   unsigned long long phase[8];
 };
 

@@ -918,6 +918,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   const int nw_exp = lm_wave ? NWAVES - 1 : NWAVES;
   if (lm_wave && wave == NWAVES - 1) {
     __builtin_amdgcn_s_setprio(3);  // the chain of dependent reads is the critical path of the phase: issue it first
+    const unsigned long long lmw_t0 = p.phase_cycles ? __builtin_readcyclecounter() : 0ull;
     const int ksp = POS_OF(al.space_id);
     unsigned lmq = 0;
     if (ksp != 0xFFFF) {
@@ -946,6 +947,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       }
     }
     if (lmq) lds_add(&sc[SC_LMQ], (int)lmq);
+    if (p.phase_cycles && lane == 0) L.acc[4 + 7] += __builtin_readcyclecounter() - lmw_t0;  // phase slot 7: the LM wave's own time
     __builtin_amdgcn_s_setprio(0);
   } else {
     uint32_t ppw = pow2_ge((uint32_t)((n + nw_exp - 1) / nw_exp));  // <= 64 (n <= 64 * 15 when the last wave is set aside: beams <= 512)

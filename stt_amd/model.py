@@ -180,7 +180,7 @@ class Model(object):
     def decoderPhaseCycles(self):
         st = (C.c_ulonglong * 8)()
         native.lib().STTX_GetDecoderPhaseCycles(self._impl, st)
-        return dict(zip(["setup", "expand_events", "expand_items", "lm", "merge", "select", "rank+write", "unused"], [int(x) for x in st]))
+        return dict(zip(["setup", "expand_events", "expand_items", "lm", "merge", "select", "rank+write", "lm_wave (parallel to expand)"], [int(x) for x in st]))
 
     def computeMfcc(self, audio_buffer):
         a, p, n = _audio(audio_buffer)
