@@ -82,13 +82,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the engine has no CPU path")
+    # STT_BENCH_BACKEND=gloo: plumbing check of the N>1 path on a box with fewer GPUs than ranks (ranks share devices,
+    # collectives on host tensors); the measured configuration is always nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("STT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else None      # where the collectives' tensors live
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         from stt_amd import dist as _sd
         _sd.assume_equal_batches()      # weak scaling: every rank decodes BATCH utterances -> the gather is one collective
 
@@ -125,7 +134,7 @@ def main():
 
     def step():
         texts = model.sttBatchDevice(ptr, stride, sizes)
-        return sdist.gather_transcripts(texts, device=dev) if world > 1 else [texts]
+        return sdist.gather_transcripts(texts, device=cdev) if world > 1 else [texts]
 
     for _ in range(args.warmup):
         step()
@@ -150,7 +159,7 @@ def main():
     dphase = model.decoderPhaseCycles()
     model.setProfiling(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -201,7 +210,9 @@ def main():
             "p50_utterance_latency_ms": 1e3 * elapsed / args.steps,   # a batch completes together: submit -> transcripts on host
             "stage_ms_per_step": {k: v / K for k, v in stage.items() if k.endswith("_ms")},
             "decoder_counters_last_step": dstats,
-            "decoder_phase_cycle_share": {k: round(v / max(1, sum(dphase.values())), 4) for k, v in dphase.items()},
+            # (the LM wave runs beside the expand phases: not part of the serial sum)
+            "decoder_phase_cycle_share": {k: round(v / max(1, sum(x for n, x in dphase.items() if not n.startswith("lm_wave"))), 4)
+                                          for k, v in dphase.items() if not k.startswith("lm_wave")},
             "decoder_phase_cycles_per_stream_step": {k: round(v / max(1, dstats["steps"]), 1) for k, v in dphase.items()},
             "roofline": roofline,
         }
