@@ -272,10 +272,12 @@ __device__ __forceinline__ float tanhf_(float x) {
   return copysignf(t, x);
 }
 
-// PF: double-buffered register prefetch of the weight / h fragments (256 VGPRs, fastest when the kernel has the chip to itself)
-// or the plain loop (<= 128 VGPRs: up to four workgroups per CU, which packs better next to the search kernel's workgroups).
-template <int NT, bool PF>
+// G = k-steps per prefetch group (two groups of weight / h fragments are in flight): G = 4 needs 272 registers (one
+// workgroup per CU), G = 2 about 150 (three per CU: all 256 workgroups stay resident in one round when the search kernel
+// holds 64 of the 256 CUs), G = 0 the plain loop.
+template <int NT, int G_>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
+  constexpr bool PF = G_ > 0;
   __shared__ __attribute__((aligned(16))) float red[4][2][NT][64][4];
   __shared__ __attribute__((aligned(16))) _Float16 hout[NT * 16][8];
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   }
   // k-steps are taken four at a time with the next group's weight and h fragments already in flight (double buffered in
   // registers: one wave per SIMD, so the register file is ours): the kernel is bound by L2/HBM latency, not by MFMA issue.
-  constexpr int G = 4;
+  constexpr int G = G_ > 0 ? G_ : 1;
   if (PF && ksteps % (2 * G) == 0) {
     uint4 wa[G][2], ha[G][NT], wb[G][2], hb[G][NT];
 #define LSTM_LOAD(W, Hh, s0)                                                                      \
@@ -390,10 +392,12 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
     if (b < B) *reinterpret_cast<uint4*>(a.h_all + ((size_t)a.t * B + b) * H + k0) = v;
   }
 }
-template __global__ void lstm_step_kernel<1, true>(LstmArgs);
-template __global__ void lstm_step_kernel<2, true>(LstmArgs);
-template __global__ void lstm_step_kernel<4, true>(LstmArgs);
-template __global__ void lstm_step_kernel<4, false>(LstmArgs);
+template __global__ void lstm_step_kernel<1, 4>(LstmArgs);
+template __global__ void lstm_step_kernel<2, 4>(LstmArgs);
+template __global__ void lstm_step_kernel<4, 4>(LstmArgs);
+template __global__ void lstm_step_kernel<4, 2>(LstmArgs);
+template __global__ void lstm_step_kernel<4, 1>(LstmArgs);
+template __global__ void lstm_step_kernel<4, 0>(LstmArgs);
 
 // h (f32 [B][H]) -> fragment-ordered f16 hp (used once per chunk to seed the recurrence from a carried state)
 __global__ void pack_h_kernel(const float* h, _Float16* hp, int B, int H, int NT) {
@@ -565,13 +569,15 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
 int lstm_nt_for_batch(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : -1; }  // 64 rows per launch (LDS reduce buffer 32 KiB)
 void launch_lstm_step(const LstmArgs& a, int NT, hipStream_t st) {
   const dim3 grid(a.n_hidden / 8), block(256);
-  static const bool pf = []() { const char* e = getenv("STT_AMD_LSTM_PREFETCH"); return !(e && e[0] == '0'); }();
+  static const int pg = []() { const char* e = getenv("STT_AMD_LSTM_PREFETCH"); return e ? atoi(e) : 2; }();
   switch (NT) {
-    case 1: hipLaunchKernelGGL((lstm_step_kernel<1, true>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((lstm_step_kernel<2, true>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((lstm_step_kernel<1, 4>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((lstm_step_kernel<2, 4>), grid, block, 0, st, a); break;
     default:
-      if (pf) hipLaunchKernelGGL((lstm_step_kernel<4, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((lstm_step_kernel<4, false>), grid, block, 0, st, a);
+      if (pg >= 4) hipLaunchKernelGGL((lstm_step_kernel<4, 4>), grid, block, 0, st, a);
+      else if (pg >= 2) hipLaunchKernelGGL((lstm_step_kernel<4, 2>), grid, block, 0, st, a);
+      else if (pg == 1) hipLaunchKernelGGL((lstm_step_kernel<4, 1>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((lstm_step_kernel<4, 0>), grid, block, 0, st, a);
       break;
   }
 }
