@@ -210,6 +210,10 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
   o.tokens = sl.out_tok.as<uint32_t>(); o.timesteps = sl.out_ts.as<uint32_t>(); o.lens = sl.out_len.as<int>();
   o.confidence = sl.out_conf.as<double>(); o.n_results = sl.out_n.as<int>(); o.num_results = nr; o.max_len = max_len;
   mark_on(m, 5, which, sl.stream_dec);
+  // A prefix that never received a finite probability (score == -NUM_FLT_INF, only reachable in an N-best list wider than
+  // the set of real hypotheses) has no timestep list -- the reference dereferences a null TimestepTreeNode there
+  // (get_history, path_trie.h:115-136); report zeros instead of whatever the buffer held.
+  HIP_CHECK(hipMemsetAsync(o.timesteps, 0, n_tok * 4, sl.stream_dec));
   launch_ctc_decode(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, o, sl.stream_dec);
   HIP_CHECK(hipMemcpyAsync(sl.h_tok.p, o.tokens, n_tok * 4, hipMemcpyDeviceToHost, sl.stream_dec));
   HIP_CHECK(hipMemcpyAsync(sl.h_ts.p, o.timesteps, n_tok * 4, hipMemcpyDeviceToHost, sl.stream_dec));

@@ -247,6 +247,7 @@ std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_
   DecParams p{};
   p.C = C; p.blank = C - 1; p.beam = beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = 0;
   DevScorer ds = m.current_scorer(sc, hot, m.ws_hot_hash, m.ws_hot_boost);
+  HIP_CHECK(hipMemsetAsync(o.timesteps, 0, (size_t)n * nr * max_len * 4, m.stream));  // (prefixes without a timestep list: see api.cpp)
   launch_ctc_decode(p, ds, m.dev_alphabet, d_table, n, o, m.stream);
   std::vector<uint32_t> tok((size_t)n * nr * max_len), ts((size_t)n * nr * max_len);
   std::vector<int> lens((size_t)n * nr), nres(n);

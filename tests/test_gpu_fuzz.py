@@ -1,0 +1,99 @@
+"""Randomised parity sweep of the HIP beam search against the oracle port: emission shapes from peaky to uniform, beam
+widths around the kernel's capacity buckets (64/128/256/512/1024), both cut-off mechanisms, random chunking of the
+frames, scorer on/off in word and byte mode, hot words, several streams per launch.  Seeds are fixed: a failure prints
+the case tuple, which reproduces it.  Bar: complete N-best lists (tokens, timesteps, f32 confidence) identical."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import canon
+from stt_amd import modelfile, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(tmp, labels, name, scorer=None):
+    from stt_amd import Model
+    w = synth.synth_weights(3, n_hidden=128, n_classes=len(labels) + 1)
+    path = str(tmp / (name + ".sttw"))
+    modelfile.write_model(path, w, labels, beam_width=100)
+    m = Model(path)
+    if scorer:
+        m.enableExternalScorer(scorer)
+    return m
+
+
+@pytest.fixture(scope="module")
+def rigs(tmp_path_factory, port, fix):
+    tmp = tmp_path_factory.mktemp("fuzz")
+    ulabels, uspace = port.utf8_alphabet()
+    elabels, espace = port.parse_alphabet_file(os.path.join(fix, "alphabet.txt"))
+    ws, bs = os.path.join(fix, "pruned_lm.scorer"), os.path.join(fix, "pruned_lm.bytes.scorer")
+    return {
+        ("word", False): (_mk(tmp, synth.ENGLISH_LABELS, "w"), None, elabels, espace),
+        ("word", True): (_mk(tmp, synth.ENGLISH_LABELS, "wl", ws), port.Scorer(ws), elabels, espace),
+        ("bytes", False): (_mk(tmp, ulabels, "b"), None, ulabels, uspace),
+        ("bytes", True): (_mk(tmp, ulabels, "bl", bs), port.Scorer(bs), ulabels, uspace),
+    }
+
+
+def _emissions(rng, T, C, blank, kind, vocab, mode):
+    if kind == "uniform":
+        x = rng.randn(T, C) * rng.choice([0.3, 1.0, 2.5])
+        p = np.exp(x - x.max(1, keepdims=True))
+        return (p / p.sum(1, keepdims=True)).astype(np.float32)
+    sent = " ".join(rng.choice(vocab, size=rng.randint(1, 5)))
+    if mode == "bytes":
+        lab = [b - 1 for b in sent.encode()]
+    else:
+        lab = [0 if ch == " " else (27 if ch == "'" else ord(ch) - ord("a") + 1) for ch in sent]
+    p = synth.peaky_emissions(lab, T, C, blank, seed=int(rng.randint(1 << 30)), noise=float(rng.choice([0.01, 0.1, 0.5, 2.0])),
+                              lead=int(rng.randint(0, 6)))
+    if kind == "ties":      # exact ties between classes and between frames: quantise the probabilities coarsely
+        p = np.round(p * 64.0) / 64.0 + 1e-6
+        p = (p / p.sum(1, keepdims=True)).astype(np.float32)
+    return p
+
+
+@pytest.mark.parametrize("mode,lm", [("word", False), ("word", True), ("bytes", False), ("bytes", True)])
+def test_fuzz_decoder_against_port(rigs, port, fix, mode, lm):
+    m, P, labels, space = rigs[(mode, lm)]
+    C = len(labels) + 1
+    vocab = open(os.path.join(fix, "vocab.pruned.txt")).read().split()
+    rng = np.random.RandomState({"word": 100, "bytes": 200}[mode] + int(lm))
+    beams = [1, 2, 3, 7, 16, 63, 64, 65, 100, 128, 129, 257, 500, 513] if mode == "word" else [1, 5, 64, 65, 200, 300]
+    n_cases = 90 if mode == "word" else 30
+    for case in range(n_cases):
+        beam = int(rng.choice(beams))
+        T = int(rng.randint(1, 48 if mode == "word" else 28))
+        kind = str(rng.choice(["peaky", "peaky", "uniform", "ties"]))
+        cp, ctn = [(1.0, 40), (1.0, 40), (0.999, 40), (0.9, 40), (1.0, 5), (0.99, 300)][int(rng.randint(6))]
+        if mode == "bytes" and not lm and cp == 1.0 and ctn >= 40:
+            cp = 0.999           # (all 256 classes x beam without a dictionary: the port takes minutes, nothing new is covered)
+        hot = {}
+        if lm and mode == "word" and rng.rand() < 0.3:
+            hot = {str(rng.choice(vocab)): float(rng.choice([-3.0, 2.5, 10.0])) for _ in range(int(rng.randint(1, 3)))}
+        n_streams = int(rng.choice([1, 1, 3]))
+        probs = [_emissions(rng, T, C, C - 1, kind, vocab, mode) for _ in range(n_streams)]
+        tag = (mode, lm, case, beam, T, kind, cp, ctn, sorted(hot.items()), n_streams)
+        if lm:
+            m.clearHotWords()
+            for wd, boost in hot.items():
+                m.addHotWord(wd, boost)
+        d = m.createDecoder(n_streams, beam, cp, ctn)
+        cuts = sorted(set(int(x) for x in rng.randint(1, T + 1, size=int(rng.randint(0, 4))))) + [T]
+        k0 = 0
+        for k1 in cuts:                                   # random chunking of the frames (streaming)
+            if k1 > k0:
+                d.next(np.stack([p[k0:k1] for p in probs]))
+            k0 = k1
+        n = min(beam, 12)
+        got = d.decode(n)
+        assert d.stats()["error"] == 0, tag
+        for s in range(n_streams):
+            o = port.Decoder(labels, space, beam, P, cp, ctn, hot or None)
+            o.next(probs[s])
+            assert canon(got[s]) == canon(o.decode(n)), tag + (s,)
+    if lm:
+        m.clearHotWords()

@@ -1,0 +1,54 @@
+"""Pins the C port (oracle/stt_port.c) against the REAL reference decoder (oracle/_ref, built from /root/reference) on
+seeded random cases beyond the committed goldens: uniform-ish and peaky emissions, both cut-off mechanisms, scorer on/off,
+word and byte mode, hot words.  Emissions are continuous (no exact probability ties), so the orders the reference leaves
+to libstdc++ do not come into play, and only the top results are compared (a prefix that never
+received a finite probability makes the reference dereference a null timestep node).  CPU only; skipped where oracle/_ref
+is not built."""
+import os
+
+import numpy as np
+
+from conftest import canon
+from stt_amd import synth
+
+
+def test_port_equals_reference_decoder_on_random_cases(port, ref, fix):
+    vocab = open(os.path.join(fix, "vocab.pruned.txt")).read().split()
+    rigs = {}
+    for mode in ("word", "bytes"):
+        if mode == "word":
+            labels, space = port.parse_alphabet_file(os.path.join(fix, "alphabet.txt"))
+            A = ref.Alphabet(os.path.join(fix, "alphabet.txt"))
+            sp = os.path.join(fix, "pruned_lm.scorer")
+        else:
+            labels, space = port.utf8_alphabet()
+            A = ref.Alphabet(None)
+            sp = os.path.join(fix, "pruned_lm.bytes.scorer")
+        rigs[mode] = (labels, space, A, port.Scorer(sp), ref.Scorer(sp, A))
+    rng = np.random.RandomState(31337)
+    for case in range(200):
+        mode = "word" if case % 4 else "bytes"
+        labels, space, A, P, S = rigs[mode]
+        C = len(labels) + 1
+        lm = bool(rng.randint(2))
+        beam = int(rng.choice([4, 16, 50, 100] if mode == "word" else [8, 32]))
+        T = int(rng.randint(6, 40 if mode == "word" else 20))
+        cp, ctn = [(1.0, 40), (0.999, 40), (0.95, 40), (1.0, 8)][int(rng.randint(4))]
+        if mode == "bytes" and not lm and cp == 1.0 and ctn >= 40:
+            cp = 0.999
+        hot = {}
+        if lm and mode == "word" and rng.rand() < 0.3:
+            hot = {str(rng.choice(vocab)): float(rng.choice([-2.0, 4.0]))}
+        if rng.rand() < 0.5:
+            x = rng.randn(T, C) * rng.choice([0.5, 1.5])
+            p = np.exp(x - x.max(1, keepdims=True)); p = (p / p.sum(1, keepdims=True)).astype(np.float32)
+        else:
+            sent = " ".join(rng.choice(vocab, size=rng.randint(1, 4)))
+            lab = [b - 1 for b in sent.encode()] if mode == "bytes" else [0 if ch == " " else (27 if ch == "'" else ord(ch) - ord("a") + 1) for ch in sent]
+            p = synth.peaky_emissions(lab, T, C, C - 1, seed=int(rng.randint(1 << 30)), noise=float(rng.choice([0.05, 0.5])), lead=2)
+        o = port.Decoder(labels, space, beam, P if lm else None, cp, ctn, hot or None)
+        r = ref.Decoder(A, beam, S if lm else None, cp, ctn, hot or None)
+        for k in range(0, T, 16):
+            o.next(p[k:k + 16]); r.next(p[k:k + 16])
+        n = 2
+        assert canon(o.decode(n)) == canon(r.decode(n)), (case, mode, lm, beam, T, cp, ctn, hot)
