@@ -98,3 +98,46 @@ def test_wide_model_end_to_end(wide, port, fix):
     b = synth.synth_audio(9000, seed=22)
     assert m.sttBatch([a, b]) == [text, m.stt(b)]
     m.disableExternalScorer()
+
+
+def test_wide_random_cases(wide, port, fix):
+    """Seeded sweep in wide mode: beams across the capacity buckets, cut-offs that make the kept-class count vary per row,
+    several streams per launch, random chunking, peaky and flat emissions."""
+    m = wide["model"]
+    C = N_LABELS + 1
+    vocab = open(os.path.join(fix, "vocab.pruned.txt")).read().split()
+    rng = np.random.RandomState(77)
+    for case in range(10):
+        lm = case % 3 == 0
+        beam = int(rng.choice([3, 64, 100]) if lm else rng.choice([1, 17, 64, 130, 600]))
+        cp, ctn = (1.0, 40) if lm else [(0.99, 40), (0.9, 40), (0.999, 12), (0.9999, 200)][int(rng.randint(4))]
+        T = int(rng.randint(3, 40))
+        n_streams = int(rng.choice([1, 2]))
+        probs = []
+        for _ in range(n_streams):
+            if rng.rand() < 0.7:
+                sent = " ".join(rng.choice(vocab, size=rng.randint(1, 4)))
+                lab = [0 if ch == " " else (27 if ch == "'" else ord(ch) - ord("a") + 1) for ch in sent]
+                lab = [int(rng.randint(28, N_LABELS)) if (not lm and rng.rand() < 0.3) else l for l in lab]   # some ideographs
+                probs.append(synth.peaky_emissions(lab, T, C, C - 1, seed=int(rng.randint(1 << 30)), noise=float(rng.choice([0.02, 0.3]))))
+            else:
+                x = rng.randn(T, C) * 2.0
+                p = np.exp(x - x.max(1, keepdims=True)); probs.append((p / p.sum(1, keepdims=True)).astype(np.float32))
+        if lm:
+            m.enableExternalScorer(os.path.join(fix, "pruned_lm.scorer"))
+        else:
+            m.disableExternalScorer()
+        d = m.createDecoder(n_streams, beam, cp, ctn)
+        cuts = sorted(set(int(x) for x in rng.randint(1, T + 1, size=int(rng.randint(0, 3))))) + [T]
+        k0 = 0
+        for k1 in cuts:
+            if k1 > k0:
+                d.next(np.stack([p[k0:k1] for p in probs]))
+            k0 = k1
+        got = d.decode(3)
+        assert d.stats()["error"] == 0
+        for s in range(n_streams):
+            o, kind = _oracle(wide, fix, port, beam, lm, cp, ctn)
+            o.next(probs[s])
+            assert canon(got[s]) == canon(o.decode(3)), (case, lm, beam, cp, ctn, T, n_streams, s, kind)
+    m.disableExternalScorer()
