@@ -252,6 +252,55 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
   }
 }
 
+// Skinny form for M <= 16 rows (one stream's 16-frame chunk: STT_FeedAudioContent / STT_SpeechToText): the tiled kernel
+// would run N/128 workgroups through 32 barrier-separated K-tiles.  Here one wave owns 16 output features for the full K
+// with operands straight from L2 into MFMA fragments (weight rows and x rows are both K-contiguous), eight k-steps of loads
+// in flight, no LDS and no barrier; N/64 workgroups.  The accumulation runs over the same 32-deep k-blocks in the same
+// order as the tiled kernel, so both give bit-identical results (streaming and batch paths agree exactly).
+template <int EPI>
+__global__ __launch_bounds__(256) void dense_skinny_kernel(DenseArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = (blockIdx.x * 4 + wave) * 16;
+  if (nb >= a.N) return;
+  const int K = a.K;
+  int row = lane & 15;
+  row = row < a.M ? row : a.M - 1;
+  const uint4* wp = reinterpret_cast<const uint4*>(a.wt + (size_t)(nb + (lane & 15)) * K + (lane >> 4) * 8);
+  const uint4* xp = reinterpret_cast<const uint4*>(a.x + (size_t)row * a.ldx + (lane >> 4) * 8);
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int D = 8;  // k-steps in flight
+  const int nks = K / 32;
+  uint4 wa[D], xa[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nks) { wa[d] = wp[d * 4]; xa[d] = xp[d * 4]; }   // 32 halfs = 4 uint4 per k-step
+  for (int s0 = 0; s0 < nks; s0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (s0 + d < nks) {
+        const f16x8 fa = *reinterpret_cast<f16x8*>(&wa[d]), fb = *reinterpret_cast<f16x8*>(&xa[d]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc, 0, 0, 0);
+        if (s0 + D + d < nks) { wa[d] = wp[(size_t)(s0 + D + d) * 4]; xa[d] = xp[(size_t)(s0 + D + d) * 4]; }
+      }
+    }
+  }
+  const int m = lane & 15;
+  if (m >= a.M) return;
+  const int n = nb + (lane >> 4) * 4;
+  const float4 bias = *reinterpret_cast<const float4*>(a.bias + n);
+  float v0 = acc[0] + bias.x, v1 = acc[1] + bias.y, v2 = acc[2] + bias.z, v3 = acc[3] + bias.w;
+  if (EPI == DENSE_EPI_RELU_F16) {
+    v0 = fminf(fmaxf(v0, 0.f), a.relu_clip); v1 = fminf(fmaxf(v1, 0.f), a.relu_clip);
+    v2 = fminf(fmaxf(v2, 0.f), a.relu_clip); v3 = fminf(fmaxf(v3, 0.f), a.relu_clip);
+    f16x4 o = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+    *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.y) + (size_t)m * a.ldy + n) = o;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + n) = make_float4(v0, v1, v2, v3);
+  }
+}
+template __global__ void dense_skinny_kernel<DENSE_EPI_RELU_F16>(DenseArgs);
+template __global__ void dense_skinny_kernel<DENSE_EPI_BIAS_F32>(DenseArgs);
+
 template __global__ void dense_kernel<DENSE_EPI_RELU_F16>(DenseArgs);
 template __global__ void dense_kernel<DENSE_EPI_BIAS_F32>(DenseArgs);
 
@@ -560,6 +609,11 @@ void launch_context(const ContextArgs& a, int rows, hipStream_t st) {
   hipLaunchKernelGGL(context_kernel, dim3(rows), dim3(256), 0, st, a);
 }
 void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
+  if (a.M <= 16 && a.K % 32 == 0 && a.N % 64 == 0) {
+    if (epi == DENSE_EPI_RELU_F16) hipLaunchKernelGGL(dense_skinny_kernel<DENSE_EPI_RELU_F16>, dim3(a.N / 64), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dense_skinny_kernel<DENSE_EPI_BIAS_F32>, dim3(a.N / 64), dim3(256), 0, st, a);
+    return;
+  }
   const int tiles = (a.N / GT_BN) * ((a.M + GT_BM - 1) / GT_BM);
   if (epi == DENSE_EPI_RELU_F16)
     hipLaunchKernelGGL(dense_kernel<DENSE_EPI_RELU_F16>, dim3(tiles), dim3(256), 0, st, a);
