@@ -203,23 +203,12 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
   const int nr = (int)std::max(1u, std::min<unsigned>(num_results, (unsigned)sl.dec.beam));
   const int max_len = t_max + 1;
   sl.nr = nr; sl.max_len = max_len;
-  const size_t n_tok = (size_t)Bg * nr * max_len;
-  sl.out_tok.reserve(n_tok * 4); sl.out_ts.reserve(n_tok * 4); sl.out_len.reserve((size_t)Bg * nr * 4); sl.out_conf.reserve((size_t)Bg * nr * 8); sl.out_n.reserve((size_t)Bg * 4);
-  sl.h_tok.reserve(n_tok * 4); sl.h_ts.reserve(n_tok * 4); sl.h_len.reserve((size_t)Bg * nr * 4); sl.h_conf.reserve((size_t)Bg * nr * 8); sl.h_n.reserve((size_t)Bg * 4);
-  DecodeOut o{};
-  o.tokens = sl.out_tok.as<uint32_t>(); o.timesteps = sl.out_ts.as<uint32_t>(); o.lens = sl.out_len.as<int>();
-  o.confidence = sl.out_conf.as<double>(); o.n_results = sl.out_n.as<int>(); o.num_results = nr; o.max_len = max_len;
+  sl.out_layout = DecodeBlock::layout(Bg, nr, max_len);
+  sl.out.reserve(sl.out_layout.bytes); sl.h_out.reserve(sl.out_layout.bytes);
+  const DecodeOut o = sl.out_layout.view(sl.out.p, nr, max_len);
   mark_on(m, 5, which, sl.stream_dec);
-  // A prefix that never received a finite probability (score == -NUM_FLT_INF, only reachable in an N-best list wider than
-  // the set of real hypotheses) has no timestep list -- the reference dereferences a null TimestepTreeNode there
-  // (get_history, path_trie.h:115-136); report zeros instead of whatever the buffer held.
-  HIP_CHECK(hipMemsetAsync(o.timesteps, 0, n_tok * 4, sl.stream_dec));
   launch_ctc_decode(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, o, sl.stream_dec);
-  HIP_CHECK(hipMemcpyAsync(sl.h_tok.p, o.tokens, n_tok * 4, hipMemcpyDeviceToHost, sl.stream_dec));
-  HIP_CHECK(hipMemcpyAsync(sl.h_ts.p, o.timesteps, n_tok * 4, hipMemcpyDeviceToHost, sl.stream_dec));
-  HIP_CHECK(hipMemcpyAsync(sl.h_len.p, o.lens, (size_t)Bg * nr * 4, hipMemcpyDeviceToHost, sl.stream_dec));
-  HIP_CHECK(hipMemcpyAsync(sl.h_conf.p, o.confidence, (size_t)Bg * nr * 8, hipMemcpyDeviceToHost, sl.stream_dec));
-  HIP_CHECK(hipMemcpyAsync(sl.h_n.p, o.n_results, (size_t)Bg * 4, hipMemcpyDeviceToHost, sl.stream_dec));
+  HIP_CHECK(hipMemcpyAsync(sl.h_out.p, sl.out.p, sl.out_layout.bytes, hipMemcpyDeviceToHost, sl.stream_dec));  // all results, one copy
   mark_on(m, -1, which, sl.stream_dec);
   HIP_CHECK(hipEventRecord(sl.done, sl.stream_dec));
 }
@@ -227,8 +216,10 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
 // Wait for a group and turn its page-locked result block into Output lists (scattered to the caller's utterance order).
 void batch_collect_group(ModelState* m, ModelState::GroupSlot& sl, std::vector<std::vector<Output>>& all, Prof& pr) {
   HIP_CHECK(hipEventSynchronize(sl.done));
-  const uint32_t* tok = sl.h_tok.as<uint32_t>(); const uint32_t* ts = sl.h_ts.as<uint32_t>();
-  const int* lens = sl.h_len.as<int>(); const double* conf = sl.h_conf.as<double>(); const int* nres = sl.h_n.as<int>();
+  const DecodeOut h = sl.out_layout.view(sl.h_out.p, sl.nr, sl.max_len);
+  const uint32_t *tok = h.tokens, *ts = h.timesteps;
+  const int *lens = h.lens, *nres = h.n_results;
+  const double* conf = h.confidence;
   for (int i = 0; i < sl.Bg; ++i) {
     std::vector<Output>& dst = all[sl.idx[i]];
     for (int r = 0; r < nres[i]; ++r) {

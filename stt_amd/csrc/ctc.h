@@ -124,6 +124,7 @@ struct DecParams {
   double cutoff_prob;
   int t_max;  // row stride of probs in frames
   int phase_cycles;  // accumulate shader cycles per phase into DecStream::phase (profiling level 2)
+  int all_begin, all_count;  // frame range of every stream when launch_ctc_next gets no frame_begin / frame_count tables
   // wide alphabets (ctc_is_wide): per-row records prepared by ctc_wide_rows_kernel; filled in by launch_ctc_next
   const unsigned char* wide_rows;
   unsigned long long wide_stride;
@@ -149,6 +150,25 @@ size_t ctc_wide_row_bytes(int C);
 inline size_t ctc_wide_ws_bytes(int beam, int C, int n_streams, int max_frames) {
   return ctc_is_wide(beam, C) ? (size_t)n_streams * (size_t)max_frames * ctc_wide_row_bytes(C) : 0;
 }
+// All outputs of a decode launch in ONE block (so they come back with one copy): [n_results | lens | confidence | tokens |
+// timesteps]; `view` points a DecodeOut into a block at `base` (device or host).
+struct DecodeBlock {
+  size_t off_n, off_len, off_conf, off_tok, off_ts, bytes;
+  static DecodeBlock layout(int n_streams, int num_results, int max_len) {
+    DecodeBlock b{};
+    const size_t nr = (size_t)n_streams * num_results;
+    b.off_n = 0; b.off_len = (size_t)n_streams * 4; b.off_conf = (b.off_len + nr * 4 + 7) & ~(size_t)7;
+    b.off_tok = b.off_conf + nr * 8; b.off_ts = b.off_tok + nr * max_len * 4; b.bytes = b.off_ts + nr * max_len * 4;
+    return b;
+  }
+  DecodeOut view(void* base, int num_results, int max_len) const {
+    unsigned char* p = (unsigned char*)base;
+    DecodeOut o{};
+    o.n_results = (int*)(p + off_n); o.lens = (int*)(p + off_len); o.confidence = (double*)(p + off_conf);
+    o.tokens = (uint32_t*)(p + off_tok); o.timesteps = (uint32_t*)(p + off_ts); o.num_results = num_results; o.max_len = max_len;
+    return o;
+  }
+};
 void launch_ctc_decode(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const DecStream* streams, int n_streams,
                        const DecodeOut& out, hipStream_t st);
 size_t ctc_next_lds_bytes(int beam, int C);

@@ -515,9 +515,9 @@ __global__ __launch_bounds__(1024) void ctc_wide_rows_kernel(DecParams p, const 
   __shared__ double log_tab[32];
   __shared__ int s_cut;
   const int s = blockIdx.x / p.wide_max_frames, tt = blockIdx.x - s * p.wide_max_frames;
-  if (tt >= frame_count[s]) return;
+  if (tt >= (frame_count ? frame_count[s] : p.all_count)) return;
   const int tid = threadIdx.x, C = p.C;
-  const float* row = probs + ((size_t)s * p.t_max + frame_begin[s] + tt) * C;
+  const float* row = probs + ((size_t)s * p.t_max + (frame_begin ? frame_begin[s] : p.all_begin) + tt) * C;
   unsigned char* rec = const_cast<unsigned char*>(p.wide_rows) + ((size_t)s * p.wide_max_frames + tt) * p.wide_stride;
   float* lpc = reinterpret_cast<float*>(rec + sizeof(WideRowHdr));
   uint16_t* pos = reinterpret_cast<uint16_t*>(rec + wide_off_pos(C));
@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   size_t lds_total;
   const Lds L = lds_carve<CAP>(WIDE ? 0 : p.C, (LDS_AS unsigned char*)smem, lds_total);
   DecStream& G = streams[blockIdx.x];
-  const int nfr = frame_count[blockIdx.x];
+  const int nfr = frame_count ? frame_count[blockIdx.x] : p.all_count;
   if (nfr <= 0) return;
   // the stream's pointers and capacities, read once into registers (field by field: a struct copy indexed in a loop would
   // live in scratch memory)
@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   int cur = 0;
   int start_expanding = G.start_expanding;
   int abs_t = G.abs_t;
-  const float* row = probs + ((size_t)blockIdx.x * p.t_max + frame_begin[blockIdx.x]) * p.C;
+  const float* row = probs + ((size_t)blockIdx.x * p.t_max + (frame_begin ? frame_begin[blockIdx.x] : p.all_begin)) * p.C;
   const float v0 = (!WIDE && tid < p.C) ? row[tid] : 0.0f;
   for (int i = tid; i < n; i += NTHREADS) {
     L.score[0][i] = g_score[i]; L.pb[0][i] = g_pb[i]; L.pnb[0][i] = g_pnb[i];
@@ -1452,8 +1452,8 @@ __global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevSc
     const int r = q >> 1;
     const uint32_t i = ssrc[r];
     const size_t ob = ((size_t)blockIdx.x * out.num_results + r);
+    int k = 0;
     if ((q & 1) == 0) {
-      int k = 0;
       for (uint32_t x = S.node[i]; x != STT_ROOT_CH;) {
         const uint2 pn = load_node(GS.pa, x);
         if (pn.y == STT_ROOT_CH) break;
@@ -1463,13 +1463,19 @@ __global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevSc
       out.lens[ob] = k;
       out.confidence[ob] = (double)sscore[i];
     } else {
-      int k = 0;
       for (uint32_t x = S.ts[i]; x != STT_ROOT_CH && x != 0;) {
         const uint2 tn = load_node(GS.ta, x);
         out.timesteps[ob * out.max_len + (k % out.max_len)] = tn.y;
         ++k; x = tn.x;
       }
     }
+    // A prefix that never received a finite probability (score == -NUM_FLT_INF; only reachable in an N-best list wider than
+    // the set of real hypotheses) has tokens but no timestep list -- the reference dereferences a null TimestepTreeNode
+    // there (get_history, path_trie.h:115-136).  Report zeros: the timestep thread clears the slots its token partner
+    // (the neighbouring lane) filled beyond its own chain.
+    const int k_tok = __shfl_xor(k, 1);
+    if (q & 1)
+      for (int z = k; z < k_tok && z < k + out.max_len; ++z) out.timesteps[ob * out.max_len + (z % out.max_len)] = 0u;
   }
 }
 

@@ -239,25 +239,19 @@ std::vector<std::vector<Output>> decode_streams(const ModelState& mc, const Deco
 std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_table, int n, int beam, int C, std::shared_ptr<ScorerDev> sc,
                                               const std::map<std::string, float>& hot, unsigned num_results, int max_len) {
   const int nr = (int)std::max(1u, std::min<unsigned>(num_results, (unsigned)beam));
-  m.ws_out_tok.reserve((size_t)n * nr * max_len * 4); m.ws_out_ts.reserve((size_t)n * nr * max_len * 4);
-  m.ws_out_len.reserve((size_t)n * nr * 4); m.ws_out_conf.reserve((size_t)n * nr * 8); m.ws_out_n.reserve((size_t)n * 4);
-  DecodeOut o{};
-  o.tokens = m.ws_out_tok.as<uint32_t>(); o.timesteps = m.ws_out_ts.as<uint32_t>(); o.lens = m.ws_out_len.as<int>();
-  o.confidence = m.ws_out_conf.as<double>(); o.n_results = m.ws_out_n.as<int>(); o.num_results = nr; o.max_len = max_len;
+  const DecodeBlock blk = DecodeBlock::layout(n, nr, max_len);
+  m.ws_out.reserve(blk.bytes); m.h_out.reserve(blk.bytes);
+  const DecodeOut o = blk.view(m.ws_out.p, nr, max_len);
   DecParams p{};
   p.C = C; p.blank = C - 1; p.beam = beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = 0;
   DevScorer ds = m.current_scorer(sc, hot, m.ws_hot_hash, m.ws_hot_boost);
-  HIP_CHECK(hipMemsetAsync(o.timesteps, 0, (size_t)n * nr * max_len * 4, m.stream));  // (prefixes without a timestep list: see api.cpp)
   launch_ctc_decode(p, ds, m.dev_alphabet, d_table, n, o, m.stream);
-  std::vector<uint32_t> tok((size_t)n * nr * max_len), ts((size_t)n * nr * max_len);
-  std::vector<int> lens((size_t)n * nr), nres(n);
-  std::vector<double> conf((size_t)n * nr);
-  HIP_CHECK(hipMemcpyAsync(tok.data(), o.tokens, tok.size() * 4, hipMemcpyDeviceToHost, m.stream));
-  HIP_CHECK(hipMemcpyAsync(ts.data(), o.timesteps, ts.size() * 4, hipMemcpyDeviceToHost, m.stream));
-  HIP_CHECK(hipMemcpyAsync(lens.data(), o.lens, lens.size() * 4, hipMemcpyDeviceToHost, m.stream));
-  HIP_CHECK(hipMemcpyAsync(conf.data(), o.confidence, conf.size() * 8, hipMemcpyDeviceToHost, m.stream));
-  HIP_CHECK(hipMemcpyAsync(nres.data(), o.n_results, nres.size() * 4, hipMemcpyDeviceToHost, m.stream));
+  HIP_CHECK(hipMemcpyAsync(m.h_out.p, m.ws_out.p, blk.bytes, hipMemcpyDeviceToHost, m.stream));  // one copy, page-locked destination
   HIP_CHECK(hipStreamSynchronize(m.stream));
+  const DecodeOut h = blk.view(m.h_out.p, nr, max_len);
+  const uint32_t *tok = h.tokens, *ts = h.timesteps;
+  const int *lens = h.lens, *nres = h.n_results;
+  const double* conf = h.confidence;
   std::vector<std::vector<Output>> out(n);
   for (int i = 0; i < n; ++i) {
     for (int r = 0; r < nres[i]; ++r) {
@@ -367,14 +361,10 @@ void StreamingState::processReady(bool flush_partial, bool final_flush) {
     reserveArena(take);
     DecParams p{};
     p.C = C; p.blank = C - 1; p.beam = dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = T;  // stt.cc:539-540
-    const int fb[2] = {0, take};
-    m.ws_fbegin.reserve(4); m.ws_fcount.reserve(4);
-    HIP_CHECK(hipMemcpyAsync(m.ws_fbegin.p, &fb[0], 4, hipMemcpyHostToDevice, m.stream));
-    HIP_CHECK(hipMemcpyAsync(m.ws_fcount.p, &fb[1], 4, hipMemcpyHostToDevice, m.stream));
-    HIP_CHECK(hipStreamSynchronize(m.stream));
+    p.all_begin = 0; p.all_count = take;  // the frame range rides in the kernel arguments: no table upload, no host sync mid-hop
     DevScorer ds = m.current_scorer(scorer_, hot_words_, hot_hash, hot_boost);
     m.ws_wide.reserve(ctc_wide_ws_bytes(p.beam, C, 1, take));
-    launch_ctc_next(p, ds, m.dev_alphabet, dec.table.as<DecStream>(), 1, m.ws_probs.as<float>(), m.ws_fbegin.as<int>(), m.ws_fcount.as<int>(), m.stream,
+    launch_ctc_next(p, ds, m.dev_alphabet, dec.table.as<DecStream>(), 1, m.ws_probs.as<float>(), nullptr, nullptr, m.stream,
                     take, m.ws_wide.p);
     windows_done_ += take;
   }

@@ -149,17 +149,19 @@ struct ModelState {
   DevAlphabet dev_alphabet{};
   // workspaces (grown on demand, reused)
   DevBuf ws_audio, ws_nsamp, ws_nframes, ws_feats, ws_x1, ws_a, ws_b, ws_xproj, ws_hall, ws_logits, ws_probs;
-  DevBuf ws_c, ws_hp0, ws_hp1, ws_hf32, ws_fbegin, ws_fcount;
+  DevBuf ws_c, ws_hp0, ws_hp1, ws_hf32;
   DevBuf ws_wide;  // wide-alphabet row records of the streaming paths
-  DevBuf ws_out_tok, ws_out_ts, ws_out_len, ws_out_conf, ws_out_n, ws_hot_hash, ws_hot_boost;
+  DevBuf ws_out, ws_hot_hash, ws_hot_boost;  // ws_out: one DecodeBlock
+  PinnedBuf h_out;
   // The batch path works on two 64-utterance groups at a time: while the beam search of group g finishes on `stream_dec`,
   // the acoustic model of group g+1 already runs on `stream`, and the host unpacks group g-1.  Everything a group owns
   // beyond the acoustic stream's scratch buffers lives in its slot.
   struct GroupSlot {
     DecoderBatch dec;
-    DevBuf probs, ints, out_tok, out_ts, out_len, out_conf, out_n;
+    DevBuf probs, ints, out;  // out: one DecodeBlock (ctc.h)
     DevBuf wide;  // per-row class records of the wide-alphabet search path (ctc.h: ctc_is_wide)
-    PinnedBuf h_ints, h_table, h_tok, h_ts, h_len, h_conf, h_n;
+    PinnedBuf h_ints, h_table, h_out;
+    DecodeBlock out_layout{};
     hipEvent_t done = nullptr;
     hipStream_t stream_dec = nullptr;  // the group's search stream (slot 0: ModelState::stream_dec, slot 1: its own)
     int Bg = 0, nr = 0, max_len = 0, t_max = 0;
