@@ -292,14 +292,18 @@ void StreamingState::pushFrames(const int16_t* span, int n_span, int n_new_frame
   const int need = frames_ + n_new_frames;
   if (need > frames_cap) { frames_cap = std::max(need * 2, 256); d_frames.reserve((size_t)frames_cap * m.g.n_input * 4, true, m.stream); }
   m.ws_audio.reserve((size_t)std::max(n_span, 1) * 2);
-  if (n_span) HIP_CHECK(hipMemcpyAsync(m.ws_audio.p, span, (size_t)n_span * 2, hipMemcpyHostToDevice, m.stream));
-  const int hn[2] = {n_span, n_new_frames};
-  m.ws_nsamp.reserve(4); m.ws_nframes.reserve(4);
-  HIP_CHECK(hipMemcpyAsync(m.ws_nsamp.p, &hn[0], 4, hipMemcpyHostToDevice, m.stream));
-  HIP_CHECK(hipMemcpyAsync(m.ws_nframes.p, &hn[1], 4, hipMemcpyHostToDevice, m.stream));
-  HIP_CHECK(hipStreamSynchronize(m.stream));  // span / hn are host temporaries
+  if (n_span) {  // span is a host temporary: stage it in page-locked memory so that the feed need not wait for the copy
+    const unsigned slot = m.audio_slot++ & 3u;
+    if (!m.ev_audio[slot]) HIP_CHECK(hipEventCreateWithFlags(&m.ev_audio[slot], hipEventDisableTiming));
+    else HIP_CHECK(hipEventSynchronize(m.ev_audio[slot]));
+    m.h_audio[slot].reserve((size_t)n_span * 2);
+    memcpy(m.h_audio[slot].p, span, (size_t)n_span * 2);
+    HIP_CHECK(hipMemcpyAsync(m.ws_audio.p, m.h_audio[slot].p, (size_t)n_span * 2, hipMemcpyHostToDevice, m.stream));
+    HIP_CHECK(hipEventRecord(m.ev_audio[slot], m.stream));
+  }
   MfccArgs a = m.mfcc_args();
-  a.audio = m.ws_audio.as<int16_t>(); a.n_samples = m.ws_nsamp.as<int>(); a.n_frames = m.ws_nframes.as<int>();
+  a.audio = m.ws_audio.as<int16_t>(); a.n_samples = nullptr; a.n_frames = nullptr;
+  a.all_n_samples = n_span; a.all_n_frames = n_new_frames;  // (in the kernel arguments: no table upload, no host sync)
   a.feats = d_frames.as<float>() + (size_t)frames_ * m.g.n_input; a.n_max = std::max(n_span, 1); a.t_max = n_new_frames;
   launch_mfcc(a, n_new_frames, m.stream);
   frames_ += n_new_frames;
@@ -344,9 +348,8 @@ void StreamingState::processReady(bool flush_partial, bool final_flush) {
     const int T = (take < g.n_steps && !final_flush) ? g.n_steps : take;  // padded steps perturb the carried state (coqui-stt.h:393-399 of the reference)
     // windows are contiguous slices of the frame list: window w = frames[w .. w+19) flattened (stt.cc:292-309)
     m.ws_x1.reserve((size_t)T * kp * 2);
-    HIP_CHECK(hipMemsetAsync(m.ws_x1.p, 0, (size_t)T * kp * 2, m.stream));
-    // raw gather: x1[t][k] = frames_flat[(windows_done_ + t) * n_input + k], k < 494; rows >= take stay zero
-    launch_window_rows(d_frames.as<float>() + (size_t)windows_done_ * g.n_input, m.ws_x1.as<_Float16>(), take, g.n_input, kw, kp, m.stream);
+    // raw gather: x1[t][k] = frames_flat[(windows_done_ + t) * n_input + k], k < 494; rows >= take are written as zeros
+    launch_window_rows(d_frames.as<float>() + (size_t)windows_done_ * g.n_input, m.ws_x1.as<_Float16>(), take, T, g.n_input, kw, kp, m.stream);
     d_c.reserve((size_t)H * 4); d_h.reserve((size_t)H * 4);
     m.ws_probs.reserve((size_t)T * C * 4);
     m.run_acoustic_rows(m.ws_x1.as<_Float16>(), 1, T, d_c.as<float>(), d_h.as<float>(), state_nonzero, m.ws_probs.as<float>(), T);

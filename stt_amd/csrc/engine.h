@@ -153,6 +153,11 @@ struct ModelState {
   DevBuf ws_wide;  // wide-alphabet row records of the streaming paths
   DevBuf ws_out, ws_hot_hash, ws_hot_boost;  // ws_out: one DecodeBlock
   PinnedBuf h_out;
+  // page-locked staging of the streaming path's audio: a feed returns without waiting for its copy; a slot is reused
+  // four feeds later, after its event
+  PinnedBuf h_audio[4];
+  hipEvent_t ev_audio[4] = {};
+  unsigned audio_slot = 0;
   // The batch path works on two 64-utterance groups at a time: while the beam search of group g finishes on `stream_dec`,
   // the acoustic model of group g+1 already runs on `stream`, and the host unpacks group g-1.  Everything a group owns
   // beyond the acoustic stream's scratch buffers lives in its slot.

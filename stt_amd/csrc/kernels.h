@@ -13,6 +13,7 @@ struct MfccArgs {
   float* feats;            // [B][t_max][n_coef]
   float* const* feats_ptrs;  // optional: per-utterance output base (frames of utterance b go to feats_ptrs[b] + f*n_coef; frames >= n_frames[b] are not written)
   int n_max, t_max;
+  int all_n_samples, all_n_frames;  // used for every utterance when n_samples / n_frames are null (one stream: no table upload)
   int win_len, win_step, n_coef, n_mel;
   const double* window;    // [win_len]
   const double2* twiddle;  // [256] (cos, -sin)(2 pi m / 512)
@@ -67,7 +68,8 @@ void launch_softmax(const SoftmaxArgs& a, hipStream_t st);
 // fused output layer + softmax for C <= 256 (returns false if the shape is not covered: caller uses dense + softmax)
 bool launch_logits_softmax(const _Float16* x, const _Float16* wt, const float* bias, float* probs, int M, int K, int C, int batch, int t_max,
                            hipStream_t st);
-void launch_window_rows(const float* frames, _Float16* x1, int rows, int n_input, int kw, int kp, hipStream_t st);
+// rows_valid windows are gathered, rows rows_valid .. rows_total-1 are written as zeros (the padded steps of a partial chunk)
+void launch_window_rows(const float* frames, _Float16* x1, int rows_valid, int rows_total, int n_input, int kw, int kp, hipStream_t st);
 // batched streaming: window t of stream b = frames_ptrs[b][(win_off[b] + t) * n_input ...], rows t >= take[b] are zero; row = t*B + b
 void launch_window_rows_batch(const float* const* frames_ptrs, const int* win_off, const int* take, _Float16* x1, int B, int T, int n_input, int kw, int kp,
                               hipStream_t st);

@@ -39,8 +39,8 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccArgs a) {
   const int frame = blockIdx.x;
   const int b = frame / a.t_max;
   const int f = frame - b * a.t_max;
-  const int n = a.n_samples[b];
-  const int nf = a.n_frames[b];
+  const int n = a.n_samples ? a.n_samples[b] : a.all_n_samples;
+  const int nf = a.n_frames ? a.n_frames[b] : a.all_n_frames;
   float* out = a.feats_ptrs ? a.feats_ptrs[b] + (size_t)f * a.n_coef : a.feats + ((size_t)b * a.t_max + f) * a.n_coef;
   if (f >= nf) {  // beyond the utterance: defined zeros (never consumed); per-stream outputs end at n_frames
     if (!a.feats_ptrs && threadIdx.x < a.n_coef) out[threadIdx.x] = 0.0f;
@@ -460,11 +460,11 @@ __global__ void pack_h_kernel(const float* h, _Float16* hp, int B, int H, int NT
 
 // streaming path: the frame list already contains the explicit zero context frames, so window t is the
 // contiguous slice frames[t*n_input .. t*n_input + kw) (stt.cc:292-309)
-__global__ void window_rows_kernel(const float* frames, _Float16* x1, int rows, int n_input, int kw, int kp) {
+__global__ void window_rows_kernel(const float* frames, _Float16* x1, int rows_valid, int rows_total, int n_input, int kw, int kp) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * kp) return;
+  if (idx >= rows_total * kp) return;
   const int t = idx / kp, k = idx - t * kp;
-  x1[idx] = (_Float16)(k < kw ? frames[(size_t)t * n_input + k] : 0.0f);
+  x1[idx] = (_Float16)((k < kw && t < rows_valid) ? frames[(size_t)t * n_input + k] : 0.0f);
 }
 __global__ void window_rows_batch_kernel(const float* const* frames_ptrs, const int* win_off, const int* take, _Float16* x1, int B, int T, int n_input, int kw, int kp) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -499,10 +499,10 @@ void launch_gather_rows(const float* const* src, const unsigned char* valid, flo
 void launch_scatter_rows(float* const* dst, const float* src, int B, int H, hipStream_t st) {
   hipLaunchKernelGGL(scatter_rows_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, dst, src, B, H);
 }
-void launch_window_rows(const float* frames, _Float16* x1, int rows, int n_input, int kw, int kp, hipStream_t st) {
-  const int n = rows * kp;
+void launch_window_rows(const float* frames, _Float16* x1, int rows_valid, int rows_total, int n_input, int kw, int kp, hipStream_t st) {
+  const int n = rows_total * kp;
   if (n <= 0) return;
-  hipLaunchKernelGGL(window_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, frames, x1, rows, n_input, kw, kp);
+  hipLaunchKernelGGL(window_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, frames, x1, rows_valid, rows_total, n_input, kw, kp);
 }
 
 // softmax over the first C of ldl logits per row (deepspeech_model.py:357); row m = t*B+b -> probs[b][t][:].

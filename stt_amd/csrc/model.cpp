@@ -72,6 +72,7 @@ ModelState::~ModelState() {
   if (stream) (void)hipStreamDestroy(stream);
   if (stream_dec) (void)hipStreamDestroy(stream_dec);
   for (auto& e : ev_chunk) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ev_audio) if (e) (void)hipEventDestroy(e);
   for (auto& sl : slots_) if (sl.done) (void)hipEventDestroy(sl.done);
   if (slots_[1].stream_dec) (void)hipStreamDestroy(slots_[1].stream_dec);
 }
