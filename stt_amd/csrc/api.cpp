@@ -31,6 +31,9 @@ struct Prof {
   unsigned long long dec_phase[8] = {};
 };
 std::unordered_map<ModelState*, Prof> g_prof;
+// live models: a stream freed after its model (a caller error the reference happens to survive) must not touch the model
+std::mutex g_models_mu;
+std::unordered_map<ModelState*, int> g_models;
 
 Prof& prof_of(ModelState* m) { return g_prof[m]; }
 void mark_on(ModelState* m, int id, int which, hipStream_t st) {
@@ -114,7 +117,12 @@ Metadata* decode_metadata(const StreamingState* s, unsigned n) {
 int create_stream(ModelState* aCtx, StreamingState** retval, bool keep_emissions) {  // stt.cc:519-593
   *retval = nullptr;
   return guarded([&]() {
-    std::unique_ptr<StreamingState> ctx(new StreamingState());
+    std::unique_ptr<StreamingState> ctx;
+    {
+      std::lock_guard<std::mutex> lk(aCtx->stream_pool_mu_);
+      if (!aCtx->stream_pool_.empty()) { ctx.reset(aCtx->stream_pool_.back()); aCtx->stream_pool_.pop_back(); }
+    }
+    if (!ctx) ctx.reset(new StreamingState());
     ctx->model_ = aCtx;
     ctx->scorer_ = aCtx->scorer_;
     ctx->hot_words_ = aCtx->hot_words_;
@@ -305,6 +313,7 @@ int STT_CreateModelFromBuffer(const char* aModelBuffer, unsigned int aBufferSize
     int err = model->InitFromBuffer(aModelBuffer, aBufferSize);
     if (err != STT_ERR_OK) return err;
     *retval = model.release();
+    { std::lock_guard<std::mutex> lk(g_models_mu); g_models[*retval] = 1; }
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_CREATE_MODEL);
 }
@@ -337,6 +346,7 @@ void STT_FreeModel(ModelState* ctx) {
   if (!ctx) return;
   auto it = g_prof.find(ctx);
   if (it != g_prof.end()) { for (auto e : it->second.pool) (void)hipEventDestroy(e); g_prof.erase(it); }
+  { std::lock_guard<std::mutex> lk(g_models_mu); g_models.erase(ctx); }
   delete ctx;
 }
 
@@ -407,7 +417,18 @@ Metadata* STT_IntermediateDecodeWithMetadataFlushBuffers(StreamingState* aSctx, 
   guarded([&]() { aSctx->flushBuffers(false); r = decode_metadata(aSctx, aNumResults); return 0; }, 0);
   return r;
 }
-void STT_FreeStream(StreamingState* aSctx) { delete aSctx; }
+void STT_FreeStream(StreamingState* aSctx) {
+  if (!aSctx) return;
+  ModelState* m = aSctx->model_;
+  { std::lock_guard<std::mutex> lk(g_models_mu); if (!g_models.count(m)) m = nullptr; }
+  if (m) {  // park the stream (and its HBM buffers) for the next STT_CreateStream; anything in flight on it is ordered before
+            // the next user's work, which runs on the same HIP stream
+    aSctx->recycle();
+    std::lock_guard<std::mutex> lk(m->stream_pool_mu_);
+    if (m->stream_pool_.size() < 1024) { m->stream_pool_.push_back(aSctx); return; }
+  }
+  delete aSctx;
+}
 // ---- many streams per call (stt_amd.h)
 static char** strings_of(const ModelState* m, const std::vector<std::vector<Output>>& outs) {
   char** r = (char**)malloc(sizeof(char*) * std::max<size_t>(1, outs.size()));

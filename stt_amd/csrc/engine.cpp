@@ -278,6 +278,10 @@ std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_
 //   frames_        MFCC frames pushed (starts at n_context zero frames, stt.cc:533)
 //   windows ready  = frames_ - 2*n_context  (a 19-frame window completes with every frame beyond the 18th)
 //   windows_done_  windows already sent through the model in batches of n_steps
+void StreamingState::recycle() {
+  scorer_.reset(); hot_words_.clear(); beam_width_ = 0; keep_emissions_ = false;
+  audio_buffer_.clear(); frames_ = 0; windows_done_ = 0; state_nonzero = false; arena_bound_ = 2; probs_.clear();
+}
 void StreamingState::pushZeroFrames(int n) {
   ModelState& m = *model_;
   const int need = frames_ + n;

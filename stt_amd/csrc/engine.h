@@ -11,6 +11,7 @@
 
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -129,6 +130,7 @@ struct DecoderBatch {
   size_t per_stream_fixed = 0;
 };
 
+struct StreamingState;
 struct ModelState {
   Geometry g;
   Alphabet alphabet_;
@@ -153,6 +155,11 @@ struct ModelState {
   DevBuf ws_wide;  // wide-alphabet row records of the streaming paths
   DevBuf ws_out, ws_hot_hash, ws_hot_boost;  // ws_out: one DecodeBlock
   PinnedBuf h_out;
+  // Finished streams are parked here with their HBM buffers (frames, LSTM state, decoder slab: seven allocations) and
+  // handed out again by STT_CreateStream: a server that opens a stream per utterance pays hipMalloc/hipFree once per
+  // concurrent stream, not once per utterance.
+  std::vector<StreamingState*> stream_pool_;
+  std::mutex stream_pool_mu_;
   // page-locked staging of the streaming path's audio: a feed returns without waiting for its copy; a slot is reused
   // four feeds later, after its event
   PinnedBuf h_audio[4];
@@ -224,6 +231,7 @@ struct StreamingState {
   DevBuf hot_hash, hot_boost;
   std::vector<double> probs_;                 // emissions of the last processed batch (keep_emissions_)
 
+  void recycle();  // back to the state of a fresh object, keeping the device buffers
   void feedAudioContent(const short* buffer, unsigned int buffer_size);
   void flushBuffers(bool addZeroMfccVectors);
   void pushFrames(const int16_t* d_audio_span_host, int n_samples_span, int n_new_frames);
