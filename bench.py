@@ -179,7 +179,7 @@ def main():
         # per utterance-timestep C*4 B of probabilities in, beam state ~ beam*40 B read + written, 8 B per counted LM probe
         dec_bytes = BATCH * T * (C * 4 + 2 * BEAM * 40) + 8.0 * dstats["lm_probes"]
         kernels = {
-            "lstm_step_kernel<4>": {"avg_ms": lstm_avg_ms, "launches_per_step": lstm_launches / K, "bytes": lstm_bytes,
+            "lstm_step_kernel<4, 2>": {"avg_ms": lstm_avg_ms, "launches_per_step": lstm_launches / K, "bytes": lstm_bytes,
                                     "share_ms": stage["lstm_ms"] / K},
             "ctc_next_kernel": {"avg_ms": dec_ms, "launches_per_step": 1, "bytes": dec_bytes, "share_ms": dec_ms},
         }
