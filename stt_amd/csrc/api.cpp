@@ -195,7 +195,7 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
   p.phase_cycles = prof_of(m).phase_cycles ? 1 : 0;
   int max_chunk = 1;
   for (int k = 0; k < n_chunks; ++k) max_chunk = std::max(max_chunk, cb[k + 1] - cb[k]);
-  sl.wide.reserve(ctc_wide_ws_bytes(p.beam, p.C, Bg, max_chunk));
+  sl.wide.reserve(ctc_rows_ws_bytes(p, Bg, max_chunk));
   for (int k = 0; k < n_chunks; ++k) {
     m->run_acoustic_chunk(m->ws_feats.as<float>(), d_nf, Bg, t_max, cb[k], cb[k + 1] - cb[k], sl.probs.as<float>());  // marks 1, 2, 3
     mark(m, -1);
@@ -729,7 +729,7 @@ int STTX_DecoderNext(STTX_Decoder* d, const float* aProbs, unsigned int aStride,
     DevScorer ds = m->current_scorer(d->scorer, d->hot, d->hh, d->hb);
     int max_frames = 1;
     for (int i = 0; i < n; ++i) max_frames = std::max(max_frames, more[i]);
-    d->wide.reserve(ctc_wide_ws_bytes(d->p.beam, d->p.C, n, max_frames));
+    d->wide.reserve(ctc_rows_ws_bytes(d->p, n, max_frames));
     launch_ctc_next(d->p, ds, m->dev_alphabet, d->db.table.as<DecStream>(), n, d->probs.as<float>(), d->fbegin.as<int>(), d->fcount.as<int>(), m->stream,
                     max_frames, d->wide.p);
     HIP_CHECK(hipStreamSynchronize(m->stream));

@@ -140,15 +140,17 @@ struct DecodeOut {
   int num_results, max_len;
 };
 
-// `max_frames` = upper bound of frame_count[]; `wide_ws` = ctc_wide_ws_bytes(...) bytes of device memory when
-// ctc_is_wide(p.beam, p.C) (may be null otherwise).
+// `max_frames` = upper bound of frame_count[]; `wide_ws` = ctc_rows_ws_bytes(...) bytes of device memory: required when
+// ctc_is_wide(p.beam, p.C); optional otherwise (with it, the per-row class sort of C > cutoff_top_n alphabets -- byte mode --
+// runs row-parallel ahead of the search instead of inside every sequential step).
 void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
                      const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st,
                      int max_frames = 0, void* wide_ws = nullptr);
 bool ctc_is_wide(int beam, int C);
 size_t ctc_wide_row_bytes(int C);
-inline size_t ctc_wide_ws_bytes(int beam, int C, int n_streams, int max_frames) {
-  return ctc_is_wide(beam, C) ? (size_t)n_streams * (size_t)max_frames * ctc_wide_row_bytes(C) : 0;
+inline bool ctc_sorts_classes(const DecParams& p) { return p.cutoff_prob < 1.0 || p.cutoff_top_n < p.C; }  // :337
+inline size_t ctc_rows_ws_bytes(const DecParams& p, int n_streams, int max_frames) {
+  return (ctc_is_wide(p.beam, p.C) || ctc_sorts_classes(p)) ? (size_t)n_streams * (size_t)max_frames * ctc_wide_row_bytes(p.C) : 0;
 }
 // All outputs of a decode launch in ONE block (so they come back with one copy): [n_results | lens | confidence | tokens |
 // timesteps]; `view` points a DecodeOut into a block at `base` (device or host).

@@ -869,7 +869,14 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; sc[SC_NQ] = 0; }
   const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
   int cutoff_len = WIDE ? wh.cutoff_len : C;
-  if (!WIDE && sort_classes) {  // std::sort by probability, descending (ties: class index)
+  if (!WIDE && sort_classes && p.wide_rows) {  // class order prepared for all rows of the chunk by ctc_wide_rows_kernel
+    const WRow R = wide_row(p, (int)blockIdx.x, t_local);
+    cutoff_len = wide_hdr(p, (int)blockIdx.x, t_local)->cutoff_len;
+    for (int c = tid; c < C; c += NTHREADS) { L.cls[c] = R.cls[c]; L.pos[c] = R.pos[c]; }
+    __syncthreads();
+    lp = L.lps;  // log-probs by class *position*
+    for (int k = tid; k < cutoff_len; k += NTHREADS) lp[k] = L.lp[buf][L.cls[k]];
+  } else if (!WIDE && sort_classes) {  // std::sort by probability, descending (ties: class index)
     for (int c = tid; c < C; c += NTHREADS) {
       const float v = pf[c];
       int rank = 0;
@@ -1530,8 +1537,8 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
   DecParams p = p_in;
   const bool wide = ctc_is_wide(p.beam, p.C);
   p.wide_rows = nullptr; p.wide_stride = 0; p.wide_max_frames = 0;
-  if (wide) {
-    if (!wide_ws || max_frames <= 0 || p.C > STT_MAX_CLASSES) { fprintf(stderr, "stt_amd: launch_ctc_next: wide alphabet without a row workspace\n"); abort(); }
+  if (wide && (!wide_ws || max_frames <= 0 || p.C > STT_MAX_CLASSES)) { fprintf(stderr, "stt_amd: launch_ctc_next: wide alphabet without a row workspace\n"); abort(); }
+  if (wide || (ctc_sorts_classes(p) && wide_ws && max_frames > 0 && p.C <= WIDE_SORT_N)) {
     p.wide_rows = (const unsigned char*)wide_ws; p.wide_stride = ctc_wide_row_bytes(p.C); p.wide_max_frames = max_frames;
     hipLaunchKernelGGL(ctc_wide_rows_kernel, dim3(n_streams * max_frames), dim3(1024), 0, st, p, probs, frame_begin, frame_count);
   }

@@ -370,7 +370,7 @@ void StreamingState::processReady(bool flush_partial, bool final_flush) {
     p.C = C; p.blank = C - 1; p.beam = dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = T;  // stt.cc:539-540
     p.all_begin = 0; p.all_count = take;  // the frame range rides in the kernel arguments: no table upload, no host sync mid-hop
     DevScorer ds = m.current_scorer(scorer_, hot_words_, hot_hash, hot_boost);
-    m.ws_wide.reserve(ctc_wide_ws_bytes(p.beam, C, 1, take));
+    m.ws_wide.reserve(ctc_rows_ws_bytes(p, 1, take));
     launch_ctc_next(p, ds, m.dev_alphabet, dec.table.as<DecStream>(), 1, m.ws_probs.as<float>(), nullptr, nullptr, m.stream,
                     take, m.ws_wide.p);
     windows_done_ += take;
@@ -458,7 +458,7 @@ void streams_process(const std::vector<StreamingState*>& ss, bool flush_partial)
       launch_gather_streams(d_tp, m.sb_table.as<DecStream>(), B, m.stream);
       DecParams p{};
       p.C = C; p.blank = C - 1; p.beam = R[g0]->dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = T;  // stt.cc:539-540
-      m.ws_wide.reserve(ctc_wide_ws_bytes(p.beam, C, B, T));
+      m.ws_wide.reserve(ctc_rows_ws_bytes(p, B, T));
       launch_ctc_next(p, ds, m.dev_alphabet, m.sb_table.as<DecStream>(), B, m.ws_probs.as<float>(), d_int + 2 * B, d_int + B, m.stream, T, m.ws_wide.p);
       launch_scatter_streams(d_tp, m.sb_table.as<DecStream>(), B, m.stream);
       HIP_CHECK(hipStreamSynchronize(m.stream));  // the page-locked table is reused by the next group
