@@ -1,0 +1,73 @@
+"""Cross-checks of the acoustic restatement (oracle/am_ref.py).  The reference pins nothing at this boundary (TensorFlow
+Lite is an un-vendored submodule, SURVEY.md 8c: "parity unpinned"), so these are independent re-derivations, not pins
+against the reference: the layer stack written a second time with torch's own Linear / LSTMCell kernels (gate order
+re-mapped: TensorFlow i, j, f, o -> torch i, f, g, o), and the spectrogram against a direct FFT (scipy)."""
+import numpy as np
+import torch
+
+from oracle import am_ref
+
+
+def test_layer_stack_against_torch_lstmcell():
+    H, C, T = 64, 29, 23
+    w = am_ref.synth_weights(7, n_hidden=H, n_classes=C)
+    w["layer_6/weights"] = (w["layer_6/weights"] * 5.0).astype(np.float32)
+    rng = np.random.default_rng(1)
+    windows = (rng.standard_normal((T, 494)) * 3.0).astype(np.float32)
+    c0 = (rng.standard_normal(H) * 0.3).astype(np.float32); h0 = (rng.standard_normal(H) * 0.3).astype(np.float32)
+    want, c_ref, h_ref = am_ref.am_forward(windows, w, c0=c0, h0=h0)
+
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))
+    clip = lambda a: torch.clamp(a, 0.0, am_ref.RELU_CLIP)                         # deepspeech_model.py:82-86
+    x = t(windows)
+    for k in ("layer_1", "layer_2", "layer_3"):
+        x = clip(x @ t(w[k + "/weights"]) + t(w[k + "/bias"]))
+    cell = torch.nn.LSTMCell(H, H, bias=True, dtype=torch.float64)
+    K, b = w["lstm/kernel"].astype(np.float64), w["lstm/bias"].astype(np.float64)  # [2H, 4H], columns i | j | f | o
+    i_, j_, f_, o_ = [K[:, g * H:(g + 1) * H] for g in range(4)]
+    bi, bj, bf, bo = [b[g * H:(g + 1) * H] for g in range(4)]
+    Kt = np.concatenate([i_, f_, j_, o_], axis=1)                                   # torch rows: i, f, g (= j), o
+    with torch.no_grad():
+        cell.weight_ih.copy_(t(Kt[:H].T)); cell.weight_hh.copy_(t(Kt[H:].T))
+        cell.bias_ih.copy_(t(np.concatenate([bi, bf, bj, bo]))); cell.bias_hh.zero_()
+        h, c = t(h0)[None], t(c0)[None]
+        hs = []
+        for step in range(T):
+            h, c = cell(x[step][None], (h, c))
+            hs.append(h[0])
+        hs = torch.stack(hs)
+        l5 = clip(hs @ t(w["layer_5/weights"]) + t(w["layer_5/bias"]))
+        probs = torch.softmax(l5 @ t(w["layer_6/weights"]) + t(w["layer_6/bias"]), dim=1).numpy()
+    assert np.abs(probs - want).max() < 1e-6
+    assert np.abs(c.numpy()[0] - c_ref).max() < 1e-9 and np.abs(h.numpy()[0] - h_ref).max() < 1e-9
+
+
+def test_power_spectrum_and_frame_count_against_scipy_fft():
+    import scipy.fft
+    rng = np.random.default_rng(3)
+    audio = (rng.standard_normal(16000) * 3000).astype(np.int16)
+    spec = am_ref.MfccSpec()
+    feats = am_ref.mfcc_utterance(audio)
+    assert feats.shape == (am_ref.n_frames_for(len(audio)), 26)                     # stt.cc frame bookkeeping
+    # frame 5 by hand: periodic Hann, 512-point FFT, |X|^2 as float32, sqrt, mel, ln, DCT-II
+    f = 5
+    x = audio[f * 320:f * 320 + 512].astype(np.float32) * np.float32(1.0 / 32768.0)
+    X = scipy.fft.rfft(x.astype(np.float64) * spec.window)
+    amp = np.sqrt((X.real ** 2 + X.imag ** 2).astype(np.float32).astype(np.float64))
+    mel = np.zeros(40)
+    hz_per_bin = 0.5 * 16000 / 256
+    melf = lambda hz: 1127.0 * np.log1p(hz / 700.0)
+    lo, hi = melf(20.0), melf(8000.0)
+    centers = lo + (hi - lo) / 41 * (np.arange(41) + 1)
+    for i in range(int(1.5 + 20.0 / hz_per_bin), int(8000.0 / hz_per_bin) + 1):
+        m = melf(i * hz_per_bin)
+        ch = int(np.searchsorted(centers, m, side="right")) - 1                     # band whose centre is just below the bin
+        below = lo if ch < 0 else centers[ch]
+        wgt = (centers[ch + 1] - m) / (centers[ch + 1] - below)                     # share of the lower band
+        if ch >= 0:
+            mel[ch] += amp[i] * wgt
+        if ch + 1 < 40:
+            mel[ch + 1] += amp[i] * (1.0 - wgt)
+    logmel = np.log(np.maximum(mel, 1e-12))
+    dct = np.sqrt(2.0 / 40) * np.cos(np.pi / 40 * np.outer(np.arange(26), np.arange(40) + 0.5))
+    assert np.abs(dct @ logmel - feats[f]).max() < 1e-4
