@@ -61,7 +61,7 @@ def test_fuzz_decoder_against_port(rigs, port, fix, mode, lm):
     m, P, labels, space = rigs[(mode, lm)]
     C = len(labels) + 1
     vocab = open(os.path.join(fix, "vocab.pruned.txt")).read().split()
-    rng = np.random.RandomState({"word": 100, "bytes": 200}[mode] + int(lm))
+    rng = np.random.RandomState({"word": 100, "bytes": 200}[mode] + int(lm) + 1000 * int(os.environ.get("STT_FUZZ_SEED", "0")))  # (other seeds: more cases)
     beams = [1, 2, 3, 7, 16, 63, 64, 65, 100, 128, 129, 257, 500, 513] if mode == "word" else [1, 5, 64, 65, 200, 300]
     n_cases = 90 if mode == "word" else 30
     for case in range(n_cases):
