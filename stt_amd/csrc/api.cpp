@@ -20,22 +20,12 @@ const char* kVersion = "1.4.0";  // training/coqui_stt_training/VERSION of the r
 // Stage timing with HIP events on the engine's own streams.  A mark says "stage `id` starts now on this stream"; the time
 // up to the next mark on the same stream is charged to that stage (id < 0 = idle / end).  Stage ids: 0 features,
 // 1 dense layers 1-3 + x-projection, 2 LSTM recurrence, 3 layers 5-6 + softmax, 4 decoder next, 5 decoder decode + D2H.
-struct Prof {
-  bool on = false;
-  bool phase_cycles = false;  // level 2: also the search kernel's per-phase cycle counters
-  std::vector<hipEvent_t> pool;
-  size_t used = 0;
-  std::vector<std::pair<int, hipEvent_t>> marks[3];  // [0] = acoustic stream, [1], [2] = the two groups' search streams
-  float ms[8] = {};
-  unsigned long long dec_stats[4] = {};
-  unsigned long long dec_phase[8] = {};
-};
-std::unordered_map<ModelState*, Prof> g_prof;
+// (struct Prof lives in ModelState, engine.h: two models may run on two threads)
 // live models: a stream freed after its model (a caller error the reference happens to survive) must not touch the model
 std::mutex g_models_mu;
 std::unordered_map<ModelState*, int> g_models;
 
-Prof& prof_of(ModelState* m) { return g_prof[m]; }
+Prof& prof_of(ModelState* m) { return m->prof_; }
 void mark_on(ModelState* m, int id, int which, hipStream_t st) {
   Prof& p = prof_of(m);
   if (!p.on) return;
@@ -344,8 +334,6 @@ int STT_SetModelBeamWidth(ModelState* aCtx, unsigned int aBeamWidth) { aCtx->bea
 int STT_GetModelSampleRate(const ModelState* aCtx) { return aCtx->g.sample_rate; }
 void STT_FreeModel(ModelState* ctx) {
   if (!ctx) return;
-  auto it = g_prof.find(ctx);
-  if (it != g_prof.end()) { for (auto e : it->second.pool) (void)hipEventDestroy(e); g_prof.erase(it); }
   { std::lock_guard<std::mutex> lk(g_models_mu); g_models.erase(ctx); }
   delete ctx;
 }

@@ -131,6 +131,18 @@ struct DecoderBatch {
 };
 
 struct StreamingState;
+// Stage timing of the batch path (STTX_SetProfiling / STTX_GetStageTimes): HIP-event marks per stream (api.cpp)
+struct Prof {
+  bool on = false;
+  bool phase_cycles = false;  // level 2: also the search kernel's per-phase cycle counters
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  std::vector<std::pair<int, hipEvent_t>> marks[3];  // [0] = acoustic stream, [1], [2] = the two groups' search streams
+  float ms[8] = {};
+  unsigned long long dec_stats[4] = {};
+  unsigned long long dec_phase[8] = {};
+  ~Prof() { for (auto e : pool) (void)hipEventDestroy(e); }
+};
 struct ModelState {
   Geometry g;
   Alphabet alphabet_;
@@ -158,6 +170,7 @@ struct ModelState {
   // Finished streams are parked here with their HBM buffers (frames, LSTM state, decoder slab: seven allocations) and
   // handed out again by STT_CreateStream: a server that opens a stream per utterance pays hipMalloc/hipFree once per
   // concurrent stream, not once per utterance.
+  Prof prof_;
   std::vector<StreamingState*> stream_pool_;
   std::mutex stream_pool_mu_;
   // page-locked staging of the streaming path's audio: a feed returns without waiting for its copy; a slot is reused
