@@ -1,3 +1,6 @@
+"""oracle/dev_compare_port_vs_ref.py -- TEST INFRASTRUCTURE ONLY (development aid, runs only where /root/reference exists):
+times and compares the C port against the real reference decoder on ad-hoc cases; the committed form of this check is
+tests/test_oracle_port.py and tests/test_oracle_fuzz.py."""
 import sys, time, numpy as np
 sys.path.insert(0, '/root/repo')
 from oracle import ref, port
