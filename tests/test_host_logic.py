@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import am_ref
+from conftest import ROOT
 from stt_amd import modelfile, synth
 
 
@@ -123,3 +124,26 @@ def test_am_oracle_self_consistency():
         parts.append(p)
     np.testing.assert_allclose(np.concatenate(parts), full, atol=1e-6)
     assert np.allclose(full.sum(1), 1.0, atol=1e-5)
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under stt_amd/ (python or C++) or include/ may import, include or link it; only
+    tests/, bench.py's cpu_baseline leg and __graft_entry__ do."""
+    import re
+    bad = []
+    for base in ("stt_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            if "lib" in dirpath.split(os.sep) or "__pycache__" in dirpath:
+                continue
+            for f in files:
+                if not f.endswith((".py", ".cpp", ".hip", ".h", ".c")):
+                    continue
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|#include\s+[\"<][^\">]*oracle/|libstt_oracle|libctcdecode_ref", src, re.M):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("from oracle import") >= 1
+    # ... and in bench.py only inside cpu_baseline()
+    body = bench.split("def cpu_baseline", 1)[1].split("\ndef ", 1)[0]
+    assert bench.count("from oracle import") == body.count("from oracle import")
