@@ -126,6 +126,15 @@ STTX_EXPORT int STTX_TestDense(int aM, int aN, int aK, const float* aX, const fl
                               int aEpilogue, float* aY);
 /* Device expf/logf/log_sum_exp of sttmath.h over arrays (aOp 0 = expf, 1 = logf, 2 = log_sum_exp(a, b)). */
 STTX_EXPORT int STTX_TestMath(int aOp, const float* aA, const float* aB, float* aOut, unsigned int aCount);
+/* KenLM FullScore (kenlm/lm/model.cc:170-176) over aNumWords words, the state carried from BeginSentence (aBos) or the null
+ * context, on a bare KenLM trie binary: aProbs[i] = log10 probability, aLens[i] = matched n-gram length of word i
+ * (lm::FullScoreReturn).  aMode 0 = the hashed n-gram index on the host (no GPU needed), 1 = the device trie walk,
+ * 2 = the device index lookup (four lanes per query, as in the search kernel). */
+STTX_EXPORT int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* const* aWords, unsigned int aNumWords, int aBos,
+                           int aMode, float* aProbs, int* aLens);
+/* Test hook: decoder arenas are sized for aFrames timesteps and never grow (0 = normal sizing), so that the overflow
+ * reporting of the decode calls can be exercised. */
+STTX_EXPORT int STTX_DebugLimitArena(int aFrames);
 /* Host-side packing of the recurrent matrix (no GPU needed): aKernel [2H][4H] f32 -> aOut [4H*H] f16 bits. */
 STTX_EXPORT int STTX_PackLstmRecurrent(const float* aKernel, int aHidden, unsigned short* aOut);
 

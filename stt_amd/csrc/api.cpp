@@ -12,6 +12,7 @@
 
 #include "../../include/stt_amd.h"
 #include "engine.h"
+#include "scorer_host.h"
 
 namespace {
 int g_device = 0;
@@ -218,6 +219,7 @@ void batch_collect_group(ModelState* m, ModelState::GroupSlot& sl, std::vector<s
   const uint32_t *tok = h.tokens, *ts = h.timesteps;
   const int *lens = h.lens, *nres = h.n_results;
   const double* conf = h.confidence;
+  check_decoder_errors(h.errors, sl.Bg);
   for (int i = 0; i < sl.Bg; ++i) {
     std::vector<Output>& dst = all[sl.idx[i]];
     for (int r = 0; r < nres[i]; ++r) {
@@ -259,13 +261,20 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
   std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return sizes[x] > sizes[y]; });
   const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
   int pending = -1, gi = 0;
-  for (unsigned g0 = 0; g0 < B; g0 += 64, ++gi) {
-    const std::vector<unsigned> idx(order.begin() + g0, order.begin() + std::min(B, g0 + 64));
-    batch_enqueue_group(m, m->slots_[gi & 1], d_audio, stride, sizes, idx, num_results, ds);
+  try {
+    for (unsigned g0 = 0; g0 < B; g0 += 64, ++gi) {
+      const std::vector<unsigned> idx(order.begin() + g0, order.begin() + std::min(B, g0 + 64));
+      batch_enqueue_group(m, m->slots_[gi & 1], d_audio, stride, sizes, idx, num_results, ds);
+      if (pending >= 0) batch_collect_group(m, m->slots_[pending & 1], all, pr);
+      pending = gi;
+    }
     if (pending >= 0) batch_collect_group(m, m->slots_[pending & 1], all, pr);
-    pending = gi;
+  } catch (...) {  // nothing of this call may still be running on the slots' buffers when the caller sees the failure
+    (void)hipStreamSynchronize(m->stream);
+    for (auto& sl : m->slots_) if (sl.stream_dec) (void)hipStreamSynchronize(sl.stream_dec);
+    if (pr.on) prof_reset(pr);
+    throw;
   }
-  if (pending >= 0) batch_collect_group(m, m->slots_[pending & 1], all, pr);
   if (pr.on) {
     HIP_CHECK(hipStreamSynchronize(m->stream));
     for (auto& sl : m->slots_) HIP_CHECK(hipStreamSynchronize(sl.stream_dec));
@@ -276,6 +285,8 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
 }  // namespace
 
 void launch_test_math(int op, const float* a, const float* b, float* out, unsigned n, hipStream_t st);  // ctc.hip
+void launch_test_lm(const DevScorer& s, const uint64_t* hashes, int n, int bos, int use_index, float* probs, int* lens, hipStream_t st);
+uint64_t stt_murmur64a(const void* key, size_t len);
 
 // hooks used by engine.cpp for the profiling marks inside run_acoustic_rows
 void stt_prof_mark(ModelState* m, int i) { mark(m, i); }
@@ -330,7 +341,12 @@ int STT_CreateModel(const char* aModelPath, ModelState** retval) {
 }
 
 unsigned int STT_GetModelBeamWidth(const ModelState* aCtx) { return aCtx->beam_width_; }
-int STT_SetModelBeamWidth(ModelState* aCtx, unsigned int aBeamWidth) { aCtx->beam_width_ = aBeamWidth; return 0; }
+int STT_SetModelBeamWidth(ModelState* aCtx, unsigned int aBeamWidth) {
+  // (the reference stores any value; here the beam lives in LDS, so the width is checked when it is set, not at the next STT_CreateStream)
+  if (aBeamWidth < 1 || aBeamWidth > STT_MAX_BEAM) return STT_ERR_INVALID_SHAPE;
+  aCtx->beam_width_ = aBeamWidth;
+  return STT_ERR_OK;
+}
 int STT_GetModelSampleRate(const ModelState* aCtx) { return aCtx->g.sample_rate; }
 void STT_FreeModel(ModelState* ctx) {
   if (!ctx) return;
@@ -387,22 +403,22 @@ void STT_FeedAudioContent(StreamingState* aSctx, const short* aBuffer, unsigned 
 }
 char* STT_IntermediateDecode(const StreamingState* aSctx) {
   char* r = nullptr;
-  guarded([&]() { r = decode_string(aSctx); return 0; }, 0);
+  guarded([&]() { HIP_CHECK(hipSetDevice(aSctx->model_->device)); r = decode_string(aSctx); return 0; }, 0);
   return r;
 }
 Metadata* STT_IntermediateDecodeWithMetadata(const StreamingState* aSctx, unsigned int aNumResults) {
   Metadata* r = nullptr;
-  guarded([&]() { r = decode_metadata(aSctx, aNumResults); return 0; }, 0);
+  guarded([&]() { HIP_CHECK(hipSetDevice(aSctx->model_->device)); r = decode_metadata(aSctx, aNumResults); return 0; }, 0);
   return r;
 }
 char* STT_IntermediateDecodeFlushBuffers(StreamingState* aSctx) {
   char* r = nullptr;
-  guarded([&]() { aSctx->flushBuffers(false); r = decode_string(aSctx); return 0; }, 0);
+  guarded([&]() { HIP_CHECK(hipSetDevice(aSctx->model_->device)); aSctx->flushBuffers(false); r = decode_string(aSctx); return 0; }, 0);
   return r;
 }
 Metadata* STT_IntermediateDecodeWithMetadataFlushBuffers(StreamingState* aSctx, unsigned int aNumResults) {
   Metadata* r = nullptr;
-  guarded([&]() { aSctx->flushBuffers(false); r = decode_metadata(aSctx, aNumResults); return 0; }, 0);
+  guarded([&]() { HIP_CHECK(hipSetDevice(aSctx->model_->device)); aSctx->flushBuffers(false); r = decode_metadata(aSctx, aNumResults); return 0; }, 0);
   return r;
 }
 void STT_FreeStream(StreamingState* aSctx) {
@@ -465,13 +481,13 @@ char** STTX_FinishStreamBatch(StreamingState* const* aStreams, unsigned int aCou
 
 char* STT_FinishStream(StreamingState* aSctx) {
   char* r = nullptr;
-  guarded([&]() { aSctx->flushBuffers(true); r = decode_string(aSctx); return 0; }, 0);
+  guarded([&]() { HIP_CHECK(hipSetDevice(aSctx->model_->device)); aSctx->flushBuffers(true); r = decode_string(aSctx); return 0; }, 0);
   STT_FreeStream(aSctx);
   return r;
 }
 Metadata* STT_FinishStreamWithMetadata(StreamingState* aSctx, unsigned int aNumResults) {
   Metadata* r = nullptr;
-  guarded([&]() { aSctx->flushBuffers(true); r = decode_metadata(aSctx, aNumResults); return 0; }, 0);
+  guarded([&]() { HIP_CHECK(hipSetDevice(aSctx->model_->device)); aSctx->flushBuffers(true); r = decode_metadata(aSctx, aNumResults); return 0; }, 0);
   STT_FreeStream(aSctx);
   return r;
 }
@@ -749,6 +765,7 @@ int STTX_DecoderBeam(const STTX_Decoder* d, unsigned int aStream, float* aScore,
   int n = 0;
   guarded([&]() {
     ModelState* m = d->m;
+    HIP_CHECK(hipSetDevice(m->device));
     DecStream S;
     HIP_CHECK(hipMemcpy(&S, d->db.table.as<DecStream>() + aStream, sizeof(DecStream), hipMemcpyDeviceToHost));
     n = std::min<int>(S.n, (int)aCap);
@@ -763,6 +780,7 @@ int STTX_DecoderBeam(const STTX_Decoder* d, unsigned int aStream, float* aScore,
 }
 int STTX_DecoderStats(const STTX_Decoder* d, unsigned long long* aOut4) {
   return guarded([&]() {
+    HIP_CHECK(hipSetDevice(d->m->device));
     std::vector<DecStream> tb(d->db.n_streams);
     HIP_CHECK(hipMemcpy(tb.data(), d->db.table.p, sizeof(DecStream) * tb.size(), hipMemcpyDeviceToHost));
     for (int k = 0; k < 4; ++k) aOut4[k] = 0;
@@ -839,6 +857,45 @@ int STTX_ReadModelTensor(const char* aModelBuffer, unsigned int aBufferSize, int
   if (aBytes) *aBytes = n;
   if (aOut && src) memcpy(aOut, src, (size_t)std::min(n, aCapBytes));
   return STT_ERR_OK;
+}
+
+int STTX_DebugLimitArena(int aFrames) { g_debug_arena_frames = aFrames; return STT_ERR_OK; }
+
+int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* const* aWords, unsigned int aNumWords, int aBos, int aMode, float* aProbs, int* aLens) {
+  return guarded([&]() {
+    if (aMode == 0) {  // host: parse + hashed index + FullScore chain, no GPU
+      std::vector<char> copy((size_t)aLmBytes + 16, 0);
+      memcpy(copy.data(), aLm, aLmBytes);
+      HostScorer hs;
+      const int rc = parse_scorer(reinterpret_cast<const uint8_t*>(copy.data()), aLmBytes, -1, true, hs);
+      if (rc != STT_ERR_OK) return rc;
+      if (!hs.lmi_ok) return (int)STT_ERR_SCORER_INVALID_LM;
+      KState st[2] = {};
+      int cur = 0;
+      if (aBos) { st[0].length = 1; st[0].words[0] = hs.bos_index; st[0].backoff[0] = hs.bos_backoff; }
+      for (unsigned i = 0; i < aNumWords; ++i) {
+        int nl = 0; uint32_t wi = 0;
+        aProbs[i] = hs.full_score_indexed(st[cur], aWords[i], strlen(aWords[i]), st[cur ^ 1], nl, wi);
+        aLens[i] = nl;
+        cur ^= 1;
+      }
+      return (int)STT_ERR_OK;
+    }
+    HIP_CHECK(hipSetDevice(g_device));
+    ScorerDev sc;
+    const int rc = sc.LoadLmOnly(aLm, aLmBytes);
+    if (rc != STT_ERR_OK) return rc;
+    if (aMode == 2 && (!sc.dev.lmi || sc.dev.order > 5 || !sc.dev.uni_in_vtab)) return (int)STT_ERR_SCORER_INVALID_LM;
+    std::vector<uint64_t> hs(aNumWords);
+    for (unsigned i = 0; i < aNumWords; ++i) hs[i] = stt_murmur64a(aWords[i], strlen(aWords[i]));
+    DevBuf dh, dp, dl;
+    dh.upload(hs.data(), hs.size() * 8); dp.reserve((size_t)aNumWords * 4); dl.reserve((size_t)aNumWords * 4);
+    launch_test_lm(sc.dev, dh.as<uint64_t>(), (int)aNumWords, aBos, aMode == 2 ? 1 : 0, dp.as<float>(), dl.as<int>(), nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(aProbs, dp.p, (size_t)aNumWords * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(aLens, dl.p, (size_t)aNumWords * 4, hipMemcpyDeviceToHost));
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
 }
 
 int STTX_PackLstmRecurrent(const float* aKernel, int aHidden, unsigned short* aOut) {

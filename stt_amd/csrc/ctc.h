@@ -74,6 +74,14 @@ struct DevScorer {
   const uint32_t* fst_state_pos;
   const uint2* fst_arcs;
   const uint8_t* fst_has_space;  // word mode: state has an out-arc for the space label (a word may end here)
+  // per state {index of its first arc with a label >= 1, bitmap of the labels 1..32 on its arcs (bit c = label c + 1)};
+  // null when some state's arcs are not strictly ascending by label (the rank of a label's bit is then not its arc)
+  const uint2* fst_rec;
+  // hashed n-gram index over the trie (lmindex.h); null = not built (vocabulary >= 2^27 words, inconsistent trie)
+  const struct LmiEntry* lmi;
+  uint32_t lmi_buckets;
+  float unk_prob, unk_backoff;  // unigram record of <unk> (word index 0)
+  int unk_indep;                // ... and whether it has no children
   // hot words (murmur hashes of the words)
   int n_hot;
   const uint64_t* hot_hash;
@@ -92,7 +100,9 @@ struct DecStream {
   int n;                // live prefixes
   int abs_t;            // abs_time_step_
   int start_expanding;  // ctc_beam_search_decoder.cpp:125-132
-  int error;            // bit0: path arena full, bit1: time arena full, bit2: candidate workspace full, bit3: scorer cache state lost
+  int error;            // bit0: path arena full, bit1: time arena full, bit2: candidate workspace full, bit3: scorer cache state lost /
+                        // boundary-entry arena full, bit4: a path-hash hit was not the child it stood for.  Sticky; every decode call
+                        // reports it (STT_* return NULL / STT_ERR_FAIL_RUN_SESS instead of a transcript from a damaged beam)
   uint32_t pa_n, ta_n, pa_cap, ta_cap;
   // beam arrays [beam_cap]
   float *score, *pb, *pnb;
@@ -129,6 +139,7 @@ struct DecParams {
   const unsigned char* wide_rows;
   unsigned long long wide_stride;
   int wide_max_frames;
+  int n_lm_waves;  // fast word path: waves of the workgroup that only run language-model queries (filled in by launch_ctc_next)
 };
 
 struct DecodeOut {
@@ -137,6 +148,7 @@ struct DecodeOut {
   int* lens;            // [n_streams][num_results]
   double* confidence;   // [n_streams][num_results]
   int* n_results;       // [n_streams]
+  int* errors;          // [n_streams] DecStream::error of the stream (0 = its search state is intact)
   int num_results, max_len;
 };
 
@@ -149,24 +161,24 @@ void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& 
 bool ctc_is_wide(int beam, int C);
 size_t ctc_wide_row_bytes(int C);
 inline bool ctc_sorts_classes(const DecParams& p) { return p.cutoff_prob < 1.0 || p.cutoff_top_n < p.C; }  // :337
-inline size_t ctc_rows_ws_bytes(const DecParams& p, int n_streams, int max_frames) {
-  return (ctc_is_wide(p.beam, p.C) || ctc_sorts_classes(p)) ? (size_t)n_streams * (size_t)max_frames * ctc_wide_row_bytes(p.C) : 0;
+inline size_t ctc_rows_ws_bytes(const DecParams& p, int n_streams, int max_frames) {  // (<= 32 classes: the fast word path reads row records as well)
+  return (ctc_is_wide(p.beam, p.C) || ctc_sorts_classes(p) || p.C <= 32) ? (size_t)n_streams * (size_t)max_frames * ctc_wide_row_bytes(p.C) : 0;
 }
-// All outputs of a decode launch in ONE block (so they come back with one copy): [n_results | lens | confidence | tokens |
+// All outputs of a decode launch in ONE block (so they come back with one copy): [n_results | errors | lens | confidence | tokens |
 // timesteps]; `view` points a DecodeOut into a block at `base` (device or host).
 struct DecodeBlock {
-  size_t off_n, off_len, off_conf, off_tok, off_ts, bytes;
+  size_t off_n, off_err, off_len, off_conf, off_tok, off_ts, bytes;
   static DecodeBlock layout(int n_streams, int num_results, int max_len) {
     DecodeBlock b{};
     const size_t nr = (size_t)n_streams * num_results;
-    b.off_n = 0; b.off_len = (size_t)n_streams * 4; b.off_conf = (b.off_len + nr * 4 + 7) & ~(size_t)7;
+    b.off_n = 0; b.off_err = (size_t)n_streams * 4; b.off_len = (size_t)n_streams * 8; b.off_conf = (b.off_len + nr * 4 + 7) & ~(size_t)7;
     b.off_tok = b.off_conf + nr * 8; b.off_ts = b.off_tok + nr * max_len * 4; b.bytes = b.off_ts + nr * max_len * 4;
     return b;
   }
   DecodeOut view(void* base, int num_results, int max_len) const {
     unsigned char* p = (unsigned char*)base;
     DecodeOut o{};
-    o.n_results = (int*)(p + off_n); o.lens = (int*)(p + off_len); o.confidence = (double*)(p + off_conf);
+    o.n_results = (int*)(p + off_n); o.errors = (int*)(p + off_err); o.lens = (int*)(p + off_len); o.confidence = (double*)(p + off_conf);
     o.tokens = (uint32_t*)(p + off_tok); o.timesteps = (uint32_t*)(p + off_ts); o.num_results = num_results; o.max_len = max_len;
     return o;
   }

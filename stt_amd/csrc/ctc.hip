@@ -23,7 +23,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
 #include "ctc.h"
+#include "lmindex.h"
 #include "sttmath.h"
 
 using sttm::stt_log_sum_exp;
@@ -54,6 +59,7 @@ struct GStream {
   GLB_AS uint32_t* pq;
   GLB_AS u32x4* be;          // BEntry = 4 x 16 bytes
   GLB_AS float* c_logp; GLB_AS uint32_t* c_pi; GLB_AS int* c_fst; GLB_AS uint64_t* sel_keys;
+  GLB_AS unsigned long long* c_key;  // fast word path: {slot in the segment array, segment} of the elements beyond two per thread
   const uint2* pa_generic;   // for the uncached scorer paths
   uint32_t cand_cap, pa_cap, ta_cap, be_cap;
 };
@@ -204,7 +210,7 @@ __device__ __forceinline__ uint32_t vocab_slot(const DevScorer& s, uint64_t h, D
 // GenericModel::FullScore (model.cc:170-176) = ScoreExceptBackoff (:285-310) + ResumeScore (:312-338).
 // Written with compile-time indices only (fully unrolled over KENLM_MAX_ORDER) so that both states stay in registers.
 __device__ __forceinline__ float kenlm_full_score(const DevScorer& s, const KState& in, uint32_t new_word, KState& out, unsigned& probes,
-                                                  const DevVocabSlot* uni = nullptr) {
+                                                  const DevVocabSlot* uni = nullptr, int* ngram_length = nullptr) {
   KNode node;
   float prob;
   if (uni) {  // unigram record copied into the vocabulary slot at load time
@@ -237,6 +243,7 @@ __device__ __forceinline__ float kenlm_full_score(const DevScorer& s, const KSta
     }
   }
   (void)at_longest;
+  if (ngram_length) *ngram_length = nl;
   out.length = out_len;
 #pragma unroll
   for (int i = 0; i < STT_KENLM_MAX_ORDER - 1; ++i)
@@ -589,6 +596,7 @@ struct Lds {
   DB<uint32_t> ch, node, ts, bnd;
   DB<int> fst;
   DB<uint32_t> a0; DB<uint16_t> an;    // out-arcs of the prefix's dictionary state: first arc, count (read when the beam is written)
+  DB<uint32_t> sm;                     // fast word path: bitmap of the labels on those arcs (same storage as `an`; a0 = first labelled arc)
   DB<uint64_t> key;
   // word mode, narrow beams: the UTF-8 bytes of the prefix's current (unfinished) word, first byte lowest (wlo = bytes
   // 0..7, whi = 8..15; all ones = longer than 16 bytes), and the BEntry of "prefix + boundary" once scored (STT_NONE before)
@@ -598,6 +606,8 @@ struct Lds {
   LDS_AS uint64_t* ht_key; LDS_AS uint16_t* ht_idx;  // path key -> beam index of the live prefixes (rebuilt whenever the beam is written)
   DB<float> pf, lp; LDS_AS float* lps;        // emissions and their logs (double buffered: the next row is prepared one step ahead); lps = by class position when pruning sorts
   LDS_AS double* lbl;                         // [2] log((double)prob[blank])
+  LDS_AS float* pbl;                          // [2] prob[blank] (fast word path: the row arrives as a prepared record)
+  LDS_AS uint8_t* wait;                       // fast word path: live prefix whose extension event waits for a score of this step's LM waves
   LDS_AS uint16_t *cls, *pos;
   LDS_AS uint8_t* lab1;                       // [C] the byte of every single-byte label (0 otherwise)
   LDS_AS uint32_t *hist, *cumb;
@@ -613,7 +623,7 @@ struct Lds {
 };
 // phase cycle counters (s_memtime is a scalar memory operation with a wait: only on request, DecParams::phase_cycles)
 #define TICK(k) do { if (p.phase_cycles && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); L.acc[4 + (k)] += now_ - tick_; tick_ = now_; } } while (0)
-enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_COUNT = 16 };
+enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_CLAMP, SC_COUNT = 16 };
 #define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
 
@@ -629,11 +639,11 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   constexpr bool arcs = cap <= 512;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
-  size_t offs[72]; int k = 0;
+  size_t offs[76]; int k = 0;
   for (int d = 0; d < 2; ++d) {
     offs[k++] = take(cap * 8);                                     // key
     for (int a = 0; a < 8; ++a) offs[k++] = take(cap * 4);         // score pb pnb ch node ts fst bnd
-    offs[k++] = take(arcs ? cap * 4 : 0); offs[k++] = take(arcs ? cap * 2 : 0);  // a0, an (wide beams read the FST instead)
+    offs[k++] = take(arcs ? cap * 4 : 0); offs[k++] = take(arcs ? cap * 4 : 0);  // a0, an / sm (wide beams read the FST instead)
     offs[k++] = take(arcs ? cap * 8 : 0); offs[k++] = take(arcs ? cap * 8 : 0); offs[k++] = take(arcs ? cap * 4 : 0);  // wlo, whi, pqe
     offs[k++] = take(arcs ? cap * 4 : 0);                                                                              // pqs
   }
@@ -650,8 +660,10 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   offs[k++] = take(12 * 8);
   offs[k++] = take(SC_COUNT * 4);
   offs[k++] = take(16);                                            // lbl[2]
+  offs[k++] = take(16);                                            // pbl[2]
+  offs[k++] = take(arcs ? cap : 0);                                // wait
   // ---- class-count dependent from here on
-  for (int a = 0; a < 5; ++a) offs[k++] = take((size_t)C * 4);     // pf[2], lp[2], lps
+  for (int a = 0; a < 5; ++a) offs[k++] = take((size_t)(C > 0 && C < 32 ? 32 : C) * 4);  // pf[2], lp[2], lps (>= 32 floats: the fast word path reads a row as 8 x float4)
   offs[k++] = take((size_t)C * 2); offs[k++] = take((size_t)C * 2);
   offs[k++] = take((size_t)C);
   // candidate staging: whatever fits under 126 KiB (leaves 34 KiB for a co-resident LSTM workgroup), at most 2048
@@ -670,7 +682,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
     db(l->score, offs[1], true); db(l->pb, offs[2], true); db(l->pnb, offs[3], true);
     db(l->ch, offs[4], true); db(l->node, offs[5], true); db(l->ts, offs[6], true);
     db(l->fst, offs[7], true); db(l->bnd, offs[8], true);
-    db(l->a0, offs[9], arcs); db(l->an, offs[10], arcs);
+    db(l->a0, offs[9], arcs); db(l->an, offs[10], arcs); db(l->sm, offs[10], arcs);
     db(l->wlo, offs[11], arcs); db(l->whi, offs[12], arcs); db(l->pqe, offs[13], arcs); db(l->pqs, offs[14], arcs);
     k = 30;
     l->ev_self = (LDS_AS float*)(base + offs[k++]); l->ev_blank = (LDS_AS float*)(base + offs[k++]); l->ev_ext = (LDS_AS float*)(base + offs[k++]);
@@ -686,6 +698,8 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
     l->acc = (LDS_AS unsigned long long*)(base + offs[k++]);
     l->sc = (LDS_AS int*)(base + offs[k++]);
     l->lbl = (LDS_AS double*)(base + offs[k++]);
+    l->pbl = (LDS_AS float*)(base + offs[k++]);
+    l->wait = (LDS_AS uint8_t*)(base + offs[k++]);
     l->pf.p0 = (LDS_AS float*)(base + offs[k]); l->pf.blk = (uint32_t)(offs[k + 1] - offs[k]); k += 2;
     l->lp.p0 = (LDS_AS float*)(base + offs[k]); l->lp.blk = (uint32_t)(offs[k + 1] - offs[k]); k += 2;
     l->lps = (LDS_AS float*)(base + offs[k++]);
@@ -803,7 +817,7 @@ __device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, co
   const float NEG = STT_NEG_INF;
 #define LSE(x, y) sttm::stt_log_sum_exp_t((x), (y), L.exp_tab, L.log_tab)
   const float e_self = L.ev_self[j], e_blank = L.ev_blank[j], e_ext = L.ev_ext[j];
-  const uint32_t ei = L.ev_exti[j] & 0x7FFFFFFFu;
+  const uint32_t ei = L.ev_exti[j] & 0xFFFFu;  // parent beam index (bits 16..30: the label in the fast word path, bit 31: waits for a score)
   const uint32_t NOUP = 0xFFFFFFFEu;  // "no pending update" (previous_timesteps == nullptr)
   const uint32_t chj = L.ch[cur][j];
   const int kblank = WIDE ? (int)W.pos[p.blank] : (int)L.pos[p.blank];
@@ -1305,6 +1319,10 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   TICK(6);
 }
 
+#include "ctc_fast.inc"
+
+// MODE: 0 = no scorer, 1 = word-level scorer, 2 = utf8 (codepoint-level) scorer, 3 = word-level scorer on the fast path
+// of ctc_fast.inc (<= 32 classes, no class pruning, label bitmaps + hashed n-gram index available, CAP <= 512)
 template <int MODE, int CAP, bool WIDE>
 __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScorer s, DevAlphabet al, DecStream* streams,
                                                             const float* probs, const int* frame_begin, const int* frame_count) {
@@ -1319,27 +1337,37 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   GStream GS;
   GS.pa = (GLB_AS uint64_t*)G.pa; GS.ta = (GLB_AS uint64_t*)G.ta; GS.pq = (GLB_AS uint32_t*)G.pq; GS.be = (GLB_AS u32x4*)G.be;
   GS.c_logp = (GLB_AS float*)G.c_logp; GS.c_pi = (GLB_AS uint32_t*)G.c_pi; GS.c_fst = (GLB_AS int*)G.c_fst; GS.sel_keys = (GLB_AS uint64_t*)G.sel_keys;
+  GS.c_key = (GLB_AS unsigned long long*)G.c_key;
   GS.pa_generic = G.pa; GS.cand_cap = G.cand_cap; GS.pa_cap = G.pa_cap; GS.ta_cap = G.ta_cap; GS.be_cap = G.be_cap;
   GLB_AS float* g_score = (GLB_AS float*)G.score; GLB_AS float* g_pb = (GLB_AS float*)G.pb; GLB_AS float* g_pnb = (GLB_AS float*)G.pnb;
   GLB_AS uint32_t* g_ch = (GLB_AS uint32_t*)G.ch; GLB_AS uint32_t* g_node = (GLB_AS uint32_t*)G.node; GLB_AS uint32_t* g_ts = (GLB_AS uint32_t*)G.ts;
   GLB_AS int* g_fst = (GLB_AS int*)G.fst; GLB_AS uint64_t* g_key = (GLB_AS uint64_t*)G.key; GLB_AS uint32_t* g_bnd = (GLB_AS uint32_t*)G.bnd;
   constexpr bool SC_ON = MODE != 0;
+  constexpr bool FAST = MODE == 3, WORDC = MODE == 1 || MODE == 3;
   const int tid = threadIdx.x;
   int n = G.n;
   int cur = 0;
   int start_expanding = G.start_expanding;
   int abs_t = G.abs_t;
   const float* row = probs + ((size_t)blockIdx.x * p.t_max + (frame_begin ? frame_begin[blockIdx.x] : p.all_begin)) * p.C;
-  const float v0 = (!WIDE && tid < p.C) ? row[tid] : 0.0f;
+  const float v0 = (!WIDE && !FAST && tid < p.C) ? row[tid] : 0.0f;
   for (int i = tid; i < n; i += NTHREADS) {
     L.score[0][i] = g_score[i]; L.pb[0][i] = g_pb[i]; L.pnb[0][i] = g_pnb[i];
     L.ch[0][i] = g_ch[i]; L.node[0][i] = g_node[i]; L.ts[0][i] = g_ts[i]; const int st = g_fst[i]; L.fst[0][i] = st; L.key[0][i] = g_key[i];
     L.bnd[0][i] = g_bnd[i];
-    if (SC_ON && L.a0.p0) {
+    if (FAST) {
+      const uint2 rec = s.fst_rec[st];
+      L.a0[0][i] = rec.x; L.sm[0][i] = rec.y;
+    } else if (SC_ON && L.a0.p0) {
       const uint32_t f0 = s.fst_state_pos[st], f1 = s.fst_state_pos[st + 1];
       const uint32_t sp = MODE == 1 ? (uint32_t)s.fst_has_space[st] : 0u;
       L.a0[0][i] = f0; L.an[0][i] = (uint16_t)((f1 - f0) | (sp << 15));
     }
+  }
+  if (FAST) {  // what the fast step expects cleared on entry (it clears them again when it writes the new beam)
+    if (tid < CAP) { L.ev_self[tid] = absent(); L.ev_blank[tid] = absent(); L.ev_ext[tid] = absent(); L.ev_exti[tid] = 0; L.wait[tid] = 0; }
+    L.hist[tid] = 0;
+    if (tid == 0) { L.sc[SC_M] = 0; L.sc[SC_LMQ] = 0; L.sc[SC_NQ] = 0; L.sc[SC_PROBES] = 0; L.sc[SC_CLAMP] = 0; }
   }
   for (int c = tid; !WIDE && c < p.C; c += NTHREADS) {
     uint8_t one = 0;
@@ -1352,10 +1380,14 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   if (tid == 0) { L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
   if (tid < 12) L.acc[tid] = 0;
   __syncthreads();  // the math tables must be in place before the first row is prepared
-  if (!WIDE) prep_row(p, L, 0, row, v0);
+  const unsigned char* rec0 = FAST ? p.wide_rows + ((size_t)blockIdx.x * p.wide_max_frames) * p.wide_stride : nullptr;  // this stream's row records
+  if (FAST) {
+    if (tid < p.C) L.lp[0][tid] = reinterpret_cast<const float*>(rec0 + sizeof(WideRowHdr))[tid];
+    else if (tid == 64) { const WideRowHdr* hdr = reinterpret_cast<const WideRowHdr*>(rec0); L.pbl[0] = hdr->pblank; L.lbl[0] = hdr->lbl; }
+  } else if (!WIDE) prep_row(p, L, 0, row, v0);
   __syncthreads();
   const LDS_AS uint8_t* const lab1 = WIDE ? (const LDS_AS uint8_t*)nullptr : (const LDS_AS uint8_t*)L.lab1;
-  if (MODE == 1 && L.pqe.p0) {
+  if (WORDC && L.pqe.p0) {
     unsigned pr = 0;
     for (int i = tid; i < n; i += NTHREADS) {
       const uint32_t nd = L.node[0][i];
@@ -1368,8 +1400,13 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   }
   for (int i = tid; i < n; i += NTHREADS) ht_insert(L, L.key[0][i], i);
   __syncthreads();
-  for (int t = 0; t < nfr; ++t)
-    ctc_step<MODE, WIDE>(p, s, al, GS, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr, t);
+  if constexpr (FAST) {
+    for (int t = 0; t < nfr; ++t)
+      ctc_step_fast<CAP>(p, s, al, GS, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? rec0 + (size_t)(t + 1) * p.wide_stride : nullptr, p.n_lm_waves);
+  } else {
+    for (int t = 0; t < nfr; ++t)
+      ctc_step<MODE, WIDE>(p, s, al, GS, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr, t);
+  }
   for (int i = tid; i < n; i += NTHREADS) {
     g_score[i] = L.score[cur][i]; g_pb[i] = L.pb[cur][i]; g_pnb[i] = L.pnb[cur][i];
     g_ch[i] = L.ch[cur][i]; g_node[i] = L.node[cur][i]; g_ts[i] = L.ts[cur][i]; g_fst[i] = L.fst[cur][i]; g_key[i] = L.key[cur][i];
@@ -1451,7 +1488,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevSc
   }
   __syncthreads();
   const int nret = n < out.num_results ? n : out.num_results;
-  if (tid == 0) out.n_results[blockIdx.x] = nret;
+  if (tid == 0) { out.n_results[blockIdx.x] = nret; out.errors[blockIdx.x] = S.error; }
   // Back-tracking is a pointer chase through the arenas (one dependent HBM read per token), so each result gets two threads
   // -- tokens and timesteps -- and each chain is walked ONCE: entry k from the end goes to ring slot k % max_len and the
   // host puts the list the right way round (token j of len sits in slot (len-1-j) % max_len).
@@ -1532,39 +1569,74 @@ void launch_scatter_streams(DecStream* const* dst, const DecStream* src, int n, 
 }
 
 // ------------------------------------------------------------------------------------ launchers
+// Fast word path (ctc_fast.inc) when everything it relies on is there; STT_AMD_FAST=0 keeps the generic step (A/B runs).
+static bool ctc_fast_ok(const DecParams& p, const DevScorer& s, const DevAlphabet& al, bool have_rows) {
+  static const int allow = []() { const char* e = getenv("STT_AMD_FAST"); return e ? atoi(e) : 1; }();
+  return allow && have_rows && s.enabled && !s.utf8 && p.C <= 32 && p.C >= 2 && p.blank == p.C - 1 && !ctc_sorts_classes(p) && cap_bucket(p.beam) <= 512 &&
+         s.fst_rec != nullptr && s.lmi != nullptr && s.order <= 5 && s.uni_in_vtab && al.space_id >= 0 && al.space_id < p.C - 1 && al.n_labels == p.C - 1;
+}
+static void check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { fprintf(stderr, "stt_amd: %s: %s\n", what, hipGetErrorString(e)); throw std::runtime_error(std::string("kernel launch failed: ") + what); }
+}
 void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
                      const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st, int max_frames, void* wide_ws) {
   DecParams p = p_in;
   const bool wide = ctc_is_wide(p.beam, p.C);
-  p.wide_rows = nullptr; p.wide_stride = 0; p.wide_max_frames = 0;
+  p.wide_rows = nullptr; p.wide_stride = 0; p.wide_max_frames = 0; p.n_lm_waves = 0;
   if (wide && (!wide_ws || max_frames <= 0 || p.C > STT_MAX_CLASSES)) { fprintf(stderr, "stt_amd: launch_ctc_next: wide alphabet without a row workspace\n"); abort(); }
-  if (wide || (ctc_sorts_classes(p) && wide_ws && max_frames > 0 && p.C <= WIDE_SORT_N)) {
+  const int cb = cap_bucket(p.beam);
+  const bool fast = !wide && ctc_fast_ok(p, s, al, wide_ws != nullptr && max_frames > 0);
+  if (fast) {
+    p.wide_rows = (const unsigned char*)wide_ws; p.wide_stride = ctc_wide_row_bytes(p.C); p.wide_max_frames = max_frames;
+    static const int lmw = []() { const char* e = getenv("STT_AMD_LM_WAVES"); return e ? atoi(e) : 0; }();
+    int nlm = lmw > 0 ? lmw : (cb >= 512 ? 2 : 1);
+    while (nlm > 1 && ((cb / 64) % nlm != 0 || nlm > cb / 64)) --nlm;  // every LM wave scans whole 64-prefix slices of the beam
+    if (nlm > 4) nlm = 4;
+    p.n_lm_waves = nlm;
+    const int rows = n_streams * max_frames;
+    hipLaunchKernelGGL(ctc_rows_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, p, probs, frame_begin, frame_count, n_streams);
+    check_launch("ctc_rows_kernel");
+  } else if (wide || (ctc_sorts_classes(p) && wide_ws && max_frames > 0 && p.C <= WIDE_SORT_N)) {
     p.wide_rows = (const unsigned char*)wide_ws; p.wide_stride = ctc_wide_row_bytes(p.C); p.wide_max_frames = max_frames;
     hipLaunchKernelGGL(ctc_wide_rows_kernel, dim3(n_streams * max_frames), dim3(1024), 0, st, p, probs, frame_begin, frame_count);
+    check_launch("ctc_wide_rows_kernel");
   }
   const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : p.C);
-  const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : 1);
-  const int cb = cap_bucket(p.beam);
+  const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : (fast ? 3 : 1));
   const int ci = cb == 64 ? 0 : cb == 128 ? 1 : cb == 256 ? 2 : cb == 512 ? 3 : 4;
-  static size_t configured[2][3][5] = {};
+  // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: remember what was set per device
+  static std::mutex mu;
+  static size_t configured[16][2][4][5] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int di = dev & 15;
 #define STT_CTC_CASE(M, CI, CAPV, W)                                                                                         \
   if (mode == M && ci == CI && wide == W) {                                                                                  \
-    if (lds > configured[W][M][CI]) {                                                                                        \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_next_kernel<M, CAPV, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      configured[W][M][CI] = lds;                                                                                            \
+    {                                                                                                                        \
+      std::lock_guard<std::mutex> lk(mu);                                                                                    \
+      if (lds > configured[di][W][M][CI]) {                                                                                  \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_next_kernel<M, CAPV, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+          throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the search kernel");          \
+        configured[di][W][M][CI] = lds;                                                                                      \
+      }                                                                                                                      \
     }                                                                                                                        \
     hipLaunchKernelGGL((ctc_next_kernel<M, CAPV, W>), dim3(n_streams), dim3(NTHREADS), lds, st, p, s, al, streams, probs, frame_begin, frame_count); \
+    check_launch("ctc_next_kernel");                                                                                         \
     return;                                                                                                                  \
   }
 #define STT_CTC_MODE(M, W) STT_CTC_CASE(M, 0, 64, W) STT_CTC_CASE(M, 1, 128, W) STT_CTC_CASE(M, 2, 256, W) STT_CTC_CASE(M, 3, 512, W) STT_CTC_CASE(M, 4, 1024, W)
   STT_CTC_MODE(0, false) STT_CTC_MODE(1, false) STT_CTC_MODE(2, false)
   STT_CTC_MODE(0, true) STT_CTC_MODE(1, true) STT_CTC_MODE(2, true)
+  STT_CTC_CASE(3, 0, 64, false) STT_CTC_CASE(3, 1, 128, false) STT_CTC_CASE(3, 2, 256, false) STT_CTC_CASE(3, 3, 512, false)
 #undef STT_CTC_MODE
 #undef STT_CTC_CASE
+  throw std::runtime_error("launch_ctc_next: no kernel instance for this configuration");
 }
 void launch_ctc_decode(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const DecStream* streams, int n_streams,
                        const DecodeOut& out, hipStream_t st) {
   hipLaunchKernelGGL(ctc_decode_kernel, dim3(n_streams), dim3(NTHREADS), 0, st, p, s, al, streams, out);
+  check_launch("ctc_decode_kernel");
 }
 
 // ------------------------------------------------------------------------------------ sttmath.h test hook
@@ -1572,6 +1644,26 @@ __global__ void test_math_kernel(int op, const float* a, const float* b, float* 
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   out[i] = op == 0 ? sttm::stt_expf(a[i]) : op == 1 ? sttm::stt_logf(a[i]) : sttm::stt_log_sum_exp(a[i], b[i]);
+}
+// LM test hook: FullScore over a word sequence (state carried from BeginSentence or the null context), through the trie walk
+// (use_index 0, one lane) or through the hashed n-gram index (use_index 1, one quad) -- against answers of the real KenLM.
+__global__ void test_lm_kernel(DevScorer s, const uint64_t* hashes, int n, int bos, int use_index, float* probs, int* lens) {
+  if (threadIdx.x >= 4) return;
+  KState st[2] = {};
+  int cur = 0;
+  if (bos) { st[0].length = 1; st[0].words[0] = s.bos_index; st[0].backoff[0] = s.bos_backoff; }
+  unsigned probes = 0;
+  for (int i = 0; i < n; ++i) {
+    float prob; int nl = 0;
+    if (use_index) { uint32_t wi; prob = lm_full_score_quad(s, st[cur], hashes[i], st[cur ^ 1], wi, nl, probes); }
+    else { const uint32_t wi = vocab_index(s, hashes[i], probes); prob = kenlm_full_score(s, st[cur], wi, st[cur ^ 1], probes, nullptr, &nl); }
+    if (threadIdx.x == 0) { probs[i] = prob; lens[i] = nl; }
+    cur ^= 1;
+  }
+}
+void launch_test_lm(const DevScorer& s, const uint64_t* hashes, int n, int bos, int use_index, float* probs, int* lens, hipStream_t st) {
+  hipLaunchKernelGGL(test_lm_kernel, dim3(1), dim3(64), 0, st, s, hashes, n, bos, use_index, probs, lens);
+  check_launch("test_lm_kernel");
 }
 void launch_test_math(int op, const float* a, const float* b, float* out, unsigned n, hipStream_t st) {
   hipLaunchKernelGGL(test_math_kernel, dim3((n + 255) / 256), dim3(256), 0, st, op, a, b, out, n);

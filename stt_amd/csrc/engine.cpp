@@ -10,6 +10,7 @@
 #include "engine.h"
 
 uint64_t stt_murmur64a(const void* key, size_t len);
+int g_debug_arena_frames = 0;  // STTX_DebugLimitArena
 
 // ------------------------------------------------------------------------------------------- features
 void ModelState::run_mfcc(const int16_t* d_audio, const int* h_nsamples, int B, int n_max, int t_max, std::vector<int>& n_frames) {
@@ -158,6 +159,7 @@ void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int e
   db.n_streams = n_streams; db.beam = beam; db.C = C;
   const uint32_t cap = (uint32_t)((beam + 63) & ~63);
   const uint32_t cand_cap = (uint32_t)beam * (uint32_t)(C - 1);
+  if (g_debug_arena_frames > 0) expected_frames = g_debug_arena_frames;  // test hook: arenas that cannot hold the utterance
   const uint32_t arena = (uint32_t)(expected_frames + 2) * (uint32_t)beam + 2;
   const size_t fixed = al256(cap * 8) + 8 * al256(cap * 4) + al256(cand_cap * 4) * 3 + al256(cand_cap * 8) + al256(((size_t)cap + cand_cap) * 8);
   const SlabLayout l = slab_layout(fixed, arena);
@@ -193,6 +195,7 @@ void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int e
 // Streaming use: make sure stream i can append `more_frames[i]` further timesteps.  Grows the whole slab
 // (copying the live state) when an arena would overflow; rare (capacity doubles).
 void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_frames) {
+  if (g_debug_arena_frames > 0) return;  // test hook: no growth
   HIP_CHECK(hipMemcpyAsync(db.host.data(), db.table.p, sizeof(DecStream) * db.n_streams, hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
   bool grow = false;
@@ -230,6 +233,14 @@ void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_
   db.table.upload(db.host.data(), sizeof(DecStream) * db.n_streams, stream);
 }
 
+// A stream whose search state overflowed an arena (or lost an invariant) has a damaged beam: no transcript is better than
+// a wrong one.  The callers' guarded() turns this into NULL / STT_ERR_FAIL_RUN_SESS.
+void check_decoder_errors(const int* errors, int n) {
+  int err = 0;
+  for (int i = 0; i < n; ++i) err |= errors[i];
+  if (err) throw std::runtime_error("decoder state error bits 0x" + std::to_string(err) + " (1 path arena, 2 time arena, 4 candidates, 8 scorer cache, 16 path hash)");
+}
+
 std::vector<std::vector<Output>> decode_streams(const ModelState& mc, const DecoderBatch& db, std::shared_ptr<ScorerDev> sc,
                                                 const std::map<std::string, float>& hot, unsigned num_results, int max_len) {
   ModelState& m = const_cast<ModelState&>(mc);  // workspaces only
@@ -252,6 +263,7 @@ std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_
   const uint32_t *tok = h.tokens, *ts = h.timesteps;
   const int *lens = h.lens, *nres = h.n_results;
   const double* conf = h.confidence;
+  check_decoder_errors(h.errors, n);
   std::vector<std::vector<Output>> out(n);
   for (int i = 0; i < n; ++i) {
     for (int r = 0; r < nres[i]; ++r) {

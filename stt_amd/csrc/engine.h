@@ -78,15 +78,16 @@ class ScorerDev {
   // returns an STT_ERR_* code (scorer.cpp:108-222)
   int LoadFile(const std::string& path, const Alphabet& alphabet);
   int LoadBuffer(const char* data, size_t len, const Alphabet& alphabet);
+  int LoadLmOnly(const char* data, size_t len);  // a bare KenLM trie binary (no dictionary): LM test hook
   void reset_params(float a, float b) { dev.alpha = a; dev.beta = b; }
   DevScorer dev{};  // alpha/beta live here (read at every launch, like the reference reads Scorer::alpha)
   bool is_utf8 = false;
   int order = 0;
-  uint64_t blob_bytes = 0;
+  uint64_t blob_bytes = 0, lmi_bytes = 0;
 
  private:
-  int Parse(const uint8_t* buf, size_t len, int space_label);
-  DevBuf blob_, fst_pos_, fst_arcs_, fst_space_, vtab_, hint_;
+  int Parse(const uint8_t* buf, size_t len, int space_label, bool lm_only);
+  DevBuf blob_, fst_pos_, fst_arcs_, fst_space_, fst_rec_, vtab_, hint_, lmi_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -266,5 +267,7 @@ void streams_feed_batch(const std::vector<StreamingState*>& ss, const short* con
 void streams_flush_batch(const std::vector<StreamingState*>& ss, bool addZeroMfccVectors);
 std::vector<std::vector<Output>> streams_decode_batch(const std::vector<StreamingState*>& ss, unsigned num_results);
 int n_frames_for(const Geometry& g, int n_samples);
+void check_decoder_errors(const int* errors, int n);  // throws when a stream's DecStream::error is set
+extern int g_debug_arena_frames;
 void stt_prof_mark(ModelState* m, int i);  // HIP-event marks for STTX_GetStageTimes (api.cpp)
 void pack_lstm_recurrent_host(const float* kernel /*[2H][4H]*/, int H, _Float16* out);

@@ -108,7 +108,12 @@ int parse_model_file(const char* buf, size_t len, ModelTensors& tfl, ModelView& 
     for (int i = 0; i < 12; ++i) { v.t[i] = f; v.count[i] = cnt[i]; f += cnt[i]; }
   }
   const int H = g.n_hidden, C = g.n_classes;
-  if (H % 128 != 0 || H < 128 || C < 2 || C > STT_MAX_CLASSES || g.win_len > 512 || g.win_len < 2 || g.win_step < 1 || g.n_input > 64 || g.n_input < 1 ||
+  // The feature kernel is a 512-point FFT with 257 bins and 40 mel channels.  TF's AudioSpectrogram uses
+  // fft_length = NextPowerOfTwo(window) (util/feeding.py:51-73 -> spectrogram.cc), so only windows of 257..512 samples
+  // (e.g. 32 ms at 16 kHz) give the reference's 257-bin spectrum here; a 256-sample window (32 ms at 8 kHz) would need the
+  // 256-point FFT / 129-bin filterbank and is refused instead of silently producing different features.  The DCT has
+  // 40 mel inputs, so at most 40 coefficients exist.
+  if (H % 128 != 0 || H < 128 || C < 2 || C > STT_MAX_CLASSES || g.win_len > 512 || g.win_len <= 256 || g.win_step < 1 || g.n_input > 40 || g.n_input < 1 ||
       g.n_steps < 1 || g.n_context < 0 || g.beam_width < 1) {
     err = "model geometry outside what the engine supports";
     return STT_ERR_INVALID_SHAPE;

@@ -6,18 +6,26 @@
 // and ConstFst::Read (openfst-1.6.7/src/include/fst/const-fst.h:195-235, src/lib/fst.cc:57-84).
 // The KenLM blob goes to HBM byte for byte; kernels read the same bit-packed records KenLM mmaps.
 // Probing-hash models (model types 0/1) are rejected with STT_ERR_SCORER_INVALID_LM.
+//
+// Two stages: parse_scorer() is host-only (layout, dictionary repacking, vocabulary table, the hashed n-gram index of
+// lmindex.h) and testable without a GPU; ScorerDev::Upload() moves the result to HBM.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <thread>
 #include <vector>
 
 #include "../../include/coqui-stt.h"
 #include "engine.h"
+#include "lmindex.h"
+#include "scorer_host.h"
 
 namespace {
 inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 inline float rdf(const uint8_t* p) { float v; memcpy(&v, p, 4); return v; }
+inline float bits_f(uint32_t u) { float v; memcpy(&v, &u, 4); return v; }
 uint8_t required_bits(uint64_t v) { if (!v) return 0; uint8_t r = 1; while (v >>= 1) ++r; return r; }  // util/bit_packing.cc:17-22
 uint64_t align8(uint64_t x) { return (x + 7) & ~(uint64_t)7; }
 uint8_t chop_bits(uint64_t max_offset, uint64_t max_next, uint8_t cfg_bits) {  // lm/bhiksha.cc:35-50
@@ -42,25 +50,172 @@ uint64_t murmur64a(const void* key, size_t len, uint64_t seed) {  // util/murmur
   h ^= h >> r; h *= m; h ^= h >> r;
   return h;
 }
+inline uint64_t rd57(const uint8_t* base, uint64_t bit_off, uint64_t mask) { return (rd64(base + (bit_off >> 3)) >> (bit_off & 7)) & mask; }
+
+template <class F> void parallel_for(uint64_t n, F&& f) {  // f(begin, end) on contiguous chunks
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 32) nt = 32;
+  if (nt < 1 || n < (1u << 16)) nt = 1;
+  if (nt == 1) { f((uint64_t)0, n); return; }
+  std::vector<std::thread> th;
+  const uint64_t per = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const uint64_t b = std::min(n, per * t), e = std::min(n, per * (t + 1));
+    if (b < e) th.emplace_back([=, &f]() { f(b, e); });
+  }
+  for (auto& x : th) x.join();
+}
 }  // namespace
 
 uint64_t stt_murmur64a(const void* key, size_t len) { return murmur64a(key, len, 0); }
 
-int ScorerDev::LoadFile(const std::string& path, const Alphabet& alphabet) {
-  std::ifstream in(path, std::ios::binary | std::ios::ate);
-  if (!in) return STT_ERR_SCORER_UNREADABLE;
-  const std::streamsize sz = in.tellg();
-  in.seekg(0);
-  std::vector<char> data((size_t)sz);
-  if (sz > 0 && !in.read(data.data(), sz)) return STT_ERR_SCORER_UNREADABLE;
-  return LoadBuffer(data.data(), data.size(), alphabet);
+// ------------------------------------------------------------------------------------------- trie records on the host
+// (the same decoding as lookup_middle / lookup_longest / read_next in ctc.hip, over a whole level)
+float HostScorer::middle_prob(int om2, uint64_t at) const {
+  const HostBitPacked& m = mid[om2];
+  const uint64_t addr = at * m.total_bits + m.word_bits;
+  const uint8_t* base = buf + m.base_off;
+  if (quant) { const uint64_t pa = addr + backoff_bits; return rdf(buf + qprob_off[om2] + 4 * (uint64_t)((rd32(base + (pa >> 3)) >> (pa & 7)) & ((1u << prob_bits) - 1))); }
+  return bits_f((uint32_t)(rd64(base + (addr >> 3)) >> (addr & 7)) | 0x80000000u);
+}
+float HostScorer::middle_backoff(int om2, uint64_t at) const {
+  const HostBitPacked& m = mid[om2];
+  const uint64_t addr = at * m.total_bits + m.word_bits;
+  const uint8_t* base = buf + m.base_off;
+  if (quant) return rdf(buf + qback_off[om2] + 4 * (uint64_t)((rd32(base + (addr >> 3)) >> (addr & 7)) & ((1u << backoff_bits) - 1)));
+  const uint64_t ba = addr + 31;
+  return bits_f((uint32_t)(rd64(base + (ba >> 3)) >> (ba & 7)));
+}
+float HostScorer::longest_prob(uint64_t at) const {
+  const uint64_t addr = at * lon.total_bits + lon.word_bits;
+  const uint8_t* base = buf + lon.base_off;
+  if (quant) return rdf(buf + qprob_off[order - 2] + 4 * (uint64_t)((rd32(base + (addr >> 3)) >> (addr & 7)) & ((1u << prob_bits) - 1)));
+  return bits_f((uint32_t)(rd64(base + (addr >> 3)) >> (addr & 7)) | 0x80000000u);
 }
 
-int ScorerDev::LoadBuffer(const char* data, size_t len, const Alphabet& alphabet) {
-  return Parse(reinterpret_cast<const uint8_t*>(data), len, alphabet.GetSpaceLabel());
+// Hashed n-gram index (lmindex.h).  Level by level: `next[c]` of every record of the level (its children start there),
+// then every parent hands its key to its children, which enter the table and remember their slot for their own children.
+static bool build_lm_index(HostScorer& hs) {
+  const int ord = hs.order;
+  uint64_t total = 0;
+  for (int k = 1; k < ord; ++k) total += hs.counts[k];
+  if (hs.counts[0] >= (1ull << 27) || total >= (1ull << 31) || ord < 2) return false;
+  for (int k = 1; k < ord; ++k) if (hs.counts[k] >= 0xFFFFFFF0ull) return false;
+  // about 1.33 entries per 4-slot bucket: 4.6 % of the buckets are full, 1 % overflow into the next one
+  uint64_t nb64 = (total * 3 + 3) / 4 + 16;
+  if (nb64 * LMI_BUCKET >= 0xFFFFFFF0ull) return false;
+  const uint32_t nb = (uint32_t)nb64;
+  std::vector<LmiEntry>& tab = hs.lmi;
+  tab.assign((size_t)nb * LMI_BUCKET, LmiEntry{LMI_EMPTY, 0u, 0.0f, 0.0f});
+  hs.lmi_buckets = nb;
+  const uint8_t* buf = hs.buf;
+  // level 1: unigrams.  key seed = the word's vocabulary hash (what a query has before it knows the index), id = index
+  const uint64_t n1 = hs.counts[0];
+  std::vector<uint64_t> key_prev(n1), key_cur;
+  std::vector<uint32_t> id_prev(n1), id_cur;
+  std::vector<uint64_t> next_prev(n1 + 1), next_cur;
+  for (uint64_t w = 0; w < n1; ++w) {
+    key_prev[w] = (w == 0 || w - 1 >= hs.vocab_n) ? LMI_UNK_H : rd64(buf + hs.vocab_off + 8 * (w - 1));
+    id_prev[w] = (uint32_t)w;
+  }
+  for (uint64_t w = 0; w <= n1; ++w) next_prev[w] = rd64(buf + hs.unigram_off + 16 * w + 8);
+  for (int level = 2; level <= ord; ++level) {
+    const bool is_longest = level == ord;
+    const int om2 = level - 2;
+    const HostBitPacked& bp = is_longest ? hs.lon : hs.mid[om2];
+    const uint64_t cnt = hs.counts[level - 1];
+    const uint8_t* base = buf + bp.base_off;
+    const uint64_t word_mask = (1ULL << bp.word_bits) - 1, next_mask = bp.next_bits >= 64 ? ~0ULL : (1ULL << bp.next_bits) - 1;
+    if (next_prev.back() != cnt) return false;  // the sentinel of the parent level must close the child level exactly
+    if (!is_longest) {  // child ranges of this level's records (ArrayBhiksha::ReadNext, lm/bhiksha.hh:76-95)
+      next_cur.assign(cnt + 1, 0);
+      const uint64_t* offs = bp.off_begin_off ? reinterpret_cast<const uint64_t*>(buf + bp.off_begin_off) : nullptr;
+      const uint32_t ocnt = bp.off_count;
+      parallel_for(cnt + 1, [&](uint64_t b, uint64_t e) {
+        uint64_t bi = 0;
+        if (offs) bi = (uint64_t)(std::upper_bound(offs, offs + ocnt, b) - offs) - 1;
+        for (uint64_t c = b; c < e; ++c) {
+          const uint64_t lo = rd57(base, c * bp.total_bits + bp.word_bits + bp.quant_bits, next_mask);
+          if (offs) { while (bi + 1 < ocnt && offs[bi + 1] <= c) ++bi; next_cur[c] = (bi << bp.next_bits) | lo; }
+          else next_cur[c] = lo;
+        }
+      });
+    }
+    key_cur.assign(cnt, 0); id_cur.assign(cnt, 0);
+    const uint64_t n_par = key_prev.size();
+    bool bad = false;
+    parallel_for(n_par, [&](uint64_t pb, uint64_t pe) {
+      for (uint64_t p = pb; p < pe; ++p) {
+        const uint64_t cb = next_prev[p], ce = next_prev[p + 1];
+        if (cb > ce || ce > cnt) { bad = true; return; }
+        for (uint64_t c = cb; c < ce; ++c) {
+          const uint32_t word = (uint32_t)rd57(base, c * bp.total_bits, word_mask);
+          const uint64_t key = lmi_step(key_prev[p], word);
+          LmiEntry e;
+          if (is_longest) { e.prob = hs.longest_prob(c); e.backoff = 0.0f; e.wl = lmi_wl(word, level, false); }
+          else { e.prob = hs.middle_prob(om2, c); e.backoff = hs.middle_backoff(om2, c); e.wl = lmi_wl(word, level, next_cur[c] == next_cur[c + 1]); }
+          e.parent = id_prev[p];
+          uint32_t b = lmi_bucket(key, nb), slot = LMI_NOT_FOUND;
+          for (uint32_t tries = 0; tries < nb && slot == LMI_NOT_FOUND; ++tries) {
+            for (int j = 0; j < LMI_BUCKET; ++j) {
+              LmiEntry* t = &tab[(size_t)b * LMI_BUCKET + j];
+              uint32_t expect = LMI_EMPTY;
+              if (__atomic_load_n(&t->wl, __ATOMIC_RELAXED) == LMI_EMPTY &&
+                  __atomic_compare_exchange_n(&t->wl, &expect, e.wl, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+                t->parent = e.parent; t->prob = e.prob; t->backoff = e.backoff;
+                slot = b * LMI_BUCKET + (uint32_t)j;
+                break;
+              }
+            }
+            b = b + 1 == nb ? 0u : b + 1;
+          }
+          key_cur[c] = key; id_cur[c] = slot;
+        }
+      }
+    });
+    if (bad) return false;
+    key_prev.swap(key_cur); id_prev.swap(id_cur); next_prev.swap(next_cur);
+  }
+  // <unk> (word index 0): its unigram record; it only matters as the *new* word of a query when it has children
+  hs.unk_prob = rdf(buf + hs.unigram_off); hs.unk_backoff = rdf(buf + hs.unigram_off + 4);
+  hs.unk_indep = rd64(buf + hs.unigram_off + 8) == rd64(buf + hs.unigram_off + 24);
+  return true;
 }
 
-int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label) {
+// SortedVocabulary::Index (lm/vocab.hh:72-83): binary search over the sorted hashes (host side)
+uint32_t HostScorer::vocab_index(uint64_t h) const {
+  uint64_t lo = 0, hi = vocab_n;
+  while (lo < hi) {
+    const uint64_t m2 = lo + (hi - lo) / 2, v = rd64(buf + vocab_off + 8 * m2);
+    if (v < h) lo = m2 + 1; else if (v > h) hi = m2; else return (uint32_t)(m2 + 1);
+  }
+  return 0;
+}
+
+// FullScore through the index, on the host: what the search kernel's LM waves do with four lanes per query.
+float HostScorer::full_score_indexed(const KState& in, const char* word, size_t word_len, KState& out, int& ngram_length, uint32_t& word_index) const {
+  const uint64_t h = murmur64a(word, word_len, 0);
+  const uint32_t wi = vocab_index(h);
+  word_index = wi;
+  const uint8_t* u = buf + unigram_off + 16 * (uint64_t)wi;
+  const float uprob = rdf(u), uback = rdf(u + 4);
+  const bool uindep = rd64(u + 8) == rd64(u + 24);
+  LmiLevel lv[LMI_MAX_HIST] = {};
+  uint64_t key = wi ? h : LMI_UNK_H;
+  uint32_t parent = wi;
+  for (int hi = 0; hi < order - 1 && hi < in.length && hi < LMI_MAX_HIST; ++hi) {
+    key = lmi_step(key, in.words[hi]);
+    LmiEntry e;
+    const uint32_t slot = lmi_probe(lmi.data(), lmi_buckets, lmi_bucket(key, lmi_buckets), hi + 2, in.words[hi], parent, e);
+    if (slot == LMI_NOT_FOUND) break;
+    lv[hi].found = 1; lv[hi].prob = e.prob; lv[hi].backoff = e.backoff; lv[hi].indep = (e.wl & LMI_INDEP_BIT) ? 1 : 0;
+    parent = slot;
+  }
+  return lmi_combine(order, in, wi, uprob, uback, uindep, lv, out, ngram_length);
+}
+
+// ------------------------------------------------------------------------------------------- parse (host only)
+int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, HostScorer& hs) {
   static const char kMagic[] = "mmap lm http://kheafield.com/code format version 5\n";
   if (len < 88 + 20 || memcmp(buf, kMagic, sizeof(kMagic)) != 0) return STT_ERR_SCORER_INVALID_LM;
   const uint8_t* fp = buf + 88;  // FixedWidthParameters after the 88-byte Sanity block
@@ -69,26 +224,25 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label) {
   if (ord < 2 || ord > STT_KENLM_MAX_ORDER) return STT_ERR_SCORER_INVALID_LM;
   if (model_type < 2 || model_type > 5) return STT_ERR_SCORER_INVALID_LM;
   const bool quant = (model_type == 3 || model_type == 5), array = (model_type == 4 || model_type == 5);
-  uint64_t counts[STT_KENLM_MAX_ORDER];
+  uint64_t* counts = hs.counts;
   if (len < 108 + 8 * (size_t)ord) return STT_ERR_SCORER_INVALID_LM;
-  for (int i = 0; i < ord; ++i) counts[i] = rd64(buf + 108 + 8 * i);
+  for (int i = 0; i < ord; ++i) { counts[i] = rd64(buf + 108 + 8 * i); if (counts[i] > (1ull << 40)) return STT_ERR_SCORER_INVALID_LM; }
+  if (counts[0] < 1) return STT_ERR_SCORER_INVALID_LM;
 
-  struct BP { uint64_t base_off; uint8_t word_bits, total_bits, quant_bits, next_bits; uint64_t off_begin_off; uint32_t off_count; uint64_t entries; };
-  BP mid[STT_KENLM_MAX_ORDER - 2]{}; BP lon{};
   uint64_t off = align8(108 + 8 * (uint64_t)ord);
   if (off + 8 > len) return STT_ERR_SCORER_INVALID_LM;
   const uint64_t vocab_n = rd64(buf + off);
   const uint64_t vocab_off = off + 8;
+  if (vocab_n > counts[0]) return STT_ERR_SCORER_INVALID_LM;
   off += 8 + 8 * counts[0];
   uint8_t prob_bits = 0, backoff_bits = 0;
-  uint64_t qprob_off[STT_KENLM_MAX_ORDER]{}, qback_off[STT_KENLM_MAX_ORDER]{};
   if (quant) {
     if (off + 8 > len) return STT_ERR_SCORER_INVALID_LM;
     prob_bits = buf[off + 1]; backoff_bits = buf[off + 2];
     if (!prob_bits || !backoff_bits || prob_bits > 25 || backoff_bits > 25) return STT_ERR_SCORER_INVALID_LM;
     uint64_t t = off + 8;
-    for (int i = 0; i < ord - 2; ++i) { qprob_off[i] = t; t += 4ULL << prob_bits; qback_off[i] = t; t += 4ULL << backoff_bits; }
-    qprob_off[ord - 2] = t; t += 4ULL << prob_bits;
+    for (int i = 0; i < ord - 2; ++i) { hs.qprob_off[i] = t; t += 4ULL << prob_bits; hs.qback_off[i] = t; t += 4ULL << backoff_bits; }
+    hs.qprob_off[ord - 2] = t; t += 4ULL << prob_bits;
     off = t;
   }
   const uint64_t unigram_off = off;
@@ -101,158 +255,217 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label) {
   for (int i = 0; i < ord - 2; ++i) {
     const uint64_t entries = counts[i + 1], max_vocab = counts[0], max_next = counts[i + 2];
     uint64_t bh_size = 0; uint8_t inline_bits;
-    BP& m = mid[i];
+    HostBitPacked& m = hs.mid[i];
     if (array) {
       const uint8_t required = required_bits(max_next), chop = chop_bits(entries + 1, max_next, cfg_bhiksha);
       const uint64_t array_count = (max_next >> (required - chop)) + 1;
       bh_size = 8 * (1 + array_count) + 7;
       inline_bits = required - chop;
-      m.off_begin_off = align8(off) + 8; m.off_count = (uint32_t)array_count; m.entries = entries;
+      m.off_begin_off = align8(off) + 8; m.off_count = (uint32_t)array_count;
     } else {
       inline_bits = required_bits(max_next);
     }
+    m.entries = entries;
     m.base_off = off + bh_size;
     m.word_bits = required_bits(max_vocab); m.quant_bits = middle_quant_bits; m.next_bits = inline_bits;
     m.total_bits = (uint8_t)(m.word_bits + middle_quant_bits + inline_bits);
     off += bh_size + (((1 + entries) * m.total_bits + 7) / 8 + 8);
+    if (off > len) return STT_ERR_SCORER_INVALID_LM;
   }
+  HostBitPacked& lon = hs.lon;
   lon.base_off = off; lon.word_bits = required_bits(counts[0]); lon.total_bits = (uint8_t)(lon.word_bits + longest_bits);
+  lon.entries = counts[ord - 1];
   off += ((1 + counts[ord - 1]) * lon.total_bits + 7) / 8 + 8;
   const uint64_t lm_end = off;  // GetEndOfSearchOffset, lm/model.cc:265-267
   if (lm_end > len) return STT_ERR_SCORER_INVALID_LM;
-  if (len <= lm_end) return STT_ERR_SCORER_NO_TRIE;
+  hs.buf = buf; hs.order = ord; hs.model_type = model_type; hs.quant = quant; hs.prob_bits = prob_bits; hs.backoff_bits = backoff_bits;
+  hs.vocab_n = vocab_n; hs.vocab_off = vocab_off; hs.unigram_off = unigram_off; hs.lm_end = lm_end;
+  hs.alpha = 0.0; hs.beta = 0.0; hs.utf8 = false; hs.fst_start = 0;
 
-  // ---- package trailer (scorer.cpp:177-222)
-  const uint8_t* p = buf + lm_end;
-  if (lm_end + 25 > len || rd32(p) != 0x54524945u) return STT_ERR_SCORER_INVALID_TRIE;
-  if ((int)rd32(p + 4) != 6) return STT_ERR_SCORER_VERSION_MISMATCH;
-  const bool utf8 = p[8] != 0;
-  double a, b; memcpy(&a, p + 9, 8); memcpy(&b, p + 17, 8);
-  uint64_t o = lm_end + 25;
-  if (o + 4 > len || rd32(buf + o) != 2125659606u) return STT_ERR_SCORER_INVALID_TRIE;
-  o += 4;
-  uint32_t l = rd32(buf + o); o += 4 + l;
-  l = rd32(buf + o); o += 4 + l;
-  o += 4;
-  const uint32_t flags = rd32(buf + o); o += 4;
-  o += 8;
-  int64_t fst_start, nstates, narcs;
-  memcpy(&fst_start, buf + o, 8); o += 8; memcpy(&nstates, buf + o, 8); o += 8; memcpy(&narcs, buf + o, 8); o += 8;
-  if (flags & 3) return STT_ERR_SCORER_INVALID_TRIE;
-  if (flags & 4) o = (o + 15) & ~(uint64_t)15;
-  const uint8_t* states = buf + o; o += (uint64_t)nstates * 20;
-  if (flags & 4) o = (o + 15) & ~(uint64_t)15;
-  const uint8_t* arcs = buf + o; o += (uint64_t)narcs * 16;
-  if (o > len || nstates <= 0) return STT_ERR_SCORER_INVALID_TRIE;
-
-  // ---- repack the dictionary: arcs sorted by ilabel within a state (SortedMatcher's precondition)
-  // The arc's second field is the dictionary state of the child prefix: Start() when the arc's target is final
-  // (a completed word, path_trie.cpp:79-87), the target otherwise -- resolved here so the kernel needs one read.
-  std::vector<uint32_t> pos((size_t)nstates + 1);
-  std::vector<uint8_t> fin((size_t)nstates);
-  std::vector<uint2> arcv((size_t)narcs);
-  std::vector<uint8_t> has_space((size_t)nstates + 1, 0);
-  for (int64_t s = 0; s < nstates; ++s) fin[s] = !(rdf(states + 20 * s) == INFINITY);  // Final(s) != TropicalWeight::Zero()
-  uint32_t w = 0;
-  for (int64_t s = 0; s < nstates; ++s) {
-    const uint8_t* S = states + 20 * s;
-    const uint32_t ap = rd32(S + 4), an = rd32(S + 8);
-    pos[s] = w;
-    for (uint32_t k = 0; k < an; ++k) {
-      const uint8_t* A = arcs + 16 * (uint64_t)(ap + k);
-      if ((uint64_t)ap + k >= (uint64_t)narcs) return STT_ERR_SCORER_INVALID_TRIE;
-      const uint32_t next = rd32(A + 12);
-      if (next >= (uint64_t)nstates) return STT_ERR_SCORER_INVALID_TRIE;
-      arcv[w++] = make_uint2(rd32(A), fin[next] ? (uint32_t)fst_start : next);
-      if (space_label >= 0 && (int64_t)rd32(A) == (int64_t)space_label + 1) has_space[s] = 1;
+  if (!lm_only) {
+    if (len <= lm_end) return STT_ERR_SCORER_NO_TRIE;
+    // ---- package trailer (scorer.cpp:177-222); every advance of `o` is checked against the buffer before the next read
+    const uint8_t* p = buf + lm_end;
+    if (lm_end + 25 > len || rd32(p) != 0x54524945u) return STT_ERR_SCORER_INVALID_TRIE;
+    if ((int)rd32(p + 4) != 6) return STT_ERR_SCORER_VERSION_MISMATCH;
+    hs.utf8 = p[8] != 0;
+    double a, b; memcpy(&a, p + 9, 8); memcpy(&b, p + 17, 8);
+    hs.alpha = a; hs.beta = b;
+    uint64_t o = lm_end + 25;
+    auto room = [&](uint64_t n) { return o <= len && n <= len - o; };
+    if (!room(4) || rd32(buf + o) != 2125659606u) return STT_ERR_SCORER_INVALID_TRIE;  // FstHeader magic (fst.cc:62-75)
+    o += 4;
+    for (int k = 0; k < 2; ++k) {  // fsttype, arctype strings
+      if (!room(4)) return STT_ERR_SCORER_INVALID_TRIE;
+      const uint32_t l = rd32(buf + o); o += 4;
+      if (!room(l)) return STT_ERR_SCORER_INVALID_TRIE;
+      o += l;
     }
+    if (!room(4 + 4 + 8 + 24)) return STT_ERR_SCORER_INVALID_TRIE;
+    o += 4;  // version
+    const uint32_t flags = rd32(buf + o); o += 4;
+    o += 8;  // properties
+    int64_t fst_start, nstates, narcs;
+    memcpy(&fst_start, buf + o, 8); o += 8; memcpy(&nstates, buf + o, 8); o += 8; memcpy(&narcs, buf + o, 8); o += 8;
+    if (flags & 3) return STT_ERR_SCORER_INVALID_TRIE;
+    if (nstates <= 0 || narcs < 0 || fst_start < 0 || fst_start >= nstates) return STT_ERR_SCORER_INVALID_TRIE;
+    if ((uint64_t)nstates > len / 20 || (uint64_t)narcs > len / 16) return STT_ERR_SCORER_INVALID_TRIE;  // cannot fit: no overflow below
+    if (flags & 4) o = (o + 15) & ~(uint64_t)15;
+    if (!room((uint64_t)nstates * 20)) return STT_ERR_SCORER_INVALID_TRIE;
+    const uint8_t* states = buf + o; o += (uint64_t)nstates * 20;
+    if (flags & 4) o = (o + 15) & ~(uint64_t)15;
+    if (!room((uint64_t)narcs * 16)) return STT_ERR_SCORER_INVALID_TRIE;
+    const uint8_t* arcs = buf + o; o += (uint64_t)narcs * 16;
+
+    // ---- repack the dictionary: arcs sorted by ilabel within a state (SortedMatcher's precondition)
+    // The arc's second field is the dictionary state of the child prefix: Start() when the arc's target is final
+    // (a completed word, path_trie.cpp:79-87), the target otherwise -- resolved here so the kernel needs one read.
+    // Per state also {first arc with a real label, bitmap of the labels 1..32 on its arcs}: with the labels of a
+    // state in one word, the search kernel intersects "labels the dictionary allows" with "labels that survive the
+    // score cut-off" before it touches a single arc (usable when every state's arcs are strictly ascending by label).
+    hs.fst_pos.assign((size_t)nstates + 1, 0);
+    std::vector<uint8_t> fin((size_t)nstates);
+    hs.fst_arcs.assign((size_t)narcs, make_uint2(0, 0));
+    hs.fst_has_space.assign((size_t)nstates + 1, 0);
+    hs.fst_rec.assign((size_t)nstates + 1, make_uint2(0, 0));
+    hs.fst_bitmap_ok = true;
+    for (int64_t s = 0; s < nstates; ++s) fin[s] = !(rdf(states + 20 * s) == INFINITY);  // Final(s) != TropicalWeight::Zero()
+    uint32_t w = 0;
+    for (int64_t s = 0; s < nstates; ++s) {
+      const uint8_t* S = states + 20 * s;
+      const uint32_t ap = rd32(S + 4), an = rd32(S + 8);
+      if ((uint64_t)ap + an > (uint64_t)narcs || (uint64_t)w + an > (uint64_t)narcs) return STT_ERR_SCORER_INVALID_TRIE;
+      hs.fst_pos[s] = w;
+      uint32_t mask = 0, first = w + an, prev_label = 0;
+      for (uint32_t k = 0; k < an; ++k) {
+        const uint8_t* A = arcs + 16 * (uint64_t)(ap + k);
+        const uint32_t ilabel = rd32(A), next = rd32(A + 12);
+        if (next >= (uint64_t)nstates) return STT_ERR_SCORER_INVALID_TRIE;
+        if (k > 0 && ilabel <= prev_label && !(ilabel == 0 && prev_label == 0)) hs.fst_bitmap_ok = false;
+        prev_label = ilabel;
+        if (ilabel >= 1) { if (first == w + an) first = w; if (ilabel <= 32) mask |= 1u << (ilabel - 1); }
+        hs.fst_arcs[w++] = make_uint2(ilabel, fin[next] ? (uint32_t)fst_start : next);
+        if (space_label >= 0 && (int64_t)ilabel == (int64_t)space_label + 1) hs.fst_has_space[s] = 1;
+      }
+      hs.fst_rec[s] = make_uint2(first, mask);
+    }
+    hs.fst_pos[nstates] = w;
+    hs.fst_start = (int)fst_start;
+    hs.n_states = (uint64_t)nstates;
   }
-  pos[nstates] = w;
 
   // ---- vocabulary hash table over KenLM's sorted hash array (index = position + 1, vocab.hh:72-83)
   uint32_t vt_n = 16;
   while ((uint64_t)vt_n < 2 * vocab_n + 2) vt_n <<= 1;
-  std::vector<DevVocabSlot> vtab(vt_n, DevVocabSlot{0, 0, 0, 0.f, 0.f, 0, 0});
-  const bool uni_ok = ord >= 2 && counts[1] < 0xFFFFFFFFull;
+  hs.vtab.assign(vt_n, DevVocabSlot{0, 0, 0, 0.f, 0.f, 0, 0});
+  hs.uni_ok = ord >= 2 && counts[1] < 0xFFFFFFFFull;
   if (vocab_off + 8 * vocab_n > len) return STT_ERR_SCORER_INVALID_LM;
   for (uint64_t i = 0; i < vocab_n; ++i) {
     const uint64_t h = rd64(buf + vocab_off + 8 * i);
     uint32_t slot = (uint32_t)h & (vt_n - 1);
-    while (vtab[slot].used) slot = (slot + 1) & (vt_n - 1);
-    vtab[slot] = DevVocabSlot{h, (uint32_t)(i + 1), 1, 0.f, 0.f, 0, 0};
-  }
-
-  // ---- upload
-  blob_.upload(buf, lm_end + 16);  // +16: the 64-bit bit-packed reads may touch up to 8 bytes past the last record
-  fst_pos_.upload(pos.data(), pos.size() * 4);
-  for (auto& e : vtab) {
-    if (!e.used) continue;
-    const uint8_t* u = buf + unigram_off + 16 * (uint64_t)e.index;
-    e.prob = rdf(u); e.backoff = rdf(u + 4);
-    e.begin = (uint32_t)rd64(u + 8); e.end = (uint32_t)rd64(u + 24);
-  }
-  vtab_.upload(vtab.data(), vtab.size() * sizeof(DevVocabSlot));
-  fst_arcs_.upload(arcv.data(), arcv.size() * sizeof(uint2));
-  fst_space_.upload(has_space.data(), has_space.size());
-  const uint8_t* d = blob_.as<uint8_t>();
-  DevScorer ds{};
-  ds.enabled = 1; ds.order = ord; ds.quant = quant; ds.utf8 = utf8;
-  ds.alpha = (double)(float)a; ds.beta = (double)(float)b;  // Scorer::reset_params(float, float)
-  ds.vocab = reinterpret_cast<const uint64_t*>(d + vocab_off); ds.vocab_n = vocab_n;
-  ds.vtab = vtab_.as<DevVocabSlot>(); ds.vtab_mask = vt_n - 1; ds.uni_in_vtab = uni_ok ? 1 : 0;
-  ds.unigram = d + unigram_off;
-  for (int i = 0; i < STT_KENLM_MAX_ORDER; ++i) {
-    ds.qprob[i] = quant && qprob_off[i] ? reinterpret_cast<const float*>(d + qprob_off[i]) : nullptr;
-    ds.qbackoff[i] = quant && qback_off[i] ? reinterpret_cast<const float*>(d + qback_off[i]) : nullptr;
+    while (hs.vtab[slot].used) slot = (slot + 1) & (vt_n - 1);
+    const uint8_t* u = buf + unigram_off + 16 * (uint64_t)(i + 1);
+    hs.vtab[slot] = DevVocabSlot{h, (uint32_t)(i + 1), 1, rdf(u), rdf(u + 4), (uint32_t)rd64(u + 8), (uint32_t)rd64(u + 24)};
   }
   // Bhiksha hint tables: the offsets array is sorted; a coarse direct-index table replaces KenLM's std::upper_bound over it
   // (lm/bhiksha.hh:76-95) by one read plus a short forward scan.  Same result, fewer dependent HBM reads.
-  std::vector<uint32_t> hints;
-  size_t hint_off[STT_KENLM_MAX_ORDER - 2] = {};
-  uint32_t hint_shift[STT_KENLM_MAX_ORDER - 2] = {};
+  hs.hints.clear();
   for (int i = 0; i < ord - 2; ++i) {
-    if (!mid[i].off_begin_off) continue;
-    const uint64_t* offs = reinterpret_cast<const uint64_t*>(buf + mid[i].off_begin_off);
-    const uint32_t cnt = mid[i].off_count;
-    const uint64_t entries = mid[i].entries + 2;
+    hs.hint_off[i] = 0; hs.hint_shift[i] = 0;
+    if (!hs.mid[i].off_begin_off) continue;
+    const uint64_t* offs = reinterpret_cast<const uint64_t*>(buf + hs.mid[i].off_begin_off);
+    const uint32_t cnt = hs.mid[i].off_count;
+    const uint64_t entries = hs.mid[i].entries + 2;
     uint32_t sh = 0;
     while (((entries >> sh) > 4ull * cnt + 1024) && sh < 40) ++sh;  // about four table slots per offset
-    hint_off[i] = hints.size(); hint_shift[i] = sh;
+    hs.hint_off[i] = hs.hints.size(); hs.hint_shift[i] = sh;
     const uint64_t slots = (entries >> sh) + 2;
     uint32_t pos = 0;  // upper_bound(offs, v) - 1 for increasing v
     for (uint64_t j = 0; j < slots; ++j) {
       const uint64_t v = j << sh;
       while (pos + 1 < cnt && offs[pos + 1] <= v) ++pos;
-      hints.push_back(pos);
+      hs.hints.push_back(pos);
     }
   }
-  if (hints.empty()) hints.push_back(0);
-  hint_.upload(hints.data(), hints.size() * 4);
-  auto fill = [&](DevBitPacked& o2, const BP& b2) {
+  if (hs.hints.empty()) hs.hints.push_back(0);
+  // <s> index and backoff (lm/model.cc:115-124)
+  hs.bos_index = hs.vocab_index(murmur64a("<s>", 3, 0));
+  hs.bos_backoff = rdf(buf + unigram_off + 16 * (uint64_t)hs.bos_index + 4);
+  hs.lmi_ok = build_lm_index(hs);
+  if (!hs.lmi_ok) { hs.lmi.clear(); hs.lmi_buckets = 0; }
+  return STT_ERR_OK;
+}
+
+// ------------------------------------------------------------------------------------------- upload
+int ScorerDev::LoadFile(const std::string& path, const Alphabet& alphabet) {
+  std::ifstream in(path, std::ios::binary | std::ios::ate);
+  if (!in) return STT_ERR_SCORER_UNREADABLE;
+  const std::streamsize sz = in.tellg();
+  in.seekg(0);
+  std::vector<char> data((size_t)sz + 16, 0);  // (+16: the 64-bit bit-packed reads may touch up to 8 bytes past the last record)
+  if (sz > 0 && !in.read(data.data(), sz)) return STT_ERR_SCORER_UNREADABLE;
+  return Parse(reinterpret_cast<const uint8_t*>(data.data()), (size_t)sz, alphabet.GetSpaceLabel(), false);
+}
+
+int ScorerDev::LoadBuffer(const char* data, size_t len, const Alphabet& alphabet) {
+  // (a package's trailer follows the KenLM blob: the bit-packed reads past the last record stay inside the buffer)
+  return Parse(reinterpret_cast<const uint8_t*>(data), len, alphabet.GetSpaceLabel(), false);
+}
+
+int ScorerDev::LoadLmOnly(const char* data, size_t len) {
+  std::vector<char> copy(len + 16, 0);
+  memcpy(copy.data(), data, len);
+  return Parse(reinterpret_cast<const uint8_t*>(copy.data()), len, -1, true);
+}
+
+int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label, bool lm_only) {
+  HostScorer hs;
+  const int rc = parse_scorer(buf, len, space_label, lm_only, hs);
+  if (rc != STT_ERR_OK) return rc;
+  const int ord = hs.order;
+  blob_.upload(buf, hs.lm_end + 16);
+  vtab_.upload(hs.vtab.data(), hs.vtab.size() * sizeof(DevVocabSlot));
+  hint_.upload(hs.hints.data(), hs.hints.size() * 4);
+  if (!lm_only) {
+    fst_pos_.upload(hs.fst_pos.data(), hs.fst_pos.size() * 4);
+    fst_arcs_.upload(hs.fst_arcs.empty() ? (const void*)&hs.fst_pos[0] : (const void*)hs.fst_arcs.data(), std::max<size_t>(8, hs.fst_arcs.size() * sizeof(uint2)));
+    fst_space_.upload(hs.fst_has_space.data(), hs.fst_has_space.size());
+    fst_rec_.upload(hs.fst_rec.data(), hs.fst_rec.size() * sizeof(uint2));
+  }
+  if (hs.lmi_ok) lmi_.upload(hs.lmi.data(), hs.lmi.size() * sizeof(LmiEntry));
+  const uint8_t* d = blob_.as<uint8_t>();
+  DevScorer ds{};
+  ds.enabled = 1; ds.order = ord; ds.quant = hs.quant; ds.utf8 = hs.utf8;
+  ds.alpha = (double)(float)hs.alpha; ds.beta = (double)(float)hs.beta;  // Scorer::reset_params(float, float)
+  ds.vocab = reinterpret_cast<const uint64_t*>(d + hs.vocab_off); ds.vocab_n = hs.vocab_n;
+  ds.vtab = vtab_.as<DevVocabSlot>(); ds.vtab_mask = (uint32_t)hs.vtab.size() - 1; ds.uni_in_vtab = hs.uni_ok ? 1 : 0;
+  ds.unigram = d + hs.unigram_off;
+  for (int i = 0; i < STT_KENLM_MAX_ORDER; ++i) {
+    ds.qprob[i] = hs.quant && hs.qprob_off[i] ? reinterpret_cast<const float*>(d + hs.qprob_off[i]) : nullptr;
+    ds.qbackoff[i] = hs.quant && hs.qback_off[i] ? reinterpret_cast<const float*>(d + hs.qback_off[i]) : nullptr;
+  }
+  auto fill = [&](DevBitPacked& o2, const HostBitPacked& b2) {
     o2.base = d + b2.base_off; o2.word_bits = b2.word_bits; o2.total_bits = b2.total_bits; o2.quant_bits = b2.quant_bits; o2.next_bits = b2.next_bits;
     o2.word_mask = (1ULL << b2.word_bits) - 1; o2.next_mask = (1ULL << b2.next_bits) - 1;
     o2.off_begin = b2.off_begin_off ? reinterpret_cast<const uint64_t*>(d + b2.off_begin_off) : nullptr; o2.off_count = b2.off_count;
-    o2.off_hint = nullptr; o2.hint_shift = 0; o2.max_word = counts[0];
+    o2.off_hint = nullptr; o2.hint_shift = 0; o2.max_word = hs.counts[0];
   };
   for (int i = 0; i < ord - 2; ++i) {
-    fill(ds.middle[i], mid[i]);
-    if (mid[i].off_begin_off) { ds.middle[i].off_hint = hint_.as<uint32_t>() + hint_off[i]; ds.middle[i].hint_shift = hint_shift[i]; }
+    fill(ds.middle[i], hs.mid[i]);
+    if (hs.mid[i].off_begin_off) { ds.middle[i].off_hint = hint_.as<uint32_t>() + hs.hint_off[i]; ds.middle[i].hint_shift = hs.hint_shift[i]; }
   }
-  fill(ds.longest, lon);
-  ds.prob_bits = prob_bits; ds.backoff_bits = backoff_bits;
-  ds.prob_mask = (1u << prob_bits) - 1; ds.backoff_mask = (1u << backoff_bits) - 1;
-  // <s> index and backoff (lm/model.cc:115-124)
-  {
-    const uint64_t h = murmur64a("<s>", 3, 0);
-    const uint64_t* v = reinterpret_cast<const uint64_t*>(buf + vocab_off);
-    uint64_t lo = 0, hi = vocab_n; uint32_t idx = 0;
-    while (lo < hi) { const uint64_t m2 = lo + (hi - lo) / 2; if (v[m2] < h) lo = m2 + 1; else if (v[m2] > h) hi = m2; else { idx = (uint32_t)(m2 + 1); break; } }
-    ds.bos_index = idx;
-    ds.bos_backoff = rdf(buf + unigram_off + 16 * (uint64_t)idx + 4);
+  fill(ds.longest, hs.lon);
+  ds.prob_bits = hs.prob_bits; ds.backoff_bits = hs.backoff_bits;
+  ds.prob_mask = (1u << hs.prob_bits) - 1; ds.backoff_mask = (1u << hs.backoff_bits) - 1;
+  ds.bos_index = hs.bos_index; ds.bos_backoff = hs.bos_backoff;
+  ds.fst_start = hs.fst_start;
+  if (!lm_only) {
+    ds.fst_state_pos = fst_pos_.as<uint32_t>(); ds.fst_arcs = fst_arcs_.as<uint2>(); ds.fst_has_space = fst_space_.as<uint8_t>();
+    ds.fst_rec = hs.fst_bitmap_ok ? fst_rec_.as<uint2>() : nullptr;
   }
-  ds.fst_start = (int)fst_start;
-  ds.fst_state_pos = fst_pos_.as<uint32_t>(); ds.fst_arcs = fst_arcs_.as<uint2>(); ds.fst_has_space = fst_space_.as<uint8_t>();
+  ds.lmi = hs.lmi_ok ? lmi_.as<LmiEntry>() : nullptr; ds.lmi_buckets = hs.lmi_buckets;
+  ds.unk_prob = hs.unk_prob; ds.unk_backoff = hs.unk_backoff; ds.unk_indep = hs.unk_indep ? 1 : 0;
   dev = ds;
-  is_utf8 = utf8; order = ord; blob_bytes = lm_end;
+  is_utf8 = hs.utf8; order = ord; blob_bytes = hs.lm_end; lmi_bytes = hs.lmi.size() * sizeof(LmiEntry);
   return STT_ERR_OK;
 }

@@ -1,0 +1,59 @@
+// stt_amd/csrc/scorer_host.h -- host-side view of a parsed .scorer package / KenLM trie binary (internal header).
+// parse_scorer() needs no GPU: layout of the KenLM blob (kenlm/lm/binary_format.cc, search_trie.cc), the repacked
+// dictionary, the vocabulary table and the hashed n-gram index of lmindex.h.  ScorerDev::Parse uploads it.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "ctc.h"
+#include "lmindex.h"
+
+struct HostBitPacked {
+  uint64_t base_off = 0, off_begin_off = 0, entries = 0;
+  uint32_t off_count = 0;
+  uint8_t word_bits = 0, total_bits = 0, quant_bits = 0, next_bits = 0;
+};
+
+struct HostScorer {
+  const uint8_t* buf = nullptr;  // caller's buffer (must stay alive; >= 8 readable bytes past lm_end)
+  int order = 0, model_type = 0;
+  bool quant = false, utf8 = false;
+  double alpha = 0.0, beta = 0.0;
+  uint64_t counts[STT_KENLM_MAX_ORDER] = {};
+  uint64_t vocab_n = 0, vocab_off = 0, unigram_off = 0, lm_end = 0;
+  uint8_t prob_bits = 0, backoff_bits = 0;
+  uint64_t qprob_off[STT_KENLM_MAX_ORDER] = {}, qback_off[STT_KENLM_MAX_ORDER] = {};
+  HostBitPacked mid[STT_KENLM_MAX_ORDER - 2], lon;
+  uint32_t bos_index = 0;
+  float bos_backoff = 0.0f;
+  // dictionary (ctc.h: DevScorer::fst_*)
+  int fst_start = 0;
+  uint64_t n_states = 0;
+  std::vector<uint32_t> fst_pos;
+  std::vector<uint2> fst_arcs, fst_rec;
+  std::vector<uint8_t> fst_has_space;
+  bool fst_bitmap_ok = false;
+  // vocabulary table, Bhiksha hints
+  std::vector<DevVocabSlot> vtab;
+  bool uni_ok = false;
+  std::vector<uint32_t> hints;
+  size_t hint_off[STT_KENLM_MAX_ORDER - 2] = {};
+  uint32_t hint_shift[STT_KENLM_MAX_ORDER - 2] = {};
+  // hashed n-gram index
+  bool lmi_ok = false;
+  std::vector<LmiEntry> lmi;
+  uint32_t lmi_buckets = 0;
+  float unk_prob = 0.0f, unk_backoff = 0.0f;
+  bool unk_indep = true;
+
+  float middle_prob(int om2, uint64_t at) const;
+  float middle_backoff(int om2, uint64_t at) const;
+  float longest_prob(uint64_t at) const;
+  uint32_t vocab_index(uint64_t murmur_hash) const;
+  // GenericModel::FullScore through the index (the arithmetic of the search kernel's LM waves, on the host)
+  float full_score_indexed(const KState& in, const char* word, size_t word_len, KState& out, int& ngram_length, uint32_t& word_index) const;
+};
+
+// STT_ERR_* code.  lm_only: a bare KenLM binary without the 'TRIE' trailer (test hook).
+int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, HostScorer& out);

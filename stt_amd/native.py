@@ -51,7 +51,7 @@ STT_AMD_H = [
     "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
     "STTX_DecoderStats", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
-    "STTX_InspectModel", "STTX_ReadModelTensor",
+    "STTX_InspectModel", "STTX_ReadModelTensor", "STTX_TestLm", "STTX_DebugLimitArena",
 ]
 
 _lib = None
@@ -127,6 +127,8 @@ def lib():
         "STTX_PackLstmRecurrent": (ci, [vp, ci, vp]),
         "STTX_InspectModel": (ci, [vp, cu, pp(ModelInfo)]),
         "STTX_ReadModelTensor": (ci, [vp, cu, ci, vp, C.c_ulonglong, pp(C.c_ulonglong)]),
+        "STTX_TestLm": (ci, [vp, cu, pp(cs), cu, ci, ci, vp, vp]),
+        "STTX_DebugLimitArena": (ci, [ci]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -142,6 +144,20 @@ def take_string(ptr):
     s = C.string_at(ptr)
     lib().STT_FreeString(ptr)
     return s
+
+
+def lm_score(lm_bytes, words, bos=True, mode=0):
+    """STTX_TestLm: KenLM FullScore over `words` -> (log10 probs f32, matched n-gram lengths).  mode 0 = hashed index on the
+    host (no GPU), 1 = device trie walk, 2 = device index lookup."""
+    import numpy as np
+    ws = [w if isinstance(w, bytes) else w.encode() for w in words]
+    arr = (C.c_char_p * len(ws))(*ws)
+    probs = np.zeros(len(ws), np.float32)
+    lens = np.zeros(len(ws), np.int32)
+    rc = lib().STTX_TestLm(lm_bytes, len(lm_bytes), arr, len(ws), int(bos), int(mode), probs.ctypes.data, lens.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("STTX_TestLm failed: 0x%x" % rc)
+    return probs, lens
 
 
 def error_message(code):
