@@ -159,6 +159,7 @@ void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& 
                      const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st,
                      int max_frames = 0, void* wide_ws = nullptr);
 bool ctc_is_wide(int beam, int C);
+void ctc_set_fast_path(int on);  // test hook: 0 = always the generic search step, 1 = the fast word path where it applies, -1 = environment
 size_t ctc_wide_row_bytes(int C);
 inline bool ctc_sorts_classes(const DecParams& p) { return p.cutoff_prob < 1.0 || p.cutoff_top_n < p.C; }  // :337
 inline size_t ctc_rows_ws_bytes(const DecParams& p, int n_streams, int max_frames) {  // (<= 32 classes: the fast word path reads row records as well)

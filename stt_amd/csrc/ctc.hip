@@ -1570,8 +1570,11 @@ void launch_scatter_streams(DecStream* const* dst, const DecStream* src, int n, 
 
 // ------------------------------------------------------------------------------------ launchers
 // Fast word path (ctc_fast.inc) when everything it relies on is there; STT_AMD_FAST=0 keeps the generic step (A/B runs).
+static int g_fast_allow = -1;  // -1: STT_AMD_FAST from the environment (default on)
+void ctc_set_fast_path(int on) { g_fast_allow = on; }
 static bool ctc_fast_ok(const DecParams& p, const DevScorer& s, const DevAlphabet& al, bool have_rows) {
-  static const int allow = []() { const char* e = getenv("STT_AMD_FAST"); return e ? atoi(e) : 1; }();
+  static const int env_allow = []() { const char* e = getenv("STT_AMD_FAST"); return e ? atoi(e) : 1; }();
+  const int allow = g_fast_allow >= 0 ? g_fast_allow : env_allow;
   return allow && have_rows && s.enabled && !s.utf8 && p.C <= 32 && p.C >= 2 && p.blank == p.C - 1 && !ctc_sorts_classes(p) && cap_bucket(p.beam) <= 512 &&
          s.fst_rec != nullptr && s.lmi != nullptr && s.order <= 5 && s.uni_in_vtab && al.space_id >= 0 && al.space_id < p.C - 1 && al.n_labels == p.C - 1;
 }

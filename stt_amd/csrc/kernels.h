@@ -38,6 +38,7 @@ struct DenseArgs {
   void* y;             // f16 or f32 [M][ldy]
   int M, N, K, ldx, ldy;
   float relu_clip;
+  int xa, xb;          // tile-grid cut over the 8 XCDs (xa blocks along M x xb along N; filled in by launch_dense)
 };
 
 // ---- LSTM ---------------------------------------------------------------------------------------

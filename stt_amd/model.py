@@ -11,6 +11,11 @@ import numpy as np
 from . import native
 
 
+def _text(s):
+    """char* result -> str; NULL (the call failed, coqui-stt.h: "NULL on error") -> None"""
+    return None if s is None else s.decode("utf-8", "replace")
+
+
 def _audio(a):
     a = np.ascontiguousarray(a, dtype=np.int16)
     return a, a.ctypes.data, a.shape[0]
@@ -283,7 +288,7 @@ class Stream(object):
 
     def intermediateDecode(self):
         self._check()
-        return native.take_string(native.lib().STT_IntermediateDecode(self._impl)).decode("utf-8", "replace")
+        return _text(native.take_string(native.lib().STT_IntermediateDecode(self._impl)))
 
     def intermediateDecodeWithMetadata(self, num_results=1):
         self._check()
@@ -291,7 +296,7 @@ class Stream(object):
 
     def intermediateDecodeFlushBuffers(self):
         self._check()
-        return native.take_string(native.lib().STT_IntermediateDecodeFlushBuffers(self._impl)).decode("utf-8", "replace")
+        return _text(native.take_string(native.lib().STT_IntermediateDecodeFlushBuffers(self._impl)))
 
     def intermediateDecodeWithMetadataFlushBuffers(self, num_results=1):
         self._check()
@@ -301,7 +306,7 @@ class Stream(object):
         self._check()
         s = native.take_string(native.lib().STT_FinishStream(self._impl))
         self._impl = None
-        return s.decode("utf-8", "replace")
+        return _text(s)
 
     def finishStreamWithMetadata(self, num_results=1):
         self._check()

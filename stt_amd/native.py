@@ -51,7 +51,7 @@ STT_AMD_H = [
     "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
     "STTX_DecoderStats", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
-    "STTX_InspectModel", "STTX_ReadModelTensor", "STTX_TestLm", "STTX_DebugLimitArena",
+    "STTX_InspectModel", "STTX_ReadModelTensor", "STTX_TestLm", "STTX_DebugLimitArena", "STTX_DebugSetFastPath",
 ]
 
 _lib = None
@@ -129,6 +129,7 @@ def lib():
         "STTX_ReadModelTensor": (ci, [vp, cu, ci, vp, C.c_ulonglong, pp(C.c_ulonglong)]),
         "STTX_TestLm": (ci, [vp, cu, pp(cs), cu, ci, ci, vp, vp]),
         "STTX_DebugLimitArena": (ci, [ci]),
+        "STTX_DebugSetFastPath": (ci, [ci]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

@@ -1,0 +1,92 @@
+"""The shapes bench.py actually times (BASELINE.json configs[1]: 64 utterances x 5 s, n_hidden 2048, 250 timesteps -- the
+B = 64 recurrent kernel instance, M = 1536/3072-row GEMM tiles, the 64-row softmax kernel) and configs[0] (the LDC93S1
+WAV, no scorer, beam 1), numerically, not only through transcripts.
+
+Stated tolerance of the acoustic half (f16 MFMA operands, f32 accumulate, f16 h between steps) against the f64 restatement
+that rounds weights and activations where the kernels store them: |p - p_ref| <= 3e-3 and |ln p - ln p_ref| <= 1e-2
+(every class of every frame within 1 %) over all 250 steps -- the recurrence does not drift."""
+import os
+import wave
+
+import numpy as np
+import pytest
+
+from conftest import dump
+from stt_amd import modelfile, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(tmp_path_factory):
+    from stt_amd import Model
+    w = synth.synth_weights(0, n_hidden=2048)          # the bench's weights
+    path = str(tmp_path_factory.mktemp("bshape") / "english.sttw")
+    modelfile.write_model(path, w, synth.ENGLISH_LABELS, beam_width=500)
+    return Model(path), w
+
+
+def test_bench_batch_probabilities_against_the_oracle_and_bitwise_batch_independence(big):
+    from oracle import am_ref
+    model, w = big
+    B = 64
+    audio = [synth.synth_audio(80000, seed=i) for i in range(B)]      # bench.py: seed = 1000 * rank + i
+    got = model.acousticProbs(audio)
+    assert all(g.shape == (250, 29) for g in got)
+    worst_abs = worst_log = 0.0
+    for i in (0, 9, 22, 37, 48, 63):
+        want = am_ref.utterance_probs(audio[i], w, weight_round=np.float16)
+        a = float(np.abs(got[i] - want).max())
+        l = float(np.abs(np.log(got[i]) - np.log(want)).max())
+        # error by timestep must not grow along the recurrence: compare the last 50 steps with the first 50
+        per_t = np.abs(np.log(got[i]) - np.log(want)).max(1)
+        dump("benchshape_%d" % i, got=got[i], want=want, per_t=per_t)
+        assert a < 3e-3 and l < 1e-2, (i, a, l)
+        assert per_t[200:].max() < 1e-2, (i, per_t[:50].max(), per_t[200:].max())
+        worst_abs, worst_log = max(worst_abs, a), max(worst_log, l)
+    print("bench shape: max |dp| %.3e  max |dlnp| %.3e" % (worst_abs, worst_log))
+    # a row computed alone (B = 1 kernels) and inside the 64-batch (B = 64 kernels): the same bits
+    for i in (0, 37, 63):
+        alone = model.acousticProbs([audio[i]])[0]
+        assert np.array_equal(alone, got[i]), (i, float(np.abs(alone - got[i]).max()))
+    # and inside a different batch composition (B = 17 -> the 32-row instance of the recurrent kernel)
+    sub = model.acousticProbs(audio[20:37])
+    assert np.array_equal(sub[2], got[22])
+
+
+def test_config0_ldc93s1_no_scorer_beam_1(big, ref, port, english, fix):
+    """BASELINE.json configs[0] (SURVEY.md 8d Config 1): data/smoke_test/LDC93S1_pcms16le_1_16000.wav, no scorer,
+    STT_SetModelBeamWidth(1) (native_client/stt.cc:336-339; ci_scripts/asserts.sh:189 runs this file).  No released model exists
+    offline, so the weights are the seeded synthetic ones: T must be 146, the probabilities must match the restatement, and
+    the decoded labels must equal the REAL reference decoder's (oracle/_ref) on the GPU's own emissions."""
+    from oracle import am_ref
+    model, w = big
+    with wave.open(os.path.join(fix, "LDC93S1_pcms16le_1_16000.wav"), "rb") as f:
+        assert (f.getframerate(), f.getnchannels(), f.getsampwidth()) == (16000, 1, 2)
+        a = np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16)
+    assert len(a) == 46797
+    model.setBeamWidth(1)
+    try:
+        probs = model.acousticProbs([a])[0]
+        assert probs.shape == (146, 29)                                   # T = 146 for 46 797 samples
+        want = am_ref.utterance_probs(a, w, weight_round=np.float16)
+        assert np.abs(probs - want).max() < 3e-3 and np.abs(np.log(probs) - np.log(want)).max() < 1e-2
+        text = model.stt(a)
+        md = model.sttWithMetadata(a, 1)
+        A = ref.Alphabet(os.path.join(fix, "alphabet.txt"))
+        d = ref.Decoder(A, 1, None)
+        d.next(probs.astype(np.float64))
+        conf, tok, ts = d.decode(1)[0]
+        labels, space = english
+        assert text == b"".join(labels[t] for t in tok).decode()
+        assert md.transcripts[0].confidence == conf
+        assert [t.timestep for t in md.transcripts[0].tokens] == list(ts)
+        # greedy path == the port as well, and streaming in 320 ms hops gives the same string
+        dp = port.Decoder(labels, space, 1, None); dp.next(probs)
+        assert tuple(dp.decode(1)[0][1]) == tuple(tok)
+        s = model.createStream()
+        for k in range(0, len(a), 5120):
+            s.feedAudioContent(a[k:k + 5120])
+        assert s.finishStream() == text
+    finally:
+        model.setBeamWidth(500)

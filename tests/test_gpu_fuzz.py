@@ -56,8 +56,19 @@ def _emissions(rng, T, C, blank, kind, vocab, mode):
     return p
 
 
-@pytest.mark.parametrize("mode,lm", [("word", False), ("word", True), ("bytes", False), ("bytes", True)])
-def test_fuzz_decoder_against_port(rigs, port, fix, mode, lm):
+@pytest.mark.parametrize("mode,lm,fast", [("word", False, 1), ("word", True, 1), ("word", True, 0), ("bytes", False, 1), ("bytes", True, 1)])
+def test_fuzz_decoder_against_port(rigs, port, fix, mode, lm, fast):
+    """fast = 0 forces the generic search step where the word-mode fast path (label bitmaps, hashed n-gram index) would
+    otherwise run: the same seeded cases must pass on both."""
+    from stt_amd import native
+    native.lib().STTX_DebugSetFastPath(fast)
+    try:
+        _fuzz(rigs, port, fix, mode, lm)
+    finally:
+        native.lib().STTX_DebugSetFastPath(-1)
+
+
+def _fuzz(rigs, port, fix, mode, lm):
     m, P, labels, space = rigs[(mode, lm)]
     C = len(labels) + 1
     vocab = open(os.path.join(fix, "vocab.pruned.txt")).read().split()

@@ -116,7 +116,10 @@ def test_batch_acoustic_probs(small_model):
         assert got[i].shape == want16.shape
         dump("am_batch_%d" % i, got=got[i], want16=want16, want64=want64)
         assert np.abs(got[i] - want16).max() < 3e-3, (i, np.abs(got[i] - want16).max())
-        assert np.abs(got[i] - want64).max() < 2e-2, (i, np.abs(got[i] - want64).max())
+        # against the unrounded f64 restatement: every probability within 0.5 % (log domain; measured 6e-4 -- the f16 storage
+        # of weights and activations is the whole difference)
+        if got[i].size:
+            assert np.abs(np.log(got[i]) - np.log(want64)).max() < 5e-3, (i, np.abs(np.log(got[i]) - np.log(want64)).max())
     # batch composition must not change a row: same utterance alone == inside the batch (bitwise)
     alone = model.acousticProbs([audio[1]])[0]
     assert np.array_equal(alone, got[1])
