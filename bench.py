@@ -158,6 +158,7 @@ def main():
     model.setProfiling(2)            # one extra, untimed step with the search kernel's phase cycle counters on
     step()
     dphase = model.decoderPhaseCycles()
+    dstamps = model.decoderStamps()
     model.setProfiling(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -215,6 +216,7 @@ def main():
             "decoder_phase_cycle_share": {k: round(v / max(1, sum(x for n, x in dphase.items() if not n.startswith("lm_wave"))), 4)
                                           for k, v in dphase.items() if not k.startswith("lm_wave")},
             "decoder_phase_cycles_per_stream_step": {k: round(v / max(1, dstats["steps"]), 1) for k, v in dphase.items()},
+            "decoder_stamp_cycles_per_stream_step": [round(v / max(1, dstats["steps"]), 1) for v in dstamps],
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -71,6 +71,9 @@ STTX_EXPORT int STTX_GetDecoderStats(ModelState* aCtx, unsigned long long* aOut4
 /* Shader cycles spent per decoder phase (summed over streams) in the last batch call: emissions + hash, expand
  * prefix-sum, expand items, LM, merge, select, rank + write, end of step. */
 STTX_EXPORT int STTX_GetDecoderPhaseCycles(ModelState* aCtx, unsigned long long* aOut8);
+/* Profiling level 2, fast word-mode search step: shader cycles between the fine-grained stamps of ctc_fast.inc, summed over
+ * the streams of the last batch call ([0..31] one expand wave, [32..63] one language-model wave; slot meanings there). */
+STTX_EXPORT int STTX_GetDecoderStamps(ModelState* aCtx, unsigned long long* aOut64);
 
 /* ---- stage-level entry points (host buffers in and out) --------------------------------------- */
 /* aOut: [aCapFrames][n_input] floats; *aNumFrames = frames produced for aNumSamples samples. */

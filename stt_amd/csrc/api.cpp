@@ -184,6 +184,11 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
   DecParams p{};
   p.C = m->g.n_classes; p.blank = p.C - 1; p.beam = sl.dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = t_max;
   p.phase_cycles = prof_of(m).phase_cycles ? 1 : 0;
+  if (p.phase_cycles) {
+    sl.stamps.reserve((size_t)Bg * 64 * 8);
+    HIP_CHECK(hipMemsetAsync(sl.stamps.p, 0, (size_t)Bg * 64 * 8, sl.stream_dec));
+    p.stamps = sl.stamps.as<unsigned long long>();
+  }
   int max_chunk = 1;
   for (int k = 0; k < n_chunks; ++k) max_chunk = std::max(max_chunk, cb[k + 1] - cb[k]);
   sl.wide.reserve(ctc_rows_ws_bytes(p, Bg, max_chunk));
@@ -240,6 +245,11 @@ void batch_collect_group(ModelState* m, ModelState::GroupSlot& sl, std::vector<s
     std::vector<DecStream> tb(sl.Bg);
     HIP_CHECK(hipMemcpy(tb.data(), sl.dec.table.p, sizeof(DecStream) * sl.Bg, hipMemcpyDeviceToHost));
     for (auto& S : tb) { for (int k = 0; k < 4; ++k) pr.dec_stats[k] += S.stat[k]; for (int k = 0; k < 8; ++k) pr.dec_phase[k] += S.phase[k]; }
+    if (pr.phase_cycles && sl.stamps.p) {
+      std::vector<unsigned long long> st((size_t)sl.Bg * 64);
+      HIP_CHECK(hipMemcpy(st.data(), sl.stamps.p, st.size() * 8, hipMemcpyDeviceToHost));
+      for (int i = 0; i < sl.Bg; ++i) for (int k = 0; k < 64; ++k) pr.dec_stamps[k] += st[(size_t)i * 64 + k];
+    }
   }
 }
 
@@ -249,7 +259,7 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
   std::vector<std::vector<Output>> all(B);
   HIP_CHECK(hipSetDevice(m->device));
   Prof& pr = prof_of(m);
-  if (pr.on) { for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; prof_reset(pr); }
+  if (pr.on) { for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; for (auto& x : pr.dec_stamps) x = 0; prof_reset(pr); }
   if (!m->ev_chunk[0]) {
     for (auto& e : m->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& sl : m->slots_) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
@@ -623,6 +633,12 @@ int STTX_GetDecoderStats(ModelState* aCtx, unsigned long long* aOut4) {
 int STTX_GetDecoderPhaseCycles(ModelState* aCtx, unsigned long long* aOut8) {
   Prof& p = prof_of(aCtx);
   for (int i = 0; i < 8; ++i) aOut8[i] = p.dec_phase[i];
+  return STT_ERR_OK;
+}
+
+int STTX_GetDecoderStamps(ModelState* aCtx, unsigned long long* aOut64) {
+  Prof& p = prof_of(aCtx);
+  for (int i = 0; i < 64; ++i) aOut64[i] = p.dec_stamps[i];
   return STT_ERR_OK;
 }
 

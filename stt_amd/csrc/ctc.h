@@ -140,6 +140,7 @@ struct DecParams {
   unsigned long long wide_stride;
   int wide_max_frames;
   int n_lm_waves;  // fast word path: waves of the workgroup that only run language-model queries (filled in by launch_ctc_next)
+  unsigned long long* stamps;  // profiling level 2: [n_streams][64] shader cycles between the stamps of ctc_fast.inc (wave 0: 0..31, last wave: 32..63)
 };
 
 struct DecodeOut {

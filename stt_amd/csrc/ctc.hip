@@ -92,9 +92,11 @@ __device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { uint32_t v; __buil
 __device__ __forceinline__ bool is_absent(float x) { return __float_as_uint(x) == ABSENT_BITS; }
 __device__ __forceinline__ float absent() { return __uint_as_float(ABSENT_BITS); }
 
+// Path key of "parent + label": one multiply-xorshift round per label (a 64-bit FNV-1a style rolling hash with a final
+// fold; the search kernel is instruction-issue bound and every expand item computes one of these).
 __device__ __forceinline__ uint64_t child_key(uint64_t parent_key, uint32_t c) {
-  uint64_t x = parent_key + 0x9E3779B97F4A7C15ULL * (uint64_t)(c + 1);
-  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31;
+  uint64_t x = (parent_key ^ (uint64_t)(c + 1)) * 0x9E3779B97F4A7C15ULL;
+  x ^= x >> 29;
   return x | 1ULL;  // 0 is the empty marker of the LDS hash
 }
 
@@ -606,6 +608,7 @@ struct Lds {
   LDS_AS uint64_t* ht_key; LDS_AS uint16_t* ht_idx;  // path key -> beam index of the live prefixes (rebuilt whenever the beam is written)
   DB<float> pf, lp; LDS_AS float* lps;        // emissions and their logs (double buffered: the next row is prepared one step ahead); lps = by class position when pruning sorts
   LDS_AS double* lbl;                         // [2] log((double)prob[blank])
+  LDS_AS uint32_t* lpm;                       // fast word path: [2][36] bitmap of the k most probable classes of the row
   LDS_AS float* pbl;                          // [2] prob[blank] (fast word path: the row arrives as a prepared record)
   LDS_AS uint8_t* wait;                       // fast word path: live prefix whose extension event waits for a score of this step's LM waves
   LDS_AS uint16_t *cls, *pos;
@@ -619,11 +622,12 @@ struct Lds {
   // the first `mcap` candidates of a step live in LDS, the rest in the stream's HBM workspace
   LDS_AS float* lc_logp; LDS_AS uint32_t* lc_pi; LDS_AS int* lc_fst; uint32_t mcap;
   LDS_AS unsigned long long* acc;  // [0..3] stat counters, [4..11] phase cycles (accumulated in LDS, flushed when the launch ends)
+  LDS_AS unsigned long long* stm;  // [64] fine-grained stamps (DecParams::stamps)
   LDS_AS int* sc;  // scalars
 };
 // phase cycle counters (s_memtime is a scalar memory operation with a wait: only on request, DecParams::phase_cycles)
 #define TICK(k) do { if (p.phase_cycles && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); L.acc[4 + (k)] += now_ - tick_; tick_ = now_; } } while (0)
-enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_CLAMP, SC_COUNT = 16 };
+enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_CLAMP, SC_NA, SC_NB, SC_COUNT = 24 };
 #define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
 
@@ -658,12 +662,15 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   offs[k++] = take(cap * 2);                                       // lmw
   offs[k++] = take(32 * 8); offs[k++] = take(32 * 8);              // exp / log tables
   offs[k++] = take(12 * 8);
+  offs[k++] = take(64 * 8);                                        // stm
   offs[k++] = take(SC_COUNT * 4);
   offs[k++] = take(16);                                            // lbl[2]
+  offs[k++] = take(2 * 36 * 4);                                    // lpm[2][36]
   offs[k++] = take(16);                                            // pbl[2]
   offs[k++] = take(arcs ? cap : 0);                                // wait
   // ---- class-count dependent from here on
-  for (int a = 0; a < 5; ++a) offs[k++] = take((size_t)(C > 0 && C < 32 ? 32 : C) * 4);  // pf[2], lp[2], lps (>= 32 floats: the fast word path reads a row as 8 x float4)
+  for (int a = 0; a < 4; ++a) offs[k++] = take((size_t)(C > 0 && C < 32 ? 32 : C) * 4);  // pf[2], lp[2]
+  offs[k++] = take((size_t)(C > 0 && C <= 32 ? 64 : C) * 4);                            // lps (fast word path: [2][32] sorted log-probs)
   offs[k++] = take((size_t)C * 2); offs[k++] = take((size_t)C * 2);
   offs[k++] = take((size_t)C);
   // candidate staging: whatever fits under 126 KiB (leaves 34 KiB for a co-resident LSTM workgroup), at most 2048
@@ -696,8 +703,10 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
     l->lmw = (LDS_AS uint16_t*)(base + offs[k++]);
     l->exp_tab = (LDS_AS uint64_t*)(base + offs[k++]); l->log_tab = (LDS_AS double*)(base + offs[k++]);
     l->acc = (LDS_AS unsigned long long*)(base + offs[k++]);
+    l->stm = (LDS_AS unsigned long long*)(base + offs[k++]);
     l->sc = (LDS_AS int*)(base + offs[k++]);
     l->lbl = (LDS_AS double*)(base + offs[k++]);
+    l->lpm = (LDS_AS uint32_t*)(base + offs[k++]);
     l->pbl = (LDS_AS float*)(base + offs[k++]);
     l->wait = (LDS_AS uint8_t*)(base + offs[k++]);
     l->pf.p0 = (LDS_AS float*)(base + offs[k]); l->pf.blk = (uint32_t)(offs[k + 1] - offs[k]); k += 2;
@@ -1367,7 +1376,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   if (FAST) {  // what the fast step expects cleared on entry (it clears them again when it writes the new beam)
     if (tid < CAP) { L.ev_self[tid] = absent(); L.ev_blank[tid] = absent(); L.ev_ext[tid] = absent(); L.ev_exti[tid] = 0; L.wait[tid] = 0; }
     L.hist[tid] = 0;
-    if (tid == 0) { L.sc[SC_M] = 0; L.sc[SC_LMQ] = 0; L.sc[SC_NQ] = 0; L.sc[SC_PROBES] = 0; L.sc[SC_CLAMP] = 0; }
+    if (tid == 0) { L.sc[SC_M] = 0; L.sc[SC_LMQ] = 0; L.sc[SC_NQ] = 0; L.sc[SC_PROBES] = 0; L.sc[SC_CLAMP] = 0; L.sc[SC_NA] = 0; L.sc[SC_NB] = 0; }
   }
   for (int c = tid; !WIDE && c < p.C; c += NTHREADS) {
     uint8_t one = 0;
@@ -1379,10 +1388,11 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   if (tid < 32) { L.exp_tab[tid] = sttm::kExp2Tab[tid]; L.log_tab[tid] = sttm::kLogfTab[tid >> 1][tid & 1]; }
   if (tid == 0) { L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
   if (tid < 12) L.acc[tid] = 0;
+  if (tid < 64) L.stm[tid] = 0;
   __syncthreads();  // the math tables must be in place before the first row is prepared
   const unsigned char* rec0 = FAST ? p.wide_rows + ((size_t)blockIdx.x * p.wide_max_frames) * p.wide_stride : nullptr;  // this stream's row records
-  if (FAST) {
-    if (tid < p.C) L.lp[0][tid] = reinterpret_cast<const float*>(rec0 + sizeof(WideRowHdr))[tid];
+  if constexpr (FAST) {
+    if (tid < 64) sort_row_classes(L, 0, p.C, tid < p.C ? reinterpret_cast<const float*>(rec0 + sizeof(WideRowHdr))[tid] : 0.0f, tid);
     else if (tid == 64) { const WideRowHdr* hdr = reinterpret_cast<const WideRowHdr*>(rec0); L.pbl[0] = hdr->pblank; L.lbl[0] = hdr->lbl; }
   } else if (!WIDE) prep_row(p, L, 0, row, v0);
   __syncthreads();
@@ -1420,6 +1430,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
 #pragma unroll
     for (int k = 0; k < 8; ++k) G.phase[k] += L.acc[4 + k];
   }
+  if (p.stamps && tid < 64) p.stamps[(size_t)blockIdx.x * 64 + tid] += L.stm[tid];
 }
 
 // ------------------------------------------------------------------------------------ decode

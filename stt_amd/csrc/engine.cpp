@@ -238,7 +238,11 @@ void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_
 void check_decoder_errors(const int* errors, int n) {
   int err = 0;
   for (int i = 0; i < n; ++i) err |= errors[i];
-  if (err) throw std::runtime_error("decoder state error bits 0x" + std::to_string(err) + " (1 path arena, 2 time arena, 4 candidates, 8 scorer cache, 16 path hash)");
+  if (err) {
+    char hex[16];
+    snprintf(hex, sizeof(hex), "0x%x", (unsigned)err);
+    throw std::runtime_error(std::string("decoder state error bits ") + hex + " (0x1 path arena, 0x2 time arena, 0x4 candidates, 0x8 scorer cache, 0x10 path hash)");
+  }
 }
 
 std::vector<std::vector<Output>> decode_streams(const ModelState& mc, const DecoderBatch& db, std::shared_ptr<ScorerDev> sc,

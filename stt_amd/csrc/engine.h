@@ -142,6 +142,7 @@ struct Prof {
   float ms[8] = {};
   unsigned long long dec_stats[4] = {};
   unsigned long long dec_phase[8] = {};
+  unsigned long long dec_stamps[64] = {};
   ~Prof() { for (auto e : pool) (void)hipEventDestroy(e); }
 };
 struct ModelState {
@@ -185,6 +186,7 @@ struct ModelState {
   struct GroupSlot {
     DecoderBatch dec;
     DevBuf probs, ints, out;  // out: one DecodeBlock (ctc.h)
+    DevBuf stamps;            // profiling level 2: DecParams::stamps
     DevBuf wide;  // per-row class records of the wide-alphabet search path (ctc.h: ctc_is_wide)
     PinnedBuf h_ints, h_table, h_out;
     DecodeBlock out_layout{};

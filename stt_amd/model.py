@@ -187,6 +187,11 @@ class Model(object):
         native.lib().STTX_GetDecoderPhaseCycles(self._impl, st)
         return dict(zip(["setup", "expand_events", "expand_items", "lm", "merge", "select", "rank+write", "lm_wave (parallel to expand)"], [int(x) for x in st]))
 
+    def decoderStamps(self):
+        st = (C.c_ulonglong * 64)()
+        native.lib().STTX_GetDecoderStamps(self._impl, st)
+        return [int(x) for x in st]
+
     def computeMfcc(self, audio_buffer):
         a, p, n = _audio(audio_buffer)
         g = self.geometry()

@@ -48,7 +48,7 @@ COQUI_STT_H = [
 STT_AMD_H = [
     "STTX_SetDevice", "STTX_GetDeviceCount", "STTX_SpeechToTextBatch", "STTX_SpeechToTextBatchWithMetadata",
     "STTX_SpeechToTextBatchDevice", "STTX_FeedAudioContentBatch", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
-    "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
+    "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_GetDecoderStamps", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
     "STTX_DecoderStats", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
     "STTX_InspectModel", "STTX_ReadModelTensor", "STTX_TestLm", "STTX_DebugLimitArena", "STTX_DebugSetFastPath",
@@ -112,6 +112,7 @@ def lib():
         "STTX_GetStageTimes": (ci, [vp, pp(cf), ci]),
         "STTX_GetDecoderStats": (ci, [vp, pp(C.c_ulonglong)]),
         "STTX_GetDecoderPhaseCycles": (ci, [vp, pp(C.c_ulonglong)]),
+        "STTX_GetDecoderStamps": (ci, [vp, pp(C.c_ulonglong)]),
         "STTX_ComputeMfcc": (ci, [vp, vp, cu, vp, cu, pp(cu)]),
         "STTX_AcousticProbs": (ci, [vp, pp(vp), pp(cu), cu, vp, cu, pp(cu)]),
         "STTX_InferChunk": (ci, [vp, vp, cu, vp, vp, vp, vp, vp]),

@@ -79,8 +79,9 @@ def test_config0_ldc93s1_no_scorer_beam_1(big, ref, port, english, fix):
         conf, tok, ts = d.decode(1)[0]
         labels, space = english
         assert text == b"".join(labels[t] for t in tok).decode()
-        assert md.transcripts[0].confidence == conf
-        assert [t.timestep for t in md.transcripts[0].tokens] == list(ts)
+        tr = md["transcripts"][0]
+        assert tr["confidence"] == conf
+        assert [t[1] for t in tr["tokens"]] == [int(x) for x in ts]
         # greedy path == the port as well, and streaming in 320 ms hops gives the same string
         dp = port.Decoder(labels, space, 1, None); dp.next(probs)
         assert tuple(dp.decode(1)[0][1]) == tuple(tok)
