@@ -765,6 +765,7 @@ __device__ __forceinline__ int ht_find(const Lds& L, uint64_t k) {
 #define OP_ADD(a, b) ((a) + (b))
 #define OP_MIN(a, b) ((b) < (a) ? (b) : (a))
 #define OP_MAX(a, b) ((b) > (a) ? (b) : (a))
+#define OP_OR(a, b) ((a) | (b))
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
   WAVE_SCAN_STEPS(OP_ADD, 0u)
   return v;
@@ -1608,6 +1609,11 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
     while (nlm > 1 && ((cb / 64) % nlm != 0 || nlm > cb / 64)) --nlm;  // every LM wave scans whole 64-prefix slices of the beam
     if (nlm > 4) nlm = 4;
     p.n_lm_waves = nlm;
+    static const int exw = []() { const char* e = getenv("STT_AMD_EXP_WAVES"); return e ? atoi(e) : 0; }();
+    int nexp = exw > 0 ? exw : NWAVES - nlm;
+    if (nexp > NWAVES - nlm) nexp = NWAVES - nlm;
+    if (nexp * 64 < cb) nexp = (cb + 63) / 64;  // a lane owns one prefix
+    p.n_exp_waves = nexp;
     const int rows = n_streams * max_frames;
     hipLaunchKernelGGL(ctc_rows_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, p, probs, frame_begin, frame_count, n_streams);
     check_launch("ctc_rows_kernel");
