@@ -8,7 +8,7 @@ if [ -z "$SKIP_TESTS" ]; then
   tail -40 $OUT/tests.log
 fi
 run() {  # name, env...
-  local name=$1; shift
+  local name=$(echo "$1" | tr -c 'A-Za-z0-9_\n' '_'); shift
   env "$@" timeout 400 python bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline > $OUT/bench_$name.json 2> $OUT/bench_$name.err; echo "bench $name rc=$?"
   python - "$OUT/bench_$name.json" <<'PY'
 import json, sys
@@ -33,6 +33,6 @@ for v in "$@"; do
     lm2) run lm2 STT_AMD_LM_WAVES=2 ;;
     lm4) run lm4 STT_AMD_LM_WAVES=4 ;;
     mband) run mband STT_AMD_DENSE_MBAND=1 ;;
-    *) run "$v" $v ;;
+    *) run "$v" $v ;;   # "ENV=1 ENV2=2" -> name sanitised
   esac
 done

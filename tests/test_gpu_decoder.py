@@ -50,7 +50,19 @@ def _gpu_decode(models, case, probs):
     return res, st, d
 
 
-def test_decoder_matches_reference_goldens(models, decoder_cases):
+@pytest.mark.parametrize("fast", [0, 1], ids=["generic-step", "fast-word-step"])
+def test_decoder_matches_reference_goldens(models, decoder_cases, fast):
+    """fast = 1: the word-mode cases with a scorer run the restructured step of ctc_fast.inc (label bitmaps, hashed n-gram
+    index, four lanes per LM query); everything else falls back to the generic step either way."""
+    from stt_amd import native
+    native.lib().STTX_DebugSetFastPath(fast)
+    try:
+        _goldens(models, decoder_cases)
+    finally:
+        native.lib().STTX_DebugSetFastPath(-1)
+
+
+def _goldens(models, decoder_cases):
     cases, gold = decoder_cases
     bad = []
     for case in cases:
