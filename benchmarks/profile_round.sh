@@ -4,7 +4,7 @@
 # the two cannot share the TCC slots, and counters never ride on a trace/timed run).
 # usage: bash benchmarks/profile_round.sh <tag>
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-TAG=${1:-r01_x}
+TAG=${1:-r02_x}
 OUT=gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do

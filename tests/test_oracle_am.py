@@ -71,3 +71,14 @@ def test_power_spectrum_and_frame_count_against_scipy_fft():
     logmel = np.log(np.maximum(mel, 1e-12))
     dct = np.sqrt(2.0 / 40) * np.cos(np.pi / 40 * np.outer(np.arange(26), np.arange(40) + 0.5))
     assert np.abs(dct @ logmel - feats[f]).max() < 1e-4
+
+
+def test_torch_f32_restatement_agrees_with_the_f64_one():
+    """oracle/am_torch.py (the CPU baseline's acoustic stage, torch f32) against oracle/am_ref.py (numpy f64): same graph."""
+    from oracle import am_ref, am_torch
+    from stt_amd import synth
+    w = am_ref.synth_weights(4, n_hidden=128)
+    a = synth.synth_audio(9000, seed=8)
+    want = am_ref.utterance_probs(a, w)
+    got = am_torch.utterance_probs(a, am_torch.to_torch(w))
+    assert got.shape == want.shape and np.abs(got - want).max() < 1e-5
