@@ -138,8 +138,10 @@ STTX_EXPORT int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* 
 /* Test hook: decoder arenas are sized for aFrames timesteps and never grow (0 = normal sizing), so that the overflow
  * reporting of the decode calls can be exercised. */
 STTX_EXPORT int STTX_DebugLimitArena(int aFrames);
-/* Test hook: 0 = the generic search step everywhere, 1 = the fast word-mode step (label bitmaps + hashed n-gram index) wherever
- * it applies (the default), -1 = as the STT_AMD_FAST environment variable says.  Both must give identical beams. */
+/* Test hook, word-mode search step: 0 = the generic step everywhere, 1 = the restructured step of ctc_fast.inc, 2 = the generic
+ * step with dictionary label bitmaps, two language-model waves and FullScore through the hashed n-gram index (the default
+ * wherever it applies: <= 32 classes, no class pruning, beam <= 512), -1 = as the STT_AMD_FAST environment variable says.
+ * All three must give identical beams. */
 STTX_EXPORT int STTX_DebugSetFastPath(int aOn);
 /* Host-side packing of the recurrent matrix (no GPU needed): aKernel [2H][4H] f32 -> aOut [4H*H] f16 bits. */
 STTX_EXPORT int STTX_PackLstmRecurrent(const float* aKernel, int aHidden, unsigned short* aOut);

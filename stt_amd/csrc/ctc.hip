@@ -54,6 +54,7 @@ __device__ __forceinline__ uint64_t lds_cas0(LDS_AS uint64_t* p, uint64_t desire
 // flat_*, so waiting for an LDS result does not also wait for the HBM reads in flight (flat ops count on both counters).
 #define GLB_AS __attribute__((address_space(1)))
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 struct GStream {
   GLB_AS uint64_t *pa, *ta;  // {parent (low word), character / timestep (high word)}
   GLB_AS uint32_t* pq;
@@ -435,6 +436,58 @@ __device__ __forceinline__ void word_walk(const DevAlphabet& al, const GStream& 
 // the last `order` words from a null context (or all words from BeginSentence when there are fewer), and a KenLM state
 // holds at most order-1 words, so the state carried from the previous boundary is the state the reference rebuilds.
 // Appends a BEntry and records it in S.pq[node]; returns log_cond_prob + hot_boost.
+// GenericModel::FullScore through the hashed n-gram index (lmindex.h), one lane per query: one 64-byte bucket per order,
+// fetched one after the other (an order-k entry is verified against the order-(k-1) hit, and most queries end at order 2 or
+// 3), instead of an interpolation search plus child-range reads per order.  Orders <= 5.  Same floats as the trie walk.
+__device__ __forceinline__ float lm_full_score_indexed(const DevScorer& s, const KState& in, uint64_t h, uint32_t wi, const DevVocabSlot& vs, KState& out,
+                                                       unsigned& probes) {
+  const float uprob = wi ? vs.prob : s.unk_prob, uback = wi ? vs.backoff : s.unk_backoff;
+  const bool uindep = wi ? (vs.begin == vs.end) : (s.unk_indep != 0);
+  const GLB_AS u32x4* tab = (const GLB_AS u32x4*)s.lmi;
+  const uint32_t nb = s.lmi_buckets;
+  LmiLevel lv[LMI_MAX_HIST];
+  uint64_t key = wi ? h : LMI_UNK_H;
+  uint32_t parent = wi;
+  bool going = !uindep;  // (a unigram without children ends ScoreExceptBackoff before any lookup, model.cc:300-305)
+#pragma unroll
+  for (int q = 0; q < LMI_MAX_HIST; ++q) {
+    lv[q].found = 0; lv[q].prob = 0.0f; lv[q].backoff = 0.0f; lv[q].indep = 0;
+    if (q < 4) {
+      if (going && q < in.length && q + 2 <= s.order) {
+        const uint32_t w = in.words[q];
+        key = lmi_step(key, w);
+        const uint32_t b = lmi_bucket(key, nb);
+        const GLB_AS u32x4* bp = tab + (size_t)b * LMI_BUCKET;
+        const u32x4 e0 = bp[0], e1 = bp[1], e2 = bp[2], e3 = bp[3];
+        ++probes;
+        const uint32_t tag = (w & LMI_WORD_MASK) | ((uint32_t)(q + 2) << LMI_LEVEL_SHIFT);
+        u32x4 hit = {LMI_EMPTY, 0u, 0u, 0u};
+        uint32_t id = LMI_NOT_FOUND;
+        if ((e0.x & ~LMI_INDEP_BIT) == tag && e0.y == parent) { hit = e0; id = b * LMI_BUCKET + 0u; }
+        else if ((e1.x & ~LMI_INDEP_BIT) == tag && e1.y == parent) { hit = e1; id = b * LMI_BUCKET + 1u; }
+        else if ((e2.x & ~LMI_INDEP_BIT) == tag && e2.y == parent) { hit = e2; id = b * LMI_BUCKET + 2u; }
+        else if ((e3.x & ~LMI_INDEP_BIT) == tag && e3.y == parent) { hit = e3; id = b * LMI_BUCKET + 3u; }
+        else if (e0.x != LMI_EMPTY && e1.x != LMI_EMPTY && e2.x != LMI_EMPTY && e3.x != LMI_EMPTY) {  // full bucket: the entry may have overflowed
+          LmiEntry e;
+          id = lmi_probe(s.lmi, nb, b + 1 == nb ? 0u : b + 1, q + 2, w, parent, e);
+          probes += 2;
+          if (id != LMI_NOT_FOUND) { hit.x = e.wl; hit.z = __float_as_uint(e.prob); hit.w = __float_as_uint(e.backoff); }
+        }
+        if (id == LMI_NOT_FOUND) going = false;
+        else {
+          lv[q].found = 1; lv[q].prob = __uint_as_float(hit.z); lv[q].backoff = __uint_as_float(hit.w); lv[q].indep = (hit.x & LMI_INDEP_BIT) ? 1 : 0;
+          parent = id;
+          if (lv[q].indep) going = false;
+        }
+      } else going = false;
+    }
+  }
+  int nl;
+  return lmi_combine(s.order, in, wi, uprob, uback, uindep, lv, out, nl);
+}
+
+// IDX: FullScore through the hashed n-gram index (the scorer must have one: orders <= 5), else the trie walk
+template <bool IDX>
 __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al, const GStream& S, const LDS_AS uint8_t* lab1, LDS_AS uint32_t* be_n, uint32_t node, uint32_t e_prev,
                                        bool have_word, uint64_t lo, uint64_t hi, uint32_t& out_entry, unsigned& probes) {
   // The word's bytes come from the beam state (have_word) or from a walk back to the previous boundary; words longer than
@@ -460,7 +513,9 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
   DevVocabSlot vs;
   const uint32_t wi = vocab_slot(s, h, vs, probes);
   BEntry en;
-  const float prob = kenlm_full_score(s, ep.st, wi, en.st, probes, (wi != 0 && s.uni_in_vtab) ? &vs : nullptr);
+  float prob;
+  if constexpr (IDX) prob = lm_full_score_indexed(s, ep.st, h, wi, vs, en.st, probes);  // (the launcher picks IDX only when the index exists)
+  else prob = kenlm_full_score(s, ep.st, wi, en.st, probes, (wi != 0 && s.uni_in_vtab) ? &vs : nullptr);
   en.oov_hist = (uint16_t)((ep.oov_hist << 1) | (wi == 0 ? 1u : 0u));
   const bool oov = (en.oov_hist & ((1u << s.order) - 1u)) != 0;  // this word + the order-1 before it
   float hot_self = 0.0f, hot_total = 0.0f;
@@ -857,9 +912,15 @@ __device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, co
 // MODE: 0 = no scorer, 1 = word-level scorer, 2 = utf8 (codepoint-level) scorer -- separate instantiations, so the
 // hot word-mode kernel does not carry the registers and code of the uncached codepoint paths.
 // WIDE: the class arrays of the row come from the HBM record `t_local` of this stream (see "wide alphabets" above).
-template <int MODE, bool WIDE>
+// MODE_T 4 = word mode (like 1) with the dictionary's label bitmaps (DevScorer::fst_rec): a prefix's work items are the
+// labels its dictionary state allows AND that survive the score cut-off of :157-159 -- the arcs that would be rejected are
+// never touched (about 5x fewer items on near-uniform emissions) --, two language-model waves, and FullScore through the
+// hashed n-gram index.  <= 32 classes, no class pruning, beam capacity <= 512.
+template <int MODE_T, bool WIDE>
 __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const GStream& S, const Lds& L, int& cur, int& n,
                          int& start_expanding, int& abs_t, int buf, const float* next_row, int t_local) {
+  constexpr int MODE = MODE_T == 4 ? 1 : MODE_T;
+  constexpr bool MASKED = MODE_T == 4;
   constexpr bool SC_ON = MODE != 0, SC_UTF8 = MODE == 2;
   WRow W{};
   WideRowHdr wh{};
@@ -946,40 +1007,125 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   // the cut-off) and runs those queries *now*, so their dependent HBM reads overlap the expand work of the other waves
   // instead of sitting between two barriers.  P3 then finds the entry in pqe and only reads its score.
   const bool lm_wave = MODE == 1 && L.pqe.p0 != nullptr && n > NWAVES;
-  const int nw_exp = lm_wave ? NWAVES - 1 : NWAVES;
-  if (lm_wave && wave == NWAVES - 1) {
+  const int nlm = lm_wave ? ((MASKED && n > 256) ? 2 : 1) : 0;  // (two lists of 256 entries in lmw: only beams that need capacity 512 get two waves)
+  const int nw_exp = NWAVES - nlm;
+  const uint32_t space_u = (uint32_t)al.space_id;
+  if (lm_wave && wave >= nw_exp) {
     __builtin_amdgcn_s_setprio(3);  // the chain of dependent reads is the critical path of the phase: issue it first
     const unsigned long long lmw_t0 = p.phase_cycles ? __builtin_readcyclecounter() : 0ull;
     const int ksp = POS_OF(al.space_id);
+    const int lw = wave - nw_exp;
+    LDS_AS uint16_t* list = L.lmw + lw * 256;
     unsigned lmq = 0;
     if (ksp != 0xFFFF) {
       const float lpsp = LP_AT(ksp, al.space_id);
       uint32_t n_need = 0;
-      for (int i0 = 0; i0 < n; i0 += 64) {
+      for (int i0 = lw * 64; i0 < n; i0 += 64 * nlm) {
         const int i = i0 + lane;
         bool need = false;
         if (i < n) {
           const float sci = L.score[cur][i];
-          need = (L.an[cur][i] >> 15) && L.pqe[cur][i] == STT_NONE && L.bnd[cur][i] != STT_NONE && sci != NEG &&
+          const bool word_may_end = MASKED ? (((L.sm[cur][i] >> space_u) & 1u) != 0) : ((L.an[cur][i] >> 15) != 0);
+          need = word_may_end && L.pqe[cur][i] == STT_NONE && L.bnd[cur][i] != STT_NONE && sci != NEG &&
                  !(full_beam && __fadd_rn(lpsp, sci) < min_cutoff);
         }
         const uint64_t mask = __ballot(need);
-        if (need) L.lmw[n_need + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        if (need) list[n_need + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)i;
         n_need += (uint32_t)__popcll(mask);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       for (uint32_t q = lane; q < n_need; q += 64) {
-        const int i = (int)L.lmw[q];
+        const int i = (int)list[q];
         uint32_t ne;
-        const double raw = lm_word_query_cached(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], L.node[cur][i], L.bnd[cur][i], true, L.wlo[cur][i], L.whi[cur][i], ne, probes);
+        const double raw = lm_word_query_cached<MASKED>(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], L.node[cur][i], L.bnd[cur][i], true, L.wlo[cur][i], L.whi[cur][i], ne, probes);
         L.pqe[cur][i] = ne; L.pqs[cur][i] = (float)__dmul_rn(raw, s.alpha);
         ++lmq;
       }
     }
     if (lmq) lds_add(&sc[SC_LMQ], (int)lmq);
-    if (p.phase_cycles && lane == 0) L.acc[4 + 7] += __builtin_readcyclecounter() - lmw_t0;  // phase slot 7: the LM wave's own time
+    if (p.phase_cycles && lane == 0 && wave == NWAVES - 1) L.acc[4 + 7] += __builtin_readcyclecounter() - lmw_t0;  // phase slot 7: the (last) LM wave's own time
     __builtin_amdgcn_s_setprio(0);
+  } else if (MASKED) {
+    // ---- expand with label bitmaps: see the comment above the function
+    const LDS_AS float* lpv = lp;
+    const uint32_t lab_mask = ((1u << (C - 1)) - 1u) & ~(1u << p.blank);  // labels 0 .. C-2, never the blank
+    const uint32_t ppw = pow2_ge((uint32_t)((n + nw_exp - 1) / nw_exp));
+    const int i0 = lane * nw_exp + wave;
+    uint32_t cnt = 0, em = 0;
+    if (lane < (int)ppw && i0 < n) {
+      const float sci = L.score[cur][i0];
+      if (sci != NEG) {  // :160-162
+        const uint32_t chi = L.ch[cur][i0];
+        uint32_t pm = 0xFFFFFFFFu;  // classes that survive the cut-off for this prefix (bit c)
+        if (full_beam) {
+          pm = 0;
+#pragma unroll
+          for (int q4 = 0; q4 < 8; ++q4) {
+            const f32x4v v = reinterpret_cast<const LDS_AS f32x4v*>(lpv)[q4];
+            pm |= (!(__fadd_rn(v.x, sci) < min_cutoff) ? 1u : 0u) << (4 * q4);
+            pm |= (!(__fadd_rn(v.y, sci) < min_cutoff) ? 2u : 0u) << (4 * q4);
+            pm |= (!(__fadd_rn(v.z, sci) < min_cutoff) ? 4u : 0u) << (4 * q4);
+            pm |= (!(__fadd_rn(v.w, sci) < min_cutoff) ? 8u : 0u) << (4 * q4);
+          }
+        }
+        if ((pm >> p.blank) & 1u) L.ev_blank[i0] = __fadd_rn(lpv[p.blank], sci);                                  // :166-179
+        if (chi != STT_ROOT_CH && ((pm >> chi) & 1u)) L.ev_self[i0] = __fadd_rn(lpv[chi], L.pnb[cur][i0]);        // :182-193
+        em = L.sm[cur][i0] & pm & lab_mask;
+        cnt = (uint32_t)__popc(em);
+      }
+    }
+    const uint32_t inc = wave_incl_scan(cnt, lane);
+    const uint32_t off = inc - cnt;
+    const uint32_t n_items = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    const bool use_tab = n_items * 2u <= L.own_cap;  // wave-uniform
+    LDS_AS uint16_t* own = (LDS_AS uint16_t*)(L.own + (uint32_t)wave * L.own_cap);
+    if (use_tab) {  // item -> (owning lane, label)
+      uint32_t mm = em, k = off;
+      while (mm) { const uint32_t c = (uint32_t)__builtin_ctz(mm); mm &= mm - 1u; own[k++] = (uint16_t)((uint32_t)lane | (c << 8)); }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    TICK(1);
+#pragma unroll 1
+    for (uint32_t xb = 0; xb < n_items; xb += 64) {
+      const uint32_t x = xb + (uint32_t)lane;
+      const bool v = x < n_items;
+      uint32_t j = 0, c = 0;
+      if (use_tab) { const uint32_t oc = v ? (uint32_t)own[x] : 0u; j = oc & 63u; c = oc >> 8; }
+      else {
+        for (uint32_t step = ppw >> 1; step >= 1; step >>= 1) { const uint32_t v_ = __shfl(off, (int)(j + step)); if (v_ <= x) j += step; }
+        const uint32_t offj = __shfl(off, (int)j);
+        uint32_t emj = __shfl(em, (int)j);
+        if (v) { for (uint32_t kk = x - offj; kk; --kk) emj &= emj - 1u; c = (uint32_t)__builtin_ctz(emj); }
+      }
+      if (!v) continue;
+      const int i = (int)j * nw_exp + wave;
+      const uint32_t smj = L.sm[cur][i];
+      const uint2 arc = s.fst_arcs[L.a0[cur][i] + (uint32_t)__popc(smj & ((1u << c) - 1u))];  // (arc.x == c + 1; arc.y = the child's dictionary state)
+      const float sci = L.score[cur][i];
+      const uint32_t chi = L.ch[cur][i];
+      const float lpc = lpv[c];
+      float log_p = NEG;  // :199-207
+      if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
+      else log_p = __fadd_rn(lpc, sci);
+      const uint32_t needs_lm = c == space_u ? 1u : 0u;
+      const uint64_t ck = child_key(L.key[cur][i], c);
+      const int jj = ht_find(L, ck);
+      if (jj >= 0) {  // the child is a live prefix: one extension event per live prefix per step
+        L.ev_ext[jj] = log_p;
+        L.ev_exti[jj] = (uint32_t)i | (needs_lm << 31);
+        if (needs_lm) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = 0x80000000u | (uint32_t)jj; }
+      } else {
+        const int slot = lds_add(&sc[SC_M], 1);
+        if ((uint32_t)slot < S.cand_cap) {
+          const uint32_t piv = (uint32_t)i | (c << 16) | (needs_lm << 31);  // (class position == class: no pruning in this mode)
+          if ((uint32_t)slot < L.mcap) { L.lc_logp[slot] = log_p; L.lc_pi[slot] = piv; L.lc_fst[slot] = (int)arc.y; }
+          else { S.c_logp[slot] = log_p; S.c_pi[slot] = piv; S.c_fst[slot] = (int)arc.y; }
+          if (needs_lm) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = (uint32_t)slot; }
+        }
+      }
+    }
   } else {
     uint32_t ppw = pow2_ge((uint32_t)((n + nw_exp - 1) / nw_exp));  // <= 64 (n <= 64 * 15 when the last wave is set aside: beams <= 512)
     const int i0 = lane * nw_exp + wave;  // interleaved: the beam is sorted by score and good prefixes survive the cut-off for more labels, so every wave gets its share of them
@@ -1127,7 +1273,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
           if (bndi == STT_NONE) { raw = 0.0; lds_or(&sc[SC_ERR], 8); }
           else {
             uint32_t ne;
-            raw = lm_word_query_cached(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], nodei, bndi, in_lds, in_lds ? L.wlo[cur][i] : 0ULL,
+            raw = lm_word_query_cached<MASKED>(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], nodei, bndi, in_lds, in_lds ? L.wlo[cur][i] : 0ULL,
                                        in_lds ? L.whi[cur][i] : 0ULL, ne, probes);
             if (in_lds) { L.pqe[cur][i] = ne; L.pqs[cur][i] = (float)__dmul_rn(raw, s.alpha); }
             ++lmq;
@@ -1264,7 +1410,8 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       if ((int)x < n) {
         L.score[nxt][r] = L.ev_ext[x]; L.pb[nxt][r] = L.ev_blank[x]; L.pnb[nxt][r] = L.ev_self[x];
         L.ch[nxt][r] = L.ch[cur][x]; L.node[nxt][r] = L.node[cur][x]; L.fst[nxt][r] = L.fst[cur][x];
-        if (L.a0.p0) { L.a0[nxt][r] = L.a0[cur][x]; L.an[nxt][r] = L.an[cur][x]; }
+        if (MASKED) { L.a0[nxt][r] = L.a0[cur][x]; L.sm[nxt][r] = L.sm[cur][x]; }
+        else if (L.a0.p0) { L.a0[nxt][r] = L.a0[cur][x]; L.an[nxt][r] = L.an[cur][x]; }
         nkey = L.key[cur][x];
         L.bnd[nxt][r] = L.bnd[cur][x];
         if (MODE == 1 && L.pqe.p0) { L.wlo[nxt][r] = L.wlo[cur][x]; L.whi[nxt][r] = L.whi[cur][x]; L.pqe[nxt][r] = L.pqe[cur][x]; L.pqs[nxt][r] = L.pqs[cur][x]; }
@@ -1279,7 +1426,10 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
         const int cf = ((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst[cx];
         L.ch[nxt][r] = c; L.fst[nxt][r] = cf;
-        if (SC_ON && L.a0.p0) {  // arc range of the child's dictionary state; top bit: a word may end here (space arc)
+        if (MASKED) {  // {first labelled arc, label bitmap} of the child's dictionary state
+          const uint2 rec = s.fst_rec[cf];
+          L.a0[nxt][r] = rec.x; L.sm[nxt][r] = rec.y;
+        } else if (SC_ON && L.a0.p0) {  // arc range of the child's dictionary state; top bit: a word may end here (space arc)
           const uint32_t f0 = s.fst_state_pos[cf], f1 = s.fst_state_pos[cf + 1];
           const uint32_t sp = MODE == 1 ? (uint32_t)s.fst_has_space[cf] : 0u;
           L.a0[nxt][r] = f0; L.an[nxt][r] = (uint16_t)((f1 - f0) | (sp << 15));
@@ -1353,7 +1503,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   GLB_AS uint32_t* g_ch = (GLB_AS uint32_t*)G.ch; GLB_AS uint32_t* g_node = (GLB_AS uint32_t*)G.node; GLB_AS uint32_t* g_ts = (GLB_AS uint32_t*)G.ts;
   GLB_AS int* g_fst = (GLB_AS int*)G.fst; GLB_AS uint64_t* g_key = (GLB_AS uint64_t*)G.key; GLB_AS uint32_t* g_bnd = (GLB_AS uint32_t*)G.bnd;
   constexpr bool SC_ON = MODE != 0;
-  constexpr bool FAST = MODE == 3, WORDC = MODE == 1 || MODE == 3;
+  constexpr bool FAST = MODE == 3, MASKED = MODE == 4, WORDC = MODE == 1 || MODE == 3 || MODE == 4;
   const int tid = threadIdx.x;
   int n = G.n;
   int cur = 0;
@@ -1365,7 +1515,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
     L.score[0][i] = g_score[i]; L.pb[0][i] = g_pb[i]; L.pnb[0][i] = g_pnb[i];
     L.ch[0][i] = g_ch[i]; L.node[0][i] = g_node[i]; L.ts[0][i] = g_ts[i]; const int st = g_fst[i]; L.fst[0][i] = st; L.key[0][i] = g_key[i];
     L.bnd[0][i] = g_bnd[i];
-    if (FAST) {
+    if (FAST || MASKED) {
       const uint2 rec = s.fst_rec[st];
       L.a0[0][i] = rec.x; L.sm[0][i] = rec.y;
     } else if (SC_ON && L.a0.p0) {
@@ -1477,7 +1627,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevSc
         if (!s.utf8 && s.n_hot == 0 && bndi != STT_NONE && al.n_labels <= 256) {
           const uint32_t e = S.pq[node];
           if (e != STT_NONE) lcp = load_be_raw(GS, e);
-          else { uint32_t ne; lcp = lm_word_query_cached(s, al, GS, (const LDS_AS uint8_t*)lab1, (LDS_AS uint32_t*)nullptr, node, bndi, false, 0ULL, 0ULL, ne, probes); }
+          else { uint32_t ne; lcp = lm_word_query_cached<false>(s, al, GS, (const LDS_AS uint8_t*)lab1, (LDS_AS uint32_t*)nullptr, node, bndi, false, 0ULL, 0ULL, ne, probes); }
         } else {
           lcp = lm_score(s, al, S.pa, node, STT_ROOT_CH, false, probes);
         }
@@ -1582,14 +1732,22 @@ void launch_scatter_streams(DecStream* const* dst, const DecStream* src, int n, 
 
 // ------------------------------------------------------------------------------------ launchers
 // Fast word path (ctc_fast.inc) when everything it relies on is there; STT_AMD_FAST=0 keeps the generic step (A/B runs).
-static int g_fast_allow = -1;  // -1: STT_AMD_FAST from the environment (default on)
+// Word-mode step selection: 0 = generic, 1 = restructured step of ctc_fast.inc, 2 = generic step with label bitmaps +
+// two LM waves + indexed FullScore (MODE 4).  -1 = STT_AMD_FAST from the environment.
+static int g_fast_allow = -1;
 void ctc_set_fast_path(int on) { g_fast_allow = on; }
+static int ctc_word_step_choice() {
+  static const int env_allow = []() { const char* e = getenv("STT_AMD_FAST"); return e ? atoi(e) : 2; }();
+  return g_fast_allow >= 0 ? g_fast_allow : env_allow;
+}
+static bool ctc_masked_ok(const DecParams& p, const DevScorer& s, const DevAlphabet& al) {
+  return ctc_word_step_choice() == 2 && s.enabled && !s.utf8 && p.C <= 32 && p.C >= 2 && p.blank == p.C - 1 && !ctc_sorts_classes(p) && cap_bucket(p.beam) <= 512 &&
+         s.fst_rec != nullptr && s.lmi != nullptr && s.order <= 5 && s.uni_in_vtab && al.space_id >= 0 && al.space_id < p.C - 1 && al.n_labels == p.C - 1;
+}
 static bool ctc_fast_ok(const DecParams& p, const DevScorer& s, const DevAlphabet& al, bool have_rows) {
-  // Off unless asked for: on the benchmark's near-uniform emissions the restructured step is bit-identical but not faster than the
+  // Only on request: on the benchmark's near-uniform emissions the restructured step is bit-identical but not faster than the
   // generic one (5.9 vs 5.3 ms of search per 64 x 5 s batch); STT_AMD_FAST=1 / STTX_DebugSetFastPath(1) select it.
-  static const int env_allow = []() { const char* e = getenv("STT_AMD_FAST"); return e ? atoi(e) : 0; }();
-  const int allow = g_fast_allow >= 0 ? g_fast_allow : env_allow;
-  return allow && have_rows && s.enabled && !s.utf8 && p.C <= 32 && p.C >= 2 && p.blank == p.C - 1 && !ctc_sorts_classes(p) && cap_bucket(p.beam) <= 512 &&
+  return ctc_word_step_choice() == 1 && have_rows && s.enabled && !s.utf8 && p.C <= 32 && p.C >= 2 && p.blank == p.C - 1 && !ctc_sorts_classes(p) && cap_bucket(p.beam) <= 512 &&
          s.fst_rec != nullptr && s.lmi != nullptr && s.order <= 5 && s.uni_in_vtab && al.space_id >= 0 && al.space_id < p.C - 1 && al.n_labels == p.C - 1;
 }
 static void check_launch(const char* what) {
@@ -1625,11 +1783,11 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
     check_launch("ctc_wide_rows_kernel");
   }
   const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : p.C);
-  const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : (fast ? 3 : 1));
+  const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : (fast ? 3 : ((!wide && ctc_masked_ok(p, s, al)) ? 4 : 1)));
   const int ci = cb == 64 ? 0 : cb == 128 ? 1 : cb == 256 ? 2 : cb == 512 ? 3 : 4;
   // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: remember what was set per device
   static std::mutex mu;
-  static size_t configured[16][2][4][5] = {};
+  static size_t configured[16][2][5][5] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   const int di = dev & 15;
@@ -1651,6 +1809,7 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
   STT_CTC_MODE(0, false) STT_CTC_MODE(1, false) STT_CTC_MODE(2, false)
   STT_CTC_MODE(0, true) STT_CTC_MODE(1, true) STT_CTC_MODE(2, true)
   STT_CTC_CASE(3, 0, 64, false) STT_CTC_CASE(3, 1, 128, false) STT_CTC_CASE(3, 2, 256, false) STT_CTC_CASE(3, 3, 512, false)
+  STT_CTC_CASE(4, 0, 64, false) STT_CTC_CASE(4, 1, 128, false) STT_CTC_CASE(4, 2, 256, false) STT_CTC_CASE(4, 3, 512, false)
 #undef STT_CTC_MODE
 #undef STT_CTC_CASE
   throw std::runtime_error("launch_ctc_next: no kernel instance for this configuration");

@@ -169,9 +169,13 @@ std::string metadata_json(const Metadata* m, bool with_emissions) {
     o << ",\n\"alphabet\":[";
     for (int i = 0; i < C; ++i) o << "\"" << e->symbols[i] << "\"" << (i + 1 < C ? ", " : "");
     o << "],\n\"emissions\":[\n";
+    // The reference prints num_symbols values per row and steps the flat [timesteps][num_symbols + 1] array by num_symbols
+    // (client.cc:169-180): rows drift against the blank column.  Kept as is: scripts that parse the reference's output
+    // see the same bytes (tests/test_gpu_refclient.py compares the two clients byte for byte).
+    const int S = e->num_symbols;
     for (int t = 0; t < e->num_timesteps; ++t) {
       o << "[";
-      for (int c = 0; c < C; ++c) o << e->emissions[(size_t)t * C + c] << (c + 1 < C ? ", " : "");
+      for (int c = 0; c < S; ++c) o << e->emissions[(size_t)t * S + c] << (c + 1 < S ? ", " : "");
       o << "]" << (t + 1 < e->num_timesteps ? "," : "") << "\n";
     }
     o << "\n]";

@@ -50,7 +50,7 @@ def _gpu_decode(models, case, probs):
     return res, st, d
 
 
-@pytest.mark.parametrize("fast", [0, 1], ids=["generic-step", "fast-word-step"])
+@pytest.mark.parametrize("fast", [0, 1, 2], ids=["generic-step", "fast-word-step", "bitmap-step"])
 def test_decoder_matches_reference_goldens(models, decoder_cases, fast):
     """fast = 1: the word-mode cases with a scorer run the restructured step of ctc_fast.inc (label bitmaps, hashed n-gram
     index, four lanes per LM query); everything else falls back to the generic step either way."""

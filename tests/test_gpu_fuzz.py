@@ -56,10 +56,10 @@ def _emissions(rng, T, C, blank, kind, vocab, mode):
     return p
 
 
-@pytest.mark.parametrize("mode,lm,fast", [("word", False, 1), ("word", True, 1), ("word", True, 0), ("bytes", False, 1), ("bytes", True, 1)])
+@pytest.mark.parametrize("mode,lm,fast", [("word", False, 2), ("word", True, 2), ("word", True, 1), ("word", True, 0), ("bytes", False, 2), ("bytes", True, 2)])
 def test_fuzz_decoder_against_port(rigs, port, fix, mode, lm, fast):
-    """fast = 0 forces the generic search step where the word-mode fast path (label bitmaps, hashed n-gram index) would
-    otherwise run: the same seeded cases must pass on both."""
+    """Word-mode step selection (STTX_DebugSetFastPath): 0 = generic step, 1 = restructured step of ctc_fast.inc, 2 = generic step
+    with label bitmaps + indexed FullScore (the default where it applies).  The same seeded cases must pass on all three."""
     from stt_amd import native
     native.lib().STTX_DebugSetFastPath(fast)
     try:
