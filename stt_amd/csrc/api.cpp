@@ -133,7 +133,7 @@ int create_stream(ModelState* aCtx, StreamingState** retval, bool keep_emissions
 // ---- batch path: every utterance goes through exactly the arithmetic of STT_SpeechToText ---------------------
 // Groups of <= 64 utterances.  Within a group the acoustic model runs in time-chunks on `stream` and the beam search of
 // chunk k runs on `stream_dec` while chunk k+1 is being computed (the search only occupies one workgroup per utterance).
-// Chunk schedule: a short first chunk (STT_AMD_CHUNK0, default 24 frames) so the beam search starts early, then chunks of STT_AMD_CHUNK (default 48) frames.
+// Chunk schedule: a short first chunk (STT_AMD_CHUNK0, default 16 frames) so the beam search starts early, then chunks of STT_AMD_CHUNK (default 48) frames.
 int batch_chunk_frames() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("STT_AMD_CHUNK"); v = e ? atoi(e) : 48; if (v < 1) v = 1 << 30; }
@@ -141,7 +141,7 @@ int batch_chunk_frames() {
 }
 int batch_first_chunk_frames() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("STT_AMD_CHUNK0"); v = e ? atoi(e) : 24; if (v < 1) v = 1 << 30; }
+  if (v < 0) { const char* e = getenv("STT_AMD_CHUNK0"); v = e ? atoi(e) : 16; if (v < 1) v = 1 << 30; }
   return v;
 }
 // Enqueue everything one group needs, on both streams, without waiting for anything: features + acoustic chunks on

@@ -1007,7 +1007,8 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   // the cut-off) and runs those queries *now*, so their dependent HBM reads overlap the expand work of the other waves
   // instead of sitting between two barriers.  P3 then finds the entry in pqe and only reads its score.
   const bool lm_wave = MODE == 1 && L.pqe.p0 != nullptr && n > NWAVES;
-  const int nlm = lm_wave ? ((MASKED && n > 256) ? 2 : 1) : 0;  // (two lists of 256 entries in lmw: only beams that need capacity 512 get two waves)
+  // bitmap mode: 2 (or 4, DecParams::n_lm_waves) language-model waves when the beam needs capacity 512 (lmw holds their lists side by side)
+  const int nlm = lm_wave ? ((MASKED && n > 256) ? (p.n_lm_waves == 4 ? 4 : (p.n_lm_waves == 1 ? 1 : 2)) : 1) : 0;
   const int nw_exp = NWAVES - nlm;
   const uint32_t space_u = (uint32_t)al.space_id;
   if (lm_wave && wave >= nw_exp) {
@@ -1015,13 +1016,17 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     const unsigned long long lmw_t0 = p.phase_cycles ? __builtin_readcyclecounter() : 0ull;
     const int ksp = POS_OF(al.space_id);
     const int lw = wave - nw_exp;
-    LDS_AS uint16_t* list = L.lmw + lw * 256;
+    LDS_AS uint16_t* list = L.lmw + lw * (512 / (nlm > 0 ? nlm : 1));
     unsigned lmq = 0;
     if (ksp != 0xFFFF) {
       const float lpsp = LP_AT(ksp, al.space_id);
       uint32_t n_need = 0;
-      for (int i0 = lw * 64; i0 < n; i0 += 64 * nlm) {
-        const int i = i0 + lane;
+      // 64-prefix slices of the (sorted) beam are dealt so that every LM wave gets good and bad ones: the top of the beam
+      // survives the cut-off more often and asks for more scores (2 waves: slices 0,3,4,7 | 1,2,5,6; 4 waves: s and 7-s)
+      for (int sl = 0; sl * 64 < n; ++sl) {
+        const int owner = nlm == 1 ? 0 : nlm == 2 ? (((sl + 1) >> 1) & 1) : ((sl & 7) < 4 ? (sl & 7) : 7 - (sl & 7));
+        if (owner != lw) continue;
+        const int i = sl * 64 + lane;
         bool need = false;
         if (i < n) {
           const float sci = L.score[cur][i];
@@ -1782,6 +1787,7 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
     hipLaunchKernelGGL(ctc_wide_rows_kernel, dim3(n_streams * max_frames), dim3(1024), 0, st, p, probs, frame_begin, frame_count);
     check_launch("ctc_wide_rows_kernel");
   }
+  if (!fast) { static const int lmw2 = []() { const char* e = getenv("STT_AMD_LM_WAVES"); return e ? atoi(e) : 0; }(); p.n_lm_waves = lmw2; }
   const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : p.C);
   const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : (fast ? 3 : ((!wide && ctc_masked_ok(p, s, al)) ? 4 : 1)));
   const int ci = cb == 64 ? 0 : cb == 128 ? 1 : cb == 256 ? 2 : cb == 512 ? 3 : 4;
