@@ -139,6 +139,7 @@ struct DecParams {
   const unsigned char* wide_rows;
   unsigned long long wide_stride;
   int wide_max_frames;
+  int lds_kb;       // LDS budget of the search kernel's layout in KiB (filled in by launch_ctc_next; host and device carve the same layout)
   int n_exp_waves;  // fast word path: waves that expand prefixes (one prefix per lane)
   int n_lm_waves;  // fast word path: waves of the workgroup that only run language-model queries (filled in by launch_ctc_next)
   unsigned long long* stamps;  // profiling level 2: [n_streams][64] shader cycles between the stamps of ctc_fast.inc (wave 0: 0..31, last wave: 32..63)

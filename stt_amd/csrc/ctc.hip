@@ -689,8 +689,14 @@ enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, 
 // Layout for a beam capacity CAP (a compile-time constant: every array that only depends on CAP sits at a constant LDS
 // address, which the compiler folds into the ds_* instructions instead of keeping ~50 pointers alive in registers).
 // The class-count dependent arrays and the candidate staging area come last.
+// (host: from the environment once; device: the launch is configured with the host's value, and the kernel recomputes the
+// same layout from the same budget passed in DecParams::lds_kb)
+__host__ inline int lds_budget_kb_host() {
+  static const int v = []() { const char* e = getenv("STT_AMD_LDS_KB"); int k = e ? atoi(e) : 160; return k < 96 ? 96 : (k > 160 ? 160 : k); }();
+  return v;
+}
 template <int CAP>
-__host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, LDS_AS unsigned char* base, size_t& total) {
+__host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, LDS_AS unsigned char* base, size_t& total, int budget_kb) {
   Lds L{};
   Lds* l = &L;
   constexpr uint32_t cap = CAP;
@@ -728,10 +734,13 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   offs[k++] = take((size_t)(C > 0 && C <= 32 ? 64 : C) * 4);                            // lps (fast word path: [2][32] sorted log-probs)
   offs[k++] = take((size_t)C * 2); offs[k++] = take((size_t)C * 2);
   offs[k++] = take((size_t)C);
-  // candidate staging: whatever fits under 126 KiB (leaves 34 KiB for a co-resident LSTM workgroup), at most 2048
+  // Candidate staging: whatever fits into the CU's 160 KiB, at most 2048 (STT_AMD_LDS_KB: budget in KiB).  Round 1 kept
+  // 34 KiB free for a co-resident LSTM workgroup; that left room for ~320-576 of the ~1320 candidates a step produces at beam
+  // 500, and every candidate beyond went through HBM: written in the expand phase, read back (dependent loads) by the score,
+  // key and write phases.  The recurrence's 256 workgroups fit two per CU on the 192 CUs the search does not occupy.
   uint32_t mcap = 0;
   {
-    const size_t budget = 126 * 1024;
+    const size_t budget = (size_t)budget_kb * 1024;
     if (o + 256 * 12 <= budget) { mcap = (uint32_t)((budget - o) / 12) & ~63u; if (mcap > 2048) mcap = 2048; }
   }
   const size_t o_lc = o;
@@ -780,11 +789,11 @@ inline int cap_bucket(int beam) { return beam <= 64 ? 64 : beam <= 128 ? 128 : b
 size_t ctc_next_lds_bytes(int beam, int C) {
   size_t t = 0;
   switch (cap_bucket(beam)) {
-    case 64: (void)lds_carve<64>(C, nullptr, t); break;
-    case 128: (void)lds_carve<128>(C, nullptr, t); break;
-    case 256: (void)lds_carve<256>(C, nullptr, t); break;
-    case 512: (void)lds_carve<512>(C, nullptr, t); break;
-    default: (void)lds_carve<1024>(C, nullptr, t); break;
+    case 64: (void)lds_carve<64>(C, nullptr, t, lds_budget_kb_host()); break;
+    case 128: (void)lds_carve<128>(C, nullptr, t, lds_budget_kb_host()); break;
+    case 256: (void)lds_carve<256>(C, nullptr, t, lds_budget_kb_host()); break;
+    case 512: (void)lds_carve<512>(C, nullptr, t, lds_budget_kb_host()); break;
+    default: (void)lds_carve<1024>(C, nullptr, t, lds_budget_kb_host()); break;
   }
   return t;
 }
@@ -1493,7 +1502,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
                                                             const float* probs, const int* frame_begin, const int* frame_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   size_t lds_total;
-  const Lds L = lds_carve<CAP>(WIDE ? 0 : p.C, (LDS_AS unsigned char*)smem, lds_total);
+  const Lds L = lds_carve<CAP>(WIDE ? 0 : p.C, (LDS_AS unsigned char*)smem, lds_total, p.lds_kb);
   DecStream& G = streams[blockIdx.x];
   const int nfr = frame_count ? frame_count[blockIdx.x] : p.all_count;
   if (nfr <= 0) return;
@@ -1789,6 +1798,7 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
   }
   if (!fast) { static const int lmw2 = []() { const char* e = getenv("STT_AMD_LM_WAVES"); return e ? atoi(e) : 0; }(); p.n_lm_waves = lmw2; }
   const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : p.C);
+  p.lds_kb = lds_budget_kb_host();
   const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : (fast ? 3 : ((!wide && ctc_masked_ok(p, s, al)) ? 4 : 1)));
   const int ci = cb == 64 ? 0 : cb == 128 ? 1 : cb == 256 ? 2 : cb == 512 ? 3 : 4;
   // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: remember what was set per device
