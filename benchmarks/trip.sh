@@ -19,8 +19,10 @@ try:
     print("  counters %s" % r.get("decoder_counters_last_step"))
     st = r.get("decoder_stamp_cycles_per_stream_step") or []
     if any(st):
-        print("  stamps expand-wave %s" % st[:22])
-        print("  stamps lm-wave     %s" % st[32:46])
+        print("  stamps[0:16]  %s" % st[:16])
+        print("  stamps[16:32] %s" % st[16:32])
+        print("  stamps[32:48] %s" % st[32:48])
+        print("  stamps[48:64] %s" % st[48:64])
 except Exception as e:
     print("  (no result: %s)" % e)
 PY

@@ -1245,7 +1245,18 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     }
   }
 #undef EXPAND_LOCATE
+  // profiling level 2: when did each wave reach the end of the expand phase (cycles since the step began; slot = wave), and
+  // how long did it then wait (slot 16 + wave)
+  // ... and which wave was last (slot 32 + wave counts the steps it was; 48: sum of the last wave's arrival, 49: of the second-last)
+  unsigned long long arrive_ = 0;
+  if (p.stamps && lane == 0) { arrive_ = __builtin_readcyclecounter(); L.stm[wave] += arrive_ - tick_; ((LDS_AS unsigned long long*)L.wtot)[wave] = arrive_; }
   __syncthreads();
+  if (p.stamps && lane == 0) L.stm[16 + wave] += __builtin_readcyclecounter() - arrive_;
+  if (p.stamps && tid == 0) {
+    unsigned long long mx = 0, mx2 = 0, mn = ~0ull; int who = 0;
+    for (int w = 0; w < NWAVES; ++w) { const unsigned long long a = ((LDS_AS unsigned long long*)L.wtot)[w]; if (a > mx) { mx2 = mx; mx = a; who = w; } else if (a > mx2) mx2 = a; if (a < mn) mn = a; }
+    L.stm[32 + who] += 1; L.stm[48] += mx - mn; L.stm[49] += mx2 - mn;
+  }
   int m = sc[SC_M];
   if ((uint32_t)m > S.cand_cap) { m = (int)S.cand_cap; if (tid == 0) sc[SC_ERR] |= 4; }
   TICK(2);
