@@ -46,6 +46,25 @@ STTX_EXPORT char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* a
 STTX_EXPORT void STTX_FreeStrings(char** aStrings, unsigned int aCount);
 STTX_EXPORT void STTX_FreeMetadataArray(Metadata** aMetadata, unsigned int aCount);
 
+/* ---- several GPUs of one node -------------------------------------------------------
+ * The reference scales this path with one process per GPU and utterances dealt from a queue
+ * (training/coqui_stt_training/transcribe.py:40-56,136-148).  A fleet does it inside the library: one replica of the model per
+ * listed HIP device, one host thread per device, utterances dealt longest-processing-time-first, no communication while
+ * decoding, transcripts gathered with RCCL over xGMI (all-gather of byte counts, then of the padded records).  librccl is
+ * loaded with dlopen when the first fleet is created. */
+typedef struct STTX_Fleet STTX_Fleet;
+STTX_EXPORT int STTX_FleetCreate(const char* aModelPath, const int* aDevices, unsigned int aNumDevices, STTX_Fleet** retval);
+STTX_EXPORT unsigned int STTX_FleetSize(const STTX_Fleet* aFleet);
+STTX_EXPORT int STTX_FleetEnableExternalScorer(STTX_Fleet* aFleet, const char* aScorerPath);
+STTX_EXPORT int STTX_FleetSetBeamWidth(STTX_Fleet* aFleet, unsigned int aBeamWidth);
+/* aBatch malloc'd strings in the caller's order (STTX_FreeStrings), or NULL if any shard failed. */
+STTX_EXPORT char** STTX_FleetSpeechToTextBatch(STTX_Fleet* aFleet, const short* const* aBuffers, const unsigned int* aBufferSizes,
+                                              unsigned int aBatch);
+STTX_EXPORT void STTX_FleetFree(STTX_Fleet* aFleet);
+/* The dealing rule alone (host only, no GPU): aShardOf[i] = shard of utterance i; by descending length (stable), each to the
+ * least loaded shard so far (lowest index on ties) -- the same rule as stt_amd/dist.py: shard_utterances. */
+STTX_EXPORT int STTX_ShardUtterances(const unsigned int* aSizes, unsigned int aCount, unsigned int aShards, unsigned int* aShardOf);
+
 /* ---- many streams at once (serving) -------------------------------------------------------------
  * The reference API advances one stream per call (stt.cc:553-639).  A server with many live streams calls these instead:
  * the semantics per stream are exactly those of STT_FeedAudioContent / STT_IntermediateDecode / STT_FinishStream, but the

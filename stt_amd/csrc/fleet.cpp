@@ -1,0 +1,208 @@
+// stt_amd/csrc/fleet.cpp -- several GPUs of one node behind the C ABI.
+//
+// The path shards by utterance: the reference scales the same way with one process per GPU and files dealt from a queue
+// (training/coqui_stt_training/transcribe.py:40-56,136-148).  A binding user of libstt.so gets that without Python:
+// STTX_FleetCreate() builds one replica of the model (and scorer) per HIP device; STTX_FleetSpeechToTextBatch() sorts the
+// utterances by length, deals them longest-processing-time-first to the devices, runs every shard on its own host thread
+// through the ordinary batch path (no communication during compute), and gathers the variable-length transcripts with
+// RCCL over xGMI: one all-gather of per-rank byte counts, one of the padded byte records.  RCCL is loaded with dlopen at
+// the first fleet creation (libstt.so itself links only libamdhip64); a missing librccl is an error, not a fallback.
+// The Python twin of the sharding and of the gather is stt_amd/dist.py (tests/test_dist_cpu.py runs both on the same cases).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+#include <iostream>
+#include <thread>
+
+#include "../../include/stt_amd.h"
+#include "engine.h"
+
+namespace {
+// the handful of RCCL entry points used, by their NCCL names (rccl.h)
+typedef struct ncclComm* ncclComm_t;
+enum { ncclSuccess = 0 };
+enum { ncclUint8 = 1, ncclInt32 = 2 };  // ncclDataType_t: ncclInt8 0, ncclUint8 1, ncclInt32 2
+struct Rccl {
+  void* h = nullptr;
+  int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load() {
+    if (h) return true;
+    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (!h) { std::cerr << "stt_amd: cannot load librccl (" << dlerror() << ")" << std::endl; return false; }
+    CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+    AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
+    GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+    return CommInitAll && CommDestroy && AllGather;
+  }
+};
+Rccl g_rccl;
+}  // namespace
+
+// Longest-processing-time-first assignment (stt_amd/dist.py: shard_utterances): utterances by descending length (stable),
+// each to the currently least loaded shard (lowest index on ties).
+extern "C" int STTX_ShardUtterances(const unsigned int* aSizes, unsigned int aCount, unsigned int aShards, unsigned int* aShardOf) {
+  if (!aShards || (!aSizes && aCount) || (!aShardOf && aCount)) return STT_ERR_INVALID_SHAPE;
+  std::vector<unsigned> order(aCount);
+  for (unsigned i = 0; i < aCount; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return aSizes[x] > aSizes[y]; });
+  std::vector<unsigned long long> load(aShards, 0);
+  for (unsigned i : order) {
+    unsigned best = 0;
+    for (unsigned r = 1; r < aShards; ++r) if (load[r] < load[best]) best = r;
+    aShardOf[i] = best;
+    load[best] += aSizes[i];
+  }
+  return STT_ERR_OK;
+}
+
+struct STTX_Fleet {
+  std::vector<int> devices;
+  std::vector<ModelState*> models;
+  std::vector<ncclComm_t> comms;
+  std::vector<hipStream_t> streams;
+  std::vector<DevBuf*> d_cnt, d_all_cnt, d_rec, d_all_rec;
+  ~STTX_Fleet() {
+    for (size_t i = 0; i < models.size(); ++i) {
+      (void)hipSetDevice(devices[i]);
+      if (i < comms.size() && comms[i] && g_rccl.CommDestroy) g_rccl.CommDestroy(comms[i]);
+      if (i < streams.size() && streams[i]) (void)hipStreamDestroy(streams[i]);
+      for (auto* v : {&d_cnt, &d_all_cnt, &d_rec, &d_all_rec}) if (i < v->size()) delete (*v)[i];
+      if (models[i]) STT_FreeModel(models[i]);
+    }
+  }
+};
+
+extern "C" {
+
+int STTX_FleetCreate(const char* aModelPath, const int* aDevices, unsigned int aNumDevices, STTX_Fleet** retval) {
+  *retval = nullptr;
+  if (!aNumDevices || !aDevices) return STT_ERR_INVALID_SHAPE;
+  try {
+    if (!g_rccl.load()) return STT_ERR_FAIL_INIT_SESS;
+    std::unique_ptr<STTX_Fleet> f(new STTX_Fleet());
+    f->devices.assign(aDevices, aDevices + aNumDevices);
+    for (unsigned i = 0; i < aNumDevices; ++i) {
+      if (STTX_SetDevice(aDevices[i]) != STT_ERR_OK) return STT_ERR_FAIL_INIT_SESS;
+      ModelState* m = nullptr;
+      const int rc = STT_CreateModel(aModelPath, &m);
+      if (rc != STT_ERR_OK) return rc;
+      f->models.push_back(m);
+    }
+    f->comms.assign(aNumDevices, nullptr);
+    const int rc = g_rccl.CommInitAll(f->comms.data(), (int)aNumDevices, f->devices.data());
+    if (rc != ncclSuccess) {
+      std::cerr << "stt_amd: ncclCommInitAll failed: " << (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?") << std::endl;
+      return STT_ERR_FAIL_INIT_SESS;
+    }
+    for (unsigned i = 0; i < aNumDevices; ++i) {
+      HIP_CHECK(hipSetDevice(aDevices[i]));
+      hipStream_t st;
+      HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      f->streams.push_back(st);
+      f->d_cnt.push_back(new DevBuf()); f->d_all_cnt.push_back(new DevBuf()); f->d_rec.push_back(new DevBuf()); f->d_all_rec.push_back(new DevBuf());
+    }
+    *retval = f.release();
+    return STT_ERR_OK;
+  } catch (const std::exception& e) {
+    std::cerr << "stt_amd: " << e.what() << std::endl;
+    return STT_ERR_FAIL_CREATE_MODEL;
+  }
+}
+
+unsigned int STTX_FleetSize(const STTX_Fleet* f) { return f ? (unsigned)f->models.size() : 0; }
+
+int STTX_FleetEnableExternalScorer(STTX_Fleet* f, const char* aScorerPath) {
+  for (ModelState* m : f->models) { const int rc = STT_EnableExternalScorer(m, aScorerPath); if (rc != STT_ERR_OK) return rc; }
+  return STT_ERR_OK;
+}
+int STTX_FleetSetBeamWidth(STTX_Fleet* f, unsigned int aBeamWidth) {
+  for (ModelState* m : f->models) { const int rc = STT_SetModelBeamWidth(m, aBeamWidth); if (rc != STT_ERR_OK) return rc; }
+  return STT_ERR_OK;
+}
+
+// Transcripts in the caller's order, or NULL if any shard failed (STTX_FreeStrings releases them).
+char** STTX_FleetSpeechToTextBatch(STTX_Fleet* f, const short* const* aBuffers, const unsigned int* aBufferSizes, unsigned int aBatch) {
+  const unsigned G = (unsigned)f->models.size();
+  std::vector<unsigned> shard_of(aBatch);
+  if (STTX_ShardUtterances(aBufferSizes, aBatch, G, shard_of.data()) != STT_ERR_OK) return nullptr;
+  std::vector<std::vector<unsigned>> idx(G);
+  for (unsigned i = 0; i < aBatch; ++i) idx[shard_of[i]].push_back(i);
+  // every rank's record: [u32 utterance index, u32 byte length, bytes] per transcript; ranks gather counts, then padded records
+  std::vector<std::vector<unsigned char>> rec(G);
+  std::vector<int> ok(G, 1);
+  std::vector<std::vector<unsigned char>> gathered(G);  // (every rank receives everything; rank 0's copy is unpacked)
+  std::vector<std::vector<int>> counts(G, std::vector<int>(G, 0));
+  auto shard_body = [&](unsigned r) {
+    try {
+      HIP_CHECK(hipSetDevice(f->devices[r]));
+      const unsigned n = (unsigned)idx[r].size();
+      std::vector<const short*> bufs(n); std::vector<unsigned> sizes(n);
+      for (unsigned k = 0; k < n; ++k) { bufs[k] = aBuffers[idx[r][k]]; sizes[k] = aBufferSizes[idx[r][k]]; }
+      char** texts = n ? STTX_SpeechToTextBatch(f->models[r], bufs.data(), sizes.data(), n) : nullptr;
+      if (n && !texts) { ok[r] = 0; }
+      for (unsigned k = 0; k < n && texts; ++k) {
+        const unsigned len = (unsigned)strlen(texts[k]), id = idx[r][k];
+        const size_t o = rec[r].size();
+        rec[r].resize(o + 8 + len);
+        memcpy(&rec[r][o], &id, 4); memcpy(&rec[r][o + 4], &len, 4); memcpy(&rec[r][o + 8], texts[k], len);
+      }
+      if (texts) STTX_FreeStrings(texts, n);
+      // ---- exchange 1: byte counts (a failed shard announces -1)
+      hipStream_t st = f->streams[r];
+      const int mine = ok[r] ? (int)rec[r].size() : -1;
+      f->d_cnt[r]->reserve(4); f->d_all_cnt[r]->reserve(4 * G);
+      HIP_CHECK(hipMemcpyAsync(f->d_cnt[r]->p, &mine, 4, hipMemcpyHostToDevice, st));
+      if (g_rccl.AllGather(f->d_cnt[r]->p, f->d_all_cnt[r]->p, 1, ncclInt32, f->comms[r], st) != ncclSuccess) throw std::runtime_error("ncclAllGather(counts) failed");
+      HIP_CHECK(hipMemcpyAsync(counts[r].data(), f->d_all_cnt[r]->p, 4 * G, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      int cap = 16;
+      for (unsigned q = 0; q < G; ++q) cap = std::max(cap, counts[r][q]);
+      cap = (cap + 15) & ~15;
+      // ---- exchange 2: the records, padded to the largest
+      f->d_rec[r]->reserve((size_t)cap); f->d_all_rec[r]->reserve((size_t)cap * G);
+      HIP_CHECK(hipMemsetAsync(f->d_rec[r]->p, 0, (size_t)cap, st));
+      if (!rec[r].empty()) HIP_CHECK(hipMemcpyAsync(f->d_rec[r]->p, rec[r].data(), rec[r].size(), hipMemcpyHostToDevice, st));
+      if (g_rccl.AllGather(f->d_rec[r]->p, f->d_all_rec[r]->p, (size_t)cap, ncclUint8, f->comms[r], st) != ncclSuccess) throw std::runtime_error("ncclAllGather(records) failed");
+      if (r == 0) {
+        gathered[0].resize((size_t)cap * G);
+        HIP_CHECK(hipMemcpyAsync(gathered[0].data(), f->d_all_rec[0]->p, (size_t)cap * G, hipMemcpyDeviceToHost, st));
+      }
+      HIP_CHECK(hipStreamSynchronize(st));
+    } catch (const std::exception& e) {
+      std::cerr << "stt_amd: fleet shard " << r << ": " << e.what() << std::endl;
+      ok[r] = 0;
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned r = 1; r < G; ++r) th.emplace_back(shard_body, r);
+  shard_body(0);
+  for (auto& t : th) t.join();
+  for (unsigned r = 0; r < G; ++r) if (!ok[r] || counts[0][r] < 0) return nullptr;
+  int cap = 16;
+  for (unsigned q = 0; q < G; ++q) cap = std::max(cap, counts[0][q]);
+  cap = (cap + 15) & ~15;
+  char** out = (char**)calloc(std::max(1u, aBatch), sizeof(char*));
+  for (unsigned r = 0; r < G; ++r) {
+    const unsigned char* p = gathered[0].data() + (size_t)r * cap;
+    size_t o = 0;
+    while (o + 8 <= (size_t)counts[0][r]) {
+      unsigned id, len;
+      memcpy(&id, p + o, 4); memcpy(&len, p + o + 4, 4);
+      if (id >= aBatch || o + 8 + len > (size_t)counts[0][r]) break;
+      out[id] = (char*)malloc((size_t)len + 1);
+      memcpy(out[id], p + o + 8, len); out[id][len] = 0;
+      o += 8 + len;
+    }
+  }
+  for (unsigned i = 0; i < aBatch; ++i) if (!out[i]) out[i] = strdup("");
+  return out;
+}
+
+void STTX_FleetFree(STTX_Fleet* f) { delete f; }
+
+}  // extern "C"

@@ -381,3 +381,57 @@ class Decoder(object):
             self.close()
         except Exception:
             pass
+
+
+class Fleet(object):
+    """Several GPUs of one node behind one handle (include/stt_amd.h: STTX_Fleet*): a replica per device, utterances dealt
+    longest-processing-time-first, one host thread per device, transcripts gathered with RCCL.  The in-library form of the
+    reference's one-process-per-GPU pattern (training/coqui_stt_training/transcribe.py:40-56)."""
+
+    def __init__(self, model_path, devices):
+        self._impl = None
+        h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        status = native.lib().STTX_FleetCreate(model_path.encode("utf-8"), devs, len(devices), C.byref(h))
+        if status != 0:
+            raise RuntimeError("STTX_FleetCreate failed with '{}' (0x{:X})".format(native.error_message(status), status))
+        self._impl = h
+
+    def __del__(self):
+        if getattr(self, "_impl", None):
+            native.lib().STTX_FleetFree(self._impl)
+            self._impl = None
+
+    def size(self):
+        return native.lib().STTX_FleetSize(self._impl)
+
+    def enableExternalScorer(self, scorer_path):
+        status = native.lib().STTX_FleetEnableExternalScorer(self._impl, scorer_path.encode("utf-8"))
+        if status != 0:
+            raise RuntimeError("STTX_FleetEnableExternalScorer failed with '{}' (0x{:X})".format(native.error_message(status), status))
+
+    def setBeamWidth(self, beam_width):
+        return native.lib().STTX_FleetSetBeamWidth(self._impl, beam_width)
+
+    def sttBatch(self, audio_buffers):
+        arrs = [_audio(a) for a in audio_buffers]
+        n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a[1] for a in arrs])
+        sizes = (C.c_uint * n)(*[a[2] for a in arrs])
+        res = native.lib().STTX_FleetSpeechToTextBatch(self._impl, ptrs, sizes, n)
+        if not res:
+            raise RuntimeError("STTX_FleetSpeechToTextBatch failed")
+        out = [C.string_at(res[i]).decode("utf-8", "replace") for i in range(n)]
+        native.lib().STTX_FreeStrings(res, n)
+        return out
+
+
+def shard_utterances_native(lengths, n_shards):
+    """STTX_ShardUtterances: shard index of every utterance (the C++ twin of stt_amd.dist.shard_utterances)."""
+    n = len(lengths)
+    sizes = (C.c_uint * n)(*[int(x) for x in lengths])
+    out = (C.c_uint * n)()
+    status = native.lib().STTX_ShardUtterances(sizes, n, n_shards, out)
+    if status != 0:
+        raise RuntimeError("STTX_ShardUtterances failed 0x%X" % status)
+    return [int(x) for x in out]

@@ -66,3 +66,22 @@ def test_gather_transcripts_two_ranks_gloo(tmp_path):
 
 def test_gather_without_process_group_is_identity():
     assert sdist.gather_transcripts(["a", "b"]) == [["a", "b"]]
+
+
+def test_native_sharding_rule_equals_the_python_twin():
+    """include/stt_amd.h: STTX_ShardUtterances (the dealing rule of STTX_FleetSpeechToTextBatch, stt_amd/csrc/fleet.cpp) against
+    stt_amd.dist.shard_utterances on random length sets, ties included.  Host only."""
+    import numpy as np
+
+    from stt_amd import dist as sd
+    from stt_amd import model as M
+    rng = np.random.RandomState(3)
+    for case in range(40):
+        n = int(rng.randint(0, 200))
+        lens = rng.randint(1, 20, size=n) * 8000 if case % 3 == 0 else rng.randint(0, 240000, size=n)
+        for shards in (1, 2, 3, 8):
+            want = sd.shard_utterances(lens, shards)
+            got = M.shard_utterances_native(lens, shards)
+            assert len(got) == n
+            for r, idx in enumerate(want):
+                assert sorted(i for i in range(n) if got[i] == r) == sorted(idx), (case, shards, r)
