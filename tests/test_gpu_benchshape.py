@@ -3,8 +3,8 @@ B = 64 recurrent kernel instance, M = 1536/3072-row GEMM tiles, the 64-row softm
 WAV, no scorer, beam 1), numerically, not only through transcripts.
 
 Stated tolerance of the acoustic half (f16 MFMA operands, f32 accumulate, f16 h between steps) against the f64 restatement
-that rounds weights and activations where the kernels store them: |p - p_ref| <= 3e-3 and |ln p - ln p_ref| <= 1e-2
-(every class of every frame within 1 %) over all 250 steps -- the recurrence does not drift."""
+that rounds weights and activations where the kernels store them: |p - p_ref| <= 1e-4 and |ln p - ln p_ref| <= 2e-3
+(every class of every frame within 0.2 %; measured 5.6e-6 and 1.4e-4) over all 250 steps -- the recurrence does not drift."""
 import os
 import wave
 
@@ -41,8 +41,8 @@ def test_bench_batch_probabilities_against_the_oracle_and_bitwise_batch_independ
         # error by timestep must not grow along the recurrence: compare the last 50 steps with the first 50
         per_t = np.abs(np.log(got[i]) - np.log(want)).max(1)
         dump("benchshape_%d" % i, got=got[i], want=want, per_t=per_t)
-        assert a < 3e-3 and l < 1e-2, (i, a, l)
-        assert per_t[200:].max() < 1e-2, (i, per_t[:50].max(), per_t[200:].max())
+        assert a < 1e-4 and l < 2e-3, (i, a, l)
+        assert per_t[200:].max() < 2e-3, (i, per_t[:50].max(), per_t[200:].max())
         worst_abs, worst_log = max(worst_abs, a), max(worst_log, l)
     print("bench shape: max |dp| %.3e  max |dlnp| %.3e" % (worst_abs, worst_log))
     # a row computed alone (B = 1 kernels) and inside the 64-batch (B = 64 kernels): the same bits
@@ -70,7 +70,7 @@ def test_config0_ldc93s1_no_scorer_beam_1(big, ref, port, english, fix):
         probs = model.acousticProbs([a])[0]
         assert probs.shape == (146, 29)                                   # T = 146 for 46 797 samples
         want = am_ref.utterance_probs(a, w, weight_round=np.float16)
-        assert np.abs(probs - want).max() < 3e-3 and np.abs(np.log(probs) - np.log(want)).max() < 1e-2
+        assert np.abs(probs - want).max() < 1e-4 and np.abs(np.log(probs) - np.log(want)).max() < 2e-3
         text = model.stt(a)
         md = model.sttWithMetadata(a, 1)
         A = ref.Alphabet(os.path.join(fix, "alphabet.txt"))
