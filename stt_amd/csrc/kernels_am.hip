@@ -20,6 +20,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "kernels.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -336,59 +338,62 @@ __device__ __forceinline__ float tanhf_(float x) {
   return copysignf(t, x);
 }
 
-// G = k-steps per prefetch group (two groups of weight / h fragments are in flight): G = 4 needs 272 registers (one
-// workgroup per CU), G = 2 about 150 (three per CU: all 256 workgroups stay resident in one round when the search kernel
-// holds 64 of the 256 CUs), G = 0 the plain loop.
-template <int NT, int G_>
+// G = k-steps per prefetch group (two groups of weight / h fragments are in flight), MT = 16-row gate tiles per workgroup:
+// MT = 2: 8 hidden units per workgroup, 256 workgroups (round 1); MT = 4: 16 units, 128 workgroups, each gate one tile.
+// Every workgroup reads ALL of h (2 * H * 64 bytes at 64 batch rows = 256 KiB) besides its slice of the recurrent matrix, so
+// with 256 workgroups the h re-reads (64 MiB per step) outweigh the weights (33.5 MiB); 128 workgroups halve them, and a
+// workgroup then has a CU to itself (64 KiB reduction buffer, ~230 VGPRs: one wave per SIMD).
+template <int NT, int G_, int MT>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   constexpr bool PF = G_ > 0;
-  __shared__ __attribute__((aligned(16))) float red[4][2][NT][64][4];
-  __shared__ __attribute__((aligned(16))) _Float16 hout[NT * 16][8];
+  constexpr int UPW = MT * 4;  // hidden units per workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
+  typedef float RedT[MT][NT][64][4];
+  RedT* red = reinterpret_cast<RedT*>(lstm_smem);                                        // [4 waves]
+  _Float16 (*hout)[UPW] = reinterpret_cast<_Float16 (*)[UPW]>(lstm_smem + 4 * sizeof(RedT));  // [NT * 16][UPW]
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
   const int wg = blockIdx.x;
   const int H = a.n_hidden;
   const int ksteps = H / 128;  // 32-deep k-steps per wave
-  const uint4* wp = reinterpret_cast<const uint4*>(a.whp) + ((size_t)(wg * 4 + q) * ksteps) * 2 * 64 + lane;
+  const uint4* wp = reinterpret_cast<const uint4*>(a.whp) + ((size_t)(wg * 4 + q) * ksteps) * MT * 64 + lane;
   const uint4* hp = reinterpret_cast<const uint4*>(a.hp_in) + ((size_t)(q * ksteps) * NT) * 64 + lane;
-  f32x4 acc[2][NT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // operands of the cell update, fetched now so that their latency hides behind the k-loop
-  constexpr int CU_ITEMS = NT * 16 * 8, CU_ITERS = (CU_ITEMS + 255) / 256;
+  constexpr int CU_ITEMS = NT * 16 * UPW, CU_ITERS = (CU_ITEMS + 255) / 256;
   const int B = a.batch;
   float xv[CU_ITERS][4], cv[CU_ITERS];
 #pragma unroll
   for (int it = 0; it < CU_ITERS; ++it) {
     const int p = tid + it * 256;
-    const int b = p >> 3, u = p & 7;
+    const int b = p / UPW, u = p % UPW;
     xv[it][0] = xv[it][1] = xv[it][2] = xv[it][3] = 0.0f; cv[it] = 0.0f;
     if (p < CU_ITEMS && b < B) {
-      const int unit = wg * 8 + u;
+      const int unit = wg * UPW + u;
       const float* xp = a.xproj + ((size_t)a.t * B + b) * (4 * H) + unit;
       xv[it][0] = xp[0]; xv[it][1] = xp[H]; xv[it][2] = xp[2 * H]; xv[it][3] = xp[3 * H];
       cv[it] = a.c[(size_t)b * H + unit];
     }
   }
-  // k-steps are taken four at a time with the next group's weight and h fragments already in flight (double buffered in
+  // k-steps are taken G at a time with the next group's weight and h fragments already in flight (double buffered in
   // registers: one wave per SIMD, so the register file is ours): the kernel is bound by L2/HBM latency, not by MFMA issue.
   constexpr int G = G_ > 0 ? G_ : 1;
   if (PF && ksteps % (2 * G) == 0) {
-    uint4 wa[G][2], ha[G][NT], wb[G][2], hb[G][NT];
+    uint4 wa[G][MT], ha[G][NT], wb[G][MT], hb[G][NT];
 #define LSTM_LOAD(W, Hh, s0)                                                                      \
   _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                 \
-    W[g][0] = wp[(size_t)(((s0) + g) * 2 + 0) * 64];                                              \
-    W[g][1] = wp[(size_t)(((s0) + g) * 2 + 1) * 64];                                              \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) W[g][i] = wp[(size_t)(((s0) + g) * MT + i) * 64]; \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) Hh[g][j] = hp[(size_t)(((s0) + g) * NT + j) * 64]; \
   }
 #define LSTM_MMA(W, Hh)                                                                           \
   _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                 \
-    const f16x8 fa0 = *reinterpret_cast<f16x8*>(&W[g][0]), fa1 = *reinterpret_cast<f16x8*>(&W[g][1]); \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                              \
       const f16x8 fb = *reinterpret_cast<f16x8*>(&Hh[g][j]);                                      \
-      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb, acc[0][j], 0, 0, 0);            \
-      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb, acc[1][j], 0, 0, 0);            \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i)                                              \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&W[g][i]), fb, acc[i][j], 0, 0, 0); \
     }                                                                                             \
   }
     LSTM_LOAD(wa, ha, 0);
@@ -402,34 +407,34 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
 #undef LSTM_MMA
   } else {
     for (int s = 0; s < ksteps; ++s) {
-      uint4 w0 = wp[(size_t)(s * 2 + 0) * 64];
-      uint4 w1 = wp[(size_t)(s * 2 + 1) * 64];
-      f16x8 fa0 = *reinterpret_cast<f16x8*>(&w0), fa1 = *reinterpret_cast<f16x8*>(&w1);
+      uint4 w[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) w[i] = wp[(size_t)(s * MT + i) * 64];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         uint4 hv = hp[(size_t)(s * NT + j) * 64];
         f16x8 fb = *reinterpret_cast<f16x8*>(&hv);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb, acc[1][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&w[i]), fb, acc[i][j], 0, 0, 0);
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&red[q][i][j][lane][0]) = acc[i][j];
   __syncthreads();
-  // cell update: (unit u in 0..7, batch row b): gate row r = g*8+u lives in tile r>>4, lane group (r&15)>>2, reg r&3
+  // cell update: (unit u, batch row b): gate row r = g*UPW+u lives in tile r>>4, lane group (r&15)>>2, reg r&3
   // (the x-projection and cell-state operands were fetched before the k-loop: xv/cv)
 #pragma unroll
   for (int it = 0; it < CU_ITERS; ++it) {
     const int p = tid + it * 256;
     if (p >= CU_ITEMS) break;
-    const int b = p >> 3, u = p & 7;
+    const int b = p / UPW, u = p % UPW;
     float z[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int r = g * 8 + u;
+      const int r = g * UPW + u;
       const int mt = r >> 4, rr = r & 15;
       const int ln = ((rr >> 2) << 4) + (b & 15);
       const int nt = b >> 4;
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
     }
     float hval = 0.0f;
     if (b < B) {
-      const int unit = wg * 8 + u;
+      const int unit = wg * UPW + u;
       const float zi = z[0] + xv[it][0], zj = z[1] + xv[it][1], zf = z[2] + xv[it][2], zo = z[3] + xv[it][3];
       const float cn = sigmoidf_(zf) * cv[it] + sigmoidf_(zi) * tanhf_(zj);
       a.c[(size_t)b * H + unit] = cn;
@@ -447,21 +452,16 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
     hout[b][u] = (_Float16)hval;
   }
   __syncthreads();
-  // publish h: one 16-byte chunk per batch row, into next step's fragment-ordered buffer and the time-major h_all
-  for (int b = tid; b < NT * 16; b += 256) {
-    const uint4 v = *reinterpret_cast<const uint4*>(&hout[b][0]);
-    const int k0 = wg * 8;
+  // publish h: 16-byte chunks (8 units) per batch row, into next step's fragment-ordered buffer and the time-major h_all
+  for (int e = tid; e < NT * 16 * (UPW / 8); e += 256) {
+    const int b = e / (UPW / 8), half = e % (UPW / 8);
+    const uint4 v = *reinterpret_cast<const uint4*>(&hout[b][half * 8]);
+    const int k0 = wg * UPW + half * 8;
     const int ksg = k0 >> 5, grp = (k0 & 31) >> 3;
     reinterpret_cast<uint4*>(a.hp_out)[((size_t)ksg * NT + (b >> 4)) * 64 + grp * 16 + (b & 15)] = v;
     if (b < B) *reinterpret_cast<uint4*>(a.h_all + ((size_t)a.t * B + b) * H + k0) = v;
   }
 }
-template __global__ void lstm_step_kernel<1, 4>(LstmArgs);
-template __global__ void lstm_step_kernel<2, 4>(LstmArgs);
-template __global__ void lstm_step_kernel<4, 4>(LstmArgs);
-template __global__ void lstm_step_kernel<4, 2>(LstmArgs);
-template __global__ void lstm_step_kernel<4, 1>(LstmArgs);
-template __global__ void lstm_step_kernel<4, 0>(LstmArgs);
 
 // h (f32 [B][H]) -> fragment-ordered f16 hp (used once per chunk to seed the recurrence from a carried state)
 __global__ void pack_h_kernel(const float* h, _Float16* hp, int B, int H, int NT) {
@@ -647,18 +647,42 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
   else
     hipLaunchKernelGGL(dense_kernel<DENSE_EPI_BIAS_F32>, dim3(8 * per_xcd), dim3(256), 0, st, b);
 }
-int lstm_nt_for_batch(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : -1; }  // 64 rows per launch (LDS reduce buffer 32 KiB)
+int lstm_nt_for_batch(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : -1; }  // 64 rows per launch
+// hidden units per workgroup of the recurrent kernel (and of the weight packing, pack_lstm_recurrent_host): 16 when the width
+// allows, 8 otherwise (STT_AMD_LSTM_UPW=8 keeps round 1's shape for A/B runs)
+int lstm_units_per_wg(int H) {
+  static const int env = []() { const char* e = getenv("STT_AMD_LSTM_UPW"); return e ? atoi(e) : 16; }();
+  return (env >= 16 && H % 16 == 0) ? 16 : 8;
+}
+template <int NT, int G, int MT>
+static void launch_lstm_inst(const LstmArgs& a, hipStream_t st) {
+  const size_t smem = 4 * sizeof(float) * MT * NT * 64 * 4 + (size_t)NT * 16 * MT * 4 * 2;
+  static std::once_flag once[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::call_once(once[dev & 15], [&]() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_kernel<NT, G, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  hipLaunchKernelGGL((lstm_step_kernel<NT, G, MT>), dim3(a.n_hidden / (MT * 4)), dim3(256), smem, st, a);
+}
 void launch_lstm_step(const LstmArgs& a, int NT, hipStream_t st) {
-  const dim3 grid(a.n_hidden / 8), block(256);
   static const int pg = []() { const char* e = getenv("STT_AMD_LSTM_PREFETCH"); return e ? atoi(e) : 2; }();
+  if (lstm_units_per_wg(a.n_hidden) == 16) {
+    switch (NT) {
+      case 1: launch_lstm_inst<1, 4, 4>(a, st); break;
+      case 2: launch_lstm_inst<2, 4, 4>(a, st); break;
+      default: if (pg >= 4) launch_lstm_inst<4, 4, 4>(a, st); else if (pg >= 2) launch_lstm_inst<4, 2, 4>(a, st); else launch_lstm_inst<4, 1, 4>(a, st); break;
+    }
+    return;
+  }
   switch (NT) {
-    case 1: hipLaunchKernelGGL((lstm_step_kernel<1, 4>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((lstm_step_kernel<2, 4>), grid, block, 0, st, a); break;
+    case 1: launch_lstm_inst<1, 4, 2>(a, st); break;
+    case 2: launch_lstm_inst<2, 4, 2>(a, st); break;
     default:
-      if (pg >= 4) hipLaunchKernelGGL((lstm_step_kernel<4, 4>), grid, block, 0, st, a);
-      else if (pg >= 2) hipLaunchKernelGGL((lstm_step_kernel<4, 2>), grid, block, 0, st, a);
-      else if (pg == 1) hipLaunchKernelGGL((lstm_step_kernel<4, 1>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((lstm_step_kernel<4, 0>), grid, block, 0, st, a);
+      if (pg >= 4) launch_lstm_inst<4, 4, 2>(a, st);
+      else if (pg >= 2) launch_lstm_inst<4, 2, 2>(a, st);
+      else if (pg == 1) launch_lstm_inst<4, 1, 2>(a, st);
+      else launch_lstm_inst<4, 0, 2>(a, st);
       break;
   }
 }

@@ -55,15 +55,16 @@ int n_frames_for(const Geometry& g, int n_samples) {  // stt.cc:105-128 + flushB
 void pack_lstm_recurrent_host(const float* kernel, int H, _Float16* out) {
   const int ksteps = H / 128;
   const size_t ld = (size_t)4 * H;
-  for (int wg = 0; wg < H / 8; ++wg)
+  const int UPW = lstm_units_per_wg(H), MT = UPW / 4;  // units and 16-row gate tiles per workgroup (kernels_am.hip: lstm_step_kernel)
+  for (int wg = 0; wg < H / UPW; ++wg)
     for (int q = 0; q < 4; ++q)
       for (int s = 0; s < ksteps; ++s)
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
           for (int lane = 0; lane < 64; ++lane) {
             const int r = mt * 16 + (lane & 15);
-            const int n = (r >> 3) * H + wg * 8 + (r & 7);
+            const int n = (r / UPW) * H + wg * UPW + (r % UPW);
             const int k0 = q * (H / 4) + s * 32 + (lane >> 4) * 8;
-            _Float16* o = out + ((((size_t)(wg * 4 + q) * ksteps + s) * 2 + mt) * 64 + lane) * 8;
+            _Float16* o = out + ((((size_t)(wg * 4 + q) * ksteps + s) * MT + mt) * 64 + lane) * 8;
             for (int e = 0; e < 8; ++e) o[e] = (_Float16)kernel[(size_t)(H + k0 + e) * ld + n];
           }
 }

@@ -53,17 +53,19 @@ def test_model_container_layout():
     assert len(blob) == off + 4 * sum(int(np.prod(w[k].shape)) for k in modelfile.TENSOR_ORDER)
 
 
-def _emulate_lstm_kernel(packed, hp, xproj_t, c, H, B, NT):
+def _emulate_lstm_kernel(packed, hp, xproj_t, c, H, B, NT, UPW):
     """numpy emulation of lstm_step_kernel's index arithmetic under the documented MFMA 16x16x32 fragment layout:
-    A[i = lane&15][k = 8*(lane>>4)+e], B[k][j = lane&15], D[i = 4*(lane>>4)+r][j = lane&15]."""
+    A[i = lane&15][k = 8*(lane>>4)+e], B[k][j = lane&15], D[i = 4*(lane>>4)+r][j = lane&15].  UPW hidden units (MT = UPW/4
+    gate tiles of 16 rows) per workgroup."""
     ksteps = H // 128
-    z = np.zeros((H // 8, 32, NT * 16), dtype=np.float64)
+    MT = UPW // 4
+    z = np.zeros((H // UPW, MT * 16, NT * 16), dtype=np.float64)
     lane = np.arange(64)
-    for wg in range(H // 8):
+    for wg in range(H // UPW):
         for q in range(4):
             for s in range(ksteps):
-                for mt in range(2):
-                    a = packed[(((wg * 4 + q) * ksteps + s) * 2 + mt)].astype(np.float64)   # [64 lanes][8]
+                for mt in range(MT):
+                    a = packed[(((wg * 4 + q) * ksteps + s) * MT + mt)].astype(np.float64)   # [64 lanes][8]
                     A = np.zeros((16, 32)); A[(lane & 15)[:, None], (lane >> 4)[:, None] * 8 + np.arange(8)[None, :]] = a
                     for nt in range(NT):
                         bfr = hp[(q * ksteps + s) * NT + nt].astype(np.float64)
@@ -71,11 +73,11 @@ def _emulate_lstm_kernel(packed, hp, xproj_t, c, H, B, NT):
                         z[wg, mt * 16:(mt + 1) * 16, nt * 16:(nt + 1) * 16] += A @ Bm
     sig = lambda x: 1 / (1 + np.exp(-x))
     h_new = np.zeros((B, H)); c_new = np.zeros((B, H))
-    for wg in range(H // 8):
-        for u in range(8):
-            unit = wg * 8 + u
+    for wg in range(H // UPW):
+        for u in range(UPW):
+            unit = wg * UPW + u
             for b in range(B):
-                zi, zj, zf, zo = (z[wg, g * 8 + u, b] + xproj_t[b, g * H + unit] for g in range(4))
+                zi, zj, zf, zo = (z[wg, g * UPW + u, b] + xproj_t[b, g * H + unit] for g in range(4))
                 cn = sig(zf) * c[b, unit] + sig(zi) * np.tanh(zj)
                 c_new[b, unit] = cn; h_new[b, unit] = sig(zo) * np.tanh(cn)
     return h_new, c_new
@@ -99,7 +101,9 @@ def test_lstm_weight_packing_matches_kernel_indexing():
             hp[k >> 5, b >> 4, ((k & 31) >> 3) * 16 + (b & 15), k & 7] = h[b, k]
     xproj = rng.standard_normal((B, 4 * H))
     c = rng.standard_normal((B, H))
-    h_new, c_new = _emulate_lstm_kernel(packed, hp.reshape(-1, 64, 8), xproj, c, H, B, NT)
+    upw = int(os.environ.get("STT_AMD_LSTM_UPW", "16"))      # the library packs for the kernel shape it will launch (kernels.h: lstm_units_per_wg)
+    upw = 16 if upw >= 16 else 8
+    h_new, c_new = _emulate_lstm_kernel(packed, hp.reshape(-1, 64, 8), xproj, c, H, B, NT, upw)
     Kh = kernel[H:].astype(np.float16).astype(np.float64)
     z = xproj + h.astype(np.float64) @ Kh
     i, j, f, o = np.split(z, 4, axis=1)
