@@ -154,7 +154,19 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
   int t_max = 1;
   for (int b = 0; b < Bg; ++b) t_max = std::max(t_max, n_frames_for(m->g, (int)sizes[idx[b]]));
   std::vector<int> cb;  // chunk boundaries
-  for (int t = 0, k = 0; t < t_max; ++k) { cb.push_back(t); t += (k == 0) ? std::min(batch_first_chunk_frames(), batch_chunk_frames()) : batch_chunk_frames(); }
+  {
+    // STT_AMD_CHUNKS="16,24,40": explicit lengths of the first chunks (then STT_AMD_CHUNK); else one short first chunk
+    static const std::vector<int> lead = []() {
+      std::vector<int> v;
+      if (const char* e = getenv("STT_AMD_CHUNKS")) { std::stringstream ss(e); std::string tok; while (std::getline(ss, tok, ',')) { const int x = atoi(tok.c_str()); if (x > 0) v.push_back(x); } }
+      return v;
+    }();
+    for (int t = 0, k = 0; t < t_max; ++k) {
+      cb.push_back(t);
+      if (!lead.empty()) t += k < (int)lead.size() ? lead[k] : batch_chunk_frames();
+      else t += (k == 0) ? std::min(batch_first_chunk_frames(), batch_chunk_frames()) : batch_chunk_frames();
+    }
+  }
   cb.push_back(t_max);
   const int n_chunks = (int)cb.size() - 1;
   // small integer tables in one page-locked block: [n_samples | n_frames | audio row | per chunk: begin, count]

@@ -135,31 +135,36 @@ __global__ __launch_bounds__(256) void context_kernel(ContextArgs a) {
 // For the 16-lane groups that a ds_read_b128 is serviced in, the rows r..r+15 at one chunk then
 // cover all 64 banks exactly once.
 // =============================================================================================
-#define GT_BM 128
-#define GT_BN 128
 #define GT_BK 64
-#define GT_TILE_BYTES (128 * GT_BK * 2)  // one operand tile: 16 KiB
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((address_space(1))) const void gvoid_c;
 
-template <int EPI>
-__global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[4 * GT_TILE_BYTES];  // [buffer][W | X]
+// T = tile side in units of 64 (2: 128 x 128 tile, 4 waves -- round 1; 4: 256 x 256 tile, 16 waves).  Every wave owns a
+// 64 x 64 piece either way (4 x 4 MFMA tiles); the bigger tile puts twice the MFMA work behind each DMA round trip and each
+// barrier (the 128-square tile with one tile of prefetch was bound by the landing latency of its global_load_lds stage:
+// 0.69 PF/s), and halves the operand bytes per flop.
+template <int EPI, int T>
+__global__ __launch_bounds__(T * T * 64) void dense_kernel(DenseArgs a) {
+  constexpr int BM = 64 * T, BN = 64 * T, NTHR = T * T * 64;
+  constexpr int TILE_BYTES = BM * GT_BK * 2;     // one operand tile (BM == BN): rows of 128 bytes
+  constexpr int RPI = NTHR / 8;                  // rows staged per DMA instruction of the whole workgroup
+  constexpr int IT = BM / RPI;                   // DMA instructions per thread, operand and stage (4 for both shapes' ... see below)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];  // [buffer][W | X], 4 * TILE_BYTES
   lds_u8* const lds = (lds_u8*)lds_raw;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wn = wave >> 1, wm = wave & 1;
+  const int wn = wave / T, wm = wave % T;
   // XCD-aware tile order.  Workgroup ids go round-robin over the 8 XCDs (id % 8), each with its own 4 MiB L2 that the
   // others cannot see, so an XCD that sweeps an M-band against ALL of N re-streams the whole weight matrix once per
   // M-tile (measured in round 1: 7.8x the algorithmic fetch on the 2048 -> 8192 projection).  Instead the tile grid is
   // cut into xa x xb rectangular blocks, one per XCD (launch_dense picks the cut that minimises operand bytes per XCD:
   // sum over XCDs of block rows + block columns), and inside a block the tiles are walked in strips of 8 N-tiles, M
-  // fastest within 8 x 8 sub-blocks: the ~64 workgroups resident on an XCD at any time share 8 activation row-tiles and
-  // 8 weight row-tiles and advance through K together, so each operand slice is fetched into that L2 about once.
-  const int n_tiles_n = a.N / GT_BN;
-  const int n_tiles_m = (a.M + GT_BM - 1) / GT_BM;
+  // fastest within 8 x 8 sub-blocks: the workgroups resident on an XCD at any time share activation row-tiles and weight
+  // row-tiles and advance through K together, so each operand slice is fetched into that L2 about once.
+  const int n_tiles_n = a.N / BN;
+  const int n_tiles_m = (a.M + BM - 1) / BM;
   int tile_m, tile_n;
   {
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -172,14 +177,14 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
     int strip, rem, w;
     if (idx < full * per_strip) { strip = idx / per_strip; rem = idx - strip * per_strip; w = sbn; }
     else { strip = full; rem = idx - full * per_strip; w = n_cnt - full * sbn; }
-    // inside a strip: blocks of 8 M-tiles x w N-tiles, N fastest inside a block
+    // inside a strip: blocks of 8 M-tiles x w N-tiles, M fastest inside a block
     const int blk = rem / (8 * w), r2 = rem - blk * 8 * w;
     const int mh = min(8, m_cnt - blk * 8);     // rows of this block (the last one may be shorter)
-    const int tn_l = r2 / mh, tm_l = r2 - tn_l * mh;  // M fastest: neighbours in id share the weight tile, the 8 x 8 set shares both
+    const int tn_l = r2 / mh, tm_l = r2 - tn_l * mh;
     tile_m = m_lo + blk * 8 + tm_l;
     tile_n = n_lo + strip * sbn + tn_l;
   }
-  const int n0 = tile_n * GT_BN, m0 = tile_m * GT_BM;
+  const int n0 = tile_n * BN, m0 = tile_m * BM;
   const int K = a.K;
 
   f32x4 acc[4][4];
@@ -188,26 +193,26 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // DMA sources: chunk q = i*256 + tid of a tile is LDS bytes [16q, 16q+16) = row q>>3, slot q&7 = K-chunk (q&7) ^ (row&7)
-  const int srow = tid >> 3;                       // rows srow + 32*i
-  const int schunk = (tid & 7) ^ (srow & 7);       // (32*i does not change row & 7)
-  const _Float16* wsrc[4];
-  const _Float16* xsrc[4];
+  // DMA sources: chunk q = i*NTHR + tid of a tile is LDS bytes [16q, 16q+16) = row q>>3, slot q&7 = K-chunk (q&7) ^ (row&7)
+  const int srow = tid >> 3;                       // rows srow + RPI*i
+  const int schunk = (tid & 7) ^ (srow & 7);       // (RPI is a multiple of 8: it does not change row & 7)
+  const _Float16* wsrc[IT];
+  const _Float16* xsrc[IT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    wsrc[i] = a.wt + (size_t)(n0 + srow + 32 * i) * K + schunk * 8;
-    int mr = m0 + srow + 32 * i;
+  for (int i = 0; i < IT; ++i) {
+    wsrc[i] = a.wt + (size_t)(n0 + srow + RPI * i) * K + schunk * 8;
+    int mr = m0 + srow + RPI * i;
     mr = mr < a.M ? mr : a.M - 1;
     xsrc[i] = a.x + (size_t)mr * a.ldx + schunk * 8;
   }
-  const unsigned wave_off = (unsigned)wave * 64 * 16;  // this wave's 1 KiB piece inside each 4 KiB (256-chunk) group
+  const unsigned wave_off = (unsigned)wave * 64 * 16;  // this wave's 1 KiB piece inside each (NTHR * 16)-byte group
 #define STAGE(buf, k0)                                                                                                   \
   do {                                                                                                                   \
-    lds_u8* const bw_ = lds + (buf) * 2 * GT_TILE_BYTES + wave_off;                                                      \
-    lds_u8* const bx_ = bw_ + GT_TILE_BYTES;                                                                             \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                      \
-      __builtin_amdgcn_global_load_lds((gvoid_c*)(wsrc[i] + (k0)), (__attribute__((address_space(3))) void*)(bw_ + i * 4096), 16, 0, 0); \
-      __builtin_amdgcn_global_load_lds((gvoid_c*)(xsrc[i] + (k0)), (__attribute__((address_space(3))) void*)(bx_ + i * 4096), 16, 0, 0); \
+    lds_u8* const bw_ = lds + (buf) * 2 * TILE_BYTES + wave_off;                                                         \
+    lds_u8* const bx_ = bw_ + TILE_BYTES;                                                                                \
+    _Pragma("unroll") for (int i = 0; i < IT; ++i) {                                                                     \
+      __builtin_amdgcn_global_load_lds((gvoid_c*)(wsrc[i] + (k0)), (__attribute__((address_space(3))) void*)(bw_ + i * NTHR * 16), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((gvoid_c*)(xsrc[i] + (k0)), (__attribute__((address_space(3))) void*)(bx_ + i * NTHR * 16), 16, 0, 0); \
     }                                                                                                                    \
   } while (0)
 
@@ -226,8 +231,8 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) STAGE(cur ^ 1, (kt + 1) * GT_BK);
-    const lds_u8* const bw = lds + cur * 2 * GT_TILE_BYTES;
-    const lds_u8* const bx = bw + GT_TILE_BYTES;
+    const lds_u8* const bw = lds + cur * 2 * TILE_BYTES;
+    const lds_u8* const bx = bw + TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       f16x8 fa[4], fb[4];
@@ -318,8 +323,6 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(DenseArgs a) {
 template __global__ void dense_skinny_kernel<DENSE_EPI_RELU_F16>(DenseArgs);
 template __global__ void dense_skinny_kernel<DENSE_EPI_BIAS_F32>(DenseArgs);
 
-template __global__ void dense_kernel<DENSE_EPI_RELU_F16>(DenseArgs);
-template __global__ void dense_kernel<DENSE_EPI_BIAS_F32>(DenseArgs);
 
 // =============================================================================================
 // LSTM recurrent step (deepspeech_model.py:144-168, tf LSTMCell semantics, forget_bias = 0):
@@ -623,15 +626,30 @@ void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st) {
 void launch_context(const ContextArgs& a, int rows, hipStream_t st) {
   hipLaunchKernelGGL(context_kernel, dim3(rows), dim3(256), 0, st, a);
 }
+template <int EPI, int T>
+static void launch_dense_inst(const DenseArgs& b, int grid, hipStream_t st) {
+  const size_t smem = (size_t)4 * (64 * T) * GT_BK * 2;  // two stages x (W tile + X tile): 64 KiB (T = 2) or 128 KiB (T = 4)
+  static std::once_flag once[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::call_once(once[dev & 15], [&]() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_kernel<EPI, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  hipLaunchKernelGGL((dense_kernel<EPI, T>), dim3(grid), dim3(T * T * 64), smem, st, b);
+}
 void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
   if (a.M <= 16 && a.K % 32 == 0 && a.N % 64 == 0) {
     if (epi == DENSE_EPI_RELU_F16) hipLaunchKernelGGL(dense_skinny_kernel<DENSE_EPI_RELU_F16>, dim3(a.N / 64), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dense_skinny_kernel<DENSE_EPI_BIAS_F32>, dim3(a.N / 64), dim3(256), 0, st, a);
     return;
   }
+  // 256-square tiles when the shape allows (N a multiple of 256 and enough rows to fill them), else 128-square
+  static const int big_ok = []() { const char* e = getenv("STT_AMD_DENSE_TILE"); return e ? atoi(e) : 256; }();
+  const bool big = big_ok >= 256 && a.N % 256 == 0 && a.M >= 256;
+  const int side = big ? 256 : 128;
   // cut of the tile grid over the 8 XCDs: xa x xb blocks, minimising (block rows + block columns) = operand bytes per XCD
   DenseArgs b = a;
-  const int ntn = a.N / GT_BN, ntm = (a.M + GT_BM - 1) / GT_BM;
+  const int ntn = a.N / side, ntm = (a.M + side - 1) / side;
   int best = 1 << 30;
   b.xa = 1; b.xb = 8;
   static const int legacy = []() { const char* e = getenv("STT_AMD_DENSE_MBAND"); return e ? atoi(e) : 0; }();  // A/B: round 1's M-bands
@@ -642,10 +660,13 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
     if (legacy ? (xa == 8) : (cost < best || (cost == best && Mx * Nx < ((ntm + b.xa - 1) / b.xa) * ((ntn + b.xb - 1) / b.xb)))) { best = cost; b.xa = xa; b.xb = xb; }
   }
   const int per_xcd = ((ntm + b.xa - 1) / b.xa) * ((ntn + b.xb - 1) / b.xb);
-  if (epi == DENSE_EPI_RELU_F16)
-    hipLaunchKernelGGL(dense_kernel<DENSE_EPI_RELU_F16>, dim3(8 * per_xcd), dim3(256), 0, st, b);
-  else
-    hipLaunchKernelGGL(dense_kernel<DENSE_EPI_BIAS_F32>, dim3(8 * per_xcd), dim3(256), 0, st, b);
+  if (big) {
+    if (epi == DENSE_EPI_RELU_F16) launch_dense_inst<DENSE_EPI_RELU_F16, 4>(b, 8 * per_xcd, st);
+    else launch_dense_inst<DENSE_EPI_BIAS_F32, 4>(b, 8 * per_xcd, st);
+  } else {
+    if (epi == DENSE_EPI_RELU_F16) launch_dense_inst<DENSE_EPI_RELU_F16, 2>(b, 8 * per_xcd, st);
+    else launch_dense_inst<DENSE_EPI_BIAS_F32, 2>(b, 8 * per_xcd, st);
+  }
 }
 int lstm_nt_for_batch(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : -1; }  // 64 rows per launch
 // hidden units per workgroup of the recurrent kernel (and of the weight packing, pack_lstm_recurrent_host): 16 when the width
