@@ -82,6 +82,12 @@ struct DevScorer {
   uint32_t lmi_buckets;
   float unk_prob, unk_backoff;  // unigram record of <unk> (word index 0)
   int unk_indep;                // ... and whether it has no children
+  // utf8 mode, orders <= 5: lossy direct-mapped cache of FullScore results shared by every stream using this scorer,
+  // 32-byte entries { context words[4] | unit hash (u64) | prob (f32) | length : 3, oov : 1, check : 28 } (ctc.hip: lm_memo_*).
+  // A hit is verified against the whole key (words, length, hash) -- exact, not a fingerprint -- and against a check word
+  // over key and value, which rejects an entry torn between two concurrent writers.  null = none.
+  uint32_t* memo;
+  uint32_t memo_mask;
   // hot words (murmur hashes of the words)
   int n_hot;
   const uint64_t* hot_hash;
@@ -93,6 +99,7 @@ struct DevAlphabet {
   int space_id;
   const uint8_t* label_bytes;
   const int* label_off;      // [n_labels] end offsets
+  int byte_labels;           // 1: label c is the single byte c + 1 for every c (UTF8Alphabet, alphabet.h:156-198)
 };
 
 // Per-stream search state; lives in HBM between launches, in LDS during a launch.
@@ -161,7 +168,7 @@ struct DecodeOut {
 void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
                      const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st,
                      int max_frames = 0, void* wide_ws = nullptr);
-bool ctc_is_wide(int beam, int C);
+bool ctc_is_wide(int beam, int C, bool utf8 = false);
 void ctc_set_fast_path(int on);  // test hook: 0 = always the generic search step, 1 = the fast word path where it applies, -1 = environment
 size_t ctc_wide_row_bytes(int C);
 inline bool ctc_sorts_classes(const DecParams& p) { return p.cutoff_prob < 1.0 || p.cutoff_top_n < p.C; }  // :337
@@ -189,7 +196,7 @@ struct DecodeBlock {
 };
 void launch_ctc_decode(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const DecStream* streams, int n_streams,
                        const DecodeOut& out, hipStream_t st);
-size_t ctc_next_lds_bytes(int beam, int C);
+size_t ctc_next_lds_bytes(int beam, int C, bool utf8 = false);
 void launch_ctc_init(DecStream* streams, int n_streams, const DevScorer* scorer_or_null, hipStream_t st);
 // batched streaming: every stream owns a one-entry table; a launch over many of them works on a gathered copy
 void launch_gather_streams(const DecStream* const* src, DecStream* dst, int n, hipStream_t st);

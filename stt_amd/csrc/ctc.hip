@@ -374,6 +374,45 @@ __device__ bool is_scoring_boundary(const DevScorer& s, const DevAlphabet& al, c
   return dist == needed;
 }
 
+// ------------------------------------------------------------------------------------ utf8-mode scorer cache
+// Narrow beams keep, per prefix, the code point in progress ("run": the bytes since the prefix's last start byte,
+// b0 | b1 << 8 | b2 << 16, their count in bits 24..31 saturating at 255; 0 = no start byte yet), so that
+// Scorer::is_scoring_boundary (scorer.cpp:272-299) is a table lookup instead of a walk up the path, and the score of a
+// completed code point is ONE FullScore from the boundary entry (BEntry) of the previous code point instead of
+// make_ngram + max_order FullScores (scorer.cpp:301-345, 228-270).  Byte sequences that are not well-formed UTF-8 make
+// the prefix's boundary entry STT_NONE and take the generic walk.
+__device__ __forceinline__ uint32_t utf8_unit_len(uint32_t first_byte) {  // scorer.cpp:283-295
+  if ((first_byte >> 3) == 0x1E) return 4;
+  if ((first_byte >> 4) == 0x0E) return 3;
+  if ((first_byte >> 5) == 0x06) return 2;
+  if ((first_byte >> 7) == 0x00) return 1;
+  return 0;
+}
+__device__ __forceinline__ uint32_t utf8_child_run(uint32_t run, uint8_t byte) {
+  if ((byte & 0xC0) != 0x80) return (uint32_t)byte | (1u << 24);
+  const uint32_t len = run >> 24;
+  if (len == 0) return 0;  // a continuation byte with no start byte below it: distance_to_codepoint_boundary finds none
+  uint32_t r = run & 0x00FFFFFFu;
+  if (len < 3) r |= (uint32_t)byte << (8 * len);
+  return r | ((len < 255u ? len + 1u : 255u) << 24);
+}
+// does `byte` on top of a prefix with this run end a code point?
+__device__ __forceinline__ bool utf8_completes(uint32_t run, uint8_t byte) {
+  const uint32_t cr = utf8_child_run(run, byte);
+  const uint32_t need = utf8_unit_len(cr & 0xFFu);
+  return (cr >> 24) != 0 && need != 0 && (cr >> 24) == need;
+}
+// Is the prefix + byte still a sequence of whole, well-formed code points plus at most one in progress (so that the
+// parent's boundary entry describes everything before the code point `byte` belongs to)?  `unit` = the bytes of that
+// code point so far, first byte lowest.
+__device__ __forceinline__ bool utf8_step_clean(uint32_t run, bool parent_root, uint8_t byte, uint32_t& unit) {
+  const uint32_t plen = run >> 24, pneed = utf8_unit_len(run & 0xFFu);
+  unit = byte;
+  if ((byte & 0xC0) != 0x80) return (parent_root ? plen == 0 : (plen != 0 && plen == pneed)) && utf8_unit_len(byte) != 0;
+  unit = (run & 0x00FFFFFFu) | ((uint32_t)byte << (8 * (plen & 3u)));
+  return plen >= 1 && plen < pneed;
+}
+
 // ------------------------------------------------------------------------------------ word-mode scorer cache
 __device__ __forceinline__ int word_nbytes(uint64_t lo, uint64_t hi) {
   if (hi) return 8 + (64 - __clzll((long long)hi) + 7) / 8;
@@ -486,6 +525,45 @@ __device__ __forceinline__ float lm_full_score_indexed(const DevScorer& s, const
   return lmi_combine(s.order, in, wi, uprob, uback, uindep, lv, out, nl);
 }
 
+// FullScore cache (DevScorer::memo).  The key is (the in-state's context words, their count, the word's hash): backoffs
+// in a KenLM state are a function of its words, so equal keys mean equal FullScore results.
+struct LmMemoKey { uint32_t w[4]; uint32_t len; uint64_t h; uint32_t slot; uint32_t mix; };
+__device__ __forceinline__ LmMemoKey lm_memo_key(const DevScorer& s, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t len, uint64_t h) {
+  LmMemoKey k;
+  k.len = len; k.h = h;
+  k.w[0] = len > 0 ? w0 : 0u; k.w[1] = len > 1 ? w1 : 0u; k.w[2] = len > 2 ? w2 : 0u; k.w[3] = len > 3 ? w3 : 0u;
+  uint64_t a = h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { a = (a ^ k.w[q]) * 0x9E3779B97F4A7C15ULL; a ^= a >> 31; }
+  a = (a ^ k.len) * 0xD6E8FEB86659FD93ULL; a ^= a >> 32;
+  k.slot = (uint32_t)(a >> 8) & s.memo_mask;
+  k.mix = (uint32_t)a;
+  return k;
+}
+__device__ __forceinline__ uint32_t lm_memo_meta(const LmMemoKey& k, float prob, bool oov) {
+  uint32_t c = (k.mix ^ (__float_as_uint(prob) * 0x85EBCA6Bu)) * 0xC2B2AE35u;
+  c ^= c >> 15;
+  return k.len | (oov ? 8u : 0u) | ((c | 1u) << 4);  // (an all-zero entry never verifies)
+}
+__device__ __forceinline__ bool lm_memo_check(const LmMemoKey& k, const u32x4& a, const u32x4& b, float& prob, bool& oov) {
+  if (a.x != k.w[0] || a.y != k.w[1] || a.z != k.w[2] || a.w != k.w[3] || b.x != (uint32_t)k.h || b.y != (uint32_t)(k.h >> 32)) return false;
+  prob = __uint_as_float(b.z); oov = (b.w & 8u) != 0;
+  return b.w == lm_memo_meta(k, prob, oov);
+}
+__device__ __forceinline__ bool lm_memo_find(const DevScorer& s, const LmMemoKey& k, float& prob, bool& oov, unsigned& probes) {
+  const GLB_AS u32x4* m = (const GLB_AS u32x4*)s.memo + (size_t)k.slot * 2;
+  const u32x4 a = m[0], b = m[1];
+  ++probes;
+  return lm_memo_check(k, a, b, prob, oov);
+}
+__device__ __forceinline__ void lm_memo_store(const DevScorer& s, const LmMemoKey& k, float prob, bool oov) {
+  GLB_AS u32x4* m = (GLB_AS u32x4*)s.memo + (size_t)k.slot * 2;
+  u32x4 a, b;
+  a.x = k.w[0]; a.y = k.w[1]; a.z = k.w[2]; a.w = k.w[3];
+  b.x = (uint32_t)k.h; b.y = (uint32_t)(k.h >> 32); b.z = __float_as_uint(prob); b.w = lm_memo_meta(k, prob, oov);
+  m[0] = a; m[1] = b;
+}
+
 // IDX: FullScore through the hashed n-gram index (the scorer must have one: orders <= 5), else the trie walk
 template <bool IDX>
 __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al, const GStream& S, const LDS_AS uint8_t* lab1, LDS_AS uint32_t* be_n, uint32_t node, uint32_t e_prev,
@@ -510,13 +588,22 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
   }
   const BEntry ep = load_be(S, e_prev);  // issued before the vocabulary probe: the two reads are independent
   ++probes;
-  DevVocabSlot vs;
-  const uint32_t wi = vocab_slot(s, h, vs, probes);
   BEntry en;
   float prob;
-  if constexpr (IDX) prob = lm_full_score_indexed(s, ep.st, h, wi, vs, en.st, probes);  // (the launcher picks IDX only when the index exists)
-  else prob = kenlm_full_score(s, ep.st, wi, en.st, probes, (wi != 0 && s.uni_in_vtab) ? &vs : nullptr);
-  en.oov_hist = (uint16_t)((ep.oov_hist << 1) | (wi == 0 ? 1u : 0u));
+  bool word_oov;
+  // a caller that only wants the value (no new entry, so no out-state) asks the FullScore cache first
+  const bool use_memo = !IDX && be_n == nullptr && s.memo != nullptr && ep.st.length <= 4;
+  LmMemoKey mk;
+  if (use_memo) mk = lm_memo_key(s, ep.st.words[0], ep.st.words[1], ep.st.words[2], ep.st.words[3], (uint32_t)ep.st.length, h);
+  if (!(use_memo && lm_memo_find(s, mk, prob, word_oov, probes))) {
+    DevVocabSlot vs;
+    const uint32_t wi = vocab_slot(s, h, vs, probes);
+    if constexpr (IDX) prob = lm_full_score_indexed(s, ep.st, h, wi, vs, en.st, probes);  // (the launcher picks IDX only when the index exists)
+    else prob = kenlm_full_score(s, ep.st, wi, en.st, probes, (wi != 0 && s.uni_in_vtab) ? &vs : nullptr);
+    word_oov = wi == 0;
+    if (use_memo) lm_memo_store(s, mk, prob, word_oov);
+  }
+  en.oov_hist = (uint16_t)((ep.oov_hist << 1) | (word_oov ? 1u : 0u));
   const bool oov = (en.oov_hist & ((1u << s.order) - 1u)) != 0;  // this word + the order-1 before it
   float hot_self = 0.0f, hot_total = 0.0f;
   if (s.n_hot) {
@@ -641,6 +728,7 @@ __global__ __launch_bounds__(1024) void ctc_wide_rows_kernel(DecParams p, const 
 #define NBUCKET 1024   // selection histogram bins (one per thread)
 #define RCAP 128       // a threshold bucket with more members than this is subdivided instead of ranked pairwise
 #define HTN 2048       // LDS hash slots (>= 2 * STT_MAX_BEAM)
+#define BLOOM_WORDS 512  // utf8 mode: filter in front of the hash (almost every lookup of the expand phase is a miss)
 
 // A double-buffered LDS array: buffer d starts `blk` bytes after buffer 0.  (An array of two pointers indexed with a
 // run-time `cur` would force the whole Lds struct into scratch memory and turn every beam access into a scratch load.)
@@ -658,9 +746,11 @@ struct Lds {
   // word mode, narrow beams: the UTF-8 bytes of the prefix's current (unfinished) word, first byte lowest (wlo = bytes
   // 0..7, whi = 8..15; all ones = longer than 16 bytes), and the BEntry of "prefix + boundary" once scored (STT_NONE before)
   DB<uint64_t> wlo, whi; DB<uint32_t> pqe; DB<float> pqs;  // pqs = (float)(raw score * alpha) of entry pqe
+  DB<uint32_t> run;  // utf8 mode: the prefix's code point in progress (utf8_child_run)
   LDS_AS float *ev_self, *ev_blank, *ev_ext;  // reused as new pnb / new pb / new score in P4
   LDS_AS uint32_t* ev_exti;                   // parent beam index | needs_lm << 31 ; reused as pending timestep parent
   LDS_AS uint64_t* ht_key; LDS_AS uint16_t* ht_idx;  // path key -> beam index of the live prefixes (rebuilt whenever the beam is written)
+  LDS_AS uint32_t* bloom;  // utf8 mode: 16384-bit filter over the live keys (one bit per key); null otherwise
   DB<float> pf, lp; LDS_AS float* lps;        // emissions and their logs (double buffered: the next row is prepared one step ahead); lps = by class position when pruning sorts
   LDS_AS double* lbl;                         // [2] log((double)prob[blank])
   LDS_AS uint32_t* lpm;                       // fast word path: [2][36] bitmap of the k most probable classes of the row
@@ -696,7 +786,7 @@ __host__ inline int lds_budget_kb_host() {
   return v;
 }
 template <int CAP>
-__host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, LDS_AS unsigned char* base, size_t& total, int budget_kb) {
+__host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, LDS_AS unsigned char* base, size_t& total, int budget_kb, bool utf8 = false) {
   Lds L{};
   Lds* l = &L;
   constexpr uint32_t cap = CAP;
@@ -704,13 +794,14 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   constexpr bool arcs = cap <= 512;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
-  size_t offs[76]; int k = 0;
+  size_t offs[80]; int k = 0;
   for (int d = 0; d < 2; ++d) {
     offs[k++] = take(cap * 8);                                     // key
     for (int a = 0; a < 8; ++a) offs[k++] = take(cap * 4);         // score pb pnb ch node ts fst bnd
     offs[k++] = take(arcs ? cap * 4 : 0); offs[k++] = take(arcs ? cap * 4 : 0);  // a0, an / sm (wide beams read the FST instead)
     offs[k++] = take(arcs ? cap * 8 : 0); offs[k++] = take(arcs ? cap * 8 : 0); offs[k++] = take(arcs ? cap * 4 : 0);  // wlo, whi, pqe
     offs[k++] = take(arcs ? cap * 4 : 0);                                                                              // pqs
+    offs[k++] = take(utf8 ? cap * 4 : 0);                                                                              // run (utf8 mode: code point in progress)
   }
   for (int a = 0; a < 4; ++a) offs[k++] = take(cap * 4);           // events
   offs[k++] = take(HTN * 8); offs[k++] = take(HTN * 2);            // hash
@@ -729,6 +820,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   offs[k++] = take(2 * 36 * 4);                                    // lpm[2][36]
   offs[k++] = take(16);                                            // pbl[2]
   offs[k++] = take(arcs ? cap : 0);                                // wait
+  offs[k++] = take(utf8 ? BLOOM_WORDS * 4 : 0);                    // bloom
   // ---- class-count dependent from here on
   for (int a = 0; a < 4; ++a) offs[k++] = take((size_t)(C > 0 && C < 32 ? 32 : C) * 4);  // pf[2], lp[2]
   offs[k++] = take((size_t)(C > 0 && C <= 32 ? 64 : C) * 4);                            // lps (fast word path: [2][32] sorted log-probs)
@@ -747,7 +839,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   o += (size_t)mcap * 12;
   {
     k = 0;
-    const uint32_t blk = (uint32_t)(offs[15] - offs[0]);  // 15 arrays per buffer
+    const uint32_t blk = (uint32_t)(offs[16] - offs[0]);  // 16 arrays per buffer
     auto db = [&](auto& m, size_t off, bool on) { using P = decltype(m.p0); m.p0 = on ? (P)(base + off) : (P) nullptr; m.blk = blk; };
     db(l->key, offs[0], true);
     db(l->score, offs[1], true); db(l->pb, offs[2], true); db(l->pnb, offs[3], true);
@@ -755,7 +847,8 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
     db(l->fst, offs[7], true); db(l->bnd, offs[8], true);
     db(l->a0, offs[9], arcs); db(l->an, offs[10], arcs); db(l->sm, offs[10], arcs);
     db(l->wlo, offs[11], arcs); db(l->whi, offs[12], arcs); db(l->pqe, offs[13], arcs); db(l->pqs, offs[14], arcs);
-    k = 30;
+    db(l->run, offs[15], utf8);
+    k = 32;
     l->ev_self = (LDS_AS float*)(base + offs[k++]); l->ev_blank = (LDS_AS float*)(base + offs[k++]); l->ev_ext = (LDS_AS float*)(base + offs[k++]);
     l->ev_exti = (LDS_AS uint32_t*)(base + offs[k++]);
     l->ht_key = (LDS_AS uint64_t*)(base + offs[k++]); l->ht_idx = (LDS_AS uint16_t*)(base + offs[k++]);
@@ -773,6 +866,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
     l->lpm = (LDS_AS uint32_t*)(base + offs[k++]);
     l->pbl = (LDS_AS float*)(base + offs[k++]);
     l->wait = (LDS_AS uint8_t*)(base + offs[k++]);
+    { const size_t ob = offs[k++]; l->bloom = utf8 ? (LDS_AS uint32_t*)(base + ob) : (LDS_AS uint32_t*)nullptr; }
     l->pf.p0 = (LDS_AS float*)(base + offs[k]); l->pf.blk = (uint32_t)(offs[k + 1] - offs[k]); k += 2;
     l->lp.p0 = (LDS_AS float*)(base + offs[k]); l->lp.blk = (uint32_t)(offs[k + 1] - offs[k]); k += 2;
     l->lps = (LDS_AS float*)(base + offs[k++]);
@@ -786,29 +880,32 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
 }
 inline int cap_bucket(int beam) { return beam <= 64 ? 64 : beam <= 128 ? 128 : beam <= 256 ? 256 : beam <= 512 ? 512 : 1024; }
 // LDS bytes of the search kernel with the class arrays of a C-class alphabet in LDS (C = 0: wide mode, none)
-size_t ctc_next_lds_bytes(int beam, int C) {
+size_t ctc_next_lds_bytes(int beam, int C, bool utf8) {
   size_t t = 0;
   switch (cap_bucket(beam)) {
-    case 64: (void)lds_carve<64>(C, nullptr, t, lds_budget_kb_host()); break;
-    case 128: (void)lds_carve<128>(C, nullptr, t, lds_budget_kb_host()); break;
-    case 256: (void)lds_carve<256>(C, nullptr, t, lds_budget_kb_host()); break;
-    case 512: (void)lds_carve<512>(C, nullptr, t, lds_budget_kb_host()); break;
-    default: (void)lds_carve<1024>(C, nullptr, t, lds_budget_kb_host()); break;
+    case 64: (void)lds_carve<64>(C, nullptr, t, lds_budget_kb_host(), utf8); break;
+    case 128: (void)lds_carve<128>(C, nullptr, t, lds_budget_kb_host(), utf8); break;
+    case 256: (void)lds_carve<256>(C, nullptr, t, lds_budget_kb_host(), utf8); break;
+    case 512: (void)lds_carve<512>(C, nullptr, t, lds_budget_kb_host(), utf8); break;
+    default: (void)lds_carve<1024>(C, nullptr, t, lds_budget_kb_host(), utf8); break;
   }
   return t;
 }
 
 #define STT_LDS_MAX (160 * 1024)
 // Wide mode when the class arrays do not fit next to the beam state (or the in-kernel class sort would dominate a step).
-bool ctc_is_wide(int beam, int C) { return C > 1024 || ctc_next_lds_bytes(beam, C) > (size_t)STT_LDS_MAX; }
+bool ctc_is_wide(int beam, int C, bool utf8) { return C > 1024 || ctc_next_lds_bytes(beam, C, utf8) > (size_t)STT_LDS_MAX; }
 
 __device__ __forceinline__ int ht_find(const Lds& L, uint64_t k) {
+  // double hashing (odd stride from other key bits): a wave pays for its slowest lane, and at beam 1024 (load 1/2)
+  // linear probing's clusters made that 30 probes per lookup round; with key-dependent strides the tail is geometric
   uint32_t h = (uint32_t)(k >> 17) & (HTN - 1);
+  const uint32_t step = (uint32_t)(k >> 40) | 1u;
   for (;;) {
     const uint64_t v = L.ht_key[h];
     if (v == k) return (int)L.ht_idx[h];
     if (v == 0) return -1;
-    h = (h + 1) & (HTN - 1);
+    h = (h + step) & (HTN - 1);
   }
 }
 
@@ -864,10 +961,12 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // LDS hash insert of a live prefix key (value = beam index)
 __device__ __forceinline__ void ht_insert(const Lds& L, uint64_t k, int idx) {
   uint32_t h = (uint32_t)(k >> 17) & (HTN - 1);
+  const uint32_t step = (uint32_t)(k >> 40) | 1u;
   for (;;) {
     if (lds_cas0(&L.ht_key[h], k) == 0ULL) { L.ht_idx[h] = (uint16_t)idx; break; }
-    h = (h + 1) & (HTN - 1);
+    h = (h + step) & (HTN - 1);
   }
+  if (L.bloom) { const uint32_t b = (uint32_t)(k >> 28) & (BLOOM_WORDS * 32 - 1); lds_or((LDS_AS int*)&L.bloom[b >> 5], (int)(1u << (b & 31u))); }
 }
 
 // Class log-probs of one emission row into buffer `buf` (get_pruned_emissions, :328-358, the part that does not depend
@@ -1196,7 +1295,10 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     if (n_items > 64) EXPAND_LOCATE(64 + lane, j_1, kk_1, v_1, arc_1)
 #pragma unroll 1
     for (uint32_t xb = 0; xb < n_items; xb += 64) {
+      unsigned long long xt0_ = 0;
+      if (p.stamps && wave == 0) xt0_ = __builtin_readcyclecounter();
       if (xb + 128 < n_items) EXPAND_LOCATE(xb + 128 + lane, j_2, kk_2, v_2, arc_2)  // uniform condition
+      if (p.stamps && wave == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) L.stm[50] += t_ - xt0_; xt0_ = t_; }
       const uint32_t iju = j_0, kku = kk_0; const uint2 arc_c = arc_0; const bool vu = v_0;
       j_0 = j_1; kk_0 = kk_1; arc_0 = arc_1; v_0 = v_1;
       j_1 = j_2; kk_1 = kk_2; arc_1 = arc_2; v_1 = v_2;
@@ -1225,9 +1327,20 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
         else log_p = __fadd_rn(lpc, sci);
         uint32_t needs_lm = 0;
-        if (SC_ON) needs_lm = SC_UTF8 ? (is_scoring_boundary(s, al, S.pa_generic, L.node[cur][i], c, c, probes) ? 1u : 0u) : ((int)c == al.space_id ? 1u : 0u);
+        if (SC_ON) {
+          if (SC_UTF8) {
+            if (al.byte_labels) needs_lm = utf8_completes(L.run[cur][i], (uint8_t)(c + 1)) ? 1u : 0u;  // (UTF8Alphabet: label c is byte c + 1)
+            else needs_lm = is_scoring_boundary(s, al, S.pa_generic, L.node[cur][i], c, c, probes) ? 1u : 0u;
+          } else needs_lm = (int)c == al.space_id ? 1u : 0u;
+        }
         const uint64_t ck = child_key(L.key[cur][i], c);
-        const int jj = ht_find(L, ck);
+        if (p.stamps && wave == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) { L.stm[51] += t_ - xt0_; L.stm[54] += 1; } xt0_ = t_; }
+        int jj = -1;
+        {  // (utf8 mode: a one-bit filter first -- a wave pays for its slowest lane's probe sequence, and ~97 % of the lookups miss)
+          const uint32_t fb = (uint32_t)(ck >> 28) & (BLOOM_WORDS * 32 - 1);
+          if (!L.bloom || ((L.bloom[fb >> 5] >> (fb & 31u)) & 1u)) jj = ht_find(L, ck);
+        }
+        if (p.stamps && wave == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) L.stm[52] += t_ - xt0_; xt0_ = t_; }
         if (jj >= 0) {  // the child is a live prefix: one extension event per live prefix per step
           L.ev_ext[jj] = log_p;
           L.ev_exti[jj] = (uint32_t)i | (needs_lm << 31);
@@ -1241,6 +1354,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
             if (needs_lm && lm_queue) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = (uint32_t)slot; }
           }
         }
+        if (p.stamps && wave == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) L.stm[53] += t_ - xt0_; }
       }
     }
   }
@@ -1266,6 +1380,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   // merge every live prefix that does not wait for a score.  Meanwhile the next row's class log-probs are prepared and
   // the (now dead) hash is cleared for the next beam.
   for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
+  if (L.bloom) for (uint32_t h = tid; h < BLOOM_WORDS; h += NTHREADS) L.bloom[h] = 0;
   if (!WIDE && next_row) prep_row(p, L, buf ^ 1, next_row, pre);
   bool merged = false;
   float my_score = NEG;
@@ -1317,7 +1432,14 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         else { const int j = x - m; pi = L.ev_exti[j]; if (!(pi >> 31) || is_absent(L.ev_ext[j])) continue; lp0 = L.ev_ext[j]; }
         const int i = (int)(pi & 0xFFFFu);
         const uint32_t first = (x < m) ? CLS_AT((pi >> 16) & 0x7FFFu) : L.ch[cur][x - m];  // utf8 mode scores the *new* prefix
-        const double raw = lm_score(s, al, S.pa_generic, L.node[cur][i], first, true, probes); ++lmq;
+        double raw;
+        uint32_t unit = 0;
+        const uint32_t bndi = L.bnd[cur][i];
+        if (al.byte_labels && bndi != STT_NONE && utf8_step_clean(L.run[cur][i], L.ch[cur][i] == STT_ROOT_CH, (uint8_t)(first + 1), unit)) {
+          uint32_t ne;  // one FullScore from the state after the previous code point
+          raw = lm_word_query_cached<false>(s, al, S, lab1, (LDS_AS uint32_t*)nullptr, 0u, bndi, true, (uint64_t)unit, 0ULL, ne, probes);
+        } else raw = lm_score(s, al, S.pa_generic, L.node[cur][i], first, true, probes);
+        ++lmq;
         const float lms = (float)__dmul_rn(raw, s.alpha);
         float lpv = __fadd_rn(lp0, lms);
         lpv = (float)__dadd_rn((double)lpv, s.beta);
@@ -1440,6 +1562,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         nkey = L.key[cur][x];
         L.bnd[nxt][r] = L.bnd[cur][x];
         if (MODE == 1 && L.pqe.p0) { L.wlo[nxt][r] = L.wlo[cur][x]; L.whi[nxt][r] = L.whi[cur][x]; L.pqe[nxt][r] = L.pqe[cur][x]; L.pqs[nxt][r] = L.pqs[cur][x]; }
+        if (MODE == 2) L.run[nxt][r] = L.run[cur][x];
         pend = L.ev_exti[x]; ts_new = L.ts[cur][x];
       } else {
         const int cx = (int)x - n;
@@ -1476,6 +1599,24 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         const uint32_t slot = lds_add((LDS_AS uint32_t*)&sc[SC_PAN], 1u);
         if (slot < S.pa_cap) { store_node(S.pa, slot, pnode, c); S.pq[slot] = STT_NONE; L.node[nxt][r] = slot; }
         else { L.node[nxt][r] = 0; lds_or(&sc[SC_ERR], 1); }
+        if (MODE == 2) {  // utf8 cache: the child's run, and its boundary entry (a new one when it completes a code point)
+          const uint8_t byte = (uint8_t)(c + 1);
+          const uint32_t prun = L.run[cur][i];
+          uint32_t unit = 0, nb = STT_NONE;
+          unsigned probes6 = 0;
+          if (al.byte_labels) {
+            L.run[nxt][r] = utf8_child_run(prun, byte);
+            if (b != STT_NONE && utf8_step_clean(prun, L.ch[cur][i] == STT_ROOT_CH, byte, unit)) {
+              if (pi >> 31) {
+                if (slot < S.pa_cap) {
+                  lm_word_query_cached<false>(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], slot, b, true, (uint64_t)unit, 0ULL, nb, probes6);
+                  if (nb == STT_NONE) lds_or(&sc[SC_ERR], 8);
+                }
+              } else nb = b;
+            }
+          } else L.run[nxt][r] = 0;  // not a UTF8Alphabet: every prefix takes the generic walk (nb stays STT_NONE)
+          L.bnd[nxt][r] = nb;
+        }
         pend = (NEG < lpv) ? L.ts[cur][i] : 0xFFFFFFFEu;  // :246-251 with log_prob_nb_cur == -inf
         ts_new = STT_ROOT_CH;                              // timesteps == nullptr
       }
@@ -1513,7 +1654,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
                                                             const float* probs, const int* frame_begin, const int* frame_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   size_t lds_total;
-  const Lds L = lds_carve<CAP>(WIDE ? 0 : p.C, (LDS_AS unsigned char*)smem, lds_total, p.lds_kb);
+  const Lds L = lds_carve<CAP>(WIDE ? 0 : p.C, (LDS_AS unsigned char*)smem, lds_total, p.lds_kb, MODE == 2);
   DecStream& G = streams[blockIdx.x];
   const int nfr = frame_count ? frame_count[blockIdx.x] : p.all_count;
   if (nfr <= 0) return;
@@ -1561,6 +1702,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
     L.cls[c] = (uint16_t)c; L.pos[c] = (uint16_t)c;  // identity class order unless pruning re-sorts it every step
   }
   for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
+  if (L.bloom) for (uint32_t h = tid; h < BLOOM_WORDS; h += NTHREADS) L.bloom[h] = 0;
   if (tid < 32) { L.exp_tab[tid] = sttm::kExp2Tab[tid]; L.log_tab[tid] = sttm::kLogfTab[tid >> 1][tid & 1]; }
   if (tid == 0) { L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
   if (tid < 12) L.acc[tid] = 0;
@@ -1582,6 +1724,20 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
       const uint32_t e0 = GS.pq[nd];
       L.wlo[0][i] = lo; L.whi[0][i] = hi; L.pqe[0][i] = e0;
       L.pqs[0][i] = e0 != STT_NONE ? (float)__dmul_rn(load_be_raw(GS, e0), s.alpha) : 0.0f;
+    }
+  }
+  if (MODE == 2) {  // utf8 cache: rebuild each prefix's code point in progress from its path (the bytes back to the last start byte)
+    for (int i = tid; i < n; i += NTHREADS) {
+      uint64_t acc = 0; uint32_t len = 0; bool found = false;
+      for (uint32_t nd = L.node[0][i]; nd != STT_ROOT_CH;) {
+        const uint2 pn = load_node(GS.pa, nd);
+        if (pn.y == STT_ROOT_CH) break;
+        const uint8_t byte = (uint8_t)(pn.y + 1);
+        acc = (acc << 8) | byte; len = len < 255u ? len + 1u : 255u;  // (newest byte first: the start byte ends up lowest)
+        if ((byte & 0xC0) != 0x80) { found = true; break; }
+        nd = pn.x;
+      }
+      L.run[0][i] = (found && al.byte_labels) ? (((uint32_t)acc & 0x00FFFFFFu) | (len << 24)) : 0u;
     }
   }
   for (int i = tid; i < n; i += NTHREADS) ht_insert(L, L.key[0][i], i);
@@ -1782,7 +1938,7 @@ static void check_launch(const char* what) {
 void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
                      const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st, int max_frames, void* wide_ws) {
   DecParams p = p_in;
-  const bool wide = ctc_is_wide(p.beam, p.C);
+  const bool wide = ctc_is_wide(p.beam, p.C, s.enabled && s.utf8);
   p.wide_rows = nullptr; p.wide_stride = 0; p.wide_max_frames = 0; p.n_lm_waves = 0;
   if (wide && (!wide_ws || max_frames <= 0 || p.C > STT_MAX_CLASSES)) { fprintf(stderr, "stt_amd: launch_ctc_next: wide alphabet without a row workspace\n"); abort(); }
   const int cb = cap_bucket(p.beam);
@@ -1808,7 +1964,7 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
     check_launch("ctc_wide_rows_kernel");
   }
   if (!fast) { static const int lmw2 = []() { const char* e = getenv("STT_AMD_LM_WAVES"); return e ? atoi(e) : 0; }(); p.n_lm_waves = lmw2; }
-  const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : p.C);
+  const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : p.C, s.enabled && s.utf8);
   p.lds_kb = lds_budget_kb_host();
   const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : (fast ? 3 : ((!wide && ctc_masked_ok(p, s, al)) ? 4 : 1)));
   const int ci = cb == 64 ? 0 : cb == 128 ? 1 : cb == 256 ? 2 : cb == 512 ? 3 : 4;

@@ -644,7 +644,7 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
     return;
   }
   // 256-square tiles when the shape allows (N a multiple of 256 and enough rows to fill them), else 128-square
-  static const int big_ok = []() { const char* e = getenv("STT_AMD_DENSE_TILE"); return e ? atoi(e) : 256; }();
+  static const int big_ok = []() { const char* e = getenv("STT_AMD_DENSE_TILE"); return e ? atoi(e) : 128; }();  // (measured: the 256-square tile is slower on these shapes -- 96 to 384 tiles for 256 CUs -- DESIGN.md 8.3)
   const bool big = big_ok >= 256 && a.N % 256 == 0 && a.M >= 256;
   const int side = big ? 256 : 128;
   // cut of the tile grid over the 8 XCDs: xa x xb blocks, minimising (block rows + block columns) = operand bytes per XCD

@@ -237,6 +237,11 @@ int ModelState::InitFromBuffer(const char* buf, size_t len) {
     dev_alphabet.space_id = alphabet_.GetSpaceLabel();
     dev_alphabet.label_bytes = al_bytes.as<uint8_t>();
     dev_alphabet.label_off = al_off.as<int>();
+    dev_alphabet.byte_labels = 1;
+    for (size_t c = 0; c < alphabet_.labels().size(); ++c) {
+      const std::string& l = alphabet_.labels()[c];
+      if (l.size() != 1 || (unsigned char)l[0] != (unsigned char)(c + 1)) { dev_alphabet.byte_labels = 0; break; }
+    }
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   return STT_ERR_OK;
