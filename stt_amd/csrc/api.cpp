@@ -226,6 +226,12 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
   launch_ctc_decode(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, o, sl.stream_dec);
   HIP_CHECK(hipMemcpyAsync(sl.h_out.p, sl.out.p, sl.out_layout.bytes, hipMemcpyDeviceToHost, sl.stream_dec));  // all results, one copy
   mark_on(m, -1, which, sl.stream_dec);
+  if (prof_of(m).on) {  // the search counters ride behind the results (no extra synchronisation when they are read)
+    const size_t tb = sizeof(DecStream) * (size_t)Bg, sb = p.stamps ? (size_t)Bg * 64 * 8 : 0;
+    sl.h_prof.reserve(tb + sb);
+    HIP_CHECK(hipMemcpyAsync(sl.h_prof.p, sl.dec.table.p, tb, hipMemcpyDeviceToHost, sl.stream_dec));
+    if (sb) HIP_CHECK(hipMemcpyAsync((char*)sl.h_prof.p + tb, sl.stamps.p, sb, hipMemcpyDeviceToHost, sl.stream_dec));
+  }
   HIP_CHECK(hipEventRecord(sl.done, sl.stream_dec));
 }
 
@@ -254,15 +260,21 @@ void batch_collect_group(ModelState* m, ModelState::GroupSlot& sl, std::vector<s
   }
   if (pr.on) {
     pr.ms[6] += (float)sl.t_max; pr.ms[7] += (float)sl.t_max * sl.Bg;
-    std::vector<DecStream> tb(sl.Bg);
-    HIP_CHECK(hipMemcpy(tb.data(), sl.dec.table.p, sizeof(DecStream) * sl.Bg, hipMemcpyDeviceToHost));
-    for (auto& S : tb) { for (int k = 0; k < 4; ++k) pr.dec_stats[k] += S.stat[k]; for (int k = 0; k < 8; ++k) pr.dec_phase[k] += S.phase[k]; }
+    const DecStream* tb = sl.h_prof.as<DecStream>();
+    for (int i = 0; i < sl.Bg; ++i) { for (int k = 0; k < 4; ++k) pr.dec_stats[k] += tb[i].stat[k]; for (int k = 0; k < 8; ++k) pr.dec_phase[k] += tb[i].phase[k]; }
     if (pr.phase_cycles && sl.stamps.p) {
-      std::vector<unsigned long long> st((size_t)sl.Bg * 64);
-      HIP_CHECK(hipMemcpy(st.data(), sl.stamps.p, st.size() * 8, hipMemcpyDeviceToHost));
+      const unsigned long long* st = reinterpret_cast<const unsigned long long*>((const char*)sl.h_prof.p + sizeof(DecStream) * (size_t)sl.Bg);
       for (int i = 0; i < sl.Bg; ++i) for (int k = 0; k < 64; ++k) pr.dec_stamps[k] += st[(size_t)i * 64 + k];
     }
   }
+}
+
+void batch_init_slots(ModelState* m) {
+  if (m->ev_chunk[0]) return;
+  for (auto& e : m->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& sl : m->slots_) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  m->slots_[0].stream_dec = m->stream_dec;
+  HIP_CHECK(hipStreamCreateWithFlags(&m->slots_[1].stream_dec, hipStreamNonBlocking));
 }
 
 // Utterances are taken longest first in groups of 64 (length-homogeneous groups: the LSTM runs every group to its longest
@@ -272,12 +284,8 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
   HIP_CHECK(hipSetDevice(m->device));
   Prof& pr = prof_of(m);
   if (pr.on) { for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; for (auto& x : pr.dec_stamps) x = 0; prof_reset(pr); }
-  if (!m->ev_chunk[0]) {
-    for (auto& e : m->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto& sl : m->slots_) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-    m->slots_[0].stream_dec = m->stream_dec;
-    HIP_CHECK(hipStreamCreateWithFlags(&m->slots_[1].stream_dec, hipStreamNonBlocking));
-  }
+  if (m->async_busy_[0] || m->async_busy_[1]) throw std::runtime_error("a batch submitted with STTX_BatchSubmitDevice has not been collected yet");
+  batch_init_slots(m);
   std::vector<unsigned> order(B);
   for (unsigned i = 0; i < B; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return sizes[x] > sizes[y]; });
@@ -300,6 +308,52 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
   if (pr.on) {
     HIP_CHECK(hipStreamSynchronize(m->stream));
     for (auto& sl : m->slots_) HIP_CHECK(hipStreamSynchronize(sl.stream_dec));
+    prof_collect(pr);
+  }
+  return all;
+}
+
+// The two group slots as a caller-driven pipeline (STTX_BatchSubmitDevice / STTX_BatchCollect): a batch of <= 64 utterances
+// is enqueued without waiting, so the acoustic model of batch k+1 runs while the beam search of batch k finishes and the
+// host turns batch k-1's results into strings -- what batch_run() does between the groups of one call, across calls.
+int batch_submit(ModelState* m, const int16_t* d_audio, unsigned stride, const unsigned* sizes, unsigned B) {
+  if (B == 0 || B > 64) throw std::runtime_error("STTX_BatchSubmitDevice takes 1..64 utterances (one group) per call");
+  HIP_CHECK(hipSetDevice(m->device));
+  batch_init_slots(m);
+  const int slot = m->async_next_ & 1;
+  if (m->async_busy_[slot]) throw std::runtime_error("two batches are already in flight: collect the older one first");
+  Prof& pr = prof_of(m);
+  if (pr.on && !m->async_busy_[0] && !m->async_busy_[1]) {
+    for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; for (auto& x : pr.dec_stamps) x = 0;
+    prof_reset(pr);
+  }
+  std::vector<unsigned> idx(B);
+  for (unsigned i = 0; i < B; ++i) idx[i] = i;
+  const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
+  batch_enqueue_group(m, m->slots_[slot], d_audio, stride, sizes, idx, 1, ds);
+  m->async_busy_[slot] = true;
+  m->async_ticket_[slot] = m->async_next_;
+  return m->async_next_++;
+}
+std::vector<std::vector<Output>> batch_collect(ModelState* m, int ticket) {
+  const int slot = ticket & 1;
+  if (ticket < 0 || !m->async_busy_[slot] || m->async_ticket_[slot] != ticket) throw std::runtime_error("STTX_BatchCollect: no such batch in flight");
+  HIP_CHECK(hipSetDevice(m->device));
+  ModelState::GroupSlot& sl = m->slots_[slot];
+  Prof& pr = prof_of(m);
+  std::vector<std::vector<Output>> all((size_t)sl.Bg);
+  m->async_busy_[slot] = false;
+  try { batch_collect_group(m, sl, all, pr); }
+  catch (...) {
+    (void)hipStreamSynchronize(m->stream);
+    for (auto& s2 : m->slots_) if (s2.stream_dec) (void)hipStreamSynchronize(s2.stream_dec);
+    m->async_busy_[0] = m->async_busy_[1] = false;  // whatever else was in flight has finished; its results are dropped
+    if (pr.on) prof_reset(pr);
+    throw;
+  }
+  if (pr.on && !m->async_busy_[0] && !m->async_busy_[1]) {  // the pipeline has drained: every mark has been reached
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    for (auto& s2 : m->slots_) HIP_CHECK(hipStreamSynchronize(s2.stream_dec));
     prof_collect(pr);
   }
   return all;
@@ -577,6 +631,26 @@ char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* aDeviceAudio,
     res = (char**)malloc(sizeof(char*) * std::max(1u, aBatch));
     for (unsigned i = 0; i < aBatch; ++i)
       res[i] = outs[i].empty() ? strdup("") : strdup(aCtx->alphabet_.Decode(outs[i][0].tokens.data(), (int)outs[i][0].tokens.size()).c_str());
+    return 0;
+  }, 0);
+  return res;
+}
+
+int STTX_BatchSubmitDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride, const unsigned int* aBufferSizes, unsigned int aBatch) {
+  int ticket = -STT_ERR_FAIL_RUN_SESS;
+  guarded([&]() { ticket = batch_submit(aCtx, aDeviceAudio, aStride, aBufferSizes, aBatch); return 0; }, 0);
+  return ticket;
+}
+
+char** STTX_BatchCollect(ModelState* aCtx, int aTicket, unsigned int* aCount) {
+  char** res = nullptr;
+  if (aCount) *aCount = 0;
+  guarded([&]() {
+    auto outs = batch_collect(aCtx, aTicket);
+    res = (char**)malloc(sizeof(char*) * std::max<size_t>(1, outs.size()));
+    for (size_t i = 0; i < outs.size(); ++i)
+      res[i] = outs[i].empty() ? strdup("") : strdup(aCtx->alphabet_.Decode(outs[i][0].tokens.data(), (int)outs[i][0].tokens.size()).c_str());
+    if (aCount) *aCount = (unsigned)outs.size();
     return 0;
   }, 0);
   return res;

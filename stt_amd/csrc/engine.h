@@ -189,6 +189,7 @@ struct ModelState {
     DevBuf stamps;            // profiling level 2: DecParams::stamps
     DevBuf wide;  // per-row class records of the wide-alphabet search path (ctc.h: ctc_is_wide)
     PinnedBuf h_ints, h_table, h_out;
+    PinnedBuf h_prof;         // profiling: the group's DecStream table (+ stamps), copied behind the results on the search stream
     DecodeBlock out_layout{};
     hipEvent_t done = nullptr;
     hipStream_t stream_dec = nullptr;  // the group's search stream (slot 0: ModelState::stream_dec, slot 1: its own)
@@ -196,6 +197,10 @@ struct ModelState {
     std::vector<unsigned> idx;  // caller's utterance index of every stream of the group
   };
   GroupSlot slots_[2];
+  // STTX_BatchSubmitDevice / STTX_BatchCollect: which slot holds an uncollected batch, and the next ticket
+  bool async_busy_[2] = {false, false};
+  int async_ticket_[2] = {-1, -1};
+  int async_next_ = 0;
   // scratch of the batched streaming calls (STTX_FeedAudioContentBatch & co.)
   DevBuf sb_audio, sb_tab, sb_c, sb_h, sb_table;
   PinnedBuf sb_haudio, sb_htab;

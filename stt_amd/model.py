@@ -167,6 +167,26 @@ class Model(object):
         native.lib().STTX_FreeStrings(r, B)
         return out
 
+    def submitBatchDevice(self, device_ptr, stride, sizes):
+        """Enqueue one batch of 1..64 utterances (audio resident in HBM) without waiting; returns a ticket for collectBatch().
+        At most two batches may be in flight (STTX_BatchSubmitDevice)."""
+        B = len(sizes)
+        sz = sizes if isinstance(sizes, C.Array) else (C.c_uint * B)(*[int(s) for s in sizes])
+        t = native.lib().STTX_BatchSubmitDevice(self._impl, C.c_void_p(device_ptr), stride, sz, B)
+        if t < 0:
+            raise RuntimeError("STTX_BatchSubmitDevice failed (%d)" % t)
+        return t
+
+    def collectBatch(self, ticket):
+        """Wait for a submitted batch; its transcripts in submission order (STTX_BatchCollect)."""
+        n = C.c_uint(0)
+        r = native.lib().STTX_BatchCollect(self._impl, int(ticket), C.byref(n))
+        if not r:
+            raise RuntimeError("STTX_BatchCollect failed")
+        out = [C.string_at(r[i]).decode("utf-8", "replace") for i in range(n.value)]
+        native.lib().STTX_FreeStrings(r, n.value)
+        return out
+
     def setProfiling(self, level):
         """0/False = off, 1/True = stage events + decoder counters, 2 = also the search kernel's phase cycle counters."""
         native.lib().STTX_SetProfiling(self._impl, int(level))
