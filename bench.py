@@ -33,6 +33,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch initialises HIP: the engine's streams each get a hardware queue (api.cpp)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 FIX = os.path.join(ROOT, "tests", "golden", "fixtures")
@@ -87,7 +89,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scorer", default="synthetic", choices=["synthetic", "fixture"])
     ap.add_argument("--no-profile", action="store_true", help="experiment: no HIP-event stage timing inside the timed region")
-    ap.add_argument("--no-pipeline", action="store_true", help="batch / bytes: one blocking call per step instead of two batches in flight")
+    ap.add_argument("--no-pipeline", action="store_true", help="batch / bytes: one blocking call per step instead of several batches in flight")
     args = ap.parse_args()
 
     import torch
@@ -229,18 +231,21 @@ def main():
     torch.cuda.synchronize()
     pipelined = wl in ("batch", "bytes") and not args.no_pipeline
     t0 = time.perf_counter()
+    depth = model.pipelineDepth() if pipelined else 1
     if pipelined:
-        # K batches through the library's two-deep pipeline (STTX_BatchSubmitDevice / STTX_BatchCollect): batch k + 1 is
-        # enqueued before batch k is collected, every batch is collected (and gathered) inside the timed region
+        # K batches through the library's own pipeline (STTX_BatchSubmitDevice / STTX_BatchCollect, STTX_BatchPipelineDepth batches in
+        # flight): a batch is submitted as soon as there is room, every batch is collected (and gathered) inside the timed region
         csz = (ctypes.c_uint * len(sizes))(*sizes)
-        pend = None
+        inflight = []
         for k in range(args.steps + 1):
-            nxt = (model.submitBatchDevice(d_audio.data_ptr(), stride, csz), time.perf_counter()) if k < args.steps else None
-            if pend is not None:
-                texts = model.collectBatch(pend[0])
+            while inflight and (len(inflight) == depth or k == args.steps):
+                tk, ts = inflight.pop(0)
+                texts = model.collectBatch(tk)
                 out = sdist.gather_transcripts(texts, device=cdev) if world > 1 else [texts]
-                step_s.append(time.perf_counter() - pend[1])      # submit -> transcripts of that batch
-            pend = nxt
+                step_s.append(time.perf_counter() - ts)           # submit -> transcripts of that batch
+            if k < args.steps:
+                ts = time.perf_counter()
+                inflight.append((model.submitBatchDevice(d_audio.data_ptr(), stride, csz), ts))
         if profiled:
             stage = dict(model.stageTimes())                      # (summed over the K batches when the pipeline drained)
     else:
@@ -277,9 +282,9 @@ def main():
             "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16 (MFMA operands, f32 accumulate/state; decoder f32+f64)", "data": "synthetic",
             "config": {"workload": desc, "global_batch": gbatch, "parallelism": "dp%d (utterance shards, RCCL transcript gather)" % world,
-                       "batches_in_flight": 2 if pipelined else 1},
+                       "batches_in_flight": depth},
             # a batch completes together (submit -> all transcripts on the host): per-utterance latency = that span; median over the timed
-            # batches (with two batches in flight it is longer than ms_per_step: the next batch's acoustic model runs beside this one's search)
+            # batches (with several batches in flight it is longer than ms_per_step: the next batches' acoustic models run beside this one's search)
             "p50_utterance_latency_ms": 1e3 * float(np.median(step_s)),
         }
         if wl == "stream":

@@ -43,11 +43,14 @@ STTX_EXPORT Metadata** STTX_SpeechToTextBatchWithMetadata(ModelState* aCtx, cons
  * aBufferSizes[i] valid samples).  This is the entry point bench.py times. */
 STTX_EXPORT char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride,
                                                const unsigned int* aBufferSizes, unsigned int aBatch);
-/* The same path as a two-deep pipeline driven by the caller (the reference's harness keeps its workers busy the same way:
+/* The same path as a pipeline driven by the caller (the reference's harness keeps its workers busy the same way:
  * evaluate_export.py:65-80 feeds a queue while results are collected).  Submit enqueues one batch of 1..64 utterances
- * (audio resident in HBM, as above) and returns a ticket >= 0 without waiting (negative: -STT_ERR_*); at most two
- * batches may be in flight.  Collect waits for that batch and returns its aCount transcripts (STTX_FreeStrings) in the
- * order submitted, or NULL on failure.  The acoustic model of the newer batch overlaps the beam search of the older. */
+ * (audio resident in HBM, as above) and returns a ticket >= 0 without waiting (negative: -STT_ERR_*); at most
+ * STTX_BatchPipelineDepth() batches (2 unless STT_AMD_PIPELINE says otherwise; 1..4) may be in flight.  Collect waits for
+ * that batch and returns its aCount transcripts (STTX_FreeStrings) in the order submitted, or NULL on failure.  The
+ * acoustic models of the batches in flight run one after the other, each batch's beam search beside the acoustic model
+ * and the searches of its neighbours. */
+STTX_EXPORT int STTX_BatchPipelineDepth(void);
 STTX_EXPORT int STTX_BatchSubmitDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride,
                                        const unsigned int* aBufferSizes, unsigned int aBatch);
 STTX_EXPORT char** STTX_BatchCollect(ModelState* aCtx, int aTicket, unsigned int* aCount);

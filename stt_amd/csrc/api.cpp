@@ -14,6 +14,13 @@
 #include "engine.h"
 #include "scorer_host.h"
 
+// The batch path runs on up to eight HIP streams (three acoustic engines, four group slots' searches, the caller's own).  The
+// HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that share a queue run
+// one after the other -- a group's output layers behind another group's 0.8 ms search launch.  Ask for 8 unless the
+// caller decided otherwise; this runs when the library is loaded, i.e. before the runtime reads its flags at the first HIP
+// call of a process that did not use HIP before (a process that did keeps its setting: nothing breaks, streams just share).
+__attribute__((constructor)) static void stt_amd_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 namespace {
 int g_device = 0;
 const char* kVersion = "1.4.0";  // training/coqui_stt_training/VERSION of the reference this ABI mirrors
@@ -132,39 +139,43 @@ int create_stream(ModelState* aCtx, StreamingState** retval, bool keep_emissions
 
 // ---- batch path: every utterance goes through exactly the arithmetic of STT_SpeechToText ---------------------
 // Groups of <= 64 utterances.  Within a group the acoustic model runs in time-chunks on `stream` and the beam search of
-// chunk k runs on `stream_dec` while chunk k+1 is being computed (the search only occupies one workgroup per utterance).
-// Chunk schedule: a short first chunk (STT_AMD_CHUNK0, default 16 frames) so the beam search starts early, then chunks of STT_AMD_CHUNK (default 48) frames.
-int batch_chunk_frames() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("STT_AMD_CHUNK"); v = e ? atoi(e) : 48; if (v < 1) v = 1 << 30; }
-  return v;
+// chunk k runs on the group's search stream while chunk k+1 is being computed (the search only occupies one workgroup per
+// utterance).  Chunk schedule of a blocking call (latency of ONE group matters): a short first chunk (STT_AMD_CHUNK0,
+// default 16 frames) so the beam search starts early, then chunks of STT_AMD_CHUNK (default 48) frames;
+// STT_AMD_CHUNKS="16,24,40" gives the first chunks explicitly.  A group submitted to the caller-driven pipeline
+// (STTX_BatchSubmitDevice: other groups fill the chip meanwhile) takes longer chunks -- fewer, better-shaped GEMMs and
+// fewer search launches: STT_AMD_PCHUNK0 / STT_AMD_PCHUNK / STT_AMD_PCHUNKS.
+struct ChunkPlan { int first, rest; std::vector<int> lead; };
+ChunkPlan read_chunk_plan(const char* e0, const char* e, const char* el, int d0, int d) {
+  ChunkPlan c{d0, d, {}};
+  if (const char* v = getenv(e0)) c.first = atoi(v);
+  if (const char* v = getenv(e)) c.rest = atoi(v);
+  if (c.rest < 1) c.rest = 1 << 30;
+  if (c.first < 1) c.first = 1 << 30;
+  if (const char* v = getenv(el)) { std::stringstream ss(v); std::string tok; while (std::getline(ss, tok, ',')) { const int x = atoi(tok.c_str()); if (x > 0) c.lead.push_back(x); } }
+  return c;
 }
-int batch_first_chunk_frames() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("STT_AMD_CHUNK0"); v = e ? atoi(e) : 16; if (v < 1) v = 1 << 30; }
-  return v;
+const ChunkPlan& chunk_plan(bool pipelined) {
+  static const ChunkPlan blocking = read_chunk_plan("STT_AMD_CHUNK0", "STT_AMD_CHUNK", "STT_AMD_CHUNKS", 16, 48);
+  static const ChunkPlan piped = read_chunk_plan("STT_AMD_PCHUNK0", "STT_AMD_PCHUNK", "STT_AMD_PCHUNKS", 16, 48);
+  return pipelined ? piped : blocking;
 }
 // Enqueue everything one group needs, on both streams, without waiting for anything: features + acoustic chunks on
 // `stream`, the beam search of every chunk + the final ranking + the copy of the results to page-locked memory on
 // `stream_dec`, then the slot's `done` event.
 void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t* d_audio, unsigned stride, const unsigned* sizes,
-                         const std::vector<unsigned>& idx, unsigned num_results, const DevScorer& ds) {
+                         const std::vector<unsigned>& idx, unsigned num_results, const DevScorer& ds, bool pipelined) {
   const int Bg = (int)idx.size();
-  const int which = (&sl == &m->slots_[0]) ? 1 : 2;  // profiling mark list of this group's search stream
+  const int which = 1 + (int)(&sl - &m->slots_[0]);  // profiling mark list of this group's search stream
   int t_max = 1;
   for (int b = 0; b < Bg; ++b) t_max = std::max(t_max, n_frames_for(m->g, (int)sizes[idx[b]]));
   std::vector<int> cb;  // chunk boundaries
   {
-    // STT_AMD_CHUNKS="16,24,40": explicit lengths of the first chunks (then STT_AMD_CHUNK); else one short first chunk
-    static const std::vector<int> lead = []() {
-      std::vector<int> v;
-      if (const char* e = getenv("STT_AMD_CHUNKS")) { std::stringstream ss(e); std::string tok; while (std::getline(ss, tok, ',')) { const int x = atoi(tok.c_str()); if (x > 0) v.push_back(x); } }
-      return v;
-    }();
+    const ChunkPlan& cp = chunk_plan(pipelined);
     for (int t = 0, k = 0; t < t_max; ++k) {
       cb.push_back(t);
-      if (!lead.empty()) t += k < (int)lead.size() ? lead[k] : batch_chunk_frames();
-      else t += (k == 0) ? std::min(batch_first_chunk_frames(), batch_chunk_frames()) : batch_chunk_frames();
+      if (!cp.lead.empty()) t += k < (int)cp.lead.size() ? cp.lead[k] : cp.rest;
+      else t += (k == 0) ? std::min(cp.first, cp.rest) : cp.rest;
     }
   }
   cb.push_back(t_max);
@@ -180,7 +191,7 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
       h_tab[(size_t)(2 * k) * Bg + b] = cb[k];
       h_tab[(size_t)(2 * k + 1) * Bg + b] = std::max(0, std::min(cb[k + 1], h_nf[b]) - cb[k]);
     }
-  HIP_CHECK(hipMemcpyAsync(sl.ints.p, hi, n_ints * 4, hipMemcpyHostToDevice, m->stream));
+  copy_h2d(sl.ints.p, sl.h_ints, n_ints * 4, m->stream);
   const int* d_ns = sl.ints.as<int>(); const int* d_nf = d_ns + Bg; const int* d_row = d_ns + 2 * Bg; const int* d_tab = d_ns + 3 * Bg;
   sl.Bg = Bg; sl.t_max = t_max; sl.idx = idx;
   // features
@@ -204,11 +215,18 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
   int max_chunk = 1;
   for (int k = 0; k < n_chunks; ++k) max_chunk = std::max(max_chunk, cb[k + 1] - cb[k]);
   sl.wide.reserve(ctc_rows_ws_bytes(p, Bg, max_chunk));
+  // the acoustic model as three engines (engine.h) when other groups are in flight beside this one; a lone group (blocking call,
+  // latency matters) keeps everything on `stream`: its own GEMMs would only slow its own recurrence (6.5 vs 5.9 ms)
+  const bool piped = pipelined && m->am_pipe_init();
   for (int k = 0; k < n_chunks; ++k) {
-    m->run_acoustic_chunk(m->ws_feats.as<float>(), d_nf, Bg, t_max, cb[k], cb[k + 1] - cb[k], sl.probs.as<float>());  // marks 1, 2, 3
-    mark(m, -1);
     hipEvent_t ev = m->ev_chunk[k % 2];  // an event may be re-recorded once the wait on it has been enqueued
-    HIP_CHECK(hipEventRecord(ev, m->stream));
+    if (piped) {
+      m->run_acoustic_chunk_piped(m->ws_feats.as<float>(), d_nf, Bg, t_max, cb[k], cb[k + 1] - cb[k], sl.probs.as<float>(), ev);  // marks 1, 2, 3
+    } else {
+      m->run_acoustic_chunk(m->ws_feats.as<float>(), d_nf, Bg, t_max, cb[k], cb[k + 1] - cb[k], sl.probs.as<float>());  // marks 1, 2, 3
+      mark(m, -1);
+      HIP_CHECK(hipEventRecord(ev, m->stream));
+    }
     HIP_CHECK(hipStreamWaitEvent(sl.stream_dec, ev, 0));
     mark_on(m, 4, which, sl.stream_dec);
     const int* fb = d_tab + (size_t)(2 * k) * Bg;
@@ -224,13 +242,13 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
   const DecodeOut o = sl.out_layout.view(sl.out.p, nr, max_len);
   mark_on(m, 5, which, sl.stream_dec);
   launch_ctc_decode(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, o, sl.stream_dec);
-  HIP_CHECK(hipMemcpyAsync(sl.h_out.p, sl.out.p, sl.out_layout.bytes, hipMemcpyDeviceToHost, sl.stream_dec));  // all results, one copy
+  copy_d2h(sl.h_out, sl.out.p, sl.out_layout.bytes, sl.stream_dec);  // all results, one block
   mark_on(m, -1, which, sl.stream_dec);
   if (prof_of(m).on) {  // the search counters ride behind the results (no extra synchronisation when they are read)
     const size_t tb = sizeof(DecStream) * (size_t)Bg, sb = p.stamps ? (size_t)Bg * 64 * 8 : 0;
     sl.h_prof.reserve(tb + sb);
-    HIP_CHECK(hipMemcpyAsync(sl.h_prof.p, sl.dec.table.p, tb, hipMemcpyDeviceToHost, sl.stream_dec));
-    if (sb) HIP_CHECK(hipMemcpyAsync((char*)sl.h_prof.p + tb, sl.stamps.p, sb, hipMemcpyDeviceToHost, sl.stream_dec));
+    copy_d2h(sl.h_prof, sl.dec.table.p, tb, sl.stream_dec);
+    if (sb) copy_d2h(sl.h_prof, sl.stamps.p, sb, sl.stream_dec, tb);
   }
   HIP_CHECK(hipEventRecord(sl.done, sl.stream_dec));
 }
@@ -269,12 +287,23 @@ void batch_collect_group(ModelState* m, ModelState::GroupSlot& sl, std::vector<s
   }
 }
 
+void sync_acoustic_streams(ModelState* m, bool check) {
+  for (hipStream_t st : {m->stream, m->stream_l, m->stream_o}) {
+    if (!st) continue;
+    if (check) HIP_CHECK(hipStreamSynchronize(st)); else (void)hipStreamSynchronize(st);
+  }
+}
 void batch_init_slots(ModelState* m) {
   if (m->ev_chunk[0]) return;
   for (auto& e : m->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& sl : m->slots_) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   m->slots_[0].stream_dec = m->stream_dec;
-  HIP_CHECK(hipStreamCreateWithFlags(&m->slots_[1].stream_dec, hipStreamNonBlocking));
+  for (int i = 1; i < ModelState::kSlots; ++i) HIP_CHECK(hipStreamCreateWithFlags(&m->slots_[i].stream_dec, hipStreamNonBlocking));
+}
+// Groups in flight (STT_AMD_PIPELINE, 1..kSlots; default 2)
+int pipeline_depth() {
+  static const int v = []() { const char* e = getenv("STT_AMD_PIPELINE"); const int d = e ? atoi(e) : 2; return d < 1 ? 1 : (d > ModelState::kSlots ? ModelState::kSlots : d); }();
+  return v;
 }
 
 // Utterances are taken longest first in groups of 64 (length-homogeneous groups: the LSTM runs every group to its longest
@@ -284,59 +313,59 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
   HIP_CHECK(hipSetDevice(m->device));
   Prof& pr = prof_of(m);
   if (pr.on) { for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; for (auto& x : pr.dec_stamps) x = 0; prof_reset(pr); }
-  if (m->async_busy_[0] || m->async_busy_[1]) throw std::runtime_error("a batch submitted with STTX_BatchSubmitDevice has not been collected yet");
+  if (m->async_any()) throw std::runtime_error("a batch submitted with STTX_BatchSubmitDevice has not been collected yet");
   batch_init_slots(m);
   std::vector<unsigned> order(B);
   for (unsigned i = 0; i < B; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return sizes[x] > sizes[y]; });
   const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
-  int pending = -1, gi = 0;
+  const int depth = pipeline_depth();
+  int oldest = 0, gi = 0;  // groups [oldest, gi) are in flight, group g in slot g % depth
   try {
     for (unsigned g0 = 0; g0 < B; g0 += 64, ++gi) {
+      if (gi - oldest == depth) { batch_collect_group(m, m->slots_[oldest % depth], all, pr); ++oldest; }
       const std::vector<unsigned> idx(order.begin() + g0, order.begin() + std::min(B, g0 + 64));
-      batch_enqueue_group(m, m->slots_[gi & 1], d_audio, stride, sizes, idx, num_results, ds);
-      if (pending >= 0) batch_collect_group(m, m->slots_[pending & 1], all, pr);
-      pending = gi;
+      batch_enqueue_group(m, m->slots_[gi % depth], d_audio, stride, sizes, idx, num_results, ds, B > 64u * (unsigned)depth);
     }
-    if (pending >= 0) batch_collect_group(m, m->slots_[pending & 1], all, pr);
+    for (; oldest < gi; ++oldest) batch_collect_group(m, m->slots_[oldest % depth], all, pr);
   } catch (...) {  // nothing of this call may still be running on the slots' buffers when the caller sees the failure
-    (void)hipStreamSynchronize(m->stream);
+    sync_acoustic_streams(m, false);
     for (auto& sl : m->slots_) if (sl.stream_dec) (void)hipStreamSynchronize(sl.stream_dec);
     if (pr.on) prof_reset(pr);
     throw;
   }
   if (pr.on) {
-    HIP_CHECK(hipStreamSynchronize(m->stream));
+    sync_acoustic_streams(m, true);
     for (auto& sl : m->slots_) HIP_CHECK(hipStreamSynchronize(sl.stream_dec));
     prof_collect(pr);
   }
   return all;
 }
 
-// The two group slots as a caller-driven pipeline (STTX_BatchSubmitDevice / STTX_BatchCollect): a batch of <= 64 utterances
+// The group slots as a caller-driven pipeline (STTX_BatchSubmitDevice / STTX_BatchCollect): a batch of <= 64 utterances
 // is enqueued without waiting, so the acoustic model of batch k+1 runs while the beam search of batch k finishes and the
 // host turns batch k-1's results into strings -- what batch_run() does between the groups of one call, across calls.
 int batch_submit(ModelState* m, const int16_t* d_audio, unsigned stride, const unsigned* sizes, unsigned B) {
   if (B == 0 || B > 64) throw std::runtime_error("STTX_BatchSubmitDevice takes 1..64 utterances (one group) per call");
   HIP_CHECK(hipSetDevice(m->device));
   batch_init_slots(m);
-  const int slot = m->async_next_ & 1;
-  if (m->async_busy_[slot]) throw std::runtime_error("two batches are already in flight: collect the older one first");
+  const int slot = m->async_next_ % pipeline_depth();
+  if (m->async_busy_[slot]) throw std::runtime_error("the pipeline is full (STTX_BatchPipelineDepth batches in flight): collect the oldest one first");
   Prof& pr = prof_of(m);
-  if (pr.on && !m->async_busy_[0] && !m->async_busy_[1]) {
+  if (pr.on && !m->async_any()) {
     for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; for (auto& x : pr.dec_stamps) x = 0;
     prof_reset(pr);
   }
   std::vector<unsigned> idx(B);
   for (unsigned i = 0; i < B; ++i) idx[i] = i;
   const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
-  batch_enqueue_group(m, m->slots_[slot], d_audio, stride, sizes, idx, 1, ds);
+  batch_enqueue_group(m, m->slots_[slot], d_audio, stride, sizes, idx, 1, ds, true);
   m->async_busy_[slot] = true;
   m->async_ticket_[slot] = m->async_next_;
   return m->async_next_++;
 }
 std::vector<std::vector<Output>> batch_collect(ModelState* m, int ticket) {
-  const int slot = ticket & 1;
+  const int slot = ticket < 0 ? 0 : ticket % pipeline_depth();
   if (ticket < 0 || !m->async_busy_[slot] || m->async_ticket_[slot] != ticket) throw std::runtime_error("STTX_BatchCollect: no such batch in flight");
   HIP_CHECK(hipSetDevice(m->device));
   ModelState::GroupSlot& sl = m->slots_[slot];
@@ -345,14 +374,14 @@ std::vector<std::vector<Output>> batch_collect(ModelState* m, int ticket) {
   m->async_busy_[slot] = false;
   try { batch_collect_group(m, sl, all, pr); }
   catch (...) {
-    (void)hipStreamSynchronize(m->stream);
+    sync_acoustic_streams(m, false);
     for (auto& s2 : m->slots_) if (s2.stream_dec) (void)hipStreamSynchronize(s2.stream_dec);
-    m->async_busy_[0] = m->async_busy_[1] = false;  // whatever else was in flight has finished; its results are dropped
+    for (bool& b : m->async_busy_) b = false;  // whatever else was in flight has finished; its results are dropped
     if (pr.on) prof_reset(pr);
     throw;
   }
-  if (pr.on && !m->async_busy_[0] && !m->async_busy_[1]) {  // the pipeline has drained: every mark has been reached
-    HIP_CHECK(hipStreamSynchronize(m->stream));
+  if (pr.on && !m->async_any()) {  // the pipeline has drained: every mark has been reached
+    sync_acoustic_streams(m, true);
     for (auto& s2 : m->slots_) HIP_CHECK(hipStreamSynchronize(s2.stream_dec));
     prof_collect(pr);
   }
@@ -366,6 +395,7 @@ uint64_t stt_murmur64a(const void* key, size_t len);
 
 // hooks used by engine.cpp for the profiling marks inside run_acoustic_rows
 void stt_prof_mark(ModelState* m, int i) { mark(m, i); }
+void stt_prof_mark_on(ModelState* m, int id, int which, hipStream_t st) { mark_on(m, id, which, st); }
 
 extern "C" {
 
@@ -635,6 +665,8 @@ char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* aDeviceAudio,
   }, 0);
   return res;
 }
+
+int STTX_BatchPipelineDepth(void) { return pipeline_depth(); }
 
 int STTX_BatchSubmitDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride, const unsigned int* aBufferSizes, unsigned int aBatch) {
   int ticket = -STT_ERR_FAIL_RUN_SESS;

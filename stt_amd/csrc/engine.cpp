@@ -4,7 +4,9 @@
 // (modelstate.cc:32-76) and StreamingState (stt.cc:60-334).  Nothing here computes on the CPU: host code
 // only sizes buffers, enqueues kernels and turns token ids into strings.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 
 #include "../../include/coqui-stt.h"
 #include "engine.h"
@@ -114,6 +116,107 @@ void ModelState::run_acoustic_chunk(const float* d_feats, const int* d_nframes, 
   acoustic_rows(*this, ws_x1.as<_Float16>(), B, T, nullptr, nullptr, t0 == 0 ? 0 : 2, t0, d_probs + (size_t)t0 * g.n_classes, t_max);
 }
 
+// ------------------------------------------------------------------------------------------- acoustic model, three engines
+// (ModelState::stream / stream_l / stream_o, see engine.h.)  The same kernels on the same operands in the same order per
+// chunk as acoustic_rows(): results are bit-identical; only what runs beside what changes.
+bool ModelState::am_pipe_init() {
+  static const int on = []() { const char* e = getenv("STT_AMD_AM_PIPE"); return e ? atoi(e) : 1; }();
+  if (!on) return false;
+  if (stream_l) return true;
+  int lo = 0, hi = 0;
+  HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi = numerically lowest = most urgent)
+  // the recurrence is the critical path: its workgroups go first whenever a CU has room
+  HIP_CHECK(hipStreamCreateWithPriority(&stream_l, hipStreamNonBlocking, hi));
+  HIP_CHECK(hipStreamCreateWithFlags(&stream_o, hipStreamNonBlocking));
+  for (int i = 0; i < kAmRing; ++i)
+    for (hipEvent_t* e : {&ev_x_ready[i], &ev_x_free[i], &ev_h_ready[i], &ev_h_free[i]}) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  return true;
+}
+
+static int dense_lds_floor() {  // bytes; > 80 KiB = one GEMM workgroup per CU while the recurrence runs beside it
+  static const int v = []() { const char* e = getenv("STT_AMD_DENSE_LDS_KB"); const int kb = e ? atoi(e) : 82; return kb <= 0 ? 0 : kb * 1024; }();
+  return v;
+}
+
+void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs, hipEvent_t done) {
+  const int H = g.n_hidden, M = T * B, C = g.n_classes;
+  const int NT = lstm_nt_for_batch(B);
+  if (NT < 0) throw std::runtime_error("run_acoustic_chunk: batch > 64");
+  const int slot = (int)(am_seq % kAmRing);
+  const bool wrapped = am_seq >= (unsigned long long)kAmRing;
+  ++am_seq;
+  // Buffers may only grow while nothing is in flight on them: DevBuf::reserve frees the old allocation (hipFree waits for the
+  // device), so a growing chunk size costs one stall, never a dangling pointer.
+  ws_x1.reserve((size_t)M * g.k1_pad() * 2);
+  ws_a.reserve((size_t)M * H * 2); ws_b.reserve((size_t)M * H * 2); ws_o.reserve((size_t)M * H * 2);
+  am_xproj[slot].reserve((size_t)M * 4 * H * 4); am_hall[slot].reserve((size_t)M * H * 2);
+  ws_logits.reserve((size_t)M * g.c_pad() * 4);
+  const size_t hp_bytes = (size_t)(H / 32) * NT * 64 * 16;
+  ws_hp0.reserve(hp_bytes); ws_hp1.reserve(hp_bytes);
+  ws_c.reserve((size_t)B * H * 4);
+
+  // ---- engine 1 (`stream`): windows, layers 1-3, x-projection of this chunk into ring slot `slot`
+  if (wrapped) HIP_CHECK(hipStreamWaitEvent(stream, ev_x_free[slot], 0));  // the recurrence of chunk seq - kAmRing has read the slot
+  ContextArgs c{};
+  c.feats = d_feats; c.n_frames = d_nframes; c.x1 = ws_x1.as<_Float16>();
+  c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = g.k1_pad(); c.t0 = t0;
+  launch_context(c, M, stream);
+  DenseArgs d{};
+  d.relu_clip = g.relu_clip; d.M = M; d.lds_floor = dense_lds_floor();
+  stt_prof_mark_on(this, 1, 0, stream);
+  d.wt = w1t.as<_Float16>(); d.x = ws_x1.as<_Float16>(); d.bias = b1.as<float>(); d.y = ws_a.p; d.N = H; d.K = g.k1_pad(); d.ldx = g.k1_pad(); d.ldy = H;
+  launch_dense(d, DENSE_EPI_RELU_F16, stream);
+  d.wt = w2t.as<_Float16>(); d.x = ws_a.as<_Float16>(); d.bias = b2.as<float>(); d.y = ws_b.p; d.K = H; d.ldx = H;
+  launch_dense(d, DENSE_EPI_RELU_F16, stream);
+  d.wt = w3t.as<_Float16>(); d.x = ws_b.as<_Float16>(); d.bias = b3.as<float>(); d.y = ws_a.p;
+  launch_dense(d, DENSE_EPI_RELU_F16, stream);
+  d.wt = wxt.as<_Float16>(); d.x = ws_a.as<_Float16>(); d.bias = bl.as<float>(); d.y = am_xproj[slot].p; d.N = 4 * H; d.ldy = 4 * H;
+  launch_dense(d, DENSE_EPI_BIAS_F32, stream);
+  stt_prof_mark_on(this, -1, 0, stream);
+  HIP_CHECK(hipEventRecord(ev_x_ready[slot], stream));
+
+  // ---- engine 2 (`stream_l`): the recurrence; state carried in ws_c / ws_hp* from the previous chunk of the batch
+  HIP_CHECK(hipStreamWaitEvent(stream_l, ev_x_ready[slot], 0));
+  if (wrapped) HIP_CHECK(hipStreamWaitEvent(stream_l, ev_h_free[slot], 0));  // layer 5 of chunk seq - kAmRing has read the slot
+  stt_prof_mark_on(this, 2, 5, stream_l);
+  void* hp_a = (t0 & 1) ? ws_hp1.p : ws_hp0.p;  // holds h_{t-1} for the first step of this chunk
+  if (t0 == 0) {
+    HIP_CHECK(hipMemsetAsync(ws_c.p, 0, (size_t)B * H * 4, stream_l));
+    HIP_CHECK(hipMemsetAsync(hp_a, 0, hp_bytes, stream_l));
+  }
+  LstmArgs l{};
+  l.whp = whp.as<_Float16>(); l.xproj = am_xproj[slot].as<float>(); l.c = ws_c.as<float>(); l.h_all = am_hall[slot].as<_Float16>();
+  l.n_hidden = H; l.batch = B; l.h_f32 = nullptr;
+  { static const int pr = []() { const char* e = getenv("STT_AMD_LSTM_PRIO"); return e ? atoi(e) : 1; }(); l.prio = pr; }
+  for (int t = 0; t < T; ++t) {
+    const bool odd = ((t0 + t) & 1) != 0;
+    l.hp_in = odd ? ws_hp1.as<_Float16>() : ws_hp0.as<_Float16>();
+    l.hp_out = odd ? ws_hp0.as<_Float16>() : ws_hp1.as<_Float16>();
+    l.t = t;
+    launch_lstm_step(l, NT, stream_l);
+  }
+  stt_prof_mark_on(this, -1, 5, stream_l);
+  HIP_CHECK(hipEventRecord(ev_x_free[slot], stream_l));
+  HIP_CHECK(hipEventRecord(ev_h_ready[slot], stream_l));
+
+  // ---- engine 3 (`stream_o`): layer 5, layer 6 + softmax -> probs[b][t0 + t][:]
+  HIP_CHECK(hipStreamWaitEvent(stream_o, ev_h_ready[slot], 0));
+  stt_prof_mark_on(this, 3, 6, stream_o);
+  float* probs_out = d_probs + (size_t)t0 * C;
+  d.wt = w5t.as<_Float16>(); d.x = am_hall[slot].as<_Float16>(); d.bias = b5.as<float>(); d.y = ws_o.p; d.N = H; d.K = H; d.ldx = H; d.ldy = H;
+  launch_dense(d, DENSE_EPI_RELU_F16, stream_o);
+  HIP_CHECK(hipEventRecord(ev_h_free[slot], stream_o));
+  if (!launch_logits_softmax(ws_o.as<_Float16>(), w6t.as<_Float16>(), b6.as<float>(), probs_out, M, H, C, B, t_max, stream_o)) {
+    d.wt = w6t.as<_Float16>(); d.x = ws_o.as<_Float16>(); d.bias = b6.as<float>(); d.y = ws_logits.p; d.N = g.c_pad(); d.ldy = g.c_pad();
+    launch_dense(d, DENSE_EPI_BIAS_F32, stream_o);
+    SoftmaxArgs sm{};
+    sm.logits = ws_logits.as<float>(); sm.probs = probs_out; sm.M = M; sm.C = C; sm.ldl = g.c_pad(); sm.batch = B; sm.t_max = t_max;
+    launch_softmax(sm, stream_o);
+  }
+  stt_prof_mark_on(this, -1, 6, stream_o);
+  HIP_CHECK(hipEventRecord(done, stream_o));
+}
+
 // ------------------------------------------------------------------------------------------- decoder state
 DevScorer ModelState::current_scorer(std::shared_ptr<ScorerDev> sc, const std::map<std::string, float>& hot, DevBuf& hh, DevBuf& hb) const {
   DevScorer s{};
@@ -185,7 +288,7 @@ void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int e
     staging->reserve(sizeof(DecStream) * n_streams);
     memcpy(staging->p, db.host.data(), sizeof(DecStream) * n_streams);
     db.table.reserve(sizeof(DecStream) * n_streams);
-    HIP_CHECK(hipMemcpyAsync(db.table.p, staging->p, sizeof(DecStream) * n_streams, hipMemcpyHostToDevice, stream));
+    copy_h2d(db.table.p, *staging, sizeof(DecStream) * n_streams, stream);
   } else {
     db.table.upload(db.host.data(), sizeof(DecStream) * n_streams, stream);
   }
@@ -261,7 +364,7 @@ std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_
   p.C = C; p.blank = C - 1; p.beam = beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = 0;
   DevScorer ds = m.current_scorer(sc, hot, m.ws_hot_hash, m.ws_hot_boost);
   launch_ctc_decode(p, ds, m.dev_alphabet, d_table, n, o, m.stream);
-  HIP_CHECK(hipMemcpyAsync(m.h_out.p, m.ws_out.p, blk.bytes, hipMemcpyDeviceToHost, m.stream));  // one copy, page-locked destination
+  copy_d2h(m.h_out, m.ws_out.p, blk.bytes, m.stream);  // one block, page-locked destination
   HIP_CHECK(hipStreamSynchronize(m.stream));
   const DecodeOut h = blk.view(m.h_out.p, nr, max_len);
   const uint32_t *tok = h.tokens, *ts = h.timesteps;
@@ -318,7 +421,7 @@ void StreamingState::pushFrames(const int16_t* span, int n_span, int n_new_frame
     else HIP_CHECK(hipEventSynchronize(m.ev_audio[slot]));
     m.h_audio[slot].reserve((size_t)n_span * 2);
     memcpy(m.h_audio[slot].p, span, (size_t)n_span * 2);
-    HIP_CHECK(hipMemcpyAsync(m.ws_audio.p, m.h_audio[slot].p, (size_t)n_span * 2, hipMemcpyHostToDevice, m.stream));
+    copy_h2d(m.ws_audio.p, m.h_audio[slot], (size_t)n_span * 2, m.stream);
     HIP_CHECK(hipEventRecord(m.ev_audio[slot], m.stream));
   }
   MfccArgs a = m.mfcc_args();

@@ -50,7 +50,14 @@ struct PinnedBuf {
   ~PinnedBuf() { if (p) (void)hipHostFree(p); }
   void reserve(size_t bytes);
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+  void* dev() const;  // the same bytes as the GPU addresses them (kernels read / write page-locked host memory over the link)
 };
+// Small tables and result blocks of the batch path move with a copy KERNEL through mapped page-locked memory, not with
+// hipMemcpyAsync: a copy-engine transfer costs a queue hand-over each way (signals between the compute queue and the DMA
+// engine), measured at 0.2 ms on some hosts and 1-2 ms on others -- per batch, on the critical stream.  A kernel that moves
+// the same 4-130 KB over the link is a few microseconds everywhere.  (STT_AMD_COPY_KERNEL=0: the copy engine, for A/B.)
+void copy_h2d(void* dst_dev, const PinnedBuf& src, size_t bytes, hipStream_t st);
+void copy_d2h(PinnedBuf& dst, const void* src_dev, size_t bytes, hipStream_t st, size_t dst_offset = 0);
 
 // ---------------------------------------------------------------------------------------------
 class Alphabet {
@@ -138,7 +145,7 @@ struct Prof {
   bool phase_cycles = false;  // level 2: also the search kernel's per-phase cycle counters
   std::vector<hipEvent_t> pool;
   size_t used = 0;
-  std::vector<std::pair<int, hipEvent_t>> marks[3];  // [0] = acoustic stream, [1], [2] = the two groups' search streams
+  std::vector<std::pair<int, hipEvent_t>> marks[7];  // [0] = acoustic stream, [1 + s] = the search stream of group slot s, [5], [6] = recurrence / output-layer streams
   float ms[8] = {};
   unsigned long long dec_stats[4] = {};
   unsigned long long dec_phase[8] = {};
@@ -180,9 +187,12 @@ struct ModelState {
   PinnedBuf h_audio[4];
   hipEvent_t ev_audio[4] = {};
   unsigned audio_slot = 0;
-  // The batch path works on two 64-utterance groups at a time: while the beam search of group g finishes on `stream_dec`,
-  // the acoustic model of group g+1 already runs on `stream`, and the host unpacks group g-1.  Everything a group owns
-  // beyond the acoustic stream's scratch buffers lives in its slot.
+  // The batch path keeps several 64-utterance groups in flight (kSlots slots, `pipeline_depth()` of them used): the
+  // acoustic models run one after the other on `stream` (two recurrences side by side delay each other's steps), every
+  // group's beam search on its slot's own stream.  While the search of group g runs on 64 compute units, the acoustic model
+  // of group g+1 has the others; when the recurrence of g+2 leaves a quarter of the chip idle, the search of g+1 is already
+  // there to take it; the host unpacks the oldest group meanwhile.  Everything a group owns beyond the acoustic stream's
+  // scratch buffers lives in its slot.
   struct GroupSlot {
     DecoderBatch dec;
     DevBuf probs, ints, out;  // out: one DecodeBlock (ctc.h)
@@ -192,19 +202,36 @@ struct ModelState {
     PinnedBuf h_prof;         // profiling: the group's DecStream table (+ stamps), copied behind the results on the search stream
     DecodeBlock out_layout{};
     hipEvent_t done = nullptr;
-    hipStream_t stream_dec = nullptr;  // the group's search stream (slot 0: ModelState::stream_dec, slot 1: its own)
+    hipStream_t stream_dec = nullptr;  // the group's search stream (slot 0: ModelState::stream_dec, the others their own)
     int Bg = 0, nr = 0, max_len = 0, t_max = 0;
     std::vector<unsigned> idx;  // caller's utterance index of every stream of the group
   };
-  GroupSlot slots_[2];
+  static constexpr int kSlots = 4;
+  GroupSlot slots_[kSlots];
   // STTX_BatchSubmitDevice / STTX_BatchCollect: which slot holds an uncollected batch, and the next ticket
-  bool async_busy_[2] = {false, false};
-  int async_ticket_[2] = {-1, -1};
+  bool async_busy_[kSlots] = {};
+  int async_ticket_[kSlots] = {-1, -1, -1, -1};
   int async_next_ = 0;
+  bool async_any() const { for (bool b : async_busy_) if (b) return true; return false; }
   // scratch of the batched streaming calls (STTX_FeedAudioContentBatch & co.)
   DevBuf sb_audio, sb_tab, sb_c, sb_h, sb_table;
   PinnedBuf sb_haudio, sb_htab;
   hipEvent_t ev_chunk[2] = {};  // chunk hand-over acoustic stream -> decoder stream (alternating)
+  // The acoustic model of the batch path as three engines (STT_AMD_AM_PIPE=0: one stream, as the streaming path runs it):
+  // `stream` = features, context windows, layers 1-3 and the x-projection of chunk k+1, k+2; `stream_l` = the recurrence of
+  // chunk k -- 250 dependent launches per batch, each leaving half of the compute units idle and the MFMA pipes of the
+  // other half mostly so --; `stream_o` = layers 5-6 + softmax of chunk k-1.  The recurrence never waits for a GEMM of its
+  // own batch (or of the next one: the x-projections run ahead across batch boundaries), and the GEMMs run at one workgroup
+  // per CU (DenseArgs::lds_floor) so that a recurrent-step workgroup always finds registers and LDS beside them.
+  // Hand-over through rings of kAmRing chunk buffers, one event pair per slot.
+  static constexpr int kAmRing = 3;
+  hipStream_t stream_l = nullptr, stream_o = nullptr;
+  DevBuf am_xproj[kAmRing], am_hall[kAmRing], ws_o;
+  hipEvent_t ev_x_ready[kAmRing] = {}, ev_x_free[kAmRing] = {}, ev_h_ready[kAmRing] = {}, ev_h_free[kAmRing] = {};
+  unsigned long long am_seq = 0;  // chunks sent through the pipe so far (slot = am_seq % kAmRing)
+  bool am_pipe_init();            // creates the streams / events on first use; false when switched off
+  // chunk [t0, t0+T) of a batch through the three engines; `done` is recorded on stream_o behind the softmax
+  void run_acoustic_chunk_piped(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs, hipEvent_t done);
 
   ~ModelState();
   int InitFromBuffer(const char* buf, size_t len);  // STT_ERR_* code
@@ -277,4 +304,5 @@ int n_frames_for(const Geometry& g, int n_samples);
 void check_decoder_errors(const int* errors, int n);  // throws when a stream's DecStream::error is set
 extern int g_debug_arena_frames;
 void stt_prof_mark(ModelState* m, int i);  // HIP-event marks for STTX_GetStageTimes (api.cpp)
+void stt_prof_mark_on(ModelState* m, int id, int which, hipStream_t st);
 void pack_lstm_recurrent_host(const float* kernel /*[2H][4H]*/, int H, _Float16* out);

@@ -1,4 +1,5 @@
 // stt_amd/csrc/hostutil.cpp -- device buffers, Alphabet (native_client/alphabet.{h,cc}).
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -26,6 +27,25 @@ void PinnedBuf::reserve(size_t bytes) {
   p = nullptr;
   cap = bytes + bytes / 4 + 256;
   HIP_CHECK(hipHostMalloc(&p, cap, hipHostMallocDefault));
+}
+void* PinnedBuf::dev() const {
+  void* d = nullptr;
+  HIP_CHECK(hipHostGetDevicePointer(&d, p, 0));
+  return d;
+}
+static bool copy_kernel_on() {
+  static const bool v = []() { const char* e = getenv("STT_AMD_COPY_KERNEL"); return !e || atoi(e) != 0; }();
+  return v;
+}
+void copy_h2d(void* dst_dev, const PinnedBuf& src, size_t bytes, hipStream_t st) {
+  if (!bytes) return;
+  if (copy_kernel_on()) launch_copy_bytes(dst_dev, src.dev(), bytes, st);
+  else HIP_CHECK(hipMemcpyAsync(dst_dev, src.p, bytes, hipMemcpyHostToDevice, st));
+}
+void copy_d2h(PinnedBuf& dst, const void* src_dev, size_t bytes, hipStream_t st, size_t dst_offset) {
+  if (!bytes) return;
+  if (copy_kernel_on()) launch_copy_bytes((char*)dst.dev() + dst_offset, src_dev, bytes, st);
+  else HIP_CHECK(hipMemcpyAsync((char*)dst.p + dst_offset, src_dev, bytes, hipMemcpyDeviceToHost, st));
 }
 void DevBuf::upload(const void* src, size_t bytes, hipStream_t st) {
   reserve(bytes ? bytes : 1);

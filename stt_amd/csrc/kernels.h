@@ -39,6 +39,8 @@ struct DenseArgs {
   int M, N, K, ldx, ldy;
   float relu_clip;
   int xa, xb;          // tile-grid cut over the 8 XCDs (xa blocks along M x xb along N; filled in by launch_dense)
+  int lds_floor;       // ask for at least this much dynamic LDS (bytes; 0 = what the tile needs): > 80 KiB keeps the kernel at ONE
+                       // workgroup per CU, so that a recurrent-step workgroup launched beside it always finds room (engine.cpp)
 };
 
 // ---- LSTM ---------------------------------------------------------------------------------------
@@ -51,6 +53,7 @@ struct LstmArgs {
   float* h_f32;           // optional [B][H] copy of h_t in f32 (state hand-back); may be null
   _Float16* h_all;        // [t_max*B][H]
   int n_hidden, batch, t;
+  int prio;               // wave priority (s_setprio 0..3) of the step's waves: beats age when other kernels' waves share the SIMDs
 };
 
 struct SoftmaxArgs {
@@ -59,6 +62,8 @@ struct SoftmaxArgs {
   int M, C, ldl, batch, t_max;
 };
 
+// dst/src: device-addressable (HBM or mapped page-locked host memory); any size, any alignment
+void launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t st);
 void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st);
 void launch_context(const ContextArgs& a, int rows, hipStream_t st);
 void launch_dense(const DenseArgs& a, int epi, hipStream_t st);

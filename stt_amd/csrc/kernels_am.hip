@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "kernels.h"
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   typedef float RedT[MT][NT][64][4];
   RedT* red = reinterpret_cast<RedT*>(lstm_smem);                                        // [4 waves]
   _Float16 (*hout)[UPW] = reinterpret_cast<_Float16 (*)[UPW]>(lstm_smem + 4 * sizeof(RedT));  // [NT * 16][UPW]
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
   const int wg = blockIdx.x;
   const int H = a.n_hidden;
@@ -620,6 +622,24 @@ bool launch_logits_softmax(const _Float16* x, const _Float16* wt, const float* b
 // ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
+// byte mover for small tables and result blocks (engine.h: copy_h2d / copy_d2h): 16-byte lanes when both ends allow
+__global__ void copy_bytes_kernel(unsigned char* dst, const unsigned char* src, size_t bytes, int wide) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)gridDim.x * blockDim.x;
+  if (wide) {
+    const size_t nv = bytes / 16;
+    for (size_t k = i; k < nv; k += n) reinterpret_cast<uint4*>(dst)[k] = reinterpret_cast<const uint4*>(src)[k];
+    for (size_t k = nv * 16 + i; k < bytes; k += n) dst[k] = src[k];
+  } else {
+    for (size_t k = i; k < bytes; k += n) dst[k] = src[k];
+  }
+}
+void launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  if (!bytes) return;
+  const int wide = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
+  const size_t items = wide ? (bytes + 15) / 16 : bytes;
+  const int blocks = (int)std::min<size_t>(64, (items + 255) / 256);
+  hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, st, (unsigned char*)dst, (const unsigned char*)src, bytes, wide);
+}
 void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st) {
   hipLaunchKernelGGL(mfcc_kernel, dim3(n_frames_total), dim3(256), 0, st, a);
 }
@@ -628,13 +648,14 @@ void launch_context(const ContextArgs& a, int rows, hipStream_t st) {
 }
 template <int EPI, int T>
 static void launch_dense_inst(const DenseArgs& b, int grid, hipStream_t st) {
-  const size_t smem = (size_t)4 * (64 * T) * GT_BK * 2;  // two stages x (W tile + X tile): 64 KiB (T = 2) or 128 KiB (T = 4)
+  size_t smem = (size_t)4 * (64 * T) * GT_BK * 2;  // two stages x (W tile + X tile): 64 KiB (T = 2) or 128 KiB (T = 4)
   static std::once_flag once[16];
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::call_once(once[dev & 15], [&]() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_kernel<EPI, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_kernel<EPI, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
+  if ((size_t)b.lds_floor > smem) smem = std::min<size_t>((size_t)b.lds_floor, 160 * 1024);
   hipLaunchKernelGGL((dense_kernel<EPI, T>), dim3(grid), dim3(T * T * 64), smem, st, b);
 }
 void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
@@ -644,8 +665,13 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
     return;
   }
   // 256-square tiles when the shape allows (N a multiple of 256 and enough rows to fill them), else 128-square
-  static const int big_ok = []() { const char* e = getenv("STT_AMD_DENSE_TILE"); return e ? atoi(e) : 128; }();  // (measured: the 256-square tile is slower on these shapes -- 96 to 384 tiles for 256 CUs -- DESIGN.md 8.3)
-  const bool big = big_ok >= 256 && a.N % 256 == 0 && a.M >= 256;
+  // (measured: with 96 to 384 tiles for 256 CUs the 256-square tile is slower than 1536 small ones; from about two tiles per
+  // CU on it wins -- the long chunks of the pipelined batch path.  STT_AMD_DENSE_TILE=128 / 256 forces a side,
+  // STT_AMD_DENSE_BIG_MIN moves the threshold)
+  static const int big_ok = []() { const char* e = getenv("STT_AMD_DENSE_TILE"); return e ? atoi(e) : 0; }();
+  static const int big_min = []() { const char* e = getenv("STT_AMD_DENSE_BIG_MIN"); return e ? atoi(e) : 480; }();
+  const bool big_fits = a.N % 256 == 0 && a.M >= 256;
+  const bool big = big_fits && (big_ok >= 256 || (big_ok == 0 && ((a.M + 255) / 256) * (a.N / 256) >= big_min));
   const int side = big ? 256 : 128;
   // cut of the tile grid over the 8 XCDs: xa x xb blocks, minimising (block rows + block columns) = operand bytes per XCD
   DenseArgs b = a;

@@ -74,9 +74,13 @@ ModelState::~ModelState() {
   if (stream) (void)hipStreamDestroy(stream);
   if (stream_dec) (void)hipStreamDestroy(stream_dec);
   for (auto& e : ev_chunk) if (e) (void)hipEventDestroy(e);
+  if (stream_l) (void)hipStreamDestroy(stream_l);
+  if (stream_o) (void)hipStreamDestroy(stream_o);
+  for (int i = 0; i < kAmRing; ++i)
+    for (hipEvent_t e : {ev_x_ready[i], ev_x_free[i], ev_h_ready[i], ev_h_free[i]}) if (e) (void)hipEventDestroy(e);
   for (auto& e : ev_audio) if (e) (void)hipEventDestroy(e);
   for (auto& sl : slots_) if (sl.done) (void)hipEventDestroy(sl.done);
-  if (slots_[1].stream_dec) (void)hipStreamDestroy(slots_[1].stream_dec);
+  for (int i = 1; i < kSlots; ++i) if (slots_[i].stream_dec) (void)hipStreamDestroy(slots_[i].stream_dec);
 }
 
 int parse_model_file(const char* buf, size_t len, ModelTensors& tfl, ModelView& v, std::string& err) {

@@ -169,13 +169,18 @@ class Model(object):
 
     def submitBatchDevice(self, device_ptr, stride, sizes):
         """Enqueue one batch of 1..64 utterances (audio resident in HBM) without waiting; returns a ticket for collectBatch().
-        At most two batches may be in flight (STTX_BatchSubmitDevice)."""
+        At most pipelineDepth() batches may be in flight (STTX_BatchSubmitDevice)."""
         B = len(sizes)
         sz = sizes if isinstance(sizes, C.Array) else (C.c_uint * B)(*[int(s) for s in sizes])
         t = native.lib().STTX_BatchSubmitDevice(self._impl, C.c_void_p(device_ptr), stride, sz, B)
         if t < 0:
             raise RuntimeError("STTX_BatchSubmitDevice failed (%d)" % t)
         return t
+
+    @staticmethod
+    def pipelineDepth():
+        """Batches STTX_BatchSubmitDevice accepts before the oldest must be collected (STTX_BatchPipelineDepth)."""
+        return int(native.lib().STTX_BatchPipelineDepth())
 
     def collectBatch(self, ticket):
         """Wait for a submitted batch; its transcripts in submission order (STTX_BatchCollect)."""

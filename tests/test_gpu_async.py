@@ -1,4 +1,4 @@
-"""STTX_BatchSubmitDevice / STTX_BatchCollect: two batches in flight give the transcripts of the blocking call (needs a MI355X)."""
+"""STTX_BatchSubmitDevice / STTX_BatchCollect: several batches in flight give the transcripts of the blocking call (needs a MI355X)."""
 import numpy as np
 import pytest
 
@@ -56,34 +56,54 @@ def _device_batches(n_batches, B, seed):
 
 
 def test_pipelined_batches_equal_blocking_calls(model):
-    batches = _device_batches(5, 9, seed=40)
+    batches = _device_batches(7, 9, seed=40)
     want = [model.sttBatchDevice(d.data_ptr(), stride, lens) for d, stride, lens in batches]
-    got = [None] * len(batches)
-    t_prev = None
-    for k, (d, stride, lens) in enumerate(batches):     # submit k, then collect k - 1: two in flight most of the time
-        t = model.submitBatchDevice(d.data_ptr(), stride, lens)
-        if t_prev is not None:
-            got[k - 1] = model.collectBatch(t_prev)
-        t_prev = t
-    got[-1] = model.collectBatch(t_prev)
+    depth = model.pipelineDepth()
+    assert 1 <= depth <= 4
+    got, inflight = [], []
+    for d, stride, lens in batches:                     # keep the pipeline full: collect the oldest only when there is no room
+        if len(inflight) == depth:
+            got.append(model.collectBatch(inflight.pop(0)))
+        inflight.append(model.submitBatchDevice(d.data_ptr(), stride, lens))
+    while inflight:
+        got.append(model.collectBatch(inflight.pop(0)))
     assert got == want
     assert any(any(s for s in b) for b in want), "empty transcripts prove nothing"
     # the blocking entry point still works afterwards (no batch left in flight)
     assert model.sttBatchDevice(batches[0][0].data_ptr(), batches[0][1], batches[0][2]) == want[0]
 
 
+def test_blocking_call_with_more_groups_than_slots(model):
+    """> 64 * depth utterances in one blocking call: the groups go round the slots (and take the pipelined chunk schedule)."""
+    depth = model.pipelineDepth()
+    n = 64 * depth + 70
+    lens = [4000 + 531 * (i % 13) for i in range(n)]
+    stride = max(lens)
+    host = np.zeros((n, stride), dtype=np.int16)
+    for i, ln in enumerate(lens):
+        host[i, :ln] = synth.synth_audio(ln, seed=300 + (i % 23))
+    d = _DeviceArray(host)
+    got = model.sttBatchDevice(d.data_ptr(), stride, lens)
+    ref = {}
+    for i in range(23 * 13):                            # utterance i only depends on (i % 23, i % 13)
+        if i < n and (i % 23, i % 13) not in ref:
+            ref[(i % 23, i % 13)] = model.stt(host[i, :lens[i]])
+    assert all(got[i] == ref[(i % 23, i % 13)] for i in range(n) if (i % 23, i % 13) in ref)
+    assert any(got)
+
+
 def test_pipeline_misuse_is_an_error(model):
     d, stride, lens = _device_batches(1, 4, seed=90)[0]
-    t0 = model.submitBatchDevice(d.data_ptr(), stride, lens)
-    t1 = model.submitBatchDevice(d.data_ptr(), stride, lens)
+    depth = model.pipelineDepth()
+    tickets = [model.submitBatchDevice(d.data_ptr(), stride, lens) for _ in range(depth)]
     with pytest.raises(RuntimeError):
-        model.submitBatchDevice(d.data_ptr(), stride, lens)          # a third batch: both slots are taken
+        model.submitBatchDevice(d.data_ptr(), stride, lens)          # one more: every slot is taken
     with pytest.raises(RuntimeError):
-        model.sttBatchDevice(d.data_ptr(), stride, lens)             # the blocking call needs both slots
-    a = model.collectBatch(t0)
+        model.sttBatchDevice(d.data_ptr(), stride, lens)             # the blocking call needs the slots
+    a = model.collectBatch(tickets[0])
     with pytest.raises(RuntimeError):
-        model.collectBatch(t0)                                       # collected already
-    b = model.collectBatch(t1)
-    assert a == b
+        model.collectBatch(tickets[0])                               # collected already
+    rest = [model.collectBatch(t) for t in tickets[1:]]
+    assert all(b == a for b in rest)
     with pytest.raises(RuntimeError):
         model.submitBatchDevice(d.data_ptr(), stride, [100] * 65)    # more than one group
