@@ -44,7 +44,18 @@ void mark_on(ModelState* m, int id, int which, hipStream_t st) {
 }
 void mark(ModelState* m, int id) { mark_on(m, id, 0, m->stream); }
 void prof_reset(Prof& p) { p.used = 0; for (auto& mk : p.marks) mk.clear(); }
-void prof_collect(Prof& p) {  // both streams must be idle
+void prof_collect(Prof& p) {  // every stream must be idle
+  // STT_AMD_DUMP_MARKS=1: the raw timeline (stream list, stage id, microseconds since the first mark of the acoustic stream) on
+  // stderr -- what ran beside what, without a tracer's overhead on the host
+  static const bool dump = []() { const char* e = getenv("STT_AMD_DUMP_MARKS"); return e && atoi(e) != 0; }();
+  if (dump && !p.marks[0].empty()) {
+    hipEvent_t base = p.marks[0][0].second;
+    for (int w = 0; w < 7; ++w)
+      for (auto& m : p.marks[w]) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, base, m.second) == hipSuccess) fprintf(stderr, "MARK %d %d %.1f\n", w, m.first, t * 1e3f);
+      }
+  }
   for (auto& mk : p.marks)
     for (size_t i = 0; i + 1 < mk.size(); ++i) {
       if (mk[i].first < 0 || mk[i].first >= 6) continue;
@@ -164,8 +175,9 @@ const ChunkPlan& chunk_plan(bool pipelined) {
 // `stream`, the beam search of every chunk + the final ranking + the copy of the results to page-locked memory on
 // `stream_dec`, then the slot's `done` event.
 void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t* d_audio, unsigned stride, const unsigned* sizes,
-                         const std::vector<unsigned>& idx, unsigned num_results, const DevScorer& ds, bool pipelined) {
+                         const std::vector<unsigned>& idx, unsigned num_results, const DevScorer& ds, bool pipelined, hipEvent_t gate = nullptr) {
   const int Bg = (int)idx.size();
+  if (gate) HIP_CHECK(hipStreamWaitEvent(sl.stream_dec, gate, 0));  // this group's SEARCH starts behind group g - active; its acoustic model does not wait
   const int which = 1 + (int)(&sl - &m->slots_[0]);  // profiling mark list of this group's search stream
   int t_max = 1;
   for (int b = 0; b < Bg; ++b) t_max = std::max(t_max, n_frames_for(m->g, (int)sizes[idx[b]]));
@@ -300,7 +312,16 @@ void batch_init_slots(ModelState* m) {
   m->slots_[0].stream_dec = m->stream_dec;
   for (int i = 1; i < ModelState::kSlots; ++i) HIP_CHECK(hipStreamCreateWithFlags(&m->slots_[i].stream_dec, hipStreamNonBlocking));
 }
-// Groups in flight (STT_AMD_PIPELINE, 1..kSlots; default 2)
+// Groups in flight (STT_AMD_PIPELINE, 1..kSlots; default 2).  With more slots than STT_AMD_ACTIVE (default 2) the beam search of
+// group g starts behind the `done` event of group g - active while its acoustic model starts as soon as the previous group's
+// has finished: the recurrence -- the longest dependent chain of a batch -- then runs back to back across batches while at
+// most `active` searches (64 compute units each) run beside it.  Measured: with two slots 4.1-4.8 ms per
+// batch depending on the machine; three slots were never better (4.6-5.2 on quiet hosts, far worse on busy ones: the host
+// side of a batch is ~170 runtime calls, 1.2 ms on a quiet host and 2.5-5 ms on a busy one).
+int active_groups() {
+  static const int v = []() { const char* e = getenv("STT_AMD_ACTIVE"); const int d = e ? atoi(e) : 2; return d < 1 ? 1 : d; }();
+  return v;
+}
 int pipeline_depth() {
   static const int v = []() { const char* e = getenv("STT_AMD_PIPELINE"); const int d = e ? atoi(e) : 2; return d < 1 ? 1 : (d > ModelState::kSlots ? ModelState::kSlots : d); }();
   return v;
@@ -325,7 +346,9 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
     for (unsigned g0 = 0; g0 < B; g0 += 64, ++gi) {
       if (gi - oldest == depth) { batch_collect_group(m, m->slots_[oldest % depth], all, pr); ++oldest; }
       const std::vector<unsigned> idx(order.begin() + g0, order.begin() + std::min(B, g0 + 64));
-      batch_enqueue_group(m, m->slots_[gi % depth], d_audio, stride, sizes, idx, num_results, ds, B > 64u * (unsigned)depth);
+      const int act = active_groups();
+      hipEvent_t gate = (act < depth && gi - act >= oldest) ? m->slots_[(gi - act) % depth].done : nullptr;
+      batch_enqueue_group(m, m->slots_[gi % depth], d_audio, stride, sizes, idx, num_results, ds, B > 64u * (unsigned)act, gate);
     }
     for (; oldest < gi; ++oldest) batch_collect_group(m, m->slots_[oldest % depth], all, pr);
   } catch (...) {  // nothing of this call may still be running on the slots' buffers when the caller sees the failure
@@ -359,7 +382,12 @@ int batch_submit(ModelState* m, const int16_t* d_audio, unsigned stride, const u
   std::vector<unsigned> idx(B);
   for (unsigned i = 0; i < B; ++i) idx[i] = i;
   const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
-  batch_enqueue_group(m, m->slots_[slot], d_audio, stride, sizes, idx, 1, ds, true);
+  hipEvent_t gate = nullptr;
+  {
+    const int depth = pipeline_depth(), act = active_groups(), older = m->async_next_ - act;
+    if (act < depth && older >= 0 && m->async_busy_[older % depth] && m->async_ticket_[older % depth] == older) gate = m->slots_[older % depth].done;
+  }
+  batch_enqueue_group(m, m->slots_[slot], d_audio, stride, sizes, idx, 1, ds, true, gate);
   m->async_busy_[slot] = true;
   m->async_ticket_[slot] = m->async_next_;
   return m->async_next_++;

@@ -162,7 +162,12 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
   c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = g.k1_pad(); c.t0 = t0;
   launch_context(c, M, stream);
   DenseArgs d{};
-  d.relu_clip = g.relu_clip; d.M = M; d.lds_floor = dense_lds_floor();
+  d.relu_clip = g.relu_clip; d.M = M;
+  static const int lstm_passes = []() { const char* e = getenv("STT_AMD_LSTM_PASSES"); return e ? atoi(e) : 3; }();  // form of the recurrent step (kernels.h); 1 = 64 KiB of LDS: no room beside the solo GEMM
+  {  // GEMMs as co-tenants of the recurrence: the three-stage one-per-CU form (default), or the two-stage form padded to one per CU
+    static const int solo = []() { const char* e = getenv("STT_AMD_DENSE_SOLO"); return e ? atoi(e) : 1; }();
+    d.solo = solo && lstm_passes >= 2; d.lds_floor = d.solo ? 0 : dense_lds_floor();  // (96 KiB beside the one-pass step's 66 would not fit)
+  }
   stt_prof_mark_on(this, 1, 0, stream);
   d.wt = w1t.as<_Float16>(); d.x = ws_x1.as<_Float16>(); d.bias = b1.as<float>(); d.y = ws_a.p; d.N = H; d.K = g.k1_pad(); d.ldx = g.k1_pad(); d.ldy = H;
   launch_dense(d, DENSE_EPI_RELU_F16, stream);
@@ -186,15 +191,38 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
   }
   LstmArgs l{};
   l.whp = whp.as<_Float16>(); l.xproj = am_xproj[slot].as<float>(); l.c = ws_c.as<float>(); l.h_all = am_hall[slot].as<_Float16>();
-  l.n_hidden = H; l.batch = B; l.h_f32 = nullptr;
+  l.n_hidden = H; l.batch = B; l.h_f32 = nullptr; l.passes = lstm_passes;
   { static const int pr = []() { const char* e = getenv("STT_AMD_LSTM_PRIO"); return e ? atoi(e) : 1; }(); l.prio = pr; }
-  for (int t = 0; t < T; ++t) {
-    const bool odd = ((t0 + t) & 1) != 0;
-    l.hp_in = odd ? ws_hp1.as<_Float16>() : ws_hp0.as<_Float16>();
-    l.hp_out = odd ? ws_hp0.as<_Float16>() : ws_hp1.as<_Float16>();
-    l.t = t;
-    launch_lstm_step(l, NT, stream_l);
-  }
+  auto steps = [&]() {
+    for (int t = 0; t < T; ++t) {
+      const bool odd = ((t0 + t) & 1) != 0;
+      l.hp_in = odd ? ws_hp1.as<_Float16>() : ws_hp0.as<_Float16>();
+      l.hp_out = odd ? ws_hp0.as<_Float16>() : ws_hp1.as<_Float16>();
+      l.t = t;
+      launch_lstm_step(l, NT, stream_l);
+    }
+  };
+  static const int use_graph = []() { const char* e = getenv("STT_AMD_LSTM_GRAPH"); return e ? atoi(e) : 1; }();
+  if (use_graph) {
+    LstmGraphKey key;
+    memset(&key, 0, sizeof(key));  // (padding bytes take part in the comparison)
+    key.xproj = am_xproj[slot].p; key.hall = am_hall[slot].p; key.c = ws_c.p; key.hp0 = ws_hp0.p; key.hp1 = ws_hp1.p; key.whp = whp.p;
+    key.T = T; key.par = t0 & 1; key.B = B; key.NT = NT; key.passes = l.passes; key.prio = l.prio; key.H = H; key.first = 0;
+    auto found = lstm_graphs_.find(key);
+    if (found == lstm_graphs_.end() && lstm_graphs_.size() >= 256) { steps(); goto recurrence_enqueued; }  // (ragged jobs: no unbounded cache)
+    LstmGraph& gr = lstm_graphs_[key];
+    if (!gr.exec && gr.seen++ >= 1) {  // second sighting: worth a graph (the first ran eagerly: module load, function attributes)
+      hipGraph_t graph = nullptr;
+      HIP_CHECK(hipStreamBeginCapture(stream_l, hipStreamCaptureModeRelaxed));
+      steps();
+      HIP_CHECK(hipStreamEndCapture(stream_l, &graph));
+      HIP_CHECK(hipGraphInstantiate(&gr.exec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+    }
+    if (gr.exec) HIP_CHECK(hipGraphLaunch(gr.exec, stream_l));
+    else steps();
+  } else steps();
+recurrence_enqueued:
   stt_prof_mark_on(this, -1, 5, stream_l);
   HIP_CHECK(hipEventRecord(ev_x_free[slot], stream_l));
   HIP_CHECK(hipEventRecord(ev_h_ready[slot], stream_l));

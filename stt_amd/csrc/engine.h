@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <map>
 #include <memory>
@@ -229,6 +230,17 @@ struct ModelState {
   DevBuf am_xproj[kAmRing], am_hall[kAmRing], ws_o;
   hipEvent_t ev_x_ready[kAmRing] = {}, ev_x_free[kAmRing] = {}, ev_h_ready[kAmRing] = {}, ev_h_free[kAmRing] = {};
   unsigned long long am_seq = 0;  // chunks sent through the pipe so far (slot = am_seq % kAmRing)
+  // The recurrence of a chunk is T dependent launches whose arguments only depend on (ring slot, T, parity of t0, batch): the
+  // second time a combination comes up it is captured into a hipGraph and replayed from then on -- one graph launch instead
+  // of 16-48 kernel launches of host time (enqueueing a 64 x 5 s batch: ~300 launches, 1.5 ms on a quiet host, 2.5-5 ms on a
+  // busy one, which then starves the GPU).  Keyed by every pointer baked into the nodes.
+  struct LstmGraphKey {
+    const void *xproj, *hall, *c, *hp0, *hp1, *whp;
+    int T, par, B, NT, passes, prio, H, first;
+    bool operator<(const LstmGraphKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
+  };
+  struct LstmGraph { hipGraphExec_t exec = nullptr; int seen = 0; };
+  std::map<LstmGraphKey, LstmGraph> lstm_graphs_;
   bool am_pipe_init();            // creates the streams / events on first use; false when switched off
   // chunk [t0, t0+T) of a batch through the three engines; `done` is recorded on stream_o behind the softmax
   void run_acoustic_chunk_piped(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs, hipEvent_t done);

@@ -41,6 +41,7 @@ struct DenseArgs {
   int xa, xb;          // tile-grid cut over the 8 XCDs (xa blocks along M x xb along N; filled in by launch_dense)
   int lds_floor;       // ask for at least this much dynamic LDS (bytes; 0 = what the tile needs): > 80 KiB keeps the kernel at ONE
                        // workgroup per CU, so that a recurrent-step workgroup launched beside it always finds room (engine.cpp)
+  int solo;            // 1: the three-stage form of the 128-square tile (96 KiB: one workgroup per CU, two K-tiles in flight)
 };
 
 // ---- LSTM ---------------------------------------------------------------------------------------
@@ -53,6 +54,8 @@ struct LstmArgs {
   float* h_f32;           // optional [B][H] copy of h_t in f32 (state hand-back); may be null
   _Float16* h_all;        // [t_max*B][H]
   int n_hidden, batch, t;
+  int passes;             // form of the cross-wave reduction: 0 = default, 1 = one pass (64 KiB of LDS), 2 = two passes over the batch
+                          // tiles (32 KiB), 3 = owner form (48 KiB, one barrier, cell update on registers); 2, 3: 64-row batches only
   int prio;               // wave priority (s_setprio 0..3) of the step's waves: beats age when other kernels' waves share the SIMDs
 };
 

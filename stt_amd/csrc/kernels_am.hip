@@ -145,7 +145,11 @@ typedef __attribute__((address_space(1))) const void gvoid_c;
 // 64 x 64 piece either way (4 x 4 MFMA tiles); the bigger tile puts twice the MFMA work behind each DMA round trip and each
 // barrier (the 128-square tile with one tile of prefetch was bound by the landing latency of its global_load_lds stage:
 // 0.69 PF/s), and halves the operand bytes per flop.
-template <int EPI, int T>
+// NS = LDS stages (K-tiles resident): 2 = one tile of prefetch behind a plain barrier (several workgroups per CU hide each
+// other's landing latency); 3 = two tiles in flight with a counted vmcnt and a raw s_barrier (a __syncthreads() would drain
+// the DMA queue) -- the shape for ONE workgroup per CU beside a recurrent-step workgroup (engine.cpp): 96 KiB of LDS, and the
+// K-tile cadence no longer waits for a full HBM/L2 round trip.  Same k order: bit-identical results.
+template <int EPI, int T, int NS>
 __global__ __launch_bounds__(T * T * 64) void dense_kernel(DenseArgs a) {
   constexpr int BM = 64 * T, BN = 64 * T, NTHR = T * T * 64;
   constexpr int TILE_BYTES = BM * GT_BK * 2;     // one operand tile (BM == BN): rows of 128 bytes
@@ -228,10 +232,22 @@ __global__ __launch_bounds__(T * T * 64) void dense_kernel(DenseArgs a) {
   }
   const int nk = K / GT_BK;
   STAGE(0, 0);
-  __syncthreads();  // (waits for the DMA: vmcnt(0) + barrier)
+  if (NS == 3 && nk > 1) STAGE(1, GT_BK);
+  if (NS == 2) __syncthreads();  // (waits for the DMA: vmcnt(0) + barrier)
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) STAGE(cur ^ 1, (kt + 1) * GT_BK);
+    if (NS == 2) {
+      if (kt + 1 < nk) STAGE(cur ^ 1, (kt + 1) * GT_BK);
+    } else {
+      // tile kt has landed once at most the 2 * IT DMA instructions of tile kt + 1 are still outstanding (loads retire in
+      // order); behind the barrier every wave's part of tile kt is there and every wave is done reading tile kt - 1, whose
+      // buffer takes tile kt + 2
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < nk) STAGE(cur >= 1 ? cur - 1 : 2, (kt + 2) * GT_BK);
+    }
     const lds_u8* const bw = lds + cur * 2 * TILE_BYTES;
     const lds_u8* const bx = bw + TILE_BYTES;
 #pragma unroll
@@ -248,8 +264,13 @@ __global__ __launch_bounds__(T * T * 64) void dense_kernel(DenseArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();  // tile kt+1 has landed; every wave is done reading tile kt (its buffer is restaged next iteration)
-    cur ^= 1;
+    if (NS == 2) {
+      __syncthreads();  // tile kt+1 has landed; every wave is done reading tile kt (its buffer is restaged next iteration)
+      cur ^= 1;
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of tile kt are complete before it reaches the next barrier
+      cur = cur == 2 ? 0 : cur + 1;
+    }
   }
 #undef STAGE
   // epilogue: lane holds features n = nb + (lane>>4)*4 + 0..3 of X row m = mb + (lane&15)
@@ -347,12 +368,16 @@ __device__ __forceinline__ float tanhf_(float x) {
 // Every workgroup reads ALL of h (2 * H * 64 bytes at 64 batch rows = 256 KiB) besides its slice of the recurrent matrix, so
 // with 256 workgroups the h re-reads (64 MiB per step) outweigh the weights (33.5 MiB); 128 workgroups halve them, and a
 // workgroup then has a CU to itself (64 KiB reduction buffer, ~230 VGPRs: one wave per SIMD).
-template <int NT, int G_, int MT>
+template <int NT, int G_, int MT, int PHS>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   constexpr bool PF = G_ > 0;
   constexpr int UPW = MT * 4;  // hidden units per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
-  typedef float RedT[MT][NT][64][4];
+  // The cross-wave reduction goes through LDS in PH passes over the batch tiles (two for 64 rows): 32 KiB instead of 64, so
+  // that the step's workgroup fits beside a 96 KiB GEMM workgroup on the same CU (engine.cpp, three engines).  The sum of a
+  // (row, unit) is red[0] + red[1] + red[2] + red[3] in every form: bit-identical results.
+  constexpr int PH = (NT >= 4 && PHS == 2) ? 2 : 1, NTP = NT / PH;  // PHS = 2: the two-pass form (the batch path's three engines)
+  typedef float RedT[MT][NTP][64][4];
   RedT* red = reinterpret_cast<RedT*>(lstm_smem);                                        // [4 waves]
   _Float16 (*hout)[UPW] = reinterpret_cast<_Float16 (*)[UPW]>(lstm_smem + 4 * sizeof(RedT));  // [NT * 16][UPW]
   if (a.prio) __builtin_amdgcn_s_setprio(3);
@@ -370,9 +395,23 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   // operands of the cell update, fetched now so that their latency hides behind the k-loop
   constexpr int CU_ITEMS = NT * 16 * UPW, CU_ITERS = (CU_ITEMS + 255) / 256;
   const int B = a.batch;
+  // PHS = 3, the "owner" form (64 batch rows, 16 units per workgroup): wave q ends up with the complete sums of batch tile q
+  // in the MFMA accumulator layout -- lane = (unit / 4) * 16 + row, four consecutive units x all four gates of ONE batch row per
+  // lane -- so the cell update runs on registers.  Each wave parks the three tiles it does not own in LDS (48 KiB in all), one
+  // barrier, each wave adds the three foreign partials of its own tile in wave order: (((r0 + r1) + r2) + r3), the order of
+  // the other forms (bit-identical results), no second pass through LDS, no second barrier, h published from registers.
+  constexpr bool OWN = PHS == 3 && NT == 4 && MT == 4;
+  const int ob = q * 16 + (lane & 15), ou = 4 * (lane >> 4);  // owner form: this lane's batch row and first unit
+  float4 oxv[4] = {}, ocv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (OWN && ob < B) {
+    const float* xp = a.xproj + ((size_t)a.t * B + ob) * (4 * H) + wg * UPW + ou;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) oxv[g] = *reinterpret_cast<const float4*>(xp + (size_t)g * H);
+    ocv = *reinterpret_cast<const float4*>(a.c + (size_t)ob * H + wg * UPW + ou);
+  }
   float xv[CU_ITERS][4], cv[CU_ITERS];
 #pragma unroll
-  for (int it = 0; it < CU_ITERS; ++it) {
+  for (int it = 0; it < (OWN ? 0 : CU_ITERS); ++it) {
     const int p = tid + it * 256;
     const int b = p / UPW, u = p % UPW;
     xv[it][0] = xv[it][1] = xv[it][2] = xv[it][3] = 0.0f; cv[it] = 0.0f;
@@ -424,37 +463,90 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
       }
     }
   }
+  if (OWN) {
+    typedef float OwnT[3][MT][64][4];                    // [writer wave][slot: the writer's foreign tiles in order][gate tile][lane]
+    OwnT* park = reinterpret_cast<OwnT*>(lstm_smem);
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+    for (int j = 0; j < NT; ++j) {
+      if (j == q) continue;                              // (wave-uniform)
+      const int sl = j - (j > q ? 1 : 0);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&red[q][i][j][lane][0]) = acc[i][j];
-  __syncthreads();
+      for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4*>(&park[q][sl][i][lane][0]) = acc[i][j];
+    }
+    f32x4 own[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) own[i] = q == 0 ? acc[i][0] : q == 1 ? acc[i][1] : q == 2 ? acc[i][2] : acc[i][NT - 1];
+    __syncthreads();
+    f32x4 z[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      f32x4 v[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int sl = q - (q > w ? 1 : 0);              // where writer w parked tile q (unused for w == q)
+        v[w] = (w == q) ? own[i] : *reinterpret_cast<const f32x4*>(&park[w][sl < 3 ? sl : 2][i][lane][0]);
+      }
+      z[i] = ((v[0] + v[1]) + v[2]) + v[3];
+    }
+    float hv[4];
+    float4 cn4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float zi = z[0][r] + (&oxv[0].x)[r], zj = z[1][r] + (&oxv[1].x)[r], zf = z[2][r] + (&oxv[2].x)[r], zo = z[3][r] + (&oxv[3].x)[r];
+      const float cn = sigmoidf_(zf) * (&ocv.x)[r] + sigmoidf_(zi) * tanhf_(zj);
+      (&cn4.x)[r] = cn;
+      hv[r] = ob < B ? sigmoidf_(zo) * tanhf_(cn) : 0.0f;
+    }
+    const int unit0 = wg * UPW + ou;
+    if (ob < B) {
+      *reinterpret_cast<float4*>(a.c + (size_t)ob * H + unit0) = cn4;
+      if (a.h_f32) *reinterpret_cast<float4*>(a.h_f32 + (size_t)ob * H + unit0) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    }
+    // publish h: this lane's four units are one half of a 16-byte (8-unit) chunk of the fragment-ordered buffer
+    const f16x4 hh = {(_Float16)hv[0], (_Float16)hv[1], (_Float16)hv[2], (_Float16)hv[3]};
+    const int k0 = wg * UPW + (ou & ~7);                 // first unit of the chunk
+    const int ksg = k0 >> 5, grp = (k0 & 31) >> 3, half = (ou >> 2) & 1;
+    reinterpret_cast<f16x4*>(a.hp_out)[(((size_t)ksg * NT + q) * 64 + grp * 16 + (lane & 15)) * 2 + half] = hh;
+    if (ob < B) *reinterpret_cast<f16x4*>(a.h_all + ((size_t)a.t * B + ob) * H + unit0) = hh;
+    return;
+  }
   // cell update: (unit u, batch row b): gate row r = g*UPW+u lives in tile r>>4, lane group (r&15)>>2, reg r&3
   // (the x-projection and cell-state operands were fetched before the k-loop: xv/cv)
 #pragma unroll
-  for (int it = 0; it < CU_ITERS; ++it) {
-    const int p = tid + it * 256;
-    if (p >= CU_ITEMS) break;
-    const int b = p / UPW, u = p % UPW;
-    float z[4];
+  for (int ph = 0; ph < PH; ++ph) {
+    if (ph) __syncthreads();  // the previous pass's sums have been read
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int r = g * UPW + u;
-      const int mt = r >> 4, rr = r & 15;
-      const int ln = ((rr >> 2) << 4) + (b & 15);
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTP; ++j) *reinterpret_cast<f32x4*>(&red[q][i][j][lane][0]) = acc[i][ph * NTP + j];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < CU_ITERS; ++it) {
+      const int p = tid + it * 256;
+      if (p >= CU_ITEMS) break;
+      const int b = p / UPW, u = p % UPW;
       const int nt = b >> 4;
-      z[g] = red[0][mt][nt][ln][rr & 3] + red[1][mt][nt][ln][rr & 3] + red[2][mt][nt][ln][rr & 3] + red[3][mt][nt][ln][rr & 3];
+      if (nt / NTP != ph) continue;  // (uniform per `it` for the shapes in use: 256 items = 16 rows of 16 units, or 32 rows of 8)
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = g * UPW + u;
+        const int mt = r >> 4, rr = r & 15;
+        const int ln = ((rr >> 2) << 4) + (b & 15);
+        const int ntl = nt - ph * NTP;
+        z[g] = red[0][mt][ntl][ln][rr & 3] + red[1][mt][ntl][ln][rr & 3] + red[2][mt][ntl][ln][rr & 3] + red[3][mt][ntl][ln][rr & 3];
+      }
+      float hval = 0.0f;
+      if (b < B) {
+        const int unit = wg * UPW + u;
+        const float zi = z[0] + xv[it][0], zj = z[1] + xv[it][1], zf = z[2] + xv[it][2], zo = z[3] + xv[it][3];
+        const float cn = sigmoidf_(zf) * cv[it] + sigmoidf_(zi) * tanhf_(zj);
+        a.c[(size_t)b * H + unit] = cn;
+        hval = sigmoidf_(zo) * tanhf_(cn);
+        if (a.h_f32) a.h_f32[(size_t)b * H + unit] = hval;
+      }
+      hout[b][u] = (_Float16)hval;
     }
-    float hval = 0.0f;
-    if (b < B) {
-      const int unit = wg * UPW + u;
-      const float zi = z[0] + xv[it][0], zj = z[1] + xv[it][1], zf = z[2] + xv[it][2], zo = z[3] + xv[it][3];
-      const float cn = sigmoidf_(zf) * cv[it] + sigmoidf_(zi) * tanhf_(zj);
-      a.c[(size_t)b * H + unit] = cn;
-      hval = sigmoidf_(zo) * tanhf_(cn);
-      if (a.h_f32) a.h_f32[(size_t)b * H + unit] = hval;
-    }
-    hout[b][u] = (_Float16)hval;
   }
   __syncthreads();
   // publish h: 16-byte chunks (8 units) per batch row, into next step's fragment-ordered buffer and the time-major h_all
@@ -646,17 +738,17 @@ void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st) {
 void launch_context(const ContextArgs& a, int rows, hipStream_t st) {
   hipLaunchKernelGGL(context_kernel, dim3(rows), dim3(256), 0, st, a);
 }
-template <int EPI, int T>
+template <int EPI, int T, int NS>
 static void launch_dense_inst(const DenseArgs& b, int grid, hipStream_t st) {
-  size_t smem = (size_t)4 * (64 * T) * GT_BK * 2;  // two stages x (W tile + X tile): 64 KiB (T = 2) or 128 KiB (T = 4)
+  size_t smem = (size_t)2 * NS * (64 * T) * GT_BK * 2;  // stages x (W tile + X tile): 64 / 96 KiB (T = 2) or 128 KiB (T = 4)
   static std::once_flag once[16];
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::call_once(once[dev & 15], [&]() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_kernel<EPI, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_kernel<EPI, T, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   if ((size_t)b.lds_floor > smem) smem = std::min<size_t>((size_t)b.lds_floor, 160 * 1024);
-  hipLaunchKernelGGL((dense_kernel<EPI, T>), dim3(grid), dim3(T * T * 64), smem, st, b);
+  hipLaunchKernelGGL((dense_kernel<EPI, T, NS>), dim3(grid), dim3(T * T * 64), smem, st, b);
 }
 void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
   if (a.M <= 16 && a.K % 32 == 0 && a.N % 64 == 0) {
@@ -671,7 +763,7 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
   static const int big_ok = []() { const char* e = getenv("STT_AMD_DENSE_TILE"); return e ? atoi(e) : 0; }();
   static const int big_min = []() { const char* e = getenv("STT_AMD_DENSE_BIG_MIN"); return e ? atoi(e) : 480; }();
   const bool big_fits = a.N % 256 == 0 && a.M >= 256;
-  const bool big = big_fits && (big_ok >= 256 || (big_ok == 0 && ((a.M + 255) / 256) * (a.N / 256) >= big_min));
+  const bool big = big_fits && !a.solo && (big_ok >= 256 || (big_ok == 0 && ((a.M + 255) / 256) * (a.N / 256) >= big_min));
   const int side = big ? 256 : 128;
   // cut of the tile grid over the 8 XCDs: xa x xb blocks, minimising (block rows + block columns) = operand bytes per XCD
   DenseArgs b = a;
@@ -687,11 +779,14 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
   }
   const int per_xcd = ((ntm + b.xa - 1) / b.xa) * ((ntn + b.xb - 1) / b.xb);
   if (big) {
-    if (epi == DENSE_EPI_RELU_F16) launch_dense_inst<DENSE_EPI_RELU_F16, 4>(b, 8 * per_xcd, st);
-    else launch_dense_inst<DENSE_EPI_BIAS_F32, 4>(b, 8 * per_xcd, st);
+    if (epi == DENSE_EPI_RELU_F16) launch_dense_inst<DENSE_EPI_RELU_F16, 4, 2>(b, 8 * per_xcd, st);
+    else launch_dense_inst<DENSE_EPI_BIAS_F32, 4, 2>(b, 8 * per_xcd, st);
+  } else if (a.solo) {
+    if (epi == DENSE_EPI_RELU_F16) launch_dense_inst<DENSE_EPI_RELU_F16, 2, 3>(b, 8 * per_xcd, st);
+    else launch_dense_inst<DENSE_EPI_BIAS_F32, 2, 3>(b, 8 * per_xcd, st);
   } else {
-    if (epi == DENSE_EPI_RELU_F16) launch_dense_inst<DENSE_EPI_RELU_F16, 2>(b, 8 * per_xcd, st);
-    else launch_dense_inst<DENSE_EPI_BIAS_F32, 2>(b, 8 * per_xcd, st);
+    if (epi == DENSE_EPI_RELU_F16) launch_dense_inst<DENSE_EPI_RELU_F16, 2, 2>(b, 8 * per_xcd, st);
+    else launch_dense_inst<DENSE_EPI_BIAS_F32, 2, 2>(b, 8 * per_xcd, st);
   }
 }
 int lstm_nt_for_batch(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : -1; }  // 64 rows per launch
@@ -701,16 +796,28 @@ int lstm_units_per_wg(int H) {
   static const int env = []() { const char* e = getenv("STT_AMD_LSTM_UPW"); return e ? atoi(e) : 16; }();
   return (env >= 16 && H % 16 == 0) ? 16 : 8;
 }
-template <int NT, int G, int MT>
-static void launch_lstm_inst(const LstmArgs& a, hipStream_t st) {
-  const size_t smem = 4 * sizeof(float) * MT * NT * 64 * 4 + (size_t)NT * 16 * MT * 4 * 2;
+template <int NT, int G, int MT, int PHS>
+static void launch_lstm_inst2(const LstmArgs& a, hipStream_t st) {
+  const size_t smem = (PHS == 3 && NT == 4 && MT == 4) ? (size_t)4 * 3 * MT * 64 * 16
+                                                      : 4 * sizeof(float) * MT * ((NT >= 4 && PHS == 2) ? NT / 2 : NT) * 64 * 4 + (size_t)NT * 16 * MT * 4 * 2;
   static std::once_flag once[16];
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::call_once(once[dev & 15], [&]() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_kernel<NT, G, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_kernel<NT, G, MT, PHS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   });
-  hipLaunchKernelGGL((lstm_step_kernel<NT, G, MT>), dim3(a.n_hidden / (MT * 4)), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((lstm_step_kernel<NT, G, MT, PHS>), dim3(a.n_hidden / (MT * 4)), dim3(256), smem, st, a);
+}
+template <int NT, int G, int MT>
+static void launch_lstm_inst(const LstmArgs& a, hipStream_t st) {
+  // a.passes: 0 / 1 = one pass (the fastest form when the step has the CU to itself: 2.88 ms per 250 steps against 2.95 for the
+  // owner form), 2 = two passes, 3 = owner form (what fits beside a GEMM workgroup: the batch path's three engines).
+  // STT_AMD_LSTM_FORM overrides every caller (A/B runs).
+  static const int form_env = []() { const char* e = getenv("STT_AMD_LSTM_FORM"); return e ? atoi(e) : 0; }();
+  const int form = form_env ? form_env : (a.passes ? a.passes : 1);
+  if (NT == 4 && MT == 4 && form == 3) launch_lstm_inst2<NT, G, MT, (NT == 4 && MT == 4 ? 3 : 1)>(a, st);
+  else if (NT >= 4 && form == 2) launch_lstm_inst2<NT, G, MT, (NT >= 4 ? 2 : 1)>(a, st);
+  else launch_lstm_inst2<NT, G, MT, 1>(a, st);
 }
 void launch_lstm_step(const LstmArgs& a, int NT, hipStream_t st) {
   static const int pg = []() { const char* e = getenv("STT_AMD_LSTM_PREFETCH"); return e ? atoi(e) : 2; }();
