@@ -51,6 +51,9 @@ STTX_EXPORT char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* a
  * acoustic models of the batches in flight run one after the other, each batch's beam search beside the acoustic model
  * and the searches of its neighbours. */
 STTX_EXPORT int STTX_BatchPipelineDepth(void);
+/* ... for THIS model as configured now: a search-bound setup (code-point scorer, beam width beyond 512) takes four slots and
+ * runs their searches side by side, everything else two. */
+STTX_EXPORT int STTX_BatchPipelineDepthFor(ModelState* aCtx);
 STTX_EXPORT int STTX_BatchSubmitDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride,
                                        const unsigned int* aBufferSizes, unsigned int aBatch);
 STTX_EXPORT char** STTX_BatchCollect(ModelState* aCtx, int aTicket, unsigned int* aCount);

@@ -318,13 +318,23 @@ void batch_init_slots(ModelState* m) {
 // most `active` searches (64 compute units each) run beside it.  Measured: with two slots 4.1-4.8 ms per
 // batch depending on the machine; three slots were never better (4.6-5.2 on quiet hosts, far worse on busy ones: the host
 // side of a batch is ~170 runtime calls, 1.2 ms on a quiet host and 2.5-5 ms on a busy one).
-int active_groups() {
-  static const int v = []() { const char* e = getenv("STT_AMD_ACTIVE"); const int d = e ? atoi(e) : 2; return d < 1 ? 1 : d; }();
+// A search-bound setup -- code-point scorer or a beam beyond 512: the search of a batch takes 45+ ms on its 64 compute units, the
+// acoustic model 5 -- gets four slots and all four searches side by side (bytes workload: 24.7 -> 16.3 ms per batch); everything
+// else two and two (a third group crowds the recurrence).  STT_AMD_PIPELINE / STT_AMD_ACTIVE override both.
+bool search_bound(const ModelState* m) { return (m->scorer_ && m->scorer_->is_utf8) || m->beam_width_ > 512; }
+int active_groups(const ModelState* m) {
+  static const int v = []() { const char* e = getenv("STT_AMD_ACTIVE"); const int d = e ? atoi(e) : 0; return d < 0 ? 0 : d; }();
+  return v ? v : (search_bound(m) ? ModelState::kSlots : 2);
+}
+int pipeline_depth_env() {
+  static const int v = []() { const char* e = getenv("STT_AMD_PIPELINE"); const int d = e ? atoi(e) : 0; return d < 0 ? 0 : (d > ModelState::kSlots ? ModelState::kSlots : d); }();
   return v;
 }
-int pipeline_depth() {
-  static const int v = []() { const char* e = getenv("STT_AMD_PIPELINE"); const int d = e ? atoi(e) : 2; return d < 1 ? 1 : (d > ModelState::kSlots ? ModelState::kSlots : d); }();
-  return v;
+// (while batches are in flight the depth they were submitted under stays in force: ModelState::async_depth_)
+int pipeline_depth(const ModelState* m) {
+  if (m && m->async_any() && m->async_depth_ > 0) return m->async_depth_;
+  const int e = pipeline_depth_env();
+  return e ? e : (m && search_bound(m) ? ModelState::kSlots : 2);
 }
 
 // Utterances are taken longest first in groups of 64 (length-homogeneous groups: the LSTM runs every group to its longest
@@ -340,13 +350,13 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
   for (unsigned i = 0; i < B; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return sizes[x] > sizes[y]; });
   const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
-  const int depth = pipeline_depth();
+  const int depth = pipeline_depth(m);
   int oldest = 0, gi = 0;  // groups [oldest, gi) are in flight, group g in slot g % depth
   try {
     for (unsigned g0 = 0; g0 < B; g0 += 64, ++gi) {
       if (gi - oldest == depth) { batch_collect_group(m, m->slots_[oldest % depth], all, pr); ++oldest; }
       const std::vector<unsigned> idx(order.begin() + g0, order.begin() + std::min(B, g0 + 64));
-      const int act = active_groups();
+      const int act = active_groups(m);
       hipEvent_t gate = (act < depth && gi - act >= oldest) ? m->slots_[(gi - act) % depth].done : nullptr;
       batch_enqueue_group(m, m->slots_[gi % depth], d_audio, stride, sizes, idx, num_results, ds, B > 64u * (unsigned)act, gate);
     }
@@ -372,7 +382,9 @@ int batch_submit(ModelState* m, const int16_t* d_audio, unsigned stride, const u
   if (B == 0 || B > 64) throw std::runtime_error("STTX_BatchSubmitDevice takes 1..64 utterances (one group) per call");
   HIP_CHECK(hipSetDevice(m->device));
   batch_init_slots(m);
-  const int slot = m->async_next_ % pipeline_depth();
+  const int depth_now = pipeline_depth(m);
+  if (!m->async_any()) m->async_depth_ = depth_now;
+  const int slot = m->async_next_ % depth_now;
   if (m->async_busy_[slot]) throw std::runtime_error("the pipeline is full (STTX_BatchPipelineDepth batches in flight): collect the oldest one first");
   Prof& pr = prof_of(m);
   if (pr.on && !m->async_any()) {
@@ -384,7 +396,7 @@ int batch_submit(ModelState* m, const int16_t* d_audio, unsigned stride, const u
   const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
   hipEvent_t gate = nullptr;
   {
-    const int depth = pipeline_depth(), act = active_groups(), older = m->async_next_ - act;
+    const int depth = depth_now, act = active_groups(m), older = m->async_next_ - act;
     if (act < depth && older >= 0 && m->async_busy_[older % depth] && m->async_ticket_[older % depth] == older) gate = m->slots_[older % depth].done;
   }
   batch_enqueue_group(m, m->slots_[slot], d_audio, stride, sizes, idx, 1, ds, true, gate);
@@ -393,7 +405,7 @@ int batch_submit(ModelState* m, const int16_t* d_audio, unsigned stride, const u
   return m->async_next_++;
 }
 std::vector<std::vector<Output>> batch_collect(ModelState* m, int ticket) {
-  const int slot = ticket < 0 ? 0 : ticket % pipeline_depth();
+  const int slot = ticket < 0 ? 0 : ticket % pipeline_depth(m);
   if (ticket < 0 || !m->async_busy_[slot] || m->async_ticket_[slot] != ticket) throw std::runtime_error("STTX_BatchCollect: no such batch in flight");
   HIP_CHECK(hipSetDevice(m->device));
   ModelState::GroupSlot& sl = m->slots_[slot];
@@ -694,7 +706,8 @@ char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* aDeviceAudio,
   return res;
 }
 
-int STTX_BatchPipelineDepth(void) { return pipeline_depth(); }
+int STTX_BatchPipelineDepth(void) { const int e = pipeline_depth_env(); return e ? e : 2; }
+int STTX_BatchPipelineDepthFor(ModelState* aCtx) { return aCtx ? pipeline_depth(aCtx) : STTX_BatchPipelineDepth(); }
 
 int STTX_BatchSubmitDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride, const unsigned int* aBufferSizes, unsigned int aBatch) {
   int ticket = -STT_ERR_FAIL_RUN_SESS;

@@ -213,6 +213,7 @@ struct ModelState {
   bool async_busy_[kSlots] = {};
   int async_ticket_[kSlots] = {-1, -1, -1, -1};
   int async_next_ = 0;
+  int async_depth_ = 0;  // slots in use while batches are in flight (api.cpp: pipeline_depth)
   bool async_any() const { for (bool b : async_busy_) if (b) return true; return false; }
   // scratch of the batched streaming calls (STTX_FeedAudioContentBatch & co.)
   DevBuf sb_audio, sb_tab, sb_c, sb_h, sb_table;

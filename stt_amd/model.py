@@ -177,10 +177,9 @@ class Model(object):
             raise RuntimeError("STTX_BatchSubmitDevice failed (%d)" % t)
         return t
 
-    @staticmethod
-    def pipelineDepth():
-        """Batches STTX_BatchSubmitDevice accepts before the oldest must be collected (STTX_BatchPipelineDepth)."""
-        return int(native.lib().STTX_BatchPipelineDepth())
+    def pipelineDepth(self):
+        """Batches STTX_BatchSubmitDevice accepts for this model before the oldest must be collected (STTX_BatchPipelineDepthFor)."""
+        return int(native.lib().STTX_BatchPipelineDepthFor(self._impl))
 
     def collectBatch(self, ticket):
         """Wait for a submitted batch; its transcripts in submission order (STTX_BatchCollect)."""
