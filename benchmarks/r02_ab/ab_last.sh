@@ -1,0 +1,10 @@
+#!/bin/bash
+out=gpurun_out/ab_last.log; : > $out
+run_b() { echo "== $*" >> $out; env "$@" timeout 120 python bench.py --no-cpu-baseline --steps 24 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(round(r['ms_per_step'],3), round(r.get('p50_utterance_latency_ms'),2), round(r.get('host_enqueue_ms_per_step'),2), {k:round(v,2) for k,v in r.get('stage_ms_per_step').items()})" >> $out; }
+run_b A=1
+run_b STT_AMD_LSTM_PREFETCH=4
+run_b STT_AMD_LSTM_PREFETCH=1
+run_b STT_AMD_PCHUNK0=48
+run_b STT_AMD_LM_WAVES=4
+run_b A=2
+cat $out

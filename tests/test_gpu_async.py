@@ -107,3 +107,27 @@ def test_pipeline_misuse_is_an_error(model):
     assert all(b == a for b in rest)
     with pytest.raises(RuntimeError):
         model.submitBatchDevice(d.data_ptr(), stride, [100] * 65)    # more than one group
+
+
+def test_search_bound_setup_takes_four_slots(tmp_path):
+    """A beam beyond 512 (or a code-point scorer) makes the search the long pole: STTX_BatchPipelineDepthFor says 4 and the
+    four batches in flight (all searches side by side) still give the blocking call's transcripts."""
+    from stt_amd import Model
+    w = synth.synth_weights(12, n_hidden=256)
+    path = str(tmp_path / "wide_beam.sttw")
+    modelfile.write_model(path, w, synth.ENGLISH_LABELS, beam_width=600)
+    m = Model(path)
+    assert m.pipelineDepth() == 4
+    batches = _device_batches(6, 5, seed=70)
+    want = [m.sttBatchDevice(d.data_ptr(), stride, lens) for d, stride, lens in batches]
+    got, inflight = [], []
+    for d, stride, lens in batches:
+        if len(inflight) == 4:
+            got.append(m.collectBatch(inflight.pop(0)))
+        inflight.append(m.submitBatchDevice(d.data_ptr(), stride, lens))
+    while inflight:
+        got.append(m.collectBatch(inflight.pop(0)))
+    assert got == want
+    m.setBeamWidth(100)                                  # nothing in flight: the depth follows the configuration
+    assert m.pipelineDepth() == 2
+
