@@ -981,6 +981,7 @@ int STTX_TestDense(int M, int N, int K, const float* aX, const float* aW, const 
     dy.reserve((size_t)M * N * 4);
     DenseArgs d{};
     d.wt = dw.as<_Float16>(); d.x = dx.as<_Float16>(); d.bias = db.as<float>(); d.y = dy.p; d.M = M; d.N = N; d.K = K; d.ldx = K; d.ldy = N; d.relu_clip = aClip;
+    if (const char* e = getenv("STT_AMD_TEST_DENSE_SOLO")) d.solo = atoi(e);  // test hook: the forms that run beside the recurrence (read per call)
     launch_dense(d, aEpilogue == 0 ? DENSE_EPI_RELU_F16 : DENSE_EPI_BIAS_F32, nullptr);
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipGetLastError());

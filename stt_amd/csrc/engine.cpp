@@ -165,8 +165,8 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
   d.relu_clip = g.relu_clip; d.M = M;
   static const int lstm_passes = []() { const char* e = getenv("STT_AMD_LSTM_PASSES"); return e ? atoi(e) : 3; }();  // form of the recurrent step (kernels.h); 1 = 64 KiB of LDS: no room beside the solo GEMM
   {  // GEMMs as co-tenants of the recurrence: the three-stage one-per-CU form (default), or the two-stage form padded to one per CU
-    static const int solo = []() { const char* e = getenv("STT_AMD_DENSE_SOLO"); return e ? atoi(e) : 1; }();
-    d.solo = solo && lstm_passes >= 2; d.lds_floor = d.solo ? 0 : dense_lds_floor();  // (96 KiB beside the one-pass step's 66 would not fit)
+    static const int solo = []() { const char* e = getenv("STT_AMD_DENSE_SOLO"); return e ? atoi(e) : 2; }();  // 2: eight waves, 1: four, 0: padded two-stage form
+    d.solo = lstm_passes >= 2 ? solo : 0; d.lds_floor = d.solo ? 0 : dense_lds_floor();  // (96 KiB beside the one-pass step's 66 would not fit)
   }
   stt_prof_mark_on(this, 1, 0, stream);
   d.wt = w1t.as<_Float16>(); d.x = ws_x1.as<_Float16>(); d.bias = b1.as<float>(); d.y = ws_a.p; d.N = H; d.K = g.k1_pad(); d.ldx = g.k1_pad(); d.ldy = H;

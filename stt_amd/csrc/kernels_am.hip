@@ -149,9 +149,14 @@ typedef __attribute__((address_space(1))) const void gvoid_c;
 // other's landing latency); 3 = two tiles in flight with a counted vmcnt and a raw s_barrier (a __syncthreads() would drain
 // the DMA queue) -- the shape for ONE workgroup per CU beside a recurrent-step workgroup (engine.cpp): 96 KiB of LDS, and the
 // K-tile cadence no longer waits for a full HBM/L2 round trip.  Same k order: bit-identical results.
-template <int EPI, int T, int NS>
-__global__ __launch_bounds__(T * T * 64) void dense_kernel(DenseArgs a) {
-  constexpr int BM = 64 * T, BN = 64 * T, NTHR = T * T * 64;
+// W8: the 128-square tile on EIGHT waves (T = 2 only): wave tile 64 features x 32 rows, two waves per SIMD that hide each
+// other's LDS and DMA latency where the four-wave solo form has nobody to switch to, <= 128 registers (launch bound) so that
+// two of them fit on a SIMD beside a recurrent-step wave (240).  Same k order per output element: bit-identical.
+template <int EPI, int T, int NS, bool W8>
+__global__ __launch_bounds__(W8 ? 512 : T * T * 64, W8 ? 4 : 1) void dense_kernel(DenseArgs a) {
+  constexpr int BM = 64 * T, BN = 64 * T, NTHR = W8 ? 512 : T * T * 64;
+  constexpr int MJ = W8 ? 2 : 4;                 // 16-row X sub-tiles per wave
+  static_assert(!W8 || T == 2, "the eight-wave form is the 128-square tile");
   constexpr int TILE_BYTES = BM * GT_BK * 2;     // one operand tile (BM == BN): rows of 128 bytes
   constexpr int RPI = NTHR / 8;                  // rows staged per DMA instruction of the whole workgroup
   constexpr int IT = BM / RPI;                   // DMA instructions per thread, operand and stage (4 for both shapes' ... see below)
@@ -160,7 +165,8 @@ __global__ __launch_bounds__(T * T * 64) void dense_kernel(DenseArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wn = wave / T, wm = wave % T;
+  const int wn = W8 ? (wave >> 2) : wave / T, wm = W8 ? (wave & 3) : wave % T;
+  const int wm_off = W8 ? wm * 32 : wm * 64;  // this wave's first X row inside the tile
   // XCD-aware tile order.  Workgroup ids go round-robin over the 8 XCDs (id % 8), each with its own 4 MiB L2 that the
   // others cannot see, so an XCD that sweeps an M-band against ALL of N re-streams the whole weight matrix once per
   // M-tile (measured in round 1: 7.8x the algorithmic fetch on the 2048 -> 8192 projection).  Instead the tile grid is
@@ -192,11 +198,11 @@ __global__ __launch_bounds__(T * T * 64) void dense_kernel(DenseArgs a) {
   const int n0 = tile_n * BN, m0 = tile_m * BM;
   const int K = a.K;
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][MJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // DMA sources: chunk q = i*NTHR + tid of a tile is LDS bytes [16q, 16q+16) = row q>>3, slot q&7 = K-chunk (q&7) ^ (row&7)
   const int srow = tid >> 3;                       // rows srow + RPI*i
@@ -223,12 +229,16 @@ __global__ __launch_bounds__(T * T * 64) void dense_kernel(DenseArgs a) {
 
   // fragment read offsets (bytes inside an operand tile): row * 128 + ((chunk ^ (row & 7)) << 4), chunk = ks*4 + (lane>>4)
   const int frow = lane & 15, fq = lane >> 4;
-  unsigned offw[4], offx[4];
+  unsigned offw[4], offx[MJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int rw = wn * 64 + i * 16 + frow, rx = wm * 64 + i * 16 + frow;
+    const int rw = wn * 64 + i * 16 + frow;
     offw[i] = (unsigned)rw * 128u + (unsigned)((fq ^ (rw & 7)) << 4);
-    offx[i] = (unsigned)rx * 128u + (unsigned)((fq ^ (rx & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    const int rx = wm_off + j * 16 + frow;
+    offx[j] = (unsigned)rx * 128u + (unsigned)((fq ^ (rx & 7)) << 4);
   }
   const int nk = K / GT_BK;
   STAGE(0, 0);
@@ -252,17 +262,16 @@ __global__ __launch_bounds__(T * T * 64) void dense_kernel(DenseArgs a) {
     const lds_u8* const bx = bw + TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      f16x8 fa[4], fb[4];
+      f16x8 fa[4], fb[MJ];
       // chunk ks*4 + fq: the slot index flips bit 2 for ks = 1 -> byte offset ^ 64
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(bw + (offw[i] ^ (unsigned)(ks << 6)));
-        fb[i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(bx + (offx[i] ^ (unsigned)(ks << 6)));
-      }
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(bw + (offw[i] ^ (unsigned)(ks << 6)));
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) fb[j] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(bx + (offx[j] ^ (unsigned)(ks << 6)));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if (NS == 2) {
       __syncthreads();  // tile kt+1 has landed; every wave is done reading tile kt (its buffer is restaged next iteration)
@@ -279,8 +288,8 @@ __global__ __launch_bounds__(T * T * 64) void dense_kernel(DenseArgs a) {
     const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
     const float4 bias = *reinterpret_cast<const float4*>(a.bias + n);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+    for (int j = 0; j < MJ; ++j) {
+      const int m = m0 + wm_off + j * 16 + (lane & 15);
       if (m >= a.M) continue;
       float v0 = acc[i][j][0] + bias.x, v1 = acc[i][j][1] + bias.y, v2 = acc[i][j][2] + bias.z, v3 = acc[i][j][3] + bias.w;
       if (EPI == DENSE_EPI_RELU_F16) {
@@ -363,13 +372,20 @@ __device__ __forceinline__ float tanhf_(float x) {
   return copysignf(t, x);
 }
 
+// c' = sigmoid(f) * c + sigmoid(i) * tanh(j) with the roundings pinned: one product rounded, the other fused into the sum.  Left to
+// the compiler's contraction the choice of WHICH product is fused follows the schedule of each instantiation, and a row
+// decoded alone (one batch tile), in a 17-batch (two) and in the 64-batch (four; owner form) must give the same bits.
+__device__ __forceinline__ float lstm_cell_(float zf, float c, float zi, float zj) {
+  return __fmaf_rn(sigmoidf_(zf), c, __fmul_rn(sigmoidf_(zi), tanhf_(zj)));
+}
+
 // G = k-steps per prefetch group (two groups of weight / h fragments are in flight), MT = 16-row gate tiles per workgroup:
 // MT = 2: 8 hidden units per workgroup, 256 workgroups (round 1); MT = 4: 16 units, 128 workgroups, each gate one tile.
 // Every workgroup reads ALL of h (2 * H * 64 bytes at 64 batch rows = 256 KiB) besides its slice of the recurrent matrix, so
 // with 256 workgroups the h re-reads (64 MiB per step) outweigh the weights (33.5 MiB); 128 workgroups halve them, and a
 // workgroup then has a CU to itself (64 KiB reduction buffer, ~230 VGPRs: one wave per SIMD).
 template <int NT, int G_, int MT, int PHS>
-__global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
+__global__ __launch_bounds__(256, 2) void lstm_step_kernel(LstmArgs a) {  // (<= 256 registers per lane: 234 instead of 170 + 96 AGPRs, which leaves two 128-register GEMM waves per SIMD beside it)
   constexpr bool PF = G_ > 0;
   constexpr int UPW = MT * 4;  // hidden units per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
@@ -493,9 +509,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float zi = z[0][r] + (&oxv[0].x)[r], zj = z[1][r] + (&oxv[1].x)[r], zf = z[2][r] + (&oxv[2].x)[r], zo = z[3][r] + (&oxv[3].x)[r];
-      const float cn = sigmoidf_(zf) * (&ocv.x)[r] + sigmoidf_(zi) * tanhf_(zj);
+      const float cn = lstm_cell_(zf, (&ocv.x)[r], zi, zj);
       (&cn4.x)[r] = cn;
-      hv[r] = ob < B ? sigmoidf_(zo) * tanhf_(cn) : 0.0f;
+      hv[r] = ob < B ? __fmul_rn(sigmoidf_(zo), tanhf_(cn)) : 0.0f;
     }
     const int unit0 = wg * UPW + ou;
     if (ob < B) {
@@ -540,9 +556,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
       if (b < B) {
         const int unit = wg * UPW + u;
         const float zi = z[0] + xv[it][0], zj = z[1] + xv[it][1], zf = z[2] + xv[it][2], zo = z[3] + xv[it][3];
-        const float cn = sigmoidf_(zf) * cv[it] + sigmoidf_(zi) * tanhf_(zj);
+        const float cn = lstm_cell_(zf, cv[it], zi, zj);
         a.c[(size_t)b * H + unit] = cn;
-        hval = sigmoidf_(zo) * tanhf_(cn);
+        hval = __fmul_rn(sigmoidf_(zo), tanhf_(cn));
         if (a.h_f32) a.h_f32[(size_t)b * H + unit] = hval;
       }
       hout[b][u] = (_Float16)hval;
@@ -738,17 +754,17 @@ void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st) {
 void launch_context(const ContextArgs& a, int rows, hipStream_t st) {
   hipLaunchKernelGGL(context_kernel, dim3(rows), dim3(256), 0, st, a);
 }
-template <int EPI, int T, int NS>
+template <int EPI, int T, int NS, bool W8 = false>
 static void launch_dense_inst(const DenseArgs& b, int grid, hipStream_t st) {
   size_t smem = (size_t)2 * NS * (64 * T) * GT_BK * 2;  // stages x (W tile + X tile): 64 / 96 KiB (T = 2) or 128 KiB (T = 4)
   static std::once_flag once[16];
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::call_once(once[dev & 15], [&]() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_kernel<EPI, T, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_kernel<EPI, T, NS, W8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   if ((size_t)b.lds_floor > smem) smem = std::min<size_t>((size_t)b.lds_floor, 160 * 1024);
-  hipLaunchKernelGGL((dense_kernel<EPI, T, NS>), dim3(grid), dim3(T * T * 64), smem, st, b);
+  hipLaunchKernelGGL((dense_kernel<EPI, T, NS, W8>), dim3(grid), dim3(W8 ? 512 : T * T * 64), smem, st, b);
 }
 void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
   if (a.M <= 16 && a.K % 32 == 0 && a.N % 64 == 0) {
@@ -781,6 +797,9 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
   if (big) {
     if (epi == DENSE_EPI_RELU_F16) launch_dense_inst<DENSE_EPI_RELU_F16, 4, 2>(b, 8 * per_xcd, st);
     else launch_dense_inst<DENSE_EPI_BIAS_F32, 4, 2>(b, 8 * per_xcd, st);
+  } else if (a.solo >= 2) {
+    if (epi == DENSE_EPI_RELU_F16) launch_dense_inst<DENSE_EPI_RELU_F16, 2, 3, true>(b, 8 * per_xcd, st);
+    else launch_dense_inst<DENSE_EPI_BIAS_F32, 2, 3, true>(b, 8 * per_xcd, st);
   } else if (a.solo) {
     if (epi == DENSE_EPI_RELU_F16) launch_dense_inst<DENSE_EPI_RELU_F16, 2, 3>(b, 8 * per_xcd, st);
     else launch_dense_inst<DENSE_EPI_BIAS_F32, 2, 3>(b, 8 * per_xcd, st);

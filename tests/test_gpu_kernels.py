@@ -80,6 +80,28 @@ def test_dense_kernel(M, N, K, epi):
     assert err.max() < (2e-3 if epi == 0 else 1e-3), (err.max(), np.unravel_index(err.argmax(), err.shape))
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(300, 256, 512, 0), (129, 128, 2048, 1), (1024, 2048, 2048, 0), (3072, 512, 512, 1)])
+def test_dense_forms_beside_the_recurrence_are_bit_identical(M, N, K, epi, monkeypatch):
+    """The three-stage one-per-CU forms of the 128-square tile (four waves; eight waves) that the batch path runs beside the
+    recurrence give the bits of the ordinary two-stage form (same k order per output element)."""
+    rng = np.random.default_rng(7 * M + N + K)
+    x = rng.standard_normal((M, K)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float16).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    outs = []
+    for solo in ("0", "1", "2"):
+        monkeypatch.setenv("STT_AMD_TEST_DENSE_SOLO", solo)
+        monkeypatch.setenv("STT_AMD_DENSE_TILE", "128")
+        y = np.zeros((M, N), dtype=np.float32)
+        assert native.lib().STTX_TestDense(M, N, K, x.ctypes.data, w.ctypes.data, bias.ctypes.data, 20.0, epi, y.ctypes.data) == 0
+        outs.append(y)
+    ref = x.astype(np.float64) @ w.astype(np.float64) + bias
+    if epi == 0:
+        ref = np.minimum(np.maximum(ref, 0), 20.0)
+    assert (np.abs(outs[0] - ref) / (1 + np.abs(ref))).max() < 2e-3
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("n", [46797, 0, 100, 512, 832, 16000])
 def test_mfcc_kernel(small_model, n):
     model, _ = small_model
