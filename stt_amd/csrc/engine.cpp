@@ -150,10 +150,10 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
   ws_x1.reserve((size_t)M * g.k1_pad() * 2);
   ws_a.reserve((size_t)M * H * 2); ws_b.reserve((size_t)M * H * 2); ws_o.reserve((size_t)M * H * 2);
   am_xproj[slot].reserve((size_t)M * 4 * H * 4); am_hall[slot].reserve((size_t)M * H * 2);
-  ws_logits.reserve((size_t)M * g.c_pad() * 4);
+  am_logits.reserve((size_t)M * g.c_pad() * 4);
   const size_t hp_bytes = (size_t)(H / 32) * NT * 64 * 16;
-  ws_hp0.reserve(hp_bytes); ws_hp1.reserve(hp_bytes);
-  ws_c.reserve((size_t)B * H * 4);
+  am_hp0.reserve(hp_bytes); am_hp1.reserve(hp_bytes);
+  am_c.reserve((size_t)B * H * 4);
 
   // ---- engine 1 (`stream`): windows, layers 1-3, x-projection of this chunk into ring slot `slot`
   if (wrapped) HIP_CHECK(hipStreamWaitEvent(stream, ev_x_free[slot], 0));  // the recurrence of chunk seq - kAmRing has read the slot
@@ -180,24 +180,24 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
   stt_prof_mark_on(this, -1, 0, stream);
   HIP_CHECK(hipEventRecord(ev_x_ready[slot], stream));
 
-  // ---- engine 2 (`stream_l`): the recurrence; state carried in ws_c / ws_hp* from the previous chunk of the batch
+  // ---- engine 2 (`stream_l`): the recurrence; state carried in am_c / am_hp* from the previous chunk of the batch
   HIP_CHECK(hipStreamWaitEvent(stream_l, ev_x_ready[slot], 0));
   if (wrapped) HIP_CHECK(hipStreamWaitEvent(stream_l, ev_h_free[slot], 0));  // layer 5 of chunk seq - kAmRing has read the slot
   stt_prof_mark_on(this, 2, 5, stream_l);
-  void* hp_a = (t0 & 1) ? ws_hp1.p : ws_hp0.p;  // holds h_{t-1} for the first step of this chunk
+  void* hp_a = (t0 & 1) ? am_hp1.p : am_hp0.p;  // holds h_{t-1} for the first step of this chunk
   if (t0 == 0) {
-    HIP_CHECK(hipMemsetAsync(ws_c.p, 0, (size_t)B * H * 4, stream_l));
+    HIP_CHECK(hipMemsetAsync(am_c.p, 0, (size_t)B * H * 4, stream_l));
     HIP_CHECK(hipMemsetAsync(hp_a, 0, hp_bytes, stream_l));
   }
   LstmArgs l{};
-  l.whp = whp.as<_Float16>(); l.xproj = am_xproj[slot].as<float>(); l.c = ws_c.as<float>(); l.h_all = am_hall[slot].as<_Float16>();
+  l.whp = whp.as<_Float16>(); l.xproj = am_xproj[slot].as<float>(); l.c = am_c.as<float>(); l.h_all = am_hall[slot].as<_Float16>();
   l.n_hidden = H; l.batch = B; l.h_f32 = nullptr; l.passes = lstm_passes;
   { static const int pr = []() { const char* e = getenv("STT_AMD_LSTM_PRIO"); return e ? atoi(e) : 1; }(); l.prio = pr; }
   auto steps = [&]() {
     for (int t = 0; t < T; ++t) {
       const bool odd = ((t0 + t) & 1) != 0;
-      l.hp_in = odd ? ws_hp1.as<_Float16>() : ws_hp0.as<_Float16>();
-      l.hp_out = odd ? ws_hp0.as<_Float16>() : ws_hp1.as<_Float16>();
+      l.hp_in = odd ? am_hp1.as<_Float16>() : am_hp0.as<_Float16>();
+      l.hp_out = odd ? am_hp0.as<_Float16>() : am_hp1.as<_Float16>();
       l.t = t;
       launch_lstm_step(l, NT, stream_l);
     }
@@ -206,7 +206,7 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
   if (use_graph) {
     LstmGraphKey key;
     memset(&key, 0, sizeof(key));  // (padding bytes take part in the comparison)
-    key.xproj = am_xproj[slot].p; key.hall = am_hall[slot].p; key.c = ws_c.p; key.hp0 = ws_hp0.p; key.hp1 = ws_hp1.p; key.whp = whp.p;
+    key.xproj = am_xproj[slot].p; key.hall = am_hall[slot].p; key.c = am_c.p; key.hp0 = am_hp0.p; key.hp1 = am_hp1.p; key.whp = whp.p;
     key.T = T; key.par = t0 & 1; key.B = B; key.NT = NT; key.passes = l.passes; key.prio = l.prio; key.H = H; key.first = 0;
     auto found = lstm_graphs_.find(key);
     if (found == lstm_graphs_.end() && lstm_graphs_.size() >= 256) { steps(); goto recurrence_enqueued; }  // (ragged jobs: no unbounded cache)
@@ -214,10 +214,12 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
     if (!gr.exec && gr.seen++ >= 1) {  // second sighting: worth a graph (the first ran eagerly: module load, function attributes)
       hipGraph_t graph = nullptr;
       HIP_CHECK(hipStreamBeginCapture(stream_l, hipStreamCaptureModeRelaxed));
-      steps();
+      try { steps(); }
+      catch (...) { (void)hipStreamEndCapture(stream_l, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }  // never leave the stream capturing
       HIP_CHECK(hipStreamEndCapture(stream_l, &graph));
-      HIP_CHECK(hipGraphInstantiate(&gr.exec, graph, nullptr, nullptr, 0));
+      const hipError_t ie = hipGraphInstantiate(&gr.exec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
+      if (ie != hipSuccess) { gr.exec = nullptr; gr.seen = -(1 << 30); (void)hipGetLastError(); }  // this combination stays on plain launches
     }
     if (gr.exec) HIP_CHECK(hipGraphLaunch(gr.exec, stream_l));
     else steps();
@@ -235,10 +237,10 @@ recurrence_enqueued:
   launch_dense(d, DENSE_EPI_RELU_F16, stream_o);
   HIP_CHECK(hipEventRecord(ev_h_free[slot], stream_o));
   if (!launch_logits_softmax(ws_o.as<_Float16>(), w6t.as<_Float16>(), b6.as<float>(), probs_out, M, H, C, B, t_max, stream_o)) {
-    d.wt = w6t.as<_Float16>(); d.x = ws_o.as<_Float16>(); d.bias = b6.as<float>(); d.y = ws_logits.p; d.N = g.c_pad(); d.ldy = g.c_pad();
+    d.wt = w6t.as<_Float16>(); d.x = ws_o.as<_Float16>(); d.bias = b6.as<float>(); d.y = am_logits.p; d.N = g.c_pad(); d.ldy = g.c_pad();
     launch_dense(d, DENSE_EPI_BIAS_F32, stream_o);
     SoftmaxArgs sm{};
-    sm.logits = ws_logits.as<float>(); sm.probs = probs_out; sm.M = M; sm.C = C; sm.ldl = g.c_pad(); sm.batch = B; sm.t_max = t_max;
+    sm.logits = am_logits.as<float>(); sm.probs = probs_out; sm.M = M; sm.C = C; sm.ldl = g.c_pad(); sm.batch = B; sm.t_max = t_max;
     launch_softmax(sm, stream_o);
   }
   stt_prof_mark_on(this, -1, 6, stream_o);

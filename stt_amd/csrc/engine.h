@@ -229,6 +229,8 @@ struct ModelState {
   static constexpr int kAmRing = 3;
   hipStream_t stream_l = nullptr, stream_o = nullptr;
   DevBuf am_xproj[kAmRing], am_hall[kAmRing], ws_o;
+  DevBuf am_c, am_hp0, am_hp1, am_logits;  // the recurrence's own state / the output engine's own logits: stream_l and stream_o never touch
+                                           // what the one-stream paths (streaming API, blocking calls) use on `stream`
   hipEvent_t ev_x_ready[kAmRing] = {}, ev_x_free[kAmRing] = {}, ev_h_ready[kAmRing] = {}, ev_h_free[kAmRing] = {};
   unsigned long long am_seq = 0;  // chunks sent through the pipe so far (slot = am_seq % kAmRing)
   // The recurrence of a chunk is T dependent launches whose arguments only depend on (ring slot, T, parity of t0, batch): the
