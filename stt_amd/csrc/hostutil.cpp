@@ -16,6 +16,9 @@ void DevBuf::reserve(size_t bytes, bool keep, hipStream_t st) {
       HIP_CHECK(hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st));
       HIP_CHECK(hipStreamSynchronize(st));
     }
+    // Growing a live buffer: engines on other streams (the batch path runs three acoustic streams and up to four search streams) may
+    // still be reading the old allocation.  hipFree waits for the device in practice; say so explicitly rather than rely on it.
+    HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipFree(p));
   }
   p = np;
@@ -23,7 +26,7 @@ void DevBuf::reserve(size_t bytes, bool keep, hipStream_t st) {
 }
 void PinnedBuf::reserve(size_t bytes) {
   if (bytes <= cap && p) return;
-  if (p) HIP_CHECK(hipHostFree(p));
+  if (p) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipHostFree(p)); }  // (a copy kernel may still be moving the old block)
   p = nullptr;
   cap = bytes + bytes / 4 + 256;
   HIP_CHECK(hipHostMalloc(&p, cap, hipHostMallocDefault));
