@@ -45,11 +45,13 @@ STTX_EXPORT char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* a
                                                const unsigned int* aBufferSizes, unsigned int aBatch);
 /* The same path as a pipeline driven by the caller (the reference's harness keeps its workers busy the same way:
  * evaluate_export.py:65-80 feeds a queue while results are collected).  Submit enqueues one batch of 1..64 utterances
- * (audio resident in HBM, as above) and returns a ticket >= 0 without waiting (negative: -STT_ERR_*); at most
- * STTX_BatchPipelineDepth() batches (2 unless STT_AMD_PIPELINE says otherwise; 1..4) may be in flight.  Collect waits for
- * that batch and returns its aCount transcripts (STTX_FreeStrings) in the order submitted, or NULL on failure.  The
- * acoustic models of the batches in flight run one after the other, each batch's beam search beside the acoustic model
- * and the searches of its neighbours. */
+ * (audio resident in HBM, as above; the array must stay valid until the batch is collected) and returns a ticket >= 0 without
+ * waiting (negative: -STT_ERR_*); at most STTX_BatchPipelineDepthFor() batches may be in flight.  Collect waits for that batch
+ * and returns its aCount transcripts (STTX_FreeStrings) in the order submitted, or NULL on failure.  The acoustic models of
+ * the groups in flight run one after the other, each group's beam search beside the acoustic model and the searches of its
+ * neighbours.  Where the recurrent kernel covers 128 rows, two consecutive submits form ONE group (the recurrent matrix is
+ * streamed once per step for both): the first of the two is enqueued together with the second -- or alone, when it is collected
+ * first.  Transcripts never depend on how batches were grouped. */
 STTX_EXPORT int STTX_BatchPipelineDepth(void);
 /* ... for THIS model as configured now: a search-bound setup (code-point scorer, beam width beyond 512) takes four slots and
  * runs their searches side by side, everything else two. */
@@ -57,6 +59,20 @@ STTX_EXPORT int STTX_BatchPipelineDepthFor(ModelState* aCtx);
 STTX_EXPORT int STTX_BatchSubmitDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride,
                                        const unsigned int* aBufferSizes, unsigned int aBatch);
 STTX_EXPORT char** STTX_BatchCollect(ModelState* aCtx, int aTicket, unsigned int* aCount);
+/* Debug / parity hook: the acoustic probabilities of a submitted, not yet collected batch exactly as the pipelined path computed
+ * them (three engines, graph-replayed recurrence, ring slots, 64 or 128 rows per recurrent step) -- the block that batch's beam
+ * search reads; stands in for the `logits` output of TFLiteModelState::infer (tflitemodelstate.cc:369-405) over the whole
+ * utterance.  aProbs [aBatch][aMaxFrames][n_classes], aNumFrames[i] = frames of utterance i.  Waits for the batch. */
+STTX_EXPORT int STTX_DebugBatchProbs(ModelState* aCtx, int aTicket, float* aProbs, unsigned int aMaxFrames, unsigned int* aNumFrames);
+/* The engine's tunables (stt_amd/csrc/tuning.h: one table, every entry with a measured default; none changes results).  Set them
+ * between calls, with nothing in flight; STT_AMD_TUNING="name=value,..." seeds the table when the library is first used.
+ * Returns STT_ERR_INVALID_SHAPE for an unknown name. */
+STTX_EXPORT int STTX_SetTuning(const char* aName, int aValue);
+STTX_EXPORT int STTX_GetTuning(const char* aName, int* aValue);
+/* Call once BEFORE the process makes its first HIP call (before STT_CreateModel): asks the HIP runtime for 8 hardware queues
+ * (GPU_MAX_HW_QUEUES, unless the caller set it), so that the batch path's streams do not share queues.  Without it everything
+ * still works; streams that share a queue run one after the other. */
+STTX_EXPORT void STTX_ConfigureRuntime(void);
 STTX_EXPORT void STTX_FreeStrings(char** aStrings, unsigned int aCount);
 STTX_EXPORT void STTX_FreeMetadataArray(Metadata** aMetadata, unsigned int aCount);
 
@@ -160,6 +176,13 @@ STTX_EXPORT int STTX_ReadModelTensor(const char* aModelBuffer, unsigned int aBuf
  * ReLU (y rounded to f16, returned as f32), 1 = bias only (f32). */
 STTX_EXPORT int STTX_TestDense(int aM, int aN, int aK, const float* aX, const float* aW, const float* aBias, float aClip,
                               int aEpilogue, float* aY);
+/* The recurrent step kernel alone (deepspeech_model.py:144-168, one LSTMCell step per launch) on the model's packed recurrent
+ * matrix: aSteps steps from a zero state, step t adding x-projection block t % aPeriod (aXproj [aPeriod * aBatch][4 * n_hidden] f32,
+ * row = block * aBatch + b).  aC, aH [aBatch][n_hidden]: the final state; aHAll (may be NULL) [aPeriod * aBatch][n_hidden] f16 bits:
+ * h of the last aPeriod steps.  aGraph != 0: the launches are captured into one hipGraph and replayed (as the batch path does).
+ * The kernel form is chosen with STTX_SetTuning("lstm_form" / "lstm_prefetch"); every form must give the same bits. */
+STTX_EXPORT int STTX_TestLstmSteps(ModelState* aCtx, unsigned int aBatch, unsigned int aSteps, unsigned int aPeriod, int aGraph,
+                                  const float* aXproj, float* aC, float* aH, unsigned short* aHAll);
 /* Device expf/logf/log_sum_exp of sttmath.h over arrays (aOp 0 = expf, 1 = logf, 2 = log_sum_exp(a, b)). */
 STTX_EXPORT int STTX_TestMath(int aOp, const float* aA, const float* aB, float* aOut, unsigned int aCount);
 /* KenLM FullScore (kenlm/lm/model.cc:170-176) over aNumWords words, the state carried from BeginSentence (aBos) or the null

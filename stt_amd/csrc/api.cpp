@@ -13,13 +13,7 @@
 #include "../../include/stt_amd.h"
 #include "engine.h"
 #include "scorer_host.h"
-
-// The batch path runs on up to eight HIP streams (three acoustic engines, four group slots' searches, the caller's own).  The
-// HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that share a queue run
-// one after the other -- a group's output layers behind another group's 0.8 ms search launch.  Ask for 8 unless the
-// caller decided otherwise; this runs when the library is loaded, i.e. before the runtime reads its flags at the first HIP
-// call of a process that did not use HIP before (a process that did keeps its setting: nothing breaks, streams just share).
-__attribute__((constructor)) static void stt_amd_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+#include "tuning.h"
 
 namespace {
 int g_device = 0;
@@ -45,9 +39,9 @@ void mark_on(ModelState* m, int id, int which, hipStream_t st) {
 void mark(ModelState* m, int id) { mark_on(m, id, 0, m->stream); }
 void prof_reset(Prof& p) { p.used = 0; for (auto& mk : p.marks) mk.clear(); }
 void prof_collect(Prof& p) {  // every stream must be idle
-  // STT_AMD_DUMP_MARKS=1: the raw timeline (stream list, stage id, microseconds since the first mark of the acoustic stream) on
+  // tunable dump_marks: the raw timeline (stream list, stage id, microseconds since the first mark of the acoustic stream) on
   // stderr -- what ran beside what, without a tracer's overhead on the host
-  static const bool dump = []() { const char* e = getenv("STT_AMD_DUMP_MARKS"); return e && atoi(e) != 0; }();
+  const bool dump = tune().dump_marks != 0;
   if (dump && !p.marks[0].empty()) {
     hipEvent_t base = p.marks[0][0].second;
     for (int w = 0; w < 7; ++w)
@@ -113,12 +107,14 @@ Metadata* with_emissions(const StreamingState* s, Metadata* m) {
   return ret;
 }
 
-char* decode_string(const StreamingState* s) {  // ModelState::decode, modelstate.cc:32-37
+char* decode_string(const StreamingState* cs) {  // ModelState::decode, modelstate.cc:32-37
+  StreamingState* s = const_cast<StreamingState*>(cs);  // (workspaces and the uploaded hot-word table only)
   std::vector<Output> out = s->decode(1);
   if (out.empty()) return strdup("");
   return strdup(s->model_->alphabet_.Decode(out[0].tokens.data(), (int)out[0].tokens.size()).c_str());
 }
-Metadata* decode_metadata(const StreamingState* s, unsigned n) {
+Metadata* decode_metadata(const StreamingState* cs, unsigned n) {
+  StreamingState* s = const_cast<StreamingState*>(cs);
   Metadata* m = make_metadata(s->model_, s->decode(n));
   return s->keep_emissions_ ? with_emissions(s, m) : m;
 }
@@ -149,55 +145,59 @@ int create_stream(ModelState* aCtx, StreamingState** retval, bool keep_emissions
 }
 
 // ---- batch path: every utterance goes through exactly the arithmetic of STT_SpeechToText ---------------------
-// Groups of <= 64 utterances.  Within a group the acoustic model runs in time-chunks on `stream` and the beam search of
+// Groups of <= 64 utterances, or <= 128 where the recurrent kernel covers 128 rows (tunable `pair`): the 33.5 MB recurrent matrix is
+// then streamed once per 128 rows.  Within a group the acoustic model runs in time-chunks on `stream` and the beam search of
 // chunk k runs on the group's search stream while chunk k+1 is being computed (the search only occupies one workgroup per
-// utterance).  Chunk schedule of a blocking call (latency of ONE group matters): a short first chunk (STT_AMD_CHUNK0,
-// default 16 frames) so the beam search starts early, then chunks of STT_AMD_CHUNK (default 48) frames;
-// STT_AMD_CHUNKS="16,24,40" gives the first chunks explicitly.  A group submitted to the caller-driven pipeline
-// (STTX_BatchSubmitDevice: other groups fill the chip meanwhile) takes longer chunks -- fewer, better-shaped GEMMs and
-// fewer search launches: STT_AMD_PCHUNK0 / STT_AMD_PCHUNK / STT_AMD_PCHUNKS.
-struct ChunkPlan { int first, rest; std::vector<int> lead; };
-ChunkPlan read_chunk_plan(const char* e0, const char* e, const char* el, int d0, int d) {
-  ChunkPlan c{d0, d, {}};
-  if (const char* v = getenv(e0)) c.first = atoi(v);
-  if (const char* v = getenv(e)) c.rest = atoi(v);
+// utterance).  Chunk schedule of a blocking call (latency of ONE group matters): a short first chunk (tunable chunk0,
+// default 16 frames) so the beam search starts early, then chunks of `chunk` (48) frames.  A group submitted to the caller-driven
+// pipeline (STTX_BatchSubmitDevice: other groups fill the chip meanwhile) takes pchunk0 / pchunk.
+struct ChunkPlan { int first, rest; };
+ChunkPlan chunk_plan(bool pipelined) {
+  ChunkPlan c{pipelined ? tune().pchunk0 : tune().chunk0, pipelined ? tune().pchunk : tune().chunk};
   if (c.rest < 1) c.rest = 1 << 30;
   if (c.first < 1) c.first = 1 << 30;
-  if (const char* v = getenv(el)) { std::stringstream ss(v); std::string tok; while (std::getline(ss, tok, ',')) { const int x = atoi(tok.c_str()); if (x > 0) c.lead.push_back(x); } }
   return c;
 }
-const ChunkPlan& chunk_plan(bool pipelined) {
-  static const ChunkPlan blocking = read_chunk_plan("STT_AMD_CHUNK0", "STT_AMD_CHUNK", "STT_AMD_CHUNKS", 16, 48);
-  static const ChunkPlan piped = read_chunk_plan("STT_AMD_PCHUNK0", "STT_AMD_PCHUNK", "STT_AMD_PCHUNKS", 16, 48);
-  return pipelined ? piped : blocking;
-}
+// One batch handed to a group: rows idx[] of the caller's [.][stride] int16 array.  A group takes one part (blocking calls) or
+// two (two submitted batches advanced together).
+struct BatchPart {
+  const int16_t* d_audio;
+  unsigned stride;
+  const unsigned* sizes;
+  std::vector<unsigned> idx;
+};
 // Enqueue everything one group needs, on both streams, without waiting for anything: features + acoustic chunks on
 // `stream`, the beam search of every chunk + the final ranking + the copy of the results to page-locked memory on
 // `stream_dec`, then the slot's `done` event.
-void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t* d_audio, unsigned stride, const unsigned* sizes,
-                         const std::vector<unsigned>& idx, unsigned num_results, const DevScorer& ds, bool pipelined, hipEvent_t gate = nullptr) {
-  const int Bg = (int)idx.size();
+void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::vector<BatchPart>& parts, unsigned num_results, const DevScorer& ds,
+                         bool pipelined, hipEvent_t gate = nullptr) {
+  int Bg = 0;
+  for (const BatchPart& pt : parts) Bg += (int)pt.idx.size();
   if (gate) HIP_CHECK(hipStreamWaitEvent(sl.stream_dec, gate, 0));  // this group's SEARCH starts behind group g - active; its acoustic model does not wait
   const int which = 1 + (int)(&sl - &m->slots_[0]);  // profiling mark list of this group's search stream
+  // small integer tables in one page-locked block: [n_samples | n_frames | audio row | per chunk: begin, count]
+  std::vector<int> ns(Bg), nf(Bg), row(Bg);
   int t_max = 1;
-  for (int b = 0; b < Bg; ++b) t_max = std::max(t_max, n_frames_for(m->g, (int)sizes[idx[b]]));
+  {
+    int b = 0;
+    for (const BatchPart& pt : parts)
+      for (unsigned i : pt.idx) { ns[b] = (int)pt.sizes[i]; nf[b] = n_frames_for(m->g, ns[b]); row[b] = (int)i; t_max = std::max(t_max, nf[b]); ++b; }
+  }
   std::vector<int> cb;  // chunk boundaries
   {
-    const ChunkPlan& cp = chunk_plan(pipelined);
+    const ChunkPlan cp = chunk_plan(pipelined);
     for (int t = 0, k = 0; t < t_max; ++k) {
       cb.push_back(t);
-      if (!cp.lead.empty()) t += k < (int)cp.lead.size() ? cp.lead[k] : cp.rest;
-      else t += (k == 0) ? std::min(cp.first, cp.rest) : cp.rest;
+      t += (k == 0) ? std::min(cp.first, cp.rest) : cp.rest;
     }
   }
   cb.push_back(t_max);
   const int n_chunks = (int)cb.size() - 1;
-  // small integer tables in one page-locked block: [n_samples | n_frames | audio row | per chunk: begin, count]
   const size_t n_ints = (size_t)(3 + 2 * n_chunks) * Bg;
   sl.h_ints.reserve(n_ints * 4); sl.ints.reserve(n_ints * 4);
   int* hi = sl.h_ints.as<int>();
   int *h_ns = hi, *h_nf = hi + Bg, *h_row = hi + 2 * Bg, *h_tab = hi + 3 * Bg;
-  for (int b = 0; b < Bg; ++b) { h_ns[b] = (int)sizes[idx[b]]; h_nf[b] = n_frames_for(m->g, h_ns[b]); h_row[b] = (int)idx[b]; }
+  for (int b = 0; b < Bg; ++b) { h_ns[b] = ns[b]; h_nf[b] = nf[b]; h_row[b] = row[b]; }
   for (int k = 0; k < n_chunks; ++k)
     for (int b = 0; b < Bg; ++b) {
       h_tab[(size_t)(2 * k) * Bg + b] = cb[k];
@@ -205,14 +205,23 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
     }
   copy_h2d(sl.ints.p, sl.h_ints, n_ints * 4, m->stream);
   const int* d_ns = sl.ints.as<int>(); const int* d_nf = d_ns + Bg; const int* d_row = d_ns + 2 * Bg; const int* d_tab = d_ns + 3 * Bg;
-  sl.Bg = Bg; sl.t_max = t_max; sl.idx = idx;
-  // features
+  sl.Bg = Bg; sl.t_max = t_max;
+  sl.idx.clear();
+  for (const BatchPart& pt : parts) sl.idx.insert(sl.idx.end(), pt.idx.begin(), pt.idx.end());
+  // features: one launch per part (each part has its own audio array), all into the group's [Bg][t_max][n_input] block
   mark(m, 0);
   m->ws_feats.reserve((size_t)Bg * t_max * m->g.n_input * 4);
-  MfccArgs fa = m->mfcc_args();
-  fa.audio = d_audio; fa.rows = d_row; fa.n_samples = d_ns; fa.n_frames = d_nf;
-  fa.feats = m->ws_feats.as<float>(); fa.n_max = (int)stride; fa.t_max = t_max;
-  launch_mfcc(fa, Bg * t_max, m->stream);
+  {
+    int off = 0;
+    for (const BatchPart& pt : parts) {
+      const int Bp = (int)pt.idx.size();
+      MfccArgs fa = m->mfcc_args();
+      fa.audio = pt.d_audio; fa.rows = d_row + off; fa.n_samples = d_ns + off; fa.n_frames = d_nf + off;
+      fa.feats = m->ws_feats.as<float>() + (size_t)off * t_max * m->g.n_input; fa.n_max = (int)pt.stride; fa.t_max = t_max;
+      if (Bp) launch_mfcc(fa, Bp * t_max, m->stream);
+      off += Bp;
+    }
+  }
   // decoder streams of the group
   m->decoder_create(sl.dec, Bg, (int)m->beam_width_, t_max, m->scorer_, &sl.h_table);
   sl.probs.reserve((size_t)Bg * t_max * m->g.n_classes * 4);
@@ -256,16 +265,18 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const int16_t
   launch_ctc_decode(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, o, sl.stream_dec);
   copy_d2h(sl.h_out, sl.out.p, sl.out_layout.bytes, sl.stream_dec);  // all results, one block
   mark_on(m, -1, which, sl.stream_dec);
-  if (prof_of(m).on) {  // the search counters ride behind the results (no extra synchronisation when they are read)
+  sl.prof_enqueued = prof_of(m).on; sl.prof_stamp_bytes = 0;
+  if (sl.prof_enqueued) {  // the search counters ride behind the results (no extra synchronisation when they are read)
     const size_t tb = sizeof(DecStream) * (size_t)Bg, sb = p.stamps ? (size_t)Bg * 64 * 8 : 0;
     sl.h_prof.reserve(tb + sb);
     copy_d2h(sl.h_prof, sl.dec.table.p, tb, sl.stream_dec);
     if (sb) copy_d2h(sl.h_prof, sl.stamps.p, sb, sl.stream_dec, tb);
+    sl.prof_stamp_bytes = sb;
   }
   HIP_CHECK(hipEventRecord(sl.done, sl.stream_dec));
 }
 
-// Wait for a group and turn its page-locked result block into Output lists (scattered to the caller's utterance order).
+// Wait for a group and turn its page-locked result block into Output lists: all[idx[i]] = results of the group's stream i.
 void batch_collect_group(ModelState* m, ModelState::GroupSlot& sl, std::vector<std::vector<Output>>& all, Prof& pr) {
   HIP_CHECK(hipEventSynchronize(sl.done));
   const DecodeOut h = sl.out_layout.view(sl.h_out.p, sl.nr, sl.max_len);
@@ -288,11 +299,11 @@ void batch_collect_group(ModelState* m, ModelState::GroupSlot& sl, std::vector<s
       dst.push_back(std::move(ou));
     }
   }
-  if (pr.on) {
+  if (pr.on && sl.prof_enqueued) {  // (only what was enqueued with profiling on carries a profiling block)
     pr.ms[6] += (float)sl.t_max; pr.ms[7] += (float)sl.t_max * sl.Bg;
     const DecStream* tb = sl.h_prof.as<DecStream>();
     for (int i = 0; i < sl.Bg; ++i) { for (int k = 0; k < 4; ++k) pr.dec_stats[k] += tb[i].stat[k]; for (int k = 0; k < 8; ++k) pr.dec_phase[k] += tb[i].phase[k]; }
-    if (pr.phase_cycles && sl.stamps.p) {
+    if (sl.prof_stamp_bytes) {
       const unsigned long long* st = reinterpret_cast<const unsigned long long*>((const char*)sl.h_prof.p + sizeof(DecStream) * (size_t)sl.Bg);
       for (int i = 0; i < sl.Bg; ++i) for (int k = 0; k < 64; ++k) pr.dec_stamps[k] += st[(size_t)i * 64 + k];
     }
@@ -305,6 +316,10 @@ void sync_acoustic_streams(ModelState* m, bool check) {
     if (check) HIP_CHECK(hipStreamSynchronize(st)); else (void)hipStreamSynchronize(st);
   }
 }
+void sync_everything(ModelState* m) {  // failure path: nothing of a call may still run on the slots' buffers when the caller sees the error
+  sync_acoustic_streams(m, false);
+  for (auto& sl : m->slots_) if (sl.stream_dec) (void)hipStreamSynchronize(sl.stream_dec);
+}
 void batch_init_slots(ModelState* m) {
   if (m->ev_chunk[0]) return;
   for (auto& e : m->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -312,58 +327,66 @@ void batch_init_slots(ModelState* m) {
   m->slots_[0].stream_dec = m->stream_dec;
   for (int i = 1; i < ModelState::kSlots; ++i) HIP_CHECK(hipStreamCreateWithFlags(&m->slots_[i].stream_dec, hipStreamNonBlocking));
 }
-// Groups in flight (STT_AMD_PIPELINE, 1..kSlots; default 2).  With more slots than STT_AMD_ACTIVE (default 2) the beam search of
+// Group slots in flight (tunable `pipeline`, 1..kSlots; default 2).  With more slots than `active` (default 2) the beam search of
 // group g starts behind the `done` event of group g - active while its acoustic model starts as soon as the previous group's
 // has finished: the recurrence -- the longest dependent chain of a batch -- then runs back to back across batches while at
-// most `active` searches (64 compute units each) run beside it.  Measured: with two slots 4.1-4.8 ms per
-// batch depending on the machine; three slots were never better (4.6-5.2 on quiet hosts, far worse on busy ones: the host
-// side of a batch is ~170 runtime calls, 1.2 ms on a quiet host and 2.5-5 ms on a busy one).
+// most `active` searches run beside it.  Measured: with two slots 4.1-4.8 ms per batch depending on the
+// machine; three slots were never better.
 // A search-bound setup -- code-point scorer or a beam beyond 512: the search of a batch takes 45+ ms on its 64 compute units, the
 // acoustic model 5 -- gets four slots and all four searches side by side (bytes workload: 24.7 -> 16.3 ms per batch); everything
-// else two and two (a third group crowds the recurrence).  STT_AMD_PIPELINE / STT_AMD_ACTIVE override both.
+// else two and two (a third group crowds the recurrence).
 bool search_bound(const ModelState* m) { return (m->scorer_ && m->scorer_->is_utf8) || m->beam_width_ > 512; }
 int active_groups(const ModelState* m) {
-  static const int v = []() { const char* e = getenv("STT_AMD_ACTIVE"); const int d = e ? atoi(e) : 0; return d < 0 ? 0 : d; }();
-  return v ? v : (search_bound(m) ? ModelState::kSlots : 2);
+  const int d = tune().active;
+  return d > 0 ? d : (search_bound(m) ? ModelState::kSlots : 2);
 }
-int pipeline_depth_env() {
-  static const int v = []() { const char* e = getenv("STT_AMD_PIPELINE"); const int d = e ? atoi(e) : 0; return d < 0 ? 0 : (d > ModelState::kSlots ? ModelState::kSlots : d); }();
-  return v;
+int pipeline_slots_cfg(const ModelState* m) {
+  const int d = tune().pipeline;
+  if (d > 0) return std::min(d, (int)ModelState::kSlots);
+  return m && search_bound(m) ? ModelState::kSlots : 2;
 }
-// (while batches are in flight the depth they were submitted under stays in force: ModelState::async_depth_)
-int pipeline_depth(const ModelState* m) {
-  if (m && m->async_any() && m->async_depth_ > 0) return m->async_depth_;
-  const int e = pipeline_depth_env();
-  return e ? e : (m && search_bound(m) ? ModelState::kSlots : 2);
+// Two submitted batches per slot (one recurrence over 128 rows) where the recurrent kernel covers them and the acoustic model is
+// what bounds the step (a search-bound setup gains nothing from it and wants its four slots' searches side by side).
+bool pairing_cfg(const ModelState* m) { return tune().pair != 0 && m && lstm_max_rows(m->g.n_hidden) >= 128 && !search_bound(m); }
+int group_rows(const ModelState* m) { return pairing_cfg(m) ? 128 : 64; }
+// (while batches are in flight the configuration they were submitted under stays in force: ModelState::async_depth_ / async_pair_)
+int pipeline_slots(const ModelState* m) { return (m && m->async_any() && m->async_depth_ > 0) ? m->async_depth_ : pipeline_slots_cfg(m); }
+bool pairing(const ModelState* m) { return (m && m->async_any() && m->async_depth_ > 0) ? m->async_pair_ : pairing_cfg(m); }
+int pipeline_depth(const ModelState* m) { return pipeline_slots(m) * (pairing(m) ? 2 : 1); }  // tickets the caller may hold
+
+void prof_begin(Prof& pr) {
+  for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; for (auto& x : pr.dec_stamps) x = 0;
+  prof_reset(pr);
 }
 
-// Utterances are taken longest first in groups of 64 (length-homogeneous groups: the LSTM runs every group to its longest
-// member), two groups in flight (see ModelState::GroupSlot).
+// Utterances are taken longest first in groups (length-homogeneous groups: the LSTM runs every group to its longest member),
+// several groups in flight (see ModelState::GroupSlot).
 std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio, unsigned stride, const unsigned* sizes, unsigned B, unsigned num_results) {
   std::vector<std::vector<Output>> all(B);
   HIP_CHECK(hipSetDevice(m->device));
   Prof& pr = prof_of(m);
-  if (pr.on) { for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; for (auto& x : pr.dec_stamps) x = 0; prof_reset(pr); }
   if (m->async_any()) throw std::runtime_error("a batch submitted with STTX_BatchSubmitDevice has not been collected yet");
+  if (pr.on) prof_begin(pr);
   batch_init_slots(m);
   std::vector<unsigned> order(B);
   for (unsigned i = 0; i < B; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return sizes[x] > sizes[y]; });
-  const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
-  const int depth = pipeline_depth(m);
+  const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->hot_tables_);
+  const int depth = pipeline_slots_cfg(m);
+  const unsigned R = B > 64 ? (unsigned)group_rows(m) : 64u;  // rows per group
   int oldest = 0, gi = 0;  // groups [oldest, gi) are in flight, group g in slot g % depth
   try {
-    for (unsigned g0 = 0; g0 < B; g0 += 64, ++gi) {
+    for (unsigned g0 = 0; g0 < B; g0 += R, ++gi) {
       if (gi - oldest == depth) { batch_collect_group(m, m->slots_[oldest % depth], all, pr); ++oldest; }
-      const std::vector<unsigned> idx(order.begin() + g0, order.begin() + std::min(B, g0 + 64));
+      std::vector<BatchPart> parts(1);
+      parts[0] = BatchPart{d_audio, stride, sizes, std::vector<unsigned>(order.begin() + g0, order.begin() + std::min(B, g0 + R))};
       const int act = active_groups(m);
       hipEvent_t gate = (act < depth && gi - act >= oldest) ? m->slots_[(gi - act) % depth].done : nullptr;
-      batch_enqueue_group(m, m->slots_[gi % depth], d_audio, stride, sizes, idx, num_results, ds, B > 64u * (unsigned)act, gate);
+      batch_enqueue_group(m, m->slots_[gi % depth], parts, num_results, ds, B > R * (unsigned)act, gate);
     }
     for (; oldest < gi; ++oldest) batch_collect_group(m, m->slots_[oldest % depth], all, pr);
-  } catch (...) {  // nothing of this call may still be running on the slots' buffers when the caller sees the failure
-    sync_acoustic_streams(m, false);
-    for (auto& sl : m->slots_) if (sl.stream_dec) (void)hipStreamSynchronize(sl.stream_dec);
+  } catch (...) {
+    sync_everything(m);
     if (pr.on) prof_reset(pr);
     throw;
   }
@@ -378,54 +401,123 @@ std::vector<std::vector<Output>> batch_run(ModelState* m, const int16_t* d_audio
 // The group slots as a caller-driven pipeline (STTX_BatchSubmitDevice / STTX_BatchCollect): a batch of <= 64 utterances
 // is enqueued without waiting, so the acoustic model of batch k+1 runs while the beam search of batch k finishes and the
 // host turns batch k-1's results into strings -- what batch_run() does between the groups of one call, across calls.
+// With pairing, the first batch of a pair is only noted; the caller's next submit sends both through the acoustic model as one
+// 128-row group (or the first one's collect sends it through alone).
+void submit_enqueue(ModelState* m, const std::vector<BatchPart>& parts, const int* tickets) {
+  const int depth = m->async_depth_;
+  const int slot = m->async_groups_ % depth;
+  ModelState::GroupSlot& sl = m->slots_[slot];
+  if (sl.busy()) throw std::runtime_error("the pipeline is full (STTX_BatchPipelineDepthFor batches in flight): collect the oldest one first");
+  const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->hot_tables_, /*in_flight=*/true);
+  hipEvent_t gate = nullptr;
+  {
+    const int act = active_groups(m), older = m->async_groups_ - act;
+    if (act < depth && older >= 0 && m->slots_[older % depth].busy()) gate = m->slots_[older % depth].done;
+  }
+  try { batch_enqueue_group(m, sl, parts, 1, ds, true, gate); }
+  catch (...) { sync_everything(m); throw; }  // half-enqueued work must not meet the next submit on the slot's buffers
+  sl.n_parts = (int)parts.size();
+  sl.part_begin[0] = 0;
+  for (int p = 0; p < sl.n_parts; ++p) {
+    sl.part_begin[p + 1] = sl.part_begin[p] + (int)parts[p].idx.size();
+    sl.part_ticket[p] = tickets[p]; sl.part_open[p] = true;
+  }
+  for (int i = 0; i < sl.Bg; ++i) sl.idx[i] = (unsigned)i;  // results by position in the group; collect cuts them by part
+  sl.results_ready = false; sl.results.clear();
+  ++m->async_groups_;
+}
 int batch_submit(ModelState* m, const int16_t* d_audio, unsigned stride, const unsigned* sizes, unsigned B) {
-  if (B == 0 || B > 64) throw std::runtime_error("STTX_BatchSubmitDevice takes 1..64 utterances (one group) per call");
+  if (B == 0 || B > 64) throw std::runtime_error("STTX_BatchSubmitDevice takes 1..64 utterances (one batch) per call");
   HIP_CHECK(hipSetDevice(m->device));
   batch_init_slots(m);
-  const int depth_now = pipeline_depth(m);
-  if (!m->async_any()) m->async_depth_ = depth_now;
-  const int slot = m->async_next_ % depth_now;
-  if (m->async_busy_[slot]) throw std::runtime_error("the pipeline is full (STTX_BatchPipelineDepth batches in flight): collect the oldest one first");
   Prof& pr = prof_of(m);
-  if (pr.on && !m->async_any()) {
-    for (float& x : pr.ms) x = 0; for (auto& x : pr.dec_stats) x = 0; for (auto& x : pr.dec_phase) x = 0; for (auto& x : pr.dec_stamps) x = 0;
-    prof_reset(pr);
+  if (!m->async_any()) {
+    m->retired_bufs_.clear();  // (the pipeline has drained: nothing reads a replaced hot-word table any more)
+    m->async_depth_ = pipeline_slots_cfg(m); m->async_pair_ = pairing_cfg(m); m->async_groups_ = 0;
+    if (pr.on) prof_begin(pr);
   }
   std::vector<unsigned> idx(B);
   for (unsigned i = 0; i < B; ++i) idx[i] = i;
-  const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->ws_hot_hash, m->ws_hot_boost);
-  hipEvent_t gate = nullptr;
-  {
-    const int depth = depth_now, act = active_groups(m), older = m->async_next_ - act;
-    if (act < depth && older >= 0 && m->async_busy_[older % depth] && m->async_ticket_[older % depth] == older) gate = m->slots_[older % depth].done;
+  if (m->async_pair_ && !m->pending_.valid) {  // first half of a pair: noted, not enqueued (its slot must be free already)
+    if (m->slots_[m->async_groups_ % m->async_depth_].busy())
+      throw std::runtime_error("the pipeline is full (STTX_BatchPipelineDepthFor batches in flight): collect the oldest one first");
+    m->pending_.valid = true; m->pending_.d_audio = d_audio; m->pending_.stride = stride;
+    m->pending_.sizes.assign(sizes, sizes + B); m->pending_.ticket = m->async_next_;
+    return m->async_next_++;
   }
-  batch_enqueue_group(m, m->slots_[slot], d_audio, stride, sizes, idx, 1, ds, true, gate);
-  m->async_busy_[slot] = true;
-  m->async_ticket_[slot] = m->async_next_;
+  std::vector<BatchPart> parts;
+  int tickets[2] = {-1, -1};
+  if (m->pending_.valid) {
+    std::vector<unsigned> pidx(m->pending_.sizes.size());
+    for (size_t i = 0; i < pidx.size(); ++i) pidx[i] = (unsigned)i;
+    parts.push_back(BatchPart{m->pending_.d_audio, m->pending_.stride, m->pending_.sizes.data(), pidx});
+    tickets[0] = m->pending_.ticket;
+  }
+  parts.push_back(BatchPart{d_audio, stride, sizes, idx});
+  tickets[parts.size() - 1] = m->async_next_;
+  submit_enqueue(m, parts, tickets);
+  m->pending_.valid = false;
   return m->async_next_++;
 }
+// the slot and part that hold `ticket` (enqueueing a noted first half alone if that is what the ticket names)
+ModelState::GroupSlot& slot_of_ticket(ModelState* m, int ticket, int& part) {
+  if (ticket >= 0 && m->pending_.valid && m->pending_.ticket == ticket) {
+    std::vector<unsigned> pidx(m->pending_.sizes.size());
+    for (size_t i = 0; i < pidx.size(); ++i) pidx[i] = (unsigned)i;
+    std::vector<BatchPart> parts{BatchPart{m->pending_.d_audio, m->pending_.stride, m->pending_.sizes.data(), pidx}};
+    const int tickets[2] = {ticket, -1};
+    submit_enqueue(m, parts, tickets);
+    m->pending_.valid = false;
+  }
+  if (ticket >= 0)
+    for (auto& sl : m->slots_)
+      for (int p = 0; p < sl.n_parts; ++p)
+        if (sl.part_open[p] && sl.part_ticket[p] == ticket) { part = p; return sl; }
+  throw std::runtime_error("no such batch in flight");
+}
 std::vector<std::vector<Output>> batch_collect(ModelState* m, int ticket) {
-  const int slot = ticket < 0 ? 0 : ticket % pipeline_depth(m);
-  if (ticket < 0 || !m->async_busy_[slot] || m->async_ticket_[slot] != ticket) throw std::runtime_error("STTX_BatchCollect: no such batch in flight");
   HIP_CHECK(hipSetDevice(m->device));
-  ModelState::GroupSlot& sl = m->slots_[slot];
+  int part = 0;
+  ModelState::GroupSlot& sl = slot_of_ticket(m, ticket, part);
   Prof& pr = prof_of(m);
-  std::vector<std::vector<Output>> all((size_t)sl.Bg);
-  m->async_busy_[slot] = false;
-  try { batch_collect_group(m, sl, all, pr); }
-  catch (...) {
-    sync_acoustic_streams(m, false);
-    for (auto& s2 : m->slots_) if (s2.stream_dec) (void)hipStreamSynchronize(s2.stream_dec);
-    for (bool& b : m->async_busy_) b = false;  // whatever else was in flight has finished; its results are dropped
+  sl.part_open[part] = false;
+  try {
+    if (!sl.results_ready) {
+      sl.results.assign((size_t)sl.Bg, {});
+      batch_collect_group(m, sl, sl.results, pr);
+      sl.results_ready = true;
+    }
+  } catch (...) {
+    sync_everything(m);
+    for (auto& s2 : m->slots_) { s2.part_open[0] = s2.part_open[1] = false; s2.results.clear(); s2.results_ready = false; }  // whatever else was in flight has finished; its results are dropped
+    m->pending_.valid = false;
     if (pr.on) prof_reset(pr);
     throw;
   }
+  std::vector<std::vector<Output>> out(sl.results.begin() + sl.part_begin[part], sl.results.begin() + sl.part_begin[part + 1]);
+  if (!sl.busy()) { sl.results.clear(); sl.results_ready = false; sl.n_parts = 0; }
   if (pr.on && !m->async_any()) {  // the pipeline has drained: every mark has been reached
     sync_acoustic_streams(m, true);
     for (auto& s2 : m->slots_) HIP_CHECK(hipStreamSynchronize(s2.stream_dec));
     prof_collect(pr);
   }
-  return all;
+  return out;
+}
+// Debug: the acoustic probabilities of a submitted batch exactly as the pipelined path computed them (three engines, graph-replayed
+// recurrence, ring slots, 64 or 128 rows per step) -- the block the group's beam search reads.  Before the batch is collected.
+void batch_probs(ModelState* m, int ticket, float* out, unsigned max_frames, unsigned* n_frames) {
+  HIP_CHECK(hipSetDevice(m->device));
+  int part = 0;
+  ModelState::GroupSlot& sl = slot_of_ticket(m, ticket, part);
+  HIP_CHECK(hipEventSynchronize(sl.done));
+  const int C = m->g.n_classes;
+  const int* h_nf = sl.h_ints.as<int>() + sl.Bg;
+  for (int i = sl.part_begin[part]; i < sl.part_begin[part + 1]; ++i) {
+    const int j = i - sl.part_begin[part], nf = h_nf[i];
+    n_frames[j] = (unsigned)nf;
+    if ((unsigned)nf > max_frames) throw std::runtime_error("STTX_DebugBatchProbs: aMaxFrames too small");
+    HIP_CHECK(hipMemcpy(out + (size_t)j * max_frames * C, sl.probs.as<float>() + (size_t)i * sl.t_max * C, (size_t)nf * C * 4, hipMemcpyDeviceToHost));
+  }
 }
 }  // namespace
 
@@ -642,6 +734,12 @@ Metadata* STT_FinishStreamWithMetadata(StreamingState* aSctx, unsigned int aNumR
 // depends on the whole utterance, so they run as a batch of one through the time-parallel path (same kernels, same
 // per-row arithmetic as the chunked streaming path).
 char* STT_SpeechToText(ModelState* aCtx, const short* aBuffer, unsigned int aBufferSize) {
+  if (aCtx->async_any()) {  // the group slots belong to the batches in flight: the reference's own form of this call (stt.cc:641-662)
+    StreamingState* ctx;
+    if (create_stream(aCtx, &ctx, false) != STT_ERR_OK) return nullptr;
+    STT_FeedAudioContent(ctx, aBuffer, aBufferSize);
+    return STT_FinishStream(ctx);
+  }
   char** r = STTX_SpeechToTextBatch(aCtx, &aBuffer, &aBufferSize, 1);
   if (!r) return nullptr;
   char* s = r[0];
@@ -649,6 +747,12 @@ char* STT_SpeechToText(ModelState* aCtx, const short* aBuffer, unsigned int aBuf
   return s;
 }
 Metadata* STT_SpeechToTextWithMetadata(ModelState* aCtx, const short* aBuffer, unsigned int aBufferSize, unsigned int aNumResults) {
+  if (aCtx->async_any()) {  // (stt.cc:664-672)
+    StreamingState* ctx;
+    if (create_stream(aCtx, &ctx, false) != STT_ERR_OK) return nullptr;
+    STT_FeedAudioContent(ctx, aBuffer, aBufferSize);
+    return STT_FinishStreamWithMetadata(ctx, aNumResults);
+  }
   Metadata** r = STTX_SpeechToTextBatchWithMetadata(aCtx, &aBuffer, &aBufferSize, 1, aNumResults);
   if (!r) return nullptr;
   Metadata* m = r[0];
@@ -706,7 +810,7 @@ char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* aDeviceAudio,
   return res;
 }
 
-int STTX_BatchPipelineDepth(void) { const int e = pipeline_depth_env(); return e ? e : 2; }
+int STTX_BatchPipelineDepth(void) { return pipeline_depth(nullptr); }
 int STTX_BatchPipelineDepthFor(ModelState* aCtx) { return aCtx ? pipeline_depth(aCtx) : STTX_BatchPipelineDepth(); }
 
 int STTX_BatchSubmitDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride, const unsigned int* aBufferSizes, unsigned int aBatch) {
@@ -727,6 +831,19 @@ char** STTX_BatchCollect(ModelState* aCtx, int aTicket, unsigned int* aCount) {
     return 0;
   }, 0);
   return res;
+}
+
+int STTX_DebugBatchProbs(ModelState* aCtx, int aTicket, float* aProbs, unsigned int aMaxFrames, unsigned int* aNumFrames) {
+  return guarded([&]() { batch_probs(aCtx, aTicket, aProbs, aMaxFrames, aNumFrames); return (int)STT_ERR_OK; }, STT_ERR_FAIL_RUN_SESS);
+}
+int STTX_SetTuning(const char* aName, int aValue) { return tuning_set(aName, aValue) == 0 ? STT_ERR_OK : STT_ERR_INVALID_SHAPE; }
+int STTX_GetTuning(const char* aName, int* aValue) { return tuning_get(aName, aValue) == 0 ? STT_ERR_OK : STT_ERR_INVALID_SHAPE; }
+void STTX_ConfigureRuntime(void) {
+  // The batch path runs on up to eight HIP streams (three acoustic engines, four group slots' searches, the caller's own).  The
+  // HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that share a queue run
+  // one after the other -- a group's output layers behind another group's 0.8 ms search launch.  The runtime reads the flag at
+  // the first HIP call of the process, so this must run before it; a value the caller set stays.
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
 }
 
 static void upload_batch_audio(ModelState* m, const short* const* bufs, const unsigned* sizes, unsigned B, unsigned& stride) {
@@ -829,7 +946,7 @@ int STTX_ComputeMfcc(ModelState* m, const short* aBuffer, unsigned int aNumSampl
 int STTX_AcousticProbs(ModelState* m, const short* const* aBuffers, const unsigned int* aBufferSizes, unsigned int aBatch, float* aProbs,
                        unsigned int aMaxFrames, unsigned int* aNumFrames) {
   return guarded([&]() {
-    if (aBatch > 64) return (int)STT_ERR_INVALID_SHAPE;
+    if ((int)aBatch > lstm_max_rows(m->g.n_hidden)) return (int)STT_ERR_INVALID_SHAPE;  // one recurrent launch: 64 rows, 128 with 16 units per workgroup
     unsigned stride;
     upload_batch_audio(m, aBuffers, aBufferSizes, aBatch, stride);
     std::vector<int> hn(aBatch), nfr;
@@ -878,7 +995,8 @@ struct STTX_Decoder {
   std::map<std::string, float> hot;
   DecoderBatch db;
   DecParams p;
-  DevBuf probs, fbegin, fcount, hh, hb, wide;
+  DevBuf probs, fbegin, fcount, wide;
+  HotTables ht;
 };
 int STTX_DecoderCreate(ModelState* m, unsigned int aNumStreams, unsigned int aBeamWidth, double aCutoffProb, unsigned int aCutoffTopN, STTX_Decoder** retval) {
   *retval = nullptr;
@@ -886,7 +1004,7 @@ int STTX_DecoderCreate(ModelState* m, unsigned int aNumStreams, unsigned int aBe
     HIP_CHECK(hipSetDevice(m->device));
     std::unique_ptr<STTX_Decoder> d(new STTX_Decoder());
     d->m = m; d->scorer = m->scorer_; d->hot = m->hot_words_;
-    m->decoder_create(d->db, (int)aNumStreams, (int)aBeamWidth, 64, d->scorer);
+    m->decoder_create(d->db, (int)aNumStreams, (int)aBeamWidth, 256, d->scorer);  // arenas for 256 frames up front, like a stream's; longer inputs grow them (decoder_reserve)
     d->p = DecParams{};
     d->p.C = m->g.n_classes; d->p.blank = d->p.C - 1; d->p.beam = (int)aBeamWidth; d->p.cutoff_top_n = (int)aCutoffTopN; d->p.cutoff_prob = aCutoffProb;
     *retval = d.release();
@@ -905,7 +1023,7 @@ int STTX_DecoderNext(STTX_Decoder* d, const float* aProbs, unsigned int aStride,
     d->fbegin.upload(zeros.data(), n * 4, m->stream);
     d->fcount.upload(more.data(), n * 4, m->stream);
     d->p.t_max = (int)aStride;
-    DevScorer ds = m->current_scorer(d->scorer, d->hot, d->hh, d->hb);
+    DevScorer ds = m->current_scorer(d->scorer, d->hot, d->ht);
     int max_frames = 1;
     for (int i = 0; i < n; ++i) max_frames = std::max(max_frames, more[i]);
     d->wide.reserve(ctc_rows_ws_bytes(d->p, n, max_frames));
@@ -920,7 +1038,7 @@ int STTX_DecoderDecode(const STTX_Decoder* d, unsigned int aNumResults, unsigned
                        double* aConfidences, int* aNumResultsOut) {
   return guarded([&]() {
     HIP_CHECK(hipSetDevice(d->m->device));
-    auto outs = decode_streams(*d->m, d->db, d->scorer, d->hot, aNumResults, (int)aMaxLen);
+    auto outs = decode_streams(*d->m, d->db, d->scorer, d->hot, const_cast<STTX_Decoder*>(d)->ht, aNumResults, (int)aMaxLen);
     for (size_t i = 0; i < outs.size(); ++i) {
       aNumResultsOut[i] = (int)outs[i].size();
       for (size_t r = 0; r < outs[i].size(); ++r) {
@@ -981,7 +1099,7 @@ int STTX_TestDense(int M, int N, int K, const float* aX, const float* aW, const 
     dy.reserve((size_t)M * N * 4);
     DenseArgs d{};
     d.wt = dw.as<_Float16>(); d.x = dx.as<_Float16>(); d.bias = db.as<float>(); d.y = dy.p; d.M = M; d.N = N; d.K = K; d.ldx = K; d.ldy = N; d.relu_clip = aClip;
-    if (const char* e = getenv("STT_AMD_TEST_DENSE_SOLO")) d.solo = atoi(e);  // test hook: the forms that run beside the recurrence (read per call)
+    if (tune().dense_solo_test >= 0) d.solo = tune().dense_solo_test;  // test hook: the forms that run beside the recurrence
     launch_dense(d, aEpilogue == 0 ? DENSE_EPI_RELU_F16 : DENSE_EPI_BIAS_F32, nullptr);
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipGetLastError());
@@ -992,6 +1110,62 @@ int STTX_TestDense(int M, int N, int K, const float* aX, const float* aW, const 
     } else {
       HIP_CHECK(hipMemcpy(aY, dy.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     }
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
+
+int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, unsigned int aPeriod, int aGraph, const float* aXproj, float* aC, float* aH,
+                       unsigned short* aHAll) {
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(m->device));
+    const int H = m->g.n_hidden, B = (int)aBatch, NT = lstm_nt_for_batch(B);
+    if (NT < 0 || B > lstm_max_rows(H) || !aPeriod || !aSteps) return (int)STT_ERR_INVALID_SHAPE;
+    DevBuf xp, c, hf, hall, hp0, hp1;
+    xp.upload(aXproj, (size_t)aPeriod * B * 4 * H * 4, m->stream);
+    const size_t hp_bytes = (size_t)(H / 32) * NT * 64 * 16;
+    c.reserve((size_t)B * H * 4); hf.reserve((size_t)B * H * 4); hall.reserve((size_t)aPeriod * B * H * 2); hp0.reserve(hp_bytes); hp1.reserve(hp_bytes);
+    HIP_CHECK(hipMemsetAsync(c.p, 0, (size_t)B * H * 4, m->stream));
+    HIP_CHECK(hipMemsetAsync(hp0.p, 0, hp_bytes, m->stream));
+    HIP_CHECK(hipMemsetAsync(hp1.p, 0, hp_bytes, m->stream));
+    LstmArgs l{};
+    l.whp = m->whp.as<_Float16>(); l.xproj = xp.as<float>(); l.c = c.as<float>(); l.h_all = hall.as<_Float16>();
+    l.n_hidden = H; l.batch = B; l.passes = 0; l.prio = 0;
+    auto steps = [&]() {
+      for (unsigned t = 0; t < aSteps; ++t) {
+        l.hp_in = (t & 1) ? hp1.as<_Float16>() : hp0.as<_Float16>();
+        l.hp_out = (t & 1) ? hp0.as<_Float16>() : hp1.as<_Float16>();
+        l.t = (int)(t % aPeriod);
+        l.h_f32 = (t + 1 == aSteps) ? hf.as<float>() : nullptr;
+        launch_lstm_step(l, NT, m->stream);
+      }
+    };
+    if (aGraph) {
+      l.hp_in = hp0.as<_Float16>(); l.hp_out = hp1.as<_Float16>(); l.t = 0; l.h_f32 = nullptr;
+      // (first launch of an instantiation sets its function attributes: not inside a capture)
+      DevBuf sc, sh0, sh1; sc.reserve((size_t)B * H * 4); sh0.reserve(hp_bytes); sh1.reserve(hp_bytes);
+      HIP_CHECK(hipMemsetAsync(sh0.p, 0, hp_bytes, m->stream));
+      LstmArgs w = l; w.c = sc.as<float>(); w.hp_in = sh0.as<_Float16>(); w.hp_out = sh1.as<_Float16>();
+      HIP_CHECK(hipMemsetAsync(sc.p, 0, (size_t)B * H * 4, m->stream));
+      launch_lstm_step(w, NT, m->stream);
+      HIP_CHECK(hipStreamSynchronize(m->stream));
+      hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+      HIP_CHECK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
+      try { steps(); } catch (...) { (void)hipStreamEndCapture(m->stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+      HIP_CHECK(hipStreamEndCapture(m->stream, &graph));
+      HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      const hipError_t le = hipGraphLaunch(exec, m->stream);
+      const hipError_t se = hipStreamSynchronize(m->stream);
+      (void)hipGraphExecDestroy(exec);
+      HIP_CHECK(le); HIP_CHECK(se);
+    } else {
+      steps();
+    }
+    HIP_CHECK(hipMemcpyAsync(aC, c.p, (size_t)B * H * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipMemcpyAsync(aH, hf.p, (size_t)B * H * 4, hipMemcpyDeviceToHost, m->stream));
+    if (aHAll) HIP_CHECK(hipMemcpyAsync(aHAll, hall.p, (size_t)aPeriod * B * H * 2, hipMemcpyDeviceToHost, m->stream));
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    HIP_CHECK(hipGetLastError());
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_RUN_SESS);
 }

@@ -10,6 +10,7 @@
 
 #include "../../include/coqui-stt.h"
 #include "engine.h"
+#include "tuning.h"
 
 uint64_t stt_murmur64a(const void* key, size_t len);
 int g_debug_arena_frames = 0;  // STTX_DebugLimitArena
@@ -39,7 +40,7 @@ static void acoustic_rows(ModelState& m, const _Float16* d_x1, int B, int T, flo
   hipStream_t stream = m.stream;
   const int H = g.n_hidden, M = T * B, C = g.n_classes;
   const int NT = lstm_nt_for_batch(B);
-  if (NT < 0) throw std::runtime_error("run_acoustic_rows: batch > 64");
+  if (NT < 0 || B > lstm_max_rows(H)) throw std::runtime_error("run_acoustic_rows: more batch rows than one recurrent launch covers");
   m.ws_a.reserve((size_t)M * H * 2); m.ws_b.reserve((size_t)M * H * 2);
   m.ws_xproj.reserve((size_t)M * 4 * H * 4); m.ws_hall.reserve((size_t)M * H * 2);
   m.ws_logits.reserve((size_t)M * g.c_pad() * 4);
@@ -120,8 +121,7 @@ void ModelState::run_acoustic_chunk(const float* d_feats, const int* d_nframes, 
 // (ModelState::stream / stream_l / stream_o, see engine.h.)  The same kernels on the same operands in the same order per
 // chunk as acoustic_rows(): results are bit-identical; only what runs beside what changes.
 bool ModelState::am_pipe_init() {
-  static const int on = []() { const char* e = getenv("STT_AMD_AM_PIPE"); return e ? atoi(e) : 1; }();
-  if (!on) return false;
+  if (!tune().am_pipe) return false;
   if (stream_l) return true;
   int lo = 0, hi = 0;
   HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi = numerically lowest = most urgent)
@@ -134,14 +134,14 @@ bool ModelState::am_pipe_init() {
 }
 
 static int dense_lds_floor() {  // bytes; > 80 KiB = one GEMM workgroup per CU while the recurrence runs beside it
-  static const int v = []() { const char* e = getenv("STT_AMD_DENSE_LDS_KB"); const int kb = e ? atoi(e) : 82; return kb <= 0 ? 0 : kb * 1024; }();
-  return v;
+  const int kb = tune().dense_lds_kb;
+  return kb <= 0 ? 0 : kb * 1024;
 }
 
 void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs, hipEvent_t done) {
   const int H = g.n_hidden, M = T * B, C = g.n_classes;
   const int NT = lstm_nt_for_batch(B);
-  if (NT < 0) throw std::runtime_error("run_acoustic_chunk: batch > 64");
+  if (NT < 0 || B > lstm_max_rows(H)) throw std::runtime_error("run_acoustic_chunk: more batch rows than one recurrent launch covers");
   const int slot = (int)(am_seq % kAmRing);
   const bool wrapped = am_seq >= (unsigned long long)kAmRing;
   ++am_seq;
@@ -163,9 +163,9 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
   launch_context(c, M, stream);
   DenseArgs d{};
   d.relu_clip = g.relu_clip; d.M = M;
-  static const int lstm_passes = []() { const char* e = getenv("STT_AMD_LSTM_PASSES"); return e ? atoi(e) : 3; }();  // form of the recurrent step (kernels.h); 1 = 64 KiB of LDS: no room beside the solo GEMM
+  const int lstm_passes = tune().lstm_passes;  // form of the recurrent step (kernels.h); 1 = 64 KiB of LDS: no room beside the solo GEMM
   {  // GEMMs as co-tenants of the recurrence: the three-stage one-per-CU form (default), or the two-stage form padded to one per CU
-    static const int solo = []() { const char* e = getenv("STT_AMD_DENSE_SOLO"); return e ? atoi(e) : 2; }();  // 2: eight waves, 1: four, 0: padded two-stage form
+    const int solo = tune().dense_solo;  // 2: eight waves, 1: four, 0: padded two-stage form
     d.solo = lstm_passes >= 2 ? solo : 0; d.lds_floor = d.solo ? 0 : dense_lds_floor();  // (96 KiB beside the one-pass step's 66 would not fit)
   }
   stt_prof_mark_on(this, 1, 0, stream);
@@ -192,7 +192,7 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
   LstmArgs l{};
   l.whp = whp.as<_Float16>(); l.xproj = am_xproj[slot].as<float>(); l.c = am_c.as<float>(); l.h_all = am_hall[slot].as<_Float16>();
   l.n_hidden = H; l.batch = B; l.h_f32 = nullptr; l.passes = lstm_passes;
-  { static const int pr = []() { const char* e = getenv("STT_AMD_LSTM_PRIO"); return e ? atoi(e) : 1; }(); l.prio = pr; }
+  l.prio = tune().lstm_prio;
   auto steps = [&]() {
     for (int t = 0; t < T; ++t) {
       const bool odd = ((t0 + t) & 1) != 0;
@@ -202,16 +202,29 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
       launch_lstm_step(l, NT, stream_l);
     }
   };
-  static const int use_graph = []() { const char* e = getenv("STT_AMD_LSTM_GRAPH"); return e ? atoi(e) : 1; }();
-  if (use_graph) {
+  if (tune().lstm_graph) {
     LstmGraphKey key;
     memset(&key, 0, sizeof(key));  // (padding bytes take part in the comparison)
     key.xproj = am_xproj[slot].p; key.hall = am_hall[slot].p; key.c = am_c.p; key.hp0 = am_hp0.p; key.hp1 = am_hp1.p; key.whp = whp.p;
-    key.T = T; key.par = t0 & 1; key.B = B; key.NT = NT; key.passes = l.passes; key.prio = l.prio; key.H = H; key.first = 0;
+    key.T = T; key.par = t0 & 1; key.B = B; key.NT = NT; key.passes = l.passes; key.prio = l.prio; key.H = H; key.first = tune().lstm_form * 16 + tune().lstm_prefetch;  // (what else selects the kernel instance)
+    // A combination is captured the SECOND time it comes up (the first ran eagerly: module load, function attributes).  First
+    // sightings live in their own small set, so a ragged job's many one-off shapes never push the graphs out of the cache; when
+    // the cache is full (or holds graphs of buffers that have since been reallocated) it is emptied and refills with what recurs.
     auto found = lstm_graphs_.find(key);
-    if (found == lstm_graphs_.end() && lstm_graphs_.size() >= 256) { steps(); goto recurrence_enqueued; }  // (ragged jobs: no unbounded cache)
-    LstmGraph& gr = lstm_graphs_[key];
-    if (!gr.exec && gr.seen++ >= 1) {  // second sighting: worth a graph (the first ran eagerly: module load, function attributes)
+    if (found != lstm_graphs_.end()) {
+      if (found->second.exec) HIP_CHECK(hipGraphLaunch(found->second.exec, stream_l));
+      else steps();                                       // instantiation failed once: this combination stays on plain launches
+    } else if (!lstm_seen_.count(key)) {
+      if (lstm_seen_.size() >= 1024) lstm_seen_.clear();
+      lstm_seen_.insert(key);
+      steps();
+    } else {
+      if (lstm_graphs_.size() >= 256) {
+        HIP_CHECK(hipStreamSynchronize(stream_l));        // (rare) nothing may still be replaying what is destroyed
+        for (auto& kv : lstm_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        lstm_graphs_.clear();
+      }
+      LstmGraph gr;
       hipGraph_t graph = nullptr;
       HIP_CHECK(hipStreamBeginCapture(stream_l, hipStreamCaptureModeRelaxed));
       try { steps(); }
@@ -219,10 +232,12 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
       HIP_CHECK(hipStreamEndCapture(stream_l, &graph));
       const hipError_t ie = hipGraphInstantiate(&gr.exec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
-      if (ie != hipSuccess) { gr.exec = nullptr; gr.seen = -(1 << 30); (void)hipGetLastError(); }  // this combination stays on plain launches
+      if (ie != hipSuccess) { gr.exec = nullptr; (void)hipGetLastError(); }
+      lstm_graphs_[key] = gr;
+      lstm_seen_.erase(key);
+      if (gr.exec) HIP_CHECK(hipGraphLaunch(gr.exec, stream_l));
+      else steps();
     }
-    if (gr.exec) HIP_CHECK(hipGraphLaunch(gr.exec, stream_l));
-    else steps();
   } else steps();
 recurrence_enqueued:
   stt_prof_mark_on(this, -1, 5, stream_l);
@@ -248,16 +263,21 @@ recurrence_enqueued:
 }
 
 // ------------------------------------------------------------------------------------------- decoder state
-DevScorer ModelState::current_scorer(std::shared_ptr<ScorerDev> sc, const std::map<std::string, float>& hot, DevBuf& hh, DevBuf& hb) const {
+DevScorer ModelState::current_scorer(std::shared_ptr<ScorerDev> sc, const std::map<std::string, float>& hot, HotTables& ht, bool in_flight) {
   DevScorer s{};
   if (!sc) return s;
   s = sc->dev;
   s.n_hot = 0;
   if (!hot.empty()) {
-    std::vector<uint64_t> hs; std::vector<float> bs;
-    for (const auto& kv : hot) { hs.push_back(stt_murmur64a(kv.first.data(), kv.first.size())); bs.push_back(kv.second); }
-    hh.upload(hs.data(), hs.size() * 8, stream); hb.upload(bs.data(), bs.size() * 4, stream);
-    s.n_hot = (int)hs.size(); s.hot_hash = hh.as<uint64_t>(); s.hot_boost = hb.as<float>();
+    if (!ht.valid || ht.loaded != hot) {
+      std::vector<uint64_t> hs; std::vector<float> bs;
+      for (const auto& kv : hot) { hs.push_back(stt_murmur64a(kv.first.data(), kv.first.size())); bs.push_back(kv.second); }
+      if (in_flight && ht.hash) { retired_bufs_.push_back(std::move(ht.hash)); retired_bufs_.push_back(std::move(ht.boost)); }  // still read by the searches in flight
+      if (!ht.hash) { ht.hash.reset(new DevBuf()); ht.boost.reset(new DevBuf()); }
+      ht.hash->upload(hs.data(), hs.size() * 8, stream); ht.boost->upload(bs.data(), bs.size() * 4, stream);  // (synchronises `stream`: only when the words changed)
+      ht.loaded = hot; ht.valid = true;
+    }
+    s.n_hot = (int)hot.size(); s.hot_hash = ht.hash->as<uint64_t>(); s.hot_boost = ht.boost->as<float>();
   }
   return s;
 }
@@ -379,20 +399,20 @@ void check_decoder_errors(const int* errors, int n) {
 }
 
 std::vector<std::vector<Output>> decode_streams(const ModelState& mc, const DecoderBatch& db, std::shared_ptr<ScorerDev> sc,
-                                                const std::map<std::string, float>& hot, unsigned num_results, int max_len) {
+                                                const std::map<std::string, float>& hot, HotTables& ht, unsigned num_results, int max_len) {
   ModelState& m = const_cast<ModelState&>(mc);  // workspaces only
-  return decode_table(m, db.table.as<DecStream>(), db.n_streams, db.beam, db.C, sc, hot, num_results, max_len);
+  return decode_table(m, db.table.as<DecStream>(), db.n_streams, db.beam, db.C, sc, hot, ht, num_results, max_len);
 }
 
 std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_table, int n, int beam, int C, std::shared_ptr<ScorerDev> sc,
-                                              const std::map<std::string, float>& hot, unsigned num_results, int max_len) {
+                                              const std::map<std::string, float>& hot, HotTables& ht, unsigned num_results, int max_len) {
   const int nr = (int)std::max(1u, std::min<unsigned>(num_results, (unsigned)beam));
   const DecodeBlock blk = DecodeBlock::layout(n, nr, max_len);
   m.ws_out.reserve(blk.bytes); m.h_out.reserve(blk.bytes);
   const DecodeOut o = blk.view(m.ws_out.p, nr, max_len);
   DecParams p{};
   p.C = C; p.blank = C - 1; p.beam = beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = 0;
-  DevScorer ds = m.current_scorer(sc, hot, m.ws_hot_hash, m.ws_hot_boost);
+  DevScorer ds = m.current_scorer(sc, hot, ht);
   launch_ctc_decode(p, ds, m.dev_alphabet, d_table, n, o, m.stream);
   copy_d2h(m.h_out, m.ws_out.p, blk.bytes, m.stream);  // one block, page-locked destination
   HIP_CHECK(hipStreamSynchronize(m.stream));
@@ -428,7 +448,7 @@ std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_
 //   windows ready  = frames_ - 2*n_context  (a 19-frame window completes with every frame beyond the 18th)
 //   windows_done_  windows already sent through the model in batches of n_steps
 void StreamingState::recycle() {
-  scorer_.reset(); hot_words_.clear(); beam_width_ = 0; keep_emissions_ = false;
+  scorer_.reset(); hot_words_.clear(); hot_tables_.valid = false; beam_width_ = 0; keep_emissions_ = false;
   audio_buffer_.clear(); frames_ = 0; windows_done_ = 0; state_nonzero = false; arena_bound_ = 2; probs_.clear();
 }
 void StreamingState::pushZeroFrames(int n) {
@@ -518,7 +538,7 @@ void StreamingState::processReady(bool flush_partial, bool final_flush) {
     DecParams p{};
     p.C = C; p.blank = C - 1; p.beam = dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = T;  // stt.cc:539-540
     p.all_begin = 0; p.all_count = take;  // the frame range rides in the kernel arguments: no table upload, no host sync mid-hop
-    DevScorer ds = m.current_scorer(scorer_, hot_words_, hot_hash, hot_boost);
+    DevScorer ds = m.current_scorer(scorer_, hot_words_, hot_tables_);
     m.ws_wide.reserve(ctc_rows_ws_bytes(p, 1, take));
     launch_ctc_next(p, ds, m.dev_alphabet, dec.table.as<DecStream>(), 1, m.ws_probs.as<float>(), nullptr, nullptr, m.stream,
                     take, m.ws_wide.p);
@@ -556,7 +576,7 @@ void streams_process(const std::vector<StreamingState*>& ss, bool flush_partial)
   ModelState& m = *ss[0]->model_;
   const Geometry& g = m.g;
   const int H = g.n_hidden, C = g.n_classes, kp = g.k1_pad(), kw = g.n_in1(), T = g.n_steps;
-  DevScorer ds = m.current_scorer(ss[0]->scorer_, ss[0]->hot_words_, ss[0]->hot_hash, ss[0]->hot_boost);
+  DevScorer ds = m.current_scorer(ss[0]->scorer_, ss[0]->hot_words_, ss[0]->hot_tables_);
   for (;;) {
     std::vector<StreamingState*> R;
     std::vector<int> takes;
@@ -698,10 +718,10 @@ std::vector<std::vector<Output>> streams_decode_batch(const std::vector<Streamin
   HIP_CHECK(hipMemcpyAsync(m.sb_tab.p, hp, bytes, hipMemcpyHostToDevice, m.stream));
   m.sb_table.reserve(sizeof(DecStream) * n);
   launch_gather_streams(reinterpret_cast<const DecStream* const*>(m.sb_tab.p), m.sb_table.as<DecStream>(), n, m.stream);
-  return decode_table(m, m.sb_table.as<DecStream>(), n, ss[0]->dec.beam, ss[0]->dec.C, ss[0]->scorer_, ss[0]->hot_words_, num_results, max_len);
+  return decode_table(m, m.sb_table.as<DecStream>(), n, ss[0]->dec.beam, ss[0]->dec.C, ss[0]->scorer_, ss[0]->hot_words_, ss[0]->hot_tables_, num_results, max_len);
 }
 
-std::vector<Output> StreamingState::decode(unsigned num_results) const {
-  auto r = decode_streams(*model_, dec, scorer_, hot_words_, num_results, std::max(1, windows_done_) + 1);  // <= one token per processed window
+std::vector<Output> StreamingState::decode(unsigned num_results) {
+  auto r = decode_streams(*model_, dec, scorer_, hot_words_, hot_tables_, num_results, std::max(1, windows_done_) + 1);  // <= one token per processed window
   return r.empty() ? std::vector<Output>() : r[0];
 }

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -139,7 +140,19 @@ struct DecoderBatch {
   size_t per_stream_fixed = 0;
 };
 
+// Hot-word table of a scorer view in HBM, uploaded when the words change, not at every launch (STT_AddHotWord & co.: stt.cc:451-497;
+// a stream copies the model's words at creation, stt.cc:547).  `retire`: where the old buffers go when the table changes while
+// kernels that read them may still be running (batches in flight); null = nothing can be.
+struct HotTables {
+  std::unique_ptr<DevBuf> hash, boost;
+  std::map<std::string, float> loaded;
+  bool valid = false;
+};
 struct StreamingState;
+struct Output {
+  double confidence;
+  std::vector<unsigned> tokens, timesteps;
+};
 // Stage timing of the batch path (STTX_SetProfiling / STTX_GetStageTimes): HIP-event marks per stream (api.cpp)
 struct Prof {
   bool on = false;
@@ -175,7 +188,9 @@ struct ModelState {
   DevBuf ws_audio, ws_nsamp, ws_nframes, ws_feats, ws_x1, ws_a, ws_b, ws_xproj, ws_hall, ws_logits, ws_probs;
   DevBuf ws_c, ws_hp0, ws_hp1, ws_hf32;
   DevBuf ws_wide;  // wide-alphabet row records of the streaming paths
-  DevBuf ws_out, ws_hot_hash, ws_hot_boost;  // ws_out: one DecodeBlock
+  DevBuf ws_out;  // one DecodeBlock
+  HotTables hot_tables_;                                   // of the model's own hot words (batch calls)
+  std::vector<std::unique_ptr<DevBuf>> retired_bufs_;      // hot-word tables replaced while batches were in flight; freed when the pipeline has drained
   PinnedBuf h_out;
   // Finished streams are parked here with their HBM buffers (frames, LSTM state, decoder slab: seven allocations) and
   // handed out again by STT_CreateStream: a server that opens a stream per utterance pays hipMalloc/hipFree once per
@@ -206,15 +221,27 @@ struct ModelState {
     hipStream_t stream_dec = nullptr;  // the group's search stream (slot 0: ModelState::stream_dec, the others their own)
     int Bg = 0, nr = 0, max_len = 0, t_max = 0;
     std::vector<unsigned> idx;  // caller's utterance index of every stream of the group
+    // STTX_BatchSubmitDevice: a slot holds one or TWO submitted batches (two 64-utterance batches advanced by one recurrence,
+    // 128 rows per recurrent step): streams [part_begin[p], part_begin[p + 1]) belong to ticket part_ticket[p]
+    int n_parts = 0, part_begin[3] = {0, 0, 0}, part_ticket[2] = {-1, -1};
+    bool part_open[2] = {false, false};          // submitted, not collected yet
+    bool prof_enqueued = false;                  // the profiling block rides behind the results of THIS enqueue
+    size_t prof_stamp_bytes = 0;
+    bool results_ready = false;
+    std::vector<std::vector<Output>> results;  // unpacked once, handed out per part
+    bool busy() const { return part_open[0] || part_open[1]; }
   };
   static constexpr int kSlots = 4;
   GroupSlot slots_[kSlots];
-  // STTX_BatchSubmitDevice / STTX_BatchCollect: which slot holds an uncollected batch, and the next ticket
-  bool async_busy_[kSlots] = {};
-  int async_ticket_[kSlots] = {-1, -1, -1, -1};
-  int async_next_ = 0;
-  int async_depth_ = 0;  // slots in use while batches are in flight (api.cpp: pipeline_depth)
-  bool async_any() const { for (bool b : async_busy_) if (b) return true; return false; }
+  // STTX_BatchSubmitDevice / STTX_BatchCollect: the next ticket, the next slot, and the first half of a pair that waits for its
+  // partner (the caller's next submit) -- or for its own collect, which sends it through alone
+  struct PendingHalf { bool valid = false; const int16_t* d_audio = nullptr; unsigned stride = 0; std::vector<unsigned> sizes; int ticket = -1; };
+  PendingHalf pending_;
+  int async_next_ = 0;    // next ticket
+  int async_groups_ = 0;  // groups enqueued by submits so far (slot = async_groups_ % depth)
+  int async_depth_ = 0;   // slots in use while batches are in flight (api.cpp: pipeline_depth)
+  bool async_pair_ = false;  // ... and whether they were submitted as pairs
+  bool async_any() const { if (pending_.valid) return true; for (const GroupSlot& s : slots_) if (s.busy()) return true; return false; }
   // scratch of the batched streaming calls (STTX_FeedAudioContentBatch & co.)
   DevBuf sb_audio, sb_tab, sb_c, sb_h, sb_table;
   PinnedBuf sb_haudio, sb_htab;
@@ -242,8 +269,9 @@ struct ModelState {
     int T, par, B, NT, passes, prio, H, first;
     bool operator<(const LstmGraphKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
   };
-  struct LstmGraph { hipGraphExec_t exec = nullptr; int seen = 0; };
+  struct LstmGraph { hipGraphExec_t exec = nullptr; };
   std::map<LstmGraphKey, LstmGraph> lstm_graphs_;
+  std::set<LstmGraphKey> lstm_seen_;  // combinations seen once, not captured yet
   bool am_pipe_init();            // creates the streams / events on first use; false when switched off
   // chunk [t0, t0+T) of a batch through the three engines; `done` is recorded on stream_o behind the softmax
   void run_acoustic_chunk_piped(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs, hipEvent_t done);
@@ -264,16 +292,12 @@ struct ModelState {
   void run_acoustic_chunk(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs);
 
   // ---- decoder ----
-  DevScorer current_scorer(std::shared_ptr<ScorerDev> sc, const std::map<std::string, float>& hot, DevBuf& hh, DevBuf& hb) const;
+  DevScorer current_scorer(std::shared_ptr<ScorerDev> sc, const std::map<std::string, float>& hot, HotTables& ht, bool in_flight = false);
   // `staging`: page-locked room for the stream table; the upload then does not wait for the stream (batch path)
   void decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc, PinnedBuf* staging = nullptr);
   void decoder_reserve(DecoderBatch& db, const std::vector<int>& more_frames);
 };
 
-struct Output {
-  double confidence;
-  std::vector<unsigned> tokens, timesteps;
-};
 
 // One resumable utterance: the three buffers of stt.cc:60-71 with the frames and LSTM state kept in HBM.
 struct StreamingState {
@@ -291,7 +315,7 @@ struct StreamingState {
   bool state_nonzero = false;
   DecoderBatch dec;                           // one stream
   uint32_t arena_bound_ = 2;                  // host-side upper bound of the arena fill (each step appends <= beam nodes)
-  DevBuf hot_hash, hot_boost;
+  HotTables hot_tables_;
   std::vector<double> probs_;                 // emissions of the last processed batch (keep_emissions_)
 
   void recycle();  // back to the state of a fresh object, keeping the device buffers
@@ -301,13 +325,13 @@ struct StreamingState {
   void pushZeroFrames(int n);
   void processReady(bool flush_partial, bool final_flush);
   void reserveArena(int take);
-  std::vector<Output> decode(unsigned num_results) const;
+  std::vector<Output> decode(unsigned num_results);
 };
 
 std::vector<std::vector<Output>> decode_streams(const ModelState& m, const DecoderBatch& db, std::shared_ptr<ScorerDev> sc,
-                                                const std::map<std::string, float>& hot, unsigned num_results, int max_len);
+                                                const std::map<std::string, float>& hot, HotTables& ht, unsigned num_results, int max_len);
 std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_table, int n, int beam, int C, std::shared_ptr<ScorerDev> sc,
-                                              const std::map<std::string, float>& hot, unsigned num_results, int max_len);
+                                              const std::map<std::string, float>& hot, HotTables& ht, unsigned num_results, int max_len);
 // Many streams of one model at once (same beam width, scorer and hot words; otherwise the callers fall back to one by one):
 // what STT_FeedAudioContent / STT_IntermediateDecode / flushBuffers do, with the ready windows of all streams pushed through
 // the acoustic model and the beam search as one batch.

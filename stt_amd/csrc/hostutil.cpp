@@ -1,10 +1,55 @@
 // stt_amd/csrc/hostutil.cpp -- device buffers, Alphabet (native_client/alphabet.{h,cc}).
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
 
 #include "engine.h"
+#include "tuning.h"
+
+// ---- tunables (tuning.h) ------------------------------------------------------------------------
+namespace {
+struct TuneEntry { const char* name; int Tuning::*field; };
+const TuneEntry kTune[] = {
+#define X(name, def, doc) {#name, &Tuning::name},
+    STT_TUNING_FIELDS(X)
+#undef X
+};
+}  // namespace
+int tuning_set(const char* name, int value) {
+  if (!name) return -1;
+  for (const TuneEntry& e : kTune)
+    if (!strcmp(e.name, name)) { tune().*(e.field) = value; return 0; }
+  return -1;
+}
+int tuning_get(const char* name, int* value) {
+  if (!name) return -1;
+  for (const TuneEntry& e : kTune)
+    if (!strcmp(e.name, name)) { if (value) *value = tune().*(e.field); return 0; }
+  return -1;
+}
+Tuning& tune() {
+  static Tuning t;
+  static const bool seeded = []() {  // STT_AMD_TUNING="name=value,name=value" (A/B scripts); unknown names are reported, not ignored
+    const char* e = getenv("STT_AMD_TUNING");
+    if (!e) return true;
+    std::stringstream ss(e);
+    std::string tok;
+    while (std::getline(ss, tok, ',')) {
+      const size_t eq = tok.find('=');
+      if (eq == std::string::npos) continue;
+      const std::string name = tok.substr(0, eq);
+      bool ok = false;
+      for (const TuneEntry& en : kTune)
+        if (name == en.name) { t.*(en.field) = atoi(tok.c_str() + eq + 1); ok = true; }
+      if (!ok) fprintf(stderr, "stt_amd: STT_AMD_TUNING: no tunable named '%s'\n", name.c_str());
+    }
+    return true;
+  }();
+  (void)seeded;
+  return t;
+}
 
 void DevBuf::reserve(size_t bytes, bool keep, hipStream_t st) {
   if (bytes <= cap && p) return;
@@ -36,10 +81,7 @@ void* PinnedBuf::dev() const {
   HIP_CHECK(hipHostGetDevicePointer(&d, p, 0));
   return d;
 }
-static bool copy_kernel_on() {
-  static const bool v = []() { const char* e = getenv("STT_AMD_COPY_KERNEL"); return !e || atoi(e) != 0; }();
-  return v;
-}
+static bool copy_kernel_on() { return tune().copy_kernel != 0; }
 void copy_h2d(void* dst_dev, const PinnedBuf& src, size_t bytes, hipStream_t st) {
   if (!bytes) return;
   if (copy_kernel_on()) launch_copy_bytes(dst_dev, src.dev(), bytes, st);

@@ -71,6 +71,7 @@ void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st);
 void launch_context(const ContextArgs& a, int rows, hipStream_t st);
 void launch_dense(const DenseArgs& a, int epi, hipStream_t st);
 int lstm_nt_for_batch(int B);
+int lstm_max_rows(int H);      // rows one recurrent launch covers: 128 with 16 units per workgroup, else 64
 int lstm_units_per_wg(int H);  // 16 or 8: shape of the recurrent kernel AND of the packed recurrent matrix
 void launch_lstm_step(const LstmArgs& a, int NT, hipStream_t st);
 void launch_pack_h(const float* h, void* hp, int B, int H, int NT, hipStream_t st);

@@ -22,8 +22,10 @@
 
 #include <algorithm>
 #include <mutex>
+#include <stdexcept>
 
 #include "kernels.h"
+#include "tuning.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -385,7 +387,7 @@ __device__ __forceinline__ float lstm_cell_(float zf, float c, float zi, float z
 // with 256 workgroups the h re-reads (64 MiB per step) outweigh the weights (33.5 MiB); 128 workgroups halve them, and a
 // workgroup then has a CU to itself (64 KiB reduction buffer, ~230 VGPRs: one wave per SIMD).
 template <int NT, int G_, int MT, int PHS>
-__global__ __launch_bounds__(256, 2) void lstm_step_kernel(LstmArgs a) {  // (<= 256 registers per lane: 234 instead of 170 + 96 AGPRs, which leaves two 128-register GEMM waves per SIMD beside it)
+__device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
   constexpr bool PF = G_ > 0;
   constexpr int UPW = MT * 4;  // hidden units per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
@@ -416,10 +418,13 @@ __global__ __launch_bounds__(256, 2) void lstm_step_kernel(LstmArgs a) {  // (<=
   // lane -- so the cell update runs on registers.  Each wave parks the three tiles it does not own in LDS (48 KiB in all), one
   // barrier, each wave adds the three foreign partials of its own tile in wave order: (((r0 + r1) + r2) + r3), the order of
   // the other forms (bit-identical results), no second pass through LDS, no second barrier, h published from registers.
-  constexpr bool OWN = PHS == 3 && NT == 4 && MT == 4;
-  const int ob = q * 16 + (lane & 15), ou = 4 * (lane >> 4);  // owner form: this lane's batch row and first unit
+  // NT = 8 (two 64-utterance batches advanced by ONE step: the 33.5 MB matrix is streamed once per 128 rows): the owner form in
+  // two rounds over the batch tiles -- round r settles tiles 4r .. 4r+3, wave q owning tile 4r + q -- through the same 48 KiB.
+  constexpr bool OWN = PHS == 3 && (NT == 4 || NT == 8) && MT == 4;
+  constexpr int ROUNDS = OWN ? NT / 4 : 1;
+  const int ob = q * 16 + (lane & 15), ou = 4 * (lane >> 4);  // owner form: this lane's batch row (of round 0) and first unit
   float4 oxv[4] = {}, ocv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (OWN && ob < B) {
+  if (OWN && NT == 4 && ob < B) {  // (NT = 8: fetched in the tail of the k-loop, when the operand double buffer has registers to spare)
     const float* xp = a.xproj + ((size_t)a.t * B + ob) * (4 * H) + wg * UPW + ou;
 #pragma unroll
     for (int g = 0; g < 4; ++g) oxv[g] = *reinterpret_cast<const float4*>(xp + (size_t)g * H);
@@ -461,6 +466,12 @@ __global__ __launch_bounds__(256, 2) void lstm_step_kernel(LstmArgs a) {  // (<=
       LSTM_LOAD(wb, hb, s0 + G);
       LSTM_MMA(wa, ha);
       if (s0 + 2 * G < ksteps) { LSTM_LOAD(wa, ha, s0 + 2 * G); }
+      else if (OWN && NT == 8 && ob < B) {  // last group: `wa` / `ha` are free -- the cell-update operands of round 0 take their place in flight
+        const float* xp = a.xproj + ((size_t)a.t * B + ob) * (4 * H) + wg * UPW + ou;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) oxv[g] = *reinterpret_cast<const float4*>(xp + (size_t)g * H);
+        ocv = *reinterpret_cast<const float4*>(a.c + (size_t)ob * H + wg * UPW + ou);
+      }
       LSTM_MMA(wb, hb);
     }
 #undef LSTM_LOAD
@@ -478,52 +489,74 @@ __global__ __launch_bounds__(256, 2) void lstm_step_kernel(LstmArgs a) {  // (<=
         for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&w[i]), fb, acc[i][j], 0, 0, 0);
       }
     }
+    if (OWN && NT == 8 && ob < B) {  // (narrow models whose k-loop takes this branch: the cell-update operands of round 0)
+      const float* xp = a.xproj + ((size_t)a.t * B + ob) * (4 * H) + wg * UPW + ou;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) oxv[g] = *reinterpret_cast<const float4*>(xp + (size_t)g * H);
+      ocv = *reinterpret_cast<const float4*>(a.c + (size_t)ob * H + wg * UPW + ou);
+    }
   }
   if (OWN) {
     typedef float OwnT[3][MT][64][4];                    // [writer wave][slot: the writer's foreign tiles in order][gate tile][lane]
     OwnT* park = reinterpret_cast<OwnT*>(lstm_smem);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      if (j == q) continue;                              // (wave-uniform)
-      const int sl = j - (j > q ? 1 : 0);
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+      const int obr = ob + rd * 64;                      // this lane's batch row in this round
+      if (rd) __syncthreads();                           // every wave has read the previous round's partials
 #pragma unroll
-      for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4*>(&park[q][sl][i][lane][0]) = acc[i][j];
-    }
-    f32x4 own[MT];
+      for (int j = 0; j < 4; ++j) {
+        if (j == q) continue;                            // (wave-uniform)
+        const int sl = j - (j > q ? 1 : 0);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) own[i] = q == 0 ? acc[i][0] : q == 1 ? acc[i][1] : q == 2 ? acc[i][2] : acc[i][NT - 1];
-    __syncthreads();
-    f32x4 z[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      f32x4 v[4];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int sl = q - (q > w ? 1 : 0);              // where writer w parked tile q (unused for w == q)
-        v[w] = (w == q) ? own[i] : *reinterpret_cast<const f32x4*>(&park[w][sl < 3 ? sl : 2][i][lane][0]);
+        for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4*>(&park[q][sl][i][lane][0]) = acc[i][rd * 4 + j];
       }
-      z[i] = ((v[0] + v[1]) + v[2]) + v[3];
-    }
-    float hv[4];
-    float4 cn4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      f32x4 own[MT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float zi = z[0][r] + (&oxv[0].x)[r], zj = z[1][r] + (&oxv[1].x)[r], zf = z[2][r] + (&oxv[2].x)[r], zo = z[3][r] + (&oxv[3].x)[r];
-      const float cn = lstm_cell_(zf, (&ocv.x)[r], zi, zj);
-      (&cn4.x)[r] = cn;
-      hv[r] = ob < B ? __fmul_rn(sigmoidf_(zo), tanhf_(cn)) : 0.0f;
+      for (int i = 0; i < MT; ++i) own[i] = q == 0 ? acc[i][rd * 4 + 0] : q == 1 ? acc[i][rd * 4 + 1] : q == 2 ? acc[i][rd * 4 + 2] : acc[i][rd * 4 + 3];
+      // the next round's cell-update operands travel while this round is settled
+      float4 nxv[4] = {}, ncv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rd + 1 < ROUNDS && obr + 64 < B) {
+        const float* xp = a.xproj + ((size_t)a.t * B + obr + 64) * (4 * H) + wg * UPW + ou;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nxv[g] = *reinterpret_cast<const float4*>(xp + (size_t)g * H);
+        ncv = *reinterpret_cast<const float4*>(a.c + (size_t)(obr + 64) * H + wg * UPW + ou);
+      }
+      __syncthreads();
+      f32x4 z[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        f32x4 v[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int sl = q - (q > w ? 1 : 0);            // where writer w parked tile q (unused for w == q)
+          v[w] = (w == q) ? own[i] : *reinterpret_cast<const f32x4*>(&park[w][sl < 3 ? sl : 2][i][lane][0]);
+        }
+        z[i] = ((v[0] + v[1]) + v[2]) + v[3];
+      }
+      float hv[4];
+      float4 cn4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float zi = z[0][r] + (&oxv[0].x)[r], zj = z[1][r] + (&oxv[1].x)[r], zf = z[2][r] + (&oxv[2].x)[r], zo = z[3][r] + (&oxv[3].x)[r];
+        const float cn = lstm_cell_(zf, (&ocv.x)[r], zi, zj);
+        (&cn4.x)[r] = cn;
+        hv[r] = obr < B ? __fmul_rn(sigmoidf_(zo), tanhf_(cn)) : 0.0f;
+      }
+      const int unit0 = wg * UPW + ou;
+      if (obr < B) {
+        *reinterpret_cast<float4*>(a.c + (size_t)obr * H + unit0) = cn4;
+        if (a.h_f32) *reinterpret_cast<float4*>(a.h_f32 + (size_t)obr * H + unit0) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+      }
+      // publish h: this lane's four units are one half of a 16-byte (8-unit) chunk of the fragment-ordered buffer
+      const f16x4 hh = {(_Float16)hv[0], (_Float16)hv[1], (_Float16)hv[2], (_Float16)hv[3]};
+      const int k0 = wg * UPW + (ou & ~7);               // first unit of the chunk
+      const int ksg = k0 >> 5, grp = (k0 & 31) >> 3, half = (ou >> 2) & 1;
+      reinterpret_cast<f16x4*>(a.hp_out)[(((size_t)ksg * NT + rd * 4 + q) * 64 + grp * 16 + (lane & 15)) * 2 + half] = hh;
+      if (obr < B) *reinterpret_cast<f16x4*>(a.h_all + ((size_t)a.t * B + obr) * H + unit0) = hh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) oxv[g] = nxv[g];
+      ocv = ncv;
     }
-    const int unit0 = wg * UPW + ou;
-    if (ob < B) {
-      *reinterpret_cast<float4*>(a.c + (size_t)ob * H + unit0) = cn4;
-      if (a.h_f32) *reinterpret_cast<float4*>(a.h_f32 + (size_t)ob * H + unit0) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-    }
-    // publish h: this lane's four units are one half of a 16-byte (8-unit) chunk of the fragment-ordered buffer
-    const f16x4 hh = {(_Float16)hv[0], (_Float16)hv[1], (_Float16)hv[2], (_Float16)hv[3]};
-    const int k0 = wg * UPW + (ou & ~7);                 // first unit of the chunk
-    const int ksg = k0 >> 5, grp = (k0 & 31) >> 3, half = (ou >> 2) & 1;
-    reinterpret_cast<f16x4*>(a.hp_out)[(((size_t)ksg * NT + q) * 64 + grp * 16 + (lane & 15)) * 2 + half] = hh;
-    if (ob < B) *reinterpret_cast<f16x4*>(a.h_all + ((size_t)a.t * B + ob) * H + unit0) = hh;
     return;
   }
   // cell update: (unit u, batch row b): gate row r = g*UPW+u lives in tile r>>4, lane group (r&15)>>2, reg r&3
@@ -574,6 +607,20 @@ __global__ __launch_bounds__(256, 2) void lstm_step_kernel(LstmArgs a) {  // (<=
     reinterpret_cast<uint4*>(a.hp_out)[((size_t)ksg * NT + (b >> 4)) * 64 + grp * 16 + (b & 15)] = v;
     if (b < B) *reinterpret_cast<uint4*>(a.h_all + ((size_t)a.t * B + b) * H + k0) = v;
   }
+}
+
+template <int NT, int G_, int MT, int PHS>
+__global__ __launch_bounds__(256, 2) void lstm_step_kernel(LstmArgs a) {  // (<= 256 registers per lane: two 128-register GEMM waves per SIMD fit beside it)
+  lstm_step_body<NT, G_, MT, PHS>(a);
+}
+// 128 rows: 128 accumulator registers + the operand double buffer do not fit in 256; one wave per SIMD may take more, as long as
+// two eight-wave GEMM waves (72 each) still fit in the SIMD's 512 beside it.
+#ifndef LSTM8_VGPRS
+#define LSTM8_VGPRS 160  /* budget = 2 x this: 312 registers allocated (248 + 64 accumulator-file), no spill */
+#endif
+template <int G_>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(LSTM8_VGPRS))) void lstm_step8_kernel(LstmArgs a) {
+  lstm_step_body<8, G_, 4, 3>(a);
 }
 
 // h (f32 [B][H]) -> fragment-ordered f16 hp (used once per chunk to seed the recurrence from a carried state)
@@ -774,10 +821,9 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
   }
   // 256-square tiles when the shape allows (N a multiple of 256 and enough rows to fill them), else 128-square
   // (measured: with 96 to 384 tiles for 256 CUs the 256-square tile is slower than 1536 small ones; from about two tiles per
-  // CU on it wins -- the long chunks of the pipelined batch path.  STT_AMD_DENSE_TILE=128 / 256 forces a side,
-  // STT_AMD_DENSE_BIG_MIN moves the threshold)
-  static const int big_ok = []() { const char* e = getenv("STT_AMD_DENSE_TILE"); return e ? atoi(e) : 0; }();
-  static const int big_min = []() { const char* e = getenv("STT_AMD_DENSE_BIG_MIN"); return e ? atoi(e) : 480; }();
+  // CU on it wins -- the long chunks of the pipelined batch path.  Tunables dense_tile = 128 / 256 force a side,
+  // dense_big_min moves the threshold)
+  const int big_ok = tune().dense_tile, big_min = tune().dense_big_min;
   const bool big_fits = a.N % 256 == 0 && a.M >= 256;
   const bool big = big_fits && !a.solo && (big_ok >= 256 || (big_ok == 0 && ((a.M + 255) / 256) * (a.N / 256) >= big_min));
   const int side = big ? 256 : 128;
@@ -786,12 +832,11 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
   const int ntn = a.N / side, ntm = (a.M + side - 1) / side;
   int best = 1 << 30;
   b.xa = 1; b.xb = 8;
-  static const int legacy = []() { const char* e = getenv("STT_AMD_DENSE_MBAND"); return e ? atoi(e) : 0; }();  // A/B: round 1's M-bands
   for (int xa = 1; xa <= 8; xa *= 2) {
     const int xb = 8 / xa;
     const int Mx = (ntm + xa - 1) / xa, Nx = (ntn + xb - 1) / xb;
     const int cost = Mx + Nx;
-    if (legacy ? (xa == 8) : (cost < best || (cost == best && Mx * Nx < ((ntm + b.xa - 1) / b.xa) * ((ntn + b.xb - 1) / b.xb)))) { best = cost; b.xa = xa; b.xb = xb; }
+    if (cost < best || (cost == best && Mx * Nx < ((ntm + b.xa - 1) / b.xa) * ((ntn + b.xb - 1) / b.xb))) { best = cost; b.xa = xa; b.xb = xb; }
   }
   const int per_xcd = ((ntm + b.xa - 1) / b.xa) * ((ntn + b.xb - 1) / b.xb);
   if (big) {
@@ -808,46 +853,53 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
     else launch_dense_inst<DENSE_EPI_BIAS_F32, 2, 2>(b, 8 * per_xcd, st);
   }
 }
-int lstm_nt_for_batch(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : -1; }  // 64 rows per launch
+// batch tiles per launch: up to 64 rows in every shape; 65 .. 128 rows (two batches advanced together, NT = 8) with 16 units per workgroup
+int lstm_nt_for_batch(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : B <= 128 ? 8 : -1; }
+int lstm_max_rows(int H) { return lstm_units_per_wg(H) == 16 ? 128 : 64; }
 // hidden units per workgroup of the recurrent kernel (and of the weight packing, pack_lstm_recurrent_host): 16 when the width
-// allows, 8 otherwise (STT_AMD_LSTM_UPW=8 keeps round 1's shape for A/B runs)
-int lstm_units_per_wg(int H) {
-  static const int env = []() { const char* e = getenv("STT_AMD_LSTM_UPW"); return e ? atoi(e) : 16; }();
-  return (env >= 16 && H % 16 == 0) ? 16 : 8;
-}
+// allows, 8 otherwise (tunable lstm_upw = 8 keeps round 1's shape for A/B runs; it must not change while a model is loaded)
+int lstm_units_per_wg(int H) { return (tune().lstm_upw >= 16 && H % 16 == 0) ? 16 : 8; }
 template <int NT, int G, int MT, int PHS>
 static void launch_lstm_inst2(const LstmArgs& a, hipStream_t st) {
-  const size_t smem = (PHS == 3 && NT == 4 && MT == 4) ? (size_t)4 * 3 * MT * 64 * 16
-                                                      : 4 * sizeof(float) * MT * ((NT >= 4 && PHS == 2) ? NT / 2 : NT) * 64 * 4 + (size_t)NT * 16 * MT * 4 * 2;
+  constexpr bool OWN = PHS == 3 && (NT == 4 || NT == 8) && MT == 4;
+  const size_t smem = OWN ? (size_t)4 * 3 * MT * 64 * 16
+                          : 4 * sizeof(float) * MT * ((NT >= 4 && PHS == 2) ? NT / 2 : NT) * 64 * 4 + (size_t)NT * 16 * MT * 4 * 2;
+  const void* fn;
+  if constexpr (NT == 8) fn = reinterpret_cast<const void*>(lstm_step8_kernel<G>);
+  else fn = reinterpret_cast<const void*>(lstm_step_kernel<NT, G, MT, PHS>);
   static std::once_flag once[16];
   int dev = 0;
   (void)hipGetDevice(&dev);
-  std::call_once(once[dev & 15], [&]() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_kernel<NT, G, MT, PHS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  });
-  hipLaunchKernelGGL((lstm_step_kernel<NT, G, MT, PHS>), dim3(a.n_hidden / (MT * 4)), dim3(256), smem, st, a);
+  std::call_once(once[dev & 15], [&]() { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+  if constexpr (NT == 8) hipLaunchKernelGGL((lstm_step8_kernel<G>), dim3(a.n_hidden / (MT * 4)), dim3(256), smem, st, a);
+  else hipLaunchKernelGGL((lstm_step_kernel<NT, G, MT, PHS>), dim3(a.n_hidden / (MT * 4)), dim3(256), smem, st, a);
 }
 template <int NT, int G, int MT>
 static void launch_lstm_inst(const LstmArgs& a, hipStream_t st) {
   // a.passes: 0 / 1 = one pass (the fastest form when the step has the CU to itself: 2.88 ms per 250 steps against 2.95 for the
   // owner form), 2 = two passes, 3 = owner form (what fits beside a GEMM workgroup: the batch path's three engines).
-  // STT_AMD_LSTM_FORM overrides every caller (A/B runs).
-  static const int form_env = []() { const char* e = getenv("STT_AMD_LSTM_FORM"); return e ? atoi(e) : 0; }();
-  const int form = form_env ? form_env : (a.passes ? a.passes : 1);
-  if (NT == 4 && MT == 4 && form == 3) launch_lstm_inst2<NT, G, MT, (NT == 4 && MT == 4 ? 3 : 1)>(a, st);
-  else if (NT >= 4 && form == 2) launch_lstm_inst2<NT, G, MT, (NT >= 4 ? 2 : 1)>(a, st);
-  else launch_lstm_inst2<NT, G, MT, 1>(a, st);
+  // The tunable lstm_form overrides every caller (A/B runs, form-vs-form tests).
+  const int form = tune().lstm_form ? tune().lstm_form : (a.passes ? a.passes : 1);
+  if constexpr (NT == 8) {
+    launch_lstm_inst2<NT, G, MT, 3>(a, st);  // 128 rows: the owner form in two rounds is the only one that fits in LDS
+  } else {
+    if (NT == 4 && MT == 4 && form == 3) launch_lstm_inst2<NT, G, MT, (NT == 4 && MT == 4 ? 3 : 1)>(a, st);
+    else if (NT >= 4 && form == 2) launch_lstm_inst2<NT, G, MT, (NT >= 4 ? 2 : 1)>(a, st);
+    else launch_lstm_inst2<NT, G, MT, 1>(a, st);
+  }
 }
 void launch_lstm_step(const LstmArgs& a, int NT, hipStream_t st) {
-  static const int pg = []() { const char* e = getenv("STT_AMD_LSTM_PREFETCH"); return e ? atoi(e) : 2; }();
+  const int pg = tune().lstm_prefetch;
   if (lstm_units_per_wg(a.n_hidden) == 16) {
     switch (NT) {
       case 1: launch_lstm_inst<1, 4, 4>(a, st); break;
       case 2: launch_lstm_inst<2, 4, 4>(a, st); break;
+      case 8: launch_lstm_inst<8, 1, 4>(a, st); break;
       default: if (pg >= 4) launch_lstm_inst<4, 4, 4>(a, st); else if (pg >= 2) launch_lstm_inst<4, 2, 4>(a, st); else launch_lstm_inst<4, 1, 4>(a, st); break;
     }
     return;
   }
+  if (NT == 8) throw std::runtime_error("lstm step: 128-row batches need 16 hidden units per workgroup");
   switch (NT) {
     case 1: launch_lstm_inst<1, 4, 2>(a, st); break;
     case 2: launch_lstm_inst<2, 4, 2>(a, st); break;

@@ -151,17 +151,6 @@ int ModelState::InitFromBuffer(const char* buf, size_t len) {
   const int H = g.n_hidden, C = g.n_classes, K1 = g.n_in1();
 
   HIP_CHECK(hipSetDevice(device));
-  // Optional CU partition (experiment, STT_AMD_CUMASK=<n>): the decoder stream gets the first n mask bits, the acoustic
-  // stream the rest, so the two pipelined halves of the batch path do not share compute units.
-  const char* cm = getenv("STT_AMD_CUMASK");
-  const int n_dec = cm ? atoi(cm) : 0;
-  if (n_dec > 0 && n_dec < 256 && !stream && !stream_dec) {
-    uint32_t md[8] = {}, ma[8] = {};
-    for (int i = 0; i < 256; ++i) (i < n_dec ? md : ma)[i / 32] |= 1u << (i % 32);
-    if (hipExtStreamCreateWithCUMask(&stream_dec, 8, md) != hipSuccess) stream_dec = nullptr;
-    if (hipExtStreamCreateWithCUMask(&stream, 8, ma) != hipSuccess) stream = nullptr;
-    (void)hipGetLastError();
-  }
   if (!stream) HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   if (!stream_dec) HIP_CHECK(hipStreamCreateWithFlags(&stream_dec, hipStreamNonBlocking));
   {

@@ -18,6 +18,7 @@
 
 #include "../../include/coqui-stt.h"
 #include "engine.h"
+#include "tuning.h"
 #include "lmindex.h"
 #include "scorer_host.h"
 
@@ -465,7 +466,7 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label, bool lm_on
   }
   ds.lmi = hs.lmi_ok ? lmi_.as<LmiEntry>() : nullptr; ds.lmi_buckets = hs.lmi_buckets;
   ds.unk_prob = hs.unk_prob; ds.unk_backoff = hs.unk_backoff; ds.unk_indep = hs.unk_indep ? 1 : 0;
-  static const bool memo_on = []() { const char* e = getenv("STT_AMD_LM_MEMO"); return !e || atoi(e) != 0; }();  // (0: measure without)
+  const bool memo_on = tune().lm_memo != 0;  // (0: measure without)
   if (hs.utf8 && ord <= 5 && !lm_only && memo_on) {  // FullScore cache of the code-point search (ctc.h: DevScorer::memo)
     const size_t n = (size_t)1 << 18;
     memo_.reserve(n * 32);

@@ -1,0 +1,46 @@
+// stt_amd/csrc/tuning.h -- the engine's tunables in ONE table (internal header).
+//
+// Every value has a measured default; nothing here changes results, only what runs beside what
+// and which of several bit-identical kernel forms is launched.  Two ways in, both for A/B runs and tests:
+//   STTX_SetTuning("name", value)        between calls, nothing in flight (include/stt_amd.h)
+//   STT_AMD_TUNING="name=value,name=value"   read once, when the table is first used
+// The reference has no equivalent: its only run-time switches are the model's beam width and the scorer's alpha/beta.
+#pragma once
+
+#define STT_TUNING_FIELDS(X)                                                                                                       \
+  X(pipeline, 0, "group slots of the batch path (0 = by configuration: 2, or 4 for a search-bound setup; 1..4)")                   \
+  X(active, 0, "slots whose beam searches may run side by side (0 = by configuration)")                                           \
+  X(pair, 1, "1: two consecutive 64-utterance batches share one recurrence (128 rows per recurrent step); 0: 64 rows")            \
+  X(chunk0, 16, "blocking call: frames of the first time-chunk")                                                                   \
+  X(chunk, 48, "blocking call: frames of the later time-chunks")                                                                   \
+  X(pchunk0, 16, "batches in flight: frames of the first time-chunk")                                                              \
+  X(pchunk, 48, "batches in flight: frames of the later time-chunks")                                                              \
+  X(am_pipe, 1, "acoustic model of the batch path as three engines (0: one stream)")                                               \
+  X(dense_lds_kb, 82, "LDS floor of the two-stage GEMM form when it runs beside the recurrence (one workgroup per CU)")            \
+  X(dense_solo, 2, "GEMM form beside the recurrence: 2 = three-stage eight-wave, 1 = three-stage four-wave, 0 = padded two-stage") \
+  X(dense_solo_test, -1, "STTX_TestDense: force DenseArgs::solo (-1 = off)")                                                       \
+  X(dense_tile, 0, "force the GEMM tile side (128 / 256; 0 = by shape)")                                                           \
+  X(dense_big_min, 480, "256-square tiles from this many tiles on")                                                                \
+  X(lstm_graph, 1, "recurrence chunks replayed as hipGraphs")                                                                      \
+  X(lstm_passes, 3, "form of the recurrent step beside the GEMMs (1 one pass, 2 two passes, 3 owner form)")                        \
+  X(lstm_form, 0, "force the form of EVERY recurrent step (0 = as the caller asks)")                                               \
+  X(lstm_prefetch, 2, "k-steps per prefetch group of the 64-row recurrent step (1, 2, 4)")                                         \
+  X(lstm_prio, 1, "recurrent step's waves at s_setprio 3")                                                                         \
+  X(lstm_upw, 16, "hidden units per recurrent workgroup (16 or 8); read when a model is loaded")                                   \
+  X(copy_kernel, 1, "small tables / result blocks through a copy kernel and mapped page-locked memory (0: copy engine)")           \
+  X(search_lds_kb, 160, "LDS budget of the search kernel's layout (96..160)")                                                      \
+  X(search_step, 2, "word-mode search step: 2 = label bitmaps + indexed FullScore where it applies, 0 = generic step")              \
+  X(lm_waves, 0, "language-model waves of the search step (0 = by beam width)")                                                    \
+  X(exp_waves, 0, "expand waves of the search step (0 = all the others)")                                                          \
+  X(lm_memo, 1, "code-point scorer: FullScore memo table")                                                                         \
+  X(lm_index_mb, 4096, "hashed n-gram index: byte cap in MiB (larger models take the trie walk)")                                  \
+  X(dump_marks, 0, "profiling: raw HIP-event timeline of the batch path on stderr")
+
+struct Tuning {
+#define X(name, def, doc) int name = def;
+  STT_TUNING_FIELDS(X)
+#undef X
+};
+Tuning& tune();                                // the table (seeded from STT_AMD_TUNING on first use)
+int tuning_set(const char* name, int value);   // 0 = ok, -1 = no such name
+int tuning_get(const char* name, int* value);

@@ -191,6 +191,32 @@ class Model(object):
         native.lib().STTX_FreeStrings(r, n.value)
         return out
 
+    def batchProbs(self, ticket, n_utterances):
+        """STTX_DebugBatchProbs: the probabilities the pipelined path computed for a submitted, not yet collected batch."""
+        g = self.geometry()
+        tmax = 1 << 12
+        nfr = (C.c_uint * n_utterances)()
+        probs = np.zeros((n_utterances, tmax, g["n_classes"]), dtype=np.float32)
+        status = native.lib().STTX_DebugBatchProbs(self._impl, int(ticket), probs.ctypes.data, tmax, nfr)
+        if status != 0:
+            raise RuntimeError("STTX_DebugBatchProbs failed 0x%X" % status)
+        return [probs[b, :nfr[b]].copy() for b in range(n_utterances)]
+
+    def lstmSteps(self, xproj, batch, steps, graph=False):
+        """STTX_TestLstmSteps: `steps` recurrent steps from a zero state; xproj f32 [period * batch][4 * n_hidden].
+        Returns (c, h, h_all bits) -- final state [batch][H] and the f16 bits of h over the last `period` steps."""
+        g = self.geometry()
+        H = g["n_hidden"]
+        x = np.ascontiguousarray(xproj, dtype=np.float32)
+        period = x.shape[0] // batch
+        assert x.shape == (period * batch, 4 * H)
+        c = np.zeros((batch, H), np.float32); h = np.zeros((batch, H), np.float32); hall = np.zeros((period * batch, H), np.uint16)
+        status = native.lib().STTX_TestLstmSteps(self._impl, batch, steps, period, int(bool(graph)), x.ctypes.data, c.ctypes.data, h.ctypes.data,
+                                                 hall.ctypes.data)
+        if status != 0:
+            raise RuntimeError("STTX_TestLstmSteps failed 0x%X" % status)
+        return c, h, hall
+
     def setProfiling(self, level):
         """0/False = off, 1/True = stage events + decoder counters, 2 = also the search kernel's phase cycle counters."""
         native.lib().STTX_SetProfiling(self._impl, int(level))

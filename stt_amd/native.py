@@ -47,7 +47,7 @@ COQUI_STT_H = [
 ]
 STT_AMD_H = [
     "STTX_SetDevice", "STTX_GetDeviceCount", "STTX_SpeechToTextBatch", "STTX_SpeechToTextBatchWithMetadata",
-    "STTX_SpeechToTextBatchDevice", "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmitDevice", "STTX_BatchCollect", "STTX_FeedAudioContentBatch", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
+    "STTX_SpeechToTextBatchDevice", "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmitDevice", "STTX_BatchCollect", "STTX_DebugBatchProbs", "STTX_SetTuning", "STTX_GetTuning", "STTX_ConfigureRuntime", "STTX_TestLstmSteps", "STTX_FeedAudioContentBatch", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
     "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_GetDecoderStamps", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
     "STTX_DecoderStats", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
@@ -67,6 +67,7 @@ def lib():
         raise RuntimeError("stt_amd: %s is missing -- build it with `python -m stt_amd.build`; "
                            "there is no fallback implementation." % LIB_PATH)
     L = C.CDLL(LIB_PATH)
+    L.STTX_ConfigureRuntime()      # before the first HIP call of this process (include/stt_amd.h)
     vp, ci, cu, cf, cd, cs = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_double, C.c_char_p
     pp = C.POINTER
     sig = {
@@ -108,6 +109,11 @@ def lib():
         "STTX_BatchPipelineDepthFor": (ci, [vp]),
         "STTX_BatchSubmitDevice": (ci, [vp, vp, cu, pp(cu), cu]),
         "STTX_BatchCollect": (pp(vp), [vp, ci, pp(cu)]),
+        "STTX_DebugBatchProbs": (ci, [vp, ci, vp, cu, pp(cu)]),
+        "STTX_SetTuning": (ci, [cs, ci]),
+        "STTX_GetTuning": (ci, [cs, pp(ci)]),
+        "STTX_ConfigureRuntime": (None, []),
+        "STTX_TestLstmSteps": (ci, [vp, cu, cu, cu, ci, vp, vp, vp, vp]),
         "STTX_FeedAudioContentBatch": (None, [pp(vp), pp(vp), pp(cu), cu]),
         "STTX_IntermediateDecodeBatch": (pp(vp), [pp(vp), cu]),
         "STTX_FinishStreamBatch": (pp(vp), [pp(vp), cu]),
@@ -172,6 +178,19 @@ def lm_score(lm_bytes, words, bos=True, mode=0):
     if rc != 0:
         raise RuntimeError("STTX_TestLm failed: 0x%x" % rc)
     return probs, lens
+
+
+def set_tuning(name, value):
+    """STTX_SetTuning: one of the engine's tunables (stt_amd/csrc/tuning.h); between calls, nothing in flight."""
+    if lib().STTX_SetTuning(name.encode(), int(value)) != 0:
+        raise KeyError("no tunable named %r" % name)
+
+
+def get_tuning(name):
+    v = C.c_int(0)
+    if lib().STTX_GetTuning(name.encode(), C.byref(v)) != 0:
+        raise KeyError("no tunable named %r" % name)
+    return v.value
 
 
 def error_message(code):

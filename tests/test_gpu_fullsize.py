@@ -50,7 +50,9 @@ def test_fullsize_acoustic_tolerance(big):
     a = synth.synth_audio(16000, seed=9)
     got = model.acousticProbs([a])[0]
     want = am_ref.utterance_probs(a, w, weight_round=np.float16)
-    assert np.abs(got - want).max() < 3e-3, np.abs(got - want).max()
+    a_err, l_err = np.abs(got - want).max(), np.abs(np.log(got) - np.log(want)).max()
+    print("fullsize acoustic: max |dp| %.3e  max |dlnp| %.3e" % (a_err, l_err))
+    assert a_err < 1e-4 and l_err < 2e-3, (a_err, l_err)          # the stated tolerance (tests/test_gpu_benchshape.py)
 
 
 def test_fullsize_huge_vocab_scorer_against_the_real_reference_decoder(big, ref, port, english, fix, tmp_path):

@@ -6,7 +6,8 @@ Tolerances (stated here, per the north star's "within a stated logit tolerance")
   * dense MFMA kernel: f16 operands, f32 accumulate; against an f64 product of the same f16-rounded operands:
     <= 1e-3 * (1 + |y|) (accumulation order only), output rounding to f16 allowed for the ReLU epilogue.
   * acoustic model (f16 weights/activations, f32 state) vs the f64 oracle fed the same f16-rounded weights/activations:
-    softmax probabilities within 3e-3 absolute; vs the unrounded f64 oracle within 2e-2 absolute.
+    softmax probabilities within 1e-4 absolute and 2e-3 on ln p (the stated tolerance, tests/test_gpu_benchshape.py);
+    vs the unrounded f64 oracle within 5e-3 on ln p.
 """
 import os
 
@@ -80,25 +81,30 @@ def test_dense_kernel(M, N, K, epi):
     assert err.max() < (2e-3 if epi == 0 else 1e-3), (err.max(), np.unravel_index(err.argmax(), err.shape))
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(300, 256, 512, 0), (129, 128, 2048, 1), (1024, 2048, 2048, 0), (3072, 512, 512, 1)])
-def test_dense_forms_beside_the_recurrence_are_bit_identical(M, N, K, epi, monkeypatch):
+@pytest.mark.parametrize("M,N,K,epi", [(300, 256, 512, 0), (129, 128, 2048, 1), (1024, 2048, 2048, 0), (3072, 512, 512, 1),
+                                       (3072, 8192, 2048, 1), (6144, 2048, 2048, 0)])
+def test_dense_forms_beside_the_recurrence_are_bit_identical(M, N, K, epi):
     """The three-stage one-per-CU forms of the 128-square tile (four waves; eight waves) that the batch path runs beside the
-    recurrence give the bits of the ordinary two-stage form (same k order per output element)."""
+    recurrence give the bits of the ordinary two-stage form (same k order per output element) -- including the shapes bench.py
+    times: the x-projection of a 48-frame chunk of 64 utterances (3072 x 8192 x 2048) and a layer of a 128-row group."""
     rng = np.random.default_rng(7 * M + N + K)
     x = rng.standard_normal((M, K)).astype(np.float16).astype(np.float32)
     w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float16).astype(np.float32)
     bias = rng.standard_normal(N).astype(np.float32)
     outs = []
-    for solo in ("0", "1", "2"):
-        monkeypatch.setenv("STT_AMD_TEST_DENSE_SOLO", solo)
-        monkeypatch.setenv("STT_AMD_DENSE_TILE", "128")
-        y = np.zeros((M, N), dtype=np.float32)
-        assert native.lib().STTX_TestDense(M, N, K, x.ctypes.data, w.ctypes.data, bias.ctypes.data, 20.0, epi, y.ctypes.data) == 0
-        outs.append(y)
-    ref = x.astype(np.float64) @ w.astype(np.float64) + bias
+    try:
+        native.set_tuning("dense_tile", 128)
+        for solo in (0, 1, 2):
+            native.set_tuning("dense_solo_test", solo)
+            y = np.zeros((M, N), dtype=np.float32)
+            assert native.lib().STTX_TestDense(M, N, K, x.ctypes.data, w.ctypes.data, bias.ctypes.data, 20.0, epi, y.ctypes.data) == 0
+            outs.append(y)
+    finally:
+        native.set_tuning("dense_solo_test", -1); native.set_tuning("dense_tile", 0)
+    ref = (x[:512].astype(np.float64) @ w.astype(np.float64) + bias) if M > 2048 else (x.astype(np.float64) @ w.astype(np.float64) + bias)
     if epi == 0:
         ref = np.minimum(np.maximum(ref, 0), 20.0)
-    assert (np.abs(outs[0] - ref) / (1 + np.abs(ref))).max() < 2e-3
+    assert (np.abs(outs[0][:len(ref)] - ref) / (1 + np.abs(ref))).max() < 2e-3
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
@@ -125,8 +131,8 @@ def test_infer_chunk_matches_oracle(small_model):
         probs, c, h = model.inferChunk(win[i:i + 16], c, h)
         want, c_o, h_o = am_ref.am_forward(win[i:i + 16], w, c0=c_o, h0=h_o, weight_round=np.float16)
         dump("infer_%d" % i, probs=probs, want=want, c=c, c_o=c_o, h=h, h_o=h_o)
-        assert np.abs(probs - want).max() < 3e-3, np.abs(probs - want).max()
-        assert np.abs(c - c_o).max() < 1e-2 and np.abs(h - h_o).max() < 1e-2
+        assert np.abs(probs - want).max() < 1e-4 and np.abs(np.log(probs) - np.log(want)).max() < 2e-3, np.abs(probs - want).max()
+        assert np.abs(c - c_o).max() < 2e-3 and np.abs(h - h_o).max() < 2e-3
         assert np.allclose(probs.sum(1), 1.0, atol=1e-4)
 
 
@@ -141,7 +147,9 @@ def test_batch_acoustic_probs(small_model):
         want64 = am_ref.utterance_probs(a, w)
         assert got[i].shape == want16.shape
         dump("am_batch_%d" % i, got=got[i], want16=want16, want64=want64)
-        assert np.abs(got[i] - want16).max() < 3e-3, (i, np.abs(got[i] - want16).max())
+        assert np.abs(got[i] - want16).max() < 1e-4, (i, np.abs(got[i] - want16).max())
+        if got[i].size:
+            assert np.abs(np.log(got[i]) - np.log(want16)).max() < 2e-3, (i, np.abs(np.log(got[i]) - np.log(want16)).max())
         # against the unrounded f64 restatement: every probability within 0.5 % (log domain; measured 6e-4 -- the f16 storage
         # of weights and activations is the whole difference)
         if got[i].size:

@@ -84,7 +84,9 @@ def test_wide_model_end_to_end(wide, port, fix):
     probs = m.acousticProbs([a])[0]
     want = am_ref.utterance_probs(a, wide["weights"], weight_round=np.float16)
     assert probs.shape == want.shape and probs.shape[1] == N_LABELS + 1
-    assert np.abs(probs - want).max() < 3e-3, np.abs(probs - want).max()
+    a_err, l_err = np.abs(probs - want).max(), np.abs(np.log(probs) - np.log(want)).max()
+    print("wide model: max |dp| %.3e  max |dlnp| %.3e" % (a_err, l_err))
+    assert a_err < 1e-4 and l_err < 2e-3, (a_err, l_err)          # the stated tolerance (tests/test_gpu_benchshape.py)
     m.enableExternalScorer(os.path.join(fix, "pruned_lm.scorer"))
     o, kind = _oracle(wide, fix, port, 32, True, 1.0, 40)
     o.next(probs)

@@ -101,7 +101,7 @@ def test_lstm_weight_packing_matches_kernel_indexing():
             hp[k >> 5, b >> 4, ((k & 31) >> 3) * 16 + (b & 15), k & 7] = h[b, k]
     xproj = rng.standard_normal((B, 4 * H))
     c = rng.standard_normal((B, H))
-    upw = int(os.environ.get("STT_AMD_LSTM_UPW", "16"))      # the library packs for the kernel shape it will launch (kernels.h: lstm_units_per_wg)
+    upw = native.get_tuning("lstm_upw")                     # the library packs for the kernel shape it will launch (kernels.h: lstm_units_per_wg)
     upw = 16 if upw >= 16 else 8
     h_new, c_new = _emulate_lstm_kernel(packed, hp.reshape(-1, 64, 8), xproj, c, H, B, NT, upw)
     Kh = kernel[H:].astype(np.float16).astype(np.float64)
