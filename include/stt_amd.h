@@ -91,6 +91,12 @@ STTX_EXPORT int STTX_FleetSetBeamWidth(STTX_Fleet* aFleet, unsigned int aBeamWid
 STTX_EXPORT char** STTX_FleetSpeechToTextBatch(STTX_Fleet* aFleet, const short* const* aBuffers, const unsigned int* aBufferSizes,
                                               unsigned int aBatch);
 STTX_EXPORT void STTX_FleetFree(STTX_Fleet* aFleet);
+/* Test hooks.  STTX_TestFleetRecords (host only): pack / pad / concatenate / unpack the transcript records exactly as the fleet's two
+ * all-gathers move them -- aTexts[i] decoded by shard aShardOf[i] of aShards -- and return the strings in the caller's order
+ * (STTX_FreeStrings), NULL on a malformed record.  STTX_DebugFleetFailShard: the next fleet batch fails on that shard before it
+ * decodes (-1 = off); the call must then return NULL on every device's thread instead of waiting inside a collective. */
+STTX_EXPORT char** STTX_TestFleetRecords(const char* const* aTexts, const unsigned int* aShardOf, unsigned int aCount, unsigned int aShards);
+STTX_EXPORT int STTX_DebugFleetFailShard(STTX_Fleet* aFleet, int aShard);
 /* The dealing rule alone (host only, no GPU): aShardOf[i] = shard of utterance i; by descending length (stable), each to the
  * least loaded shard so far (lowest index on ties) -- the same rule as stt_amd/dist.py: shard_utterances. */
 STTX_EXPORT int STTX_ShardUtterances(const unsigned int* aSizes, unsigned int aCount, unsigned int aShards, unsigned int* aShardOf);
@@ -180,9 +186,10 @@ STTX_EXPORT int STTX_TestDense(int aM, int aN, int aK, const float* aX, const fl
  * matrix: aSteps steps from a zero state, step t adding x-projection block t % aPeriod (aXproj [aPeriod * aBatch][4 * n_hidden] f32,
  * row = block * aBatch + b).  aC, aH [aBatch][n_hidden]: the final state; aHAll (may be NULL) [aPeriod * aBatch][n_hidden] f16 bits:
  * h of the last aPeriod steps.  aGraph != 0: the launches are captured into one hipGraph and replayed (as the batch path does).
- * The kernel form is chosen with STTX_SetTuning("lstm_form" / "lstm_prefetch"); every form must give the same bits. */
+ * The kernel form is chosen with STTX_SetTuning("lstm_form" / "lstm_prefetch"); every form must give the same bits.
+ * aElapsedMs (may be NULL): HIP-event time of the aSteps launches (or of the one graph launch). */
 STTX_EXPORT int STTX_TestLstmSteps(ModelState* aCtx, unsigned int aBatch, unsigned int aSteps, unsigned int aPeriod, int aGraph,
-                                  const float* aXproj, float* aC, float* aH, unsigned short* aHAll);
+                                  const float* aXproj, float* aC, float* aH, unsigned short* aHAll, float* aElapsedMs);
 /* Device expf/logf/log_sum_exp of sttmath.h over arrays (aOp 0 = expf, 1 = logf, 2 = log_sum_exp(a, b)). */
 STTX_EXPORT int STTX_TestMath(int aOp, const float* aA, const float* aB, float* aOut, unsigned int aCount);
 /* KenLM FullScore (kenlm/lm/model.cc:170-176) over aNumWords words, the state carried from BeginSentence (aBos) or the null

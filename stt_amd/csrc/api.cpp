@@ -438,9 +438,13 @@ int batch_submit(ModelState* m, const int16_t* d_audio, unsigned stride, const u
   }
   std::vector<unsigned> idx(B);
   for (unsigned i = 0; i < B; ++i) idx[i] = i;
-  if (m->async_pair_ && !m->pending_.valid) {  // first half of a pair: noted, not enqueued (its slot must be free already)
-    if (m->slots_[m->async_groups_ % m->async_depth_].busy())
+  {
+    int held = m->pending_.valid ? 1 : 0;  // tickets the caller holds
+    for (const auto& sl : m->slots_) held += (sl.part_open[0] ? 1 : 0) + (sl.part_open[1] ? 1 : 0);
+    if (held >= m->async_depth_ * (m->async_pair_ ? 2 : 1))
       throw std::runtime_error("the pipeline is full (STTX_BatchPipelineDepthFor batches in flight): collect the oldest one first");
+  }
+  if (m->async_pair_ && !m->pending_.valid) {  // first half of a pair: noted, not enqueued (its slot need only be free when its partner arrives)
     m->pending_.valid = true; m->pending_.d_audio = d_audio; m->pending_.stride = stride;
     m->pending_.sizes.assign(sizes, sizes + B); m->pending_.ticket = m->async_next_;
     return m->async_next_++;
@@ -795,7 +799,11 @@ char* STT_ErrorCodeToErrorMessage(int aErrorCode) {
 }
 
 // ================================================================ stt_amd.h
-int STTX_SetDevice(int aDevice) { g_device = aDevice; return hipSetDevice(aDevice) == hipSuccess ? STT_ERR_OK : STT_ERR_FAIL_INIT_SESS; }
+int STTX_SetDevice(int aDevice) {
+  if (aDevice < 0 || aDevice >= 16) return STT_ERR_FAIL_INIT_SESS;  // per-device launch state is kept in tables of 16 (a node holds 8)
+  g_device = aDevice;
+  return hipSetDevice(aDevice) == hipSuccess ? STT_ERR_OK : STT_ERR_FAIL_INIT_SESS;
+}
 int STTX_GetDeviceCount(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : -STT_ERR_FAIL_INIT_SESS; }
 
 char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride, const unsigned int* aBufferSizes, unsigned int aBatch) {
@@ -1115,7 +1123,7 @@ int STTX_TestDense(int M, int N, int K, const float* aX, const float* aW, const 
 }
 
 int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, unsigned int aPeriod, int aGraph, const float* aXproj, float* aC, float* aH,
-                       unsigned short* aHAll) {
+                       unsigned short* aHAll, float* aElapsedMs) {
   return guarded([&]() {
     HIP_CHECK(hipSetDevice(m->device));
     const int H = m->g.n_hidden, B = (int)aBatch, NT = lstm_nt_for_batch(B);
@@ -1129,7 +1137,9 @@ int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, 
     HIP_CHECK(hipMemsetAsync(hp1.p, 0, hp_bytes, m->stream));
     LstmArgs l{};
     l.whp = m->whp.as<_Float16>(); l.xproj = xp.as<float>(); l.c = c.as<float>(); l.h_all = hall.as<_Float16>();
-    l.n_hidden = H; l.batch = B; l.passes = 0; l.prio = 0;
+    l.n_hidden = H; l.batch = B; l.passes = 0; l.prio = 0; l.probe = 1;
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
     auto steps = [&]() {
       for (unsigned t = 0; t < aSteps; ++t) {
         l.hp_in = (t & 1) ? hp1.as<_Float16>() : hp0.as<_Float16>();
@@ -1154,18 +1164,33 @@ int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, 
       HIP_CHECK(hipStreamEndCapture(m->stream, &graph));
       HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
+      (void)hipEventRecord(e0, m->stream);
       const hipError_t le = hipGraphLaunch(exec, m->stream);
+      (void)hipEventRecord(e1, m->stream);
       const hipError_t se = hipStreamSynchronize(m->stream);
       (void)hipGraphExecDestroy(exec);
       HIP_CHECK(le); HIP_CHECK(se);
     } else {
+      {  // (the first launch of an instantiation loads its code object: not inside the timed span)
+        DevBuf sc, sh0, sh1; sc.reserve((size_t)B * H * 4); sh0.reserve(hp_bytes); sh1.reserve(hp_bytes);
+        HIP_CHECK(hipMemsetAsync(sh0.p, 0, hp_bytes, m->stream)); HIP_CHECK(hipMemsetAsync(sc.p, 0, (size_t)B * H * 4, m->stream));
+        LstmArgs w = l; w.c = sc.as<float>(); w.hp_in = sh0.as<_Float16>(); w.hp_out = sh1.as<_Float16>(); w.t = 0; w.h_f32 = nullptr;
+        launch_lstm_step(w, NT, m->stream);
+        HIP_CHECK(hipStreamSynchronize(m->stream));
+      }
+      HIP_CHECK(hipEventRecord(e0, m->stream));
       steps();
+      HIP_CHECK(hipEventRecord(e1, m->stream));
     }
     HIP_CHECK(hipMemcpyAsync(aC, c.p, (size_t)B * H * 4, hipMemcpyDeviceToHost, m->stream));
     HIP_CHECK(hipMemcpyAsync(aH, hf.p, (size_t)B * H * 4, hipMemcpyDeviceToHost, m->stream));
     if (aHAll) HIP_CHECK(hipMemcpyAsync(aHAll, hall.p, (size_t)aPeriod * B * H * 2, hipMemcpyDeviceToHost, m->stream));
     HIP_CHECK(hipStreamSynchronize(m->stream));
     HIP_CHECK(hipGetLastError());
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (aElapsedMs) *aElapsedMs = ms;
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_RUN_SESS);
 }

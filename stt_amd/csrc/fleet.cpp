@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstring>
 #include <iostream>
+#include <mutex>
 #include <thread>
 
 #include "../../include/stt_amd.h"
@@ -66,6 +67,9 @@ struct STTX_Fleet {
   std::vector<ncclComm_t> comms;
   std::vector<hipStream_t> streams;
   std::vector<DevBuf*> d_cnt, d_all_cnt, d_rec, d_all_rec;
+  size_t rec_cap = 1 << 20;  // bytes per rank and round of the record exchange (buffers allocated at creation)
+  int fail_shard = -1;       // STTX_DebugFleetFailShard
+  std::mutex mu;
   ~STTX_Fleet() {
     for (size_t i = 0; i < models.size(); ++i) {
       (void)hipSetDevice(devices[i]);
@@ -83,7 +87,11 @@ int STTX_FleetCreate(const char* aModelPath, const int* aDevices, unsigned int a
   *retval = nullptr;
   if (!aNumDevices || !aDevices) return STT_ERR_INVALID_SHAPE;
   try {
-    if (!g_rccl.load()) return STT_ERR_FAIL_INIT_SESS;
+    {
+      static std::mutex load_mu;  // (two threads creating their first fleets at once)
+      std::lock_guard<std::mutex> lk(load_mu);
+      if (!g_rccl.load()) return STT_ERR_FAIL_INIT_SESS;
+    }
     std::unique_ptr<STTX_Fleet> f(new STTX_Fleet());
     f->devices.assign(aDevices, aDevices + aNumDevices);
     for (unsigned i = 0; i < aNumDevices; ++i) {
@@ -105,6 +113,10 @@ int STTX_FleetCreate(const char* aModelPath, const int* aDevices, unsigned int a
       HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
       f->streams.push_back(st);
       f->d_cnt.push_back(new DevBuf()); f->d_all_cnt.push_back(new DevBuf()); f->d_rec.push_back(new DevBuf()); f->d_all_rec.push_back(new DevBuf());
+      // everything the exchange touches exists before the first batch: a rank can then only leave a collective through a HIP / RCCL
+      // error, never through an allocation
+      f->d_cnt.back()->reserve(4); f->d_all_cnt.back()->reserve((size_t)4 * aNumDevices);
+      f->d_rec.back()->reserve(f->rec_cap); f->d_all_rec.back()->reserve(f->rec_cap * aNumDevices);
     }
     *retval = f.release();
     return STT_ERR_OK;
@@ -125,56 +137,100 @@ int STTX_FleetSetBeamWidth(STTX_Fleet* f, unsigned int aBeamWidth) {
   return STT_ERR_OK;
 }
 
+// ---- the records that travel (host side, no GPU): rank r packs [u32 utterance index, u32 byte length, bytes] per transcript
+void fleet_pack_record(std::vector<unsigned char>& rec, unsigned id, const char* text) {
+  const unsigned len = (unsigned)strlen(text);
+  const size_t o = rec.size();
+  rec.resize(o + 8 + len);
+  memcpy(&rec[o], &id, 4); memcpy(&rec[o + 4], &len, 4); memcpy(&rec[o + 8], text, len);
+}
+// `gathered` = what an all-gather of the records padded to `cap` bytes leaves on every rank; counts[r] = bytes rank r really sent.
+// Fills out[id] (malloc'd) for every record; returns false on a malformed record (index out of range, length past the count).
+bool fleet_unpack_records(const unsigned char* gathered, size_t cap, const int* counts, unsigned G, unsigned n_out, char** out) {
+  for (unsigned r = 0; r < G; ++r) {
+    if (counts[r] < 0 || (size_t)counts[r] > cap) return false;
+    const unsigned char* p = gathered + (size_t)r * cap;
+    size_t o = 0;
+    while (o < (size_t)counts[r]) {
+      unsigned id, len;
+      if (o + 8 > (size_t)counts[r]) return false;
+      memcpy(&id, p + o, 4); memcpy(&len, p + o + 4, 4);
+      if (id >= n_out || o + 8 + (size_t)len > (size_t)counts[r] || out[id]) return false;
+      out[id] = (char*)malloc((size_t)len + 1);
+      memcpy(out[id], p + o + 8, len); out[id][len] = 0;
+      o += 8 + len;
+    }
+  }
+  return true;
+}
+static size_t fleet_cap(const int* counts, unsigned G) {
+  int cap = 16;
+  for (unsigned q = 0; q < G; ++q) cap = std::max(cap, counts[q]);
+  return (size_t)((cap + 15) & ~15);
+}
+
 // Transcripts in the caller's order, or NULL if any shard failed (STTX_FreeStrings releases them).
+// Every rank ALWAYS enters the first all-gather (a rank whose decode failed announces -1 there), and because every rank then holds
+// the same counts, all of them take the same decision about the second one: a failure on one device can never leave the others
+// waiting inside a collective.  Nothing is allocated between the two collectives (the record buffers are sized when the fleet is
+// created; larger records travel in rounds of that size), so a rank cannot drop out there either.
 char** STTX_FleetSpeechToTextBatch(STTX_Fleet* f, const short* const* aBuffers, const unsigned int* aBufferSizes, unsigned int aBatch) {
+  std::lock_guard<std::mutex> call_lock(f->mu);  // one batch at a time per fleet (the communicators and record buffers are per fleet)
   const unsigned G = (unsigned)f->models.size();
   std::vector<unsigned> shard_of(aBatch);
   if (STTX_ShardUtterances(aBufferSizes, aBatch, G, shard_of.data()) != STT_ERR_OK) return nullptr;
   std::vector<std::vector<unsigned>> idx(G);
   for (unsigned i = 0; i < aBatch; ++i) idx[shard_of[i]].push_back(i);
-  // every rank's record: [u32 utterance index, u32 byte length, bytes] per transcript; ranks gather counts, then padded records
   std::vector<std::vector<unsigned char>> rec(G);
   std::vector<int> ok(G, 1);
-  std::vector<std::vector<unsigned char>> gathered(G);  // (every rank receives everything; rank 0's copy is unpacked)
+  std::vector<unsigned char> gathered;                  // (every rank receives everything; rank 0's copy is unpacked)
   std::vector<std::vector<int>> counts(G, std::vector<int>(G, 0));
+  const size_t R = f->rec_cap;                          // bytes per rank and round of the record exchange
   auto shard_body = [&](unsigned r) {
+    // ---- decode this shard (may fail: the rank still takes part in the exchange below)
     try {
       HIP_CHECK(hipSetDevice(f->devices[r]));
       const unsigned n = (unsigned)idx[r].size();
       std::vector<const short*> bufs(n); std::vector<unsigned> sizes(n);
       for (unsigned k = 0; k < n; ++k) { bufs[k] = aBuffers[idx[r][k]]; sizes[k] = aBufferSizes[idx[r][k]]; }
+      if (f->fail_shard == (int)r) throw std::runtime_error("injected failure (STTX_DebugFleetFailShard)");
       char** texts = n ? STTX_SpeechToTextBatch(f->models[r], bufs.data(), sizes.data(), n) : nullptr;
-      if (n && !texts) { ok[r] = 0; }
-      for (unsigned k = 0; k < n && texts; ++k) {
-        const unsigned len = (unsigned)strlen(texts[k]), id = idx[r][k];
-        const size_t o = rec[r].size();
-        rec[r].resize(o + 8 + len);
-        memcpy(&rec[r][o], &id, 4); memcpy(&rec[r][o + 4], &len, 4); memcpy(&rec[r][o + 8], texts[k], len);
-      }
+      if (n && !texts) ok[r] = 0;
+      for (unsigned k = 0; k < n && texts; ++k) fleet_pack_record(rec[r], idx[r][k], texts[k]);
       if (texts) STTX_FreeStrings(texts, n);
-      // ---- exchange 1: byte counts (a failed shard announces -1)
-      hipStream_t st = f->streams[r];
-      const int mine = ok[r] ? (int)rec[r].size() : -1;
-      f->d_cnt[r]->reserve(4); f->d_all_cnt[r]->reserve(4 * G);
-      HIP_CHECK(hipMemcpyAsync(f->d_cnt[r]->p, &mine, 4, hipMemcpyHostToDevice, st));
-      if (g_rccl.AllGather(f->d_cnt[r]->p, f->d_all_cnt[r]->p, 1, ncclInt32, f->comms[r], st) != ncclSuccess) throw std::runtime_error("ncclAllGather(counts) failed");
-      HIP_CHECK(hipMemcpyAsync(counts[r].data(), f->d_all_cnt[r]->p, 4 * G, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      int cap = 16;
-      for (unsigned q = 0; q < G; ++q) cap = std::max(cap, counts[r][q]);
-      cap = (cap + 15) & ~15;
-      // ---- exchange 2: the records, padded to the largest
-      f->d_rec[r]->reserve((size_t)cap); f->d_all_rec[r]->reserve((size_t)cap * G);
-      HIP_CHECK(hipMemsetAsync(f->d_rec[r]->p, 0, (size_t)cap, st));
-      if (!rec[r].empty()) HIP_CHECK(hipMemcpyAsync(f->d_rec[r]->p, rec[r].data(), rec[r].size(), hipMemcpyHostToDevice, st));
-      if (g_rccl.AllGather(f->d_rec[r]->p, f->d_all_rec[r]->p, (size_t)cap, ncclUint8, f->comms[r], st) != ncclSuccess) throw std::runtime_error("ncclAllGather(records) failed");
-      if (r == 0) {
-        gathered[0].resize((size_t)cap * G);
-        HIP_CHECK(hipMemcpyAsync(gathered[0].data(), f->d_all_rec[0]->p, (size_t)cap * G, hipMemcpyDeviceToHost, st));
-      }
-      HIP_CHECK(hipStreamSynchronize(st));
     } catch (const std::exception& e) {
       std::cerr << "stt_amd: fleet shard " << r << ": " << e.what() << std::endl;
+      ok[r] = 0;
+    }
+    // ---- exchange 1: byte counts (a failed shard announces -1)
+    try {
+      (void)hipSetDevice(f->devices[r]);
+      hipStream_t st = f->streams[r];
+      const int mine = ok[r] ? (int)rec[r].size() : -1;
+      (void)hipMemcpyAsync(f->d_cnt[r]->p, &mine, 4, hipMemcpyHostToDevice, st);   // (pre-allocated buffers: nothing here allocates)
+      const int a1 = g_rccl.AllGather(f->d_cnt[r]->p, f->d_all_cnt[r]->p, 1, ncclInt32, f->comms[r], st);
+      HIP_CHECK(hipMemcpyAsync(counts[r].data(), f->d_all_cnt[r]->p, 4 * G, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (a1 != ncclSuccess) throw std::runtime_error("ncclAllGather(counts) failed");
+      bool all_ok = true;
+      for (unsigned q = 0; q < G; ++q) all_ok = all_ok && counts[r][q] >= 0;
+      if (!all_ok) { ok[r] = 0; return; }               // every rank sees the same counts: none of them enters exchange 2
+      // ---- exchange 2: the records, padded to the largest, in rounds of the pre-allocated size
+      const size_t cap = fleet_cap(counts[r].data(), G);
+      if (r == 0) gathered.assign(cap * G, 0);
+      for (size_t off = 0; off < cap; off += R) {
+        const size_t len = std::min(R, cap - off);
+        const size_t have = rec[r].size() > off ? std::min(len, rec[r].size() - off) : 0;
+        HIP_CHECK(hipMemsetAsync(f->d_rec[r]->p, 0, len, st));
+        if (have) HIP_CHECK(hipMemcpyAsync(f->d_rec[r]->p, rec[r].data() + off, have, hipMemcpyHostToDevice, st));
+        if (g_rccl.AllGather(f->d_rec[r]->p, f->d_all_rec[r]->p, len, ncclUint8, f->comms[r], st) != ncclSuccess) throw std::runtime_error("ncclAllGather(records) failed");
+        if (r == 0)
+          for (unsigned q = 0; q < G; ++q)
+            HIP_CHECK(hipMemcpyAsync(gathered.data() + (size_t)q * cap + off, (const char*)f->d_all_rec[0]->p + (size_t)q * len, len, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+      }
+    } catch (const std::exception& e) {
+      std::cerr << "stt_amd: fleet shard " << r << " (exchange): " << e.what() << std::endl;
       ok[r] = 0;
     }
   };
@@ -183,25 +239,34 @@ char** STTX_FleetSpeechToTextBatch(STTX_Fleet* f, const short* const* aBuffers, 
   shard_body(0);
   for (auto& t : th) t.join();
   for (unsigned r = 0; r < G; ++r) if (!ok[r] || counts[0][r] < 0) return nullptr;
-  int cap = 16;
-  for (unsigned q = 0; q < G; ++q) cap = std::max(cap, counts[0][q]);
-  cap = (cap + 15) & ~15;
   char** out = (char**)calloc(std::max(1u, aBatch), sizeof(char*));
-  for (unsigned r = 0; r < G; ++r) {
-    const unsigned char* p = gathered[0].data() + (size_t)r * cap;
-    size_t o = 0;
-    while (o + 8 <= (size_t)counts[0][r]) {
-      unsigned id, len;
-      memcpy(&id, p + o, 4); memcpy(&len, p + o + 4, 4);
-      if (id >= aBatch || o + 8 + len > (size_t)counts[0][r]) break;
-      out[id] = (char*)malloc((size_t)len + 1);
-      memcpy(out[id], p + o + 8, len); out[id][len] = 0;
-      o += 8 + len;
-    }
+  if (!fleet_unpack_records(gathered.data(), fleet_cap(counts[0].data(), G), counts[0].data(), G, aBatch, out)) {
+    for (unsigned i = 0; i < aBatch; ++i) free(out[i]);
+    free(out);
+    return nullptr;
   }
   for (unsigned i = 0; i < aBatch; ++i) if (!out[i]) out[i] = strdup("");
   return out;
 }
+
+// Test hooks.  (1) Pack / pad / concatenate / unpack exactly as the two all-gathers do, on the host: aTexts[i] is the transcript of
+// utterance i, decoded by shard aShardOf[i] of aShards; returns the strings in the caller's order (STTX_FreeStrings) or NULL.
+char** STTX_TestFleetRecords(const char* const* aTexts, const unsigned int* aShardOf, unsigned int aCount, unsigned int aShards) {
+  if (!aShards) return nullptr;
+  std::vector<std::vector<unsigned char>> rec(aShards);
+  for (unsigned i = 0; i < aCount; ++i) { if (aShardOf[i] >= aShards) return nullptr; fleet_pack_record(rec[aShardOf[i]], i, aTexts[i]); }
+  std::vector<int> counts(aShards);
+  for (unsigned r = 0; r < aShards; ++r) counts[r] = (int)rec[r].size();
+  const size_t cap = fleet_cap(counts.data(), aShards);
+  std::vector<unsigned char> gathered(cap * aShards, 0);
+  for (unsigned r = 0; r < aShards; ++r) if (!rec[r].empty()) memcpy(&gathered[(size_t)r * cap], rec[r].data(), rec[r].size());
+  char** out = (char**)calloc(std::max(1u, aCount), sizeof(char*));
+  if (!fleet_unpack_records(gathered.data(), cap, counts.data(), aShards, aCount, out)) { for (unsigned i = 0; i < aCount; ++i) free(out[i]); free(out); return nullptr; }
+  for (unsigned i = 0; i < aCount; ++i) if (!out[i]) out[i] = strdup("");
+  return out;
+}
+// (2) The next STTX_FleetSpeechToTextBatch call fails on shard aShard before decoding (-1: off): the call must return NULL, not hang.
+int STTX_DebugFleetFailShard(STTX_Fleet* f, int aShard) { f->fail_shard = aShard; return STT_ERR_OK; }
 
 void STTX_FleetFree(STTX_Fleet* f) { delete f; }
 

@@ -386,7 +386,9 @@ __device__ __forceinline__ float lstm_cell_(float zf, float c, float zi, float z
 // Every workgroup reads ALL of h (2 * H * 64 bytes at 64 batch rows = 256 KiB) besides its slice of the recurrent matrix, so
 // with 256 workgroups the h re-reads (64 MiB per step) outweigh the weights (33.5 MiB); 128 workgroups halve them, and a
 // workgroup then has a CU to itself (64 KiB reduction buffer, ~230 VGPRs: one wave per SIMD).
-template <int NT, int G_, int MT, int PHS>
+// DBG (timing probes only, wrong results): bit 0 = every h fragment load reads the wave's first one (h served by the L1: what the
+// step would cost if h were free), bit 1 = the same for the weight fragments (what it would cost if the weight stream were free).
+template <int NT, int G_, int MT, int PHS, int DBG = 0>
 __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
   constexpr bool PF = G_ > 0;
   constexpr int UPW = MT * 4;  // hidden units per workgroup
@@ -450,8 +452,8 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
     uint4 wa[G][MT], ha[G][NT], wb[G][MT], hb[G][NT];
 #define LSTM_LOAD(W, Hh, s0)                                                                      \
   _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                 \
-    _Pragma("unroll") for (int i = 0; i < MT; ++i) W[g][i] = wp[(size_t)(((s0) + g) * MT + i) * 64]; \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j) Hh[g][j] = hp[(size_t)(((s0) + g) * NT + j) * 64]; \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) W[g][i] = wp[(DBG & 2) ? (size_t)0 : (size_t)(((s0) + g) * MT + i) * 64]; \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) Hh[g][j] = hp[(DBG & 1) ? (size_t)0 : (size_t)(((s0) + g) * NT + j) * 64]; \
   }
 #define LSTM_MMA(W, Hh)                                                                           \
   _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                 \
@@ -622,6 +624,14 @@ template <int G_>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(LSTM8_VGPRS))) void lstm_step8_kernel(LstmArgs a) {
   lstm_step_body<8, G_, 4, 3>(a);
 }
+// Timing probes (STTX_TestLstmSteps with the tunable lstm_probe; benchmarks/lstm_micro.py): the shipped 64- and 128-row steps with
+// one operand stream served by the L1, and the 128-row step with two k-steps of prefetch and no register cap (runs alone only).
+template <int DBG>
+__global__ __launch_bounds__(256, 2) void lstm_probe4_kernel(LstmArgs a) { lstm_step_body<4, 2, 4, 3, DBG>(a); }
+template <int DBG>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(LSTM8_VGPRS))) void lstm_probe8_kernel(LstmArgs a) { lstm_step_body<8, 1, 4, 3, DBG>(a); }
+template <int DBG>
+__global__ __launch_bounds__(256, 1) void lstm_probe8g2_kernel(LstmArgs a) { lstm_step_body<8, 2, 4, 3, DBG>(a); }
 
 // h (f32 [B][H]) -> fragment-ordered f16 hp (used once per chunk to seed the recurrence from a carried state)
 __global__ void pack_h_kernel(const float* h, _Float16* hp, int B, int H, int NT) {
@@ -888,7 +898,22 @@ static void launch_lstm_inst(const LstmArgs& a, hipStream_t st) {
     else launch_lstm_inst2<NT, G, MT, 1>(a, st);
   }
 }
+static bool launch_lstm_probe(const LstmArgs& a, int NT, hipStream_t st) {
+  const int pr = tune().lstm_probe;  // 0 = off; 1..3 = DBG bits on the shipped kernel of this row count; 10 + DBG = the 128-row step with G = 2
+  if (!pr || (NT != 4 && NT != 8) || lstm_units_per_wg(a.n_hidden) != 16) return false;
+  const size_t smem = (size_t)4 * 3 * 4 * 64 * 16;
+  const dim3 grid(a.n_hidden / 16), block(256);
+#define PROBE(K) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL((K), grid, block, smem, st, a); return true; } while (0)
+  if (NT == 4) { switch (pr) { case 1: PROBE(lstm_probe4_kernel<1>); case 2: PROBE(lstm_probe4_kernel<2>); case 3: PROBE(lstm_probe4_kernel<3>); default: return false; } }
+  switch (pr) {
+    case 1: PROBE(lstm_probe8_kernel<1>); case 2: PROBE(lstm_probe8_kernel<2>); case 3: PROBE(lstm_probe8_kernel<3>);
+    case 10: PROBE(lstm_probe8g2_kernel<0>); case 11: PROBE(lstm_probe8g2_kernel<1>); case 12: PROBE(lstm_probe8g2_kernel<2>); case 13: PROBE(lstm_probe8g2_kernel<3>);
+    default: return false;
+  }
+#undef PROBE
+}
 void launch_lstm_step(const LstmArgs& a, int NT, hipStream_t st) {
+  if (a.probe && launch_lstm_probe(a, NT, st)) return;
   const int pg = tune().lstm_prefetch;
   if (lstm_units_per_wg(a.n_hidden) == 16) {
     switch (NT) {

@@ -105,6 +105,9 @@ static bool build_lm_index(HostScorer& hs) {
   // about 1.33 entries per 4-slot bucket: 4.6 % of the buckets are full, 1 % overflow into the next one
   uint64_t nb64 = (total * 3 + 3) / 4 + 16;
   if (nb64 * LMI_BUCKET >= 0xFFFFFFF0ull) return false;
+  // byte cap (tunable lm_index_mb): the table costs 48 B per n-gram on the host and again in HBM, on every replica of a fleet;
+  // a model beyond the cap keeps the trie walk, which reads the blob the reference mmaps and nothing else
+  if (nb64 * LMI_BUCKET * sizeof(LmiEntry) > (uint64_t)std::max(0, tune().lm_index_mb) * (1ull << 20)) return false;
   const uint32_t nb = (uint32_t)nb64;
   std::vector<LmiEntry>& tab = hs.lmi;
   tab.assign((size_t)nb * LMI_BUCKET, LmiEntry{LMI_EMPTY, 0u, 0.0f, 0.0f});
@@ -392,8 +395,12 @@ int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, 
   // <s> index and backoff (lm/model.cc:115-124)
   hs.bos_index = hs.vocab_index(murmur64a("<s>", 3, 0));
   hs.bos_backoff = rdf(buf + unigram_off + 16 * (uint64_t)hs.bos_index + 4);
-  hs.lmi_ok = build_lm_index(hs);
-  if (!hs.lmi_ok) { hs.lmi.clear(); hs.lmi_buckets = 0; }
+  // The index is read by the word-mode search step with label bitmaps (ctc.hip: ctc_masked_ok) and by the LM test hooks; code-point
+  // scorers, order-6 models and dictionaries without bitmaps never touch it: do not build what cannot be used.
+  const bool index_usable = lm_only || (!hs.utf8 && ord <= 5 && hs.fst_bitmap_ok && hs.uni_ok);
+  try { hs.lmi_ok = index_usable && build_lm_index(hs); }
+  catch (const std::bad_alloc&) { hs.lmi_ok = false; }  // no memory for the table: the scorer still loads (trie walk), as it does in the reference
+  if (!hs.lmi_ok) { hs.lmi.clear(); hs.lmi.shrink_to_fit(); hs.lmi_buckets = 0; }
   return STT_ERR_OK;
 }
 
@@ -433,7 +440,10 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label, bool lm_on
     fst_space_.upload(hs.fst_has_space.data(), hs.fst_has_space.size());
     fst_rec_.upload(hs.fst_rec.data(), hs.fst_rec.size() * sizeof(uint2));
   }
-  if (hs.lmi_ok) lmi_.upload(hs.lmi.data(), hs.lmi.size() * sizeof(LmiEntry));
+  if (hs.lmi_ok) {
+    try { lmi_.upload(hs.lmi.data(), hs.lmi.size() * sizeof(LmiEntry)); }
+    catch (const std::exception&) { hs.lmi_ok = false; (void)hipGetLastError(); }  // no HBM for it: trie walk
+  }
   const uint8_t* d = blob_.as<uint8_t>();
   DevScorer ds{};
   ds.enabled = 1; ds.order = ord; ds.quant = hs.quant; ds.utf8 = hs.utf8;

@@ -202,7 +202,7 @@ class Model(object):
             raise RuntimeError("STTX_DebugBatchProbs failed 0x%X" % status)
         return [probs[b, :nfr[b]].copy() for b in range(n_utterances)]
 
-    def lstmSteps(self, xproj, batch, steps, graph=False):
+    def lstmSteps(self, xproj, batch, steps, graph=False, timing=False):
         """STTX_TestLstmSteps: `steps` recurrent steps from a zero state; xproj f32 [period * batch][4 * n_hidden].
         Returns (c, h, h_all bits) -- final state [batch][H] and the f16 bits of h over the last `period` steps."""
         g = self.geometry()
@@ -211,11 +211,12 @@ class Model(object):
         period = x.shape[0] // batch
         assert x.shape == (period * batch, 4 * H)
         c = np.zeros((batch, H), np.float32); h = np.zeros((batch, H), np.float32); hall = np.zeros((period * batch, H), np.uint16)
+        ms = C.c_float(0.0)
         status = native.lib().STTX_TestLstmSteps(self._impl, batch, steps, period, int(bool(graph)), x.ctypes.data, c.ctypes.data, h.ctypes.data,
-                                                 hall.ctypes.data)
+                                                 hall.ctypes.data, C.byref(ms))
         if status != 0:
             raise RuntimeError("STTX_TestLstmSteps failed 0x%X" % status)
-        return c, h, hall
+        return (c, h, hall, ms.value) if timing else (c, h, hall)
 
     def setProfiling(self, level):
         """0/False = off, 1/True = stage events + decoder counters, 2 = also the search kernel's phase cycle counters."""

@@ -52,7 +52,7 @@ STT_AMD_H = [
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
     "STTX_DecoderStats", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
     "STTX_InspectModel", "STTX_ReadModelTensor", "STTX_TestLm", "STTX_DebugLimitArena", "STTX_DebugSetFastPath", "STTX_FleetCreate", "STTX_FleetSize",
-    "STTX_FleetEnableExternalScorer", "STTX_FleetSetBeamWidth", "STTX_FleetSpeechToTextBatch", "STTX_FleetFree", "STTX_ShardUtterances",
+    "STTX_FleetEnableExternalScorer", "STTX_FleetSetBeamWidth", "STTX_FleetSpeechToTextBatch", "STTX_FleetFree", "STTX_ShardUtterances", "STTX_TestFleetRecords", "STTX_DebugFleetFailShard",
 ]
 
 _lib = None
@@ -113,7 +113,7 @@ def lib():
         "STTX_SetTuning": (ci, [cs, ci]),
         "STTX_GetTuning": (ci, [cs, pp(ci)]),
         "STTX_ConfigureRuntime": (None, []),
-        "STTX_TestLstmSteps": (ci, [vp, cu, cu, cu, ci, vp, vp, vp, vp]),
+        "STTX_TestLstmSteps": (ci, [vp, cu, cu, cu, ci, vp, vp, vp, vp, pp(cf)]),
         "STTX_FeedAudioContentBatch": (None, [pp(vp), pp(vp), pp(cu), cu]),
         "STTX_IntermediateDecodeBatch": (pp(vp), [pp(vp), cu]),
         "STTX_FinishStreamBatch": (pp(vp), [pp(vp), cu]),
@@ -149,6 +149,8 @@ def lib():
         "STTX_FleetSpeechToTextBatch": (pp(vp), [vp, pp(vp), pp(cu), cu]),
         "STTX_FleetFree": (None, [vp]),
         "STTX_ShardUtterances": (ci, [pp(cu), cu, cu, pp(cu)]),
+        "STTX_TestFleetRecords": (pp(vp), [pp(cs), pp(cu), cu, cu]),
+        "STTX_DebugFleetFailShard": (ci, [vp, ci]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 from stt_amd import dist as sdist
@@ -85,3 +86,34 @@ def test_native_sharding_rule_equals_the_python_twin():
             assert len(got) == n
             for r, idx in enumerate(want):
                 assert sorted(i for i in range(n) if got[i] == r) == sorted(idx), (case, shards, r)
+
+
+@pytest.mark.parametrize("shards", [1, 2, 4, 8])
+def test_fleet_record_pack_and_unpack(shards):
+    """stt_amd/csrc/fleet.cpp: the transcript records exactly as the two all-gathers move them (per-rank [index, length, bytes]
+    records, padded to the longest rank, concatenated), packed and unpacked on the host -- empty strings, empty shards, UTF-8."""
+    import ctypes as C
+
+    from stt_amd import model as M
+    from stt_amd import native
+    if not os.path.exists(native.LIB_PATH):
+        pytest.skip("libstt.so not built")
+    L = native.lib()
+    rng = np.random.RandomState(shards)
+    texts = ["", "a", "she had your dark suit", "naïve café 北京", " ", "x" * 3000] + ["w%d " % i * int(rng.randint(0, 9)) for i in range(40)]
+    for layout in ("lpt", "one_rank", "round_robin"):
+        n = len(texts)
+        if layout == "lpt":
+            shard_of = M.shard_utterances_native([len(t) + 1 for t in texts], shards)
+        elif layout == "one_rank":
+            shard_of = [shards - 1] * n               # every other shard sends an empty record
+        else:
+            shard_of = [i % shards for i in range(n)]
+        arr = (C.c_char_p * n)(*[t.encode("utf-8") for t in texts])
+        so = (C.c_uint * n)(*shard_of)
+        r = L.STTX_TestFleetRecords(arr, so, n, shards)
+        assert r, layout
+        got = [C.string_at(r[i]).decode("utf-8") for i in range(n)]
+        L.STTX_FreeStrings(r, n)
+        assert got == texts, layout
+    assert not L.STTX_TestFleetRecords((C.c_char_p * 1)(b"x"), (C.c_uint * 1)(shards), 1, shards)   # a shard index out of range

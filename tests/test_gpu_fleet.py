@@ -34,3 +34,24 @@ def test_fleet_transcripts_equal_the_single_model_batch(tmp_path, fix):
     assert f.sttBatch(audio[:1]) == want[:1]                 # fewer utterances than devices is fine
     assert f.sttBatch([]) == []
     native.lib().STTX_SetDevice(0)
+
+
+def test_a_failing_shard_returns_null_instead_of_hanging(tmp_path, fix):
+    """A shard that fails before it decodes still enters the first all-gather and announces -1; every rank sees it and none enters
+    the second one (round 2: the other ranks would have waited inside the collective forever).  The fleet stays usable."""
+    from stt_amd import native
+    from stt_amd.model import Fleet
+    w = synth.synth_weights(6, n_hidden=256)
+    path = str(tmp_path / "m.sttw")
+    modelfile.write_model(path, w, synth.ENGLISH_LABELS, beam_width=50)
+    ndev = native.lib().STTX_GetDeviceCount()
+    f = Fleet(path, list(range(ndev)))
+    audio = [synth.synth_audio(9000 + 1000 * i, seed=30 + i) for i in range(5)]
+    want = f.sttBatch(audio)
+    for shard in range(ndev):
+        assert native.lib().STTX_DebugFleetFailShard(f._impl, shard) == 0
+        with pytest.raises(RuntimeError):
+            f.sttBatch(audio)
+    native.lib().STTX_DebugFleetFailShard(f._impl, -1)
+    assert f.sttBatch(audio) == want
+    native.lib().STTX_SetDevice(0)
