@@ -49,6 +49,12 @@ def main():
         run(128, True, lstm_probe=probe)
     for rows in (16, 32, 96):
         run(rows, True)
+    # where the time of a step goes: in-kernel REFCLK stamps (summary lines on stderr)
+    for rows in (64, 128):
+        for probe in (0, 3):
+            run(rows, False, lstm_form=3, lstm_probe=probe, lstm_stamps=1)
+    run(128, False, lstm_probe=10, lstm_stamps=1)
+    run(128, False, lstm_probe=13, lstm_stamps=1)
 
 
 if __name__ == "__main__":

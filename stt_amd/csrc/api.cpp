@@ -1140,8 +1140,13 @@ int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, 
     l.n_hidden = H; l.batch = B; l.passes = 0; l.prio = 0; l.probe = 1;
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    DevBuf stamps;
+    const int n_wg = H / lstm_units_per_wg(H);
+    const size_t stamp_n = (size_t)aSteps * n_wg * 16;
+    if (tune().lstm_stamps) { stamps.reserve(stamp_n * 8); HIP_CHECK(hipMemsetAsync(stamps.p, 0, stamp_n * 8, m->stream)); l.stamps = stamps.as<unsigned long long>(); }
     auto steps = [&]() {
       for (unsigned t = 0; t < aSteps; ++t) {
+        l.stamp_step = (int)t;
         l.hp_in = (t & 1) ? hp1.as<_Float16>() : hp0.as<_Float16>();
         l.hp_out = (t & 1) ? hp0.as<_Float16>() : hp1.as<_Float16>();
         l.t = (int)(t % aPeriod);
@@ -1189,6 +1194,26 @@ int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, 
     HIP_CHECK(hipGetLastError());
     float ms = 0.0f;
     (void)hipEventElapsedTime(&ms, e0, e1);
+    if (l.stamps) {  // per step: first entry .. last exit over all waves; gaps between steps; where the waves are inside a step (units of 10 ns)
+      std::vector<unsigned long long> st(stamp_n);
+      HIP_CHECK(hipMemcpy(st.data(), stamps.p, stamp_n * 8, hipMemcpyDeviceToHost));
+      double span = 0, gap = 0, loop = 0, bar = 0, epi = 0, skew_in = 0, loop_max = 0; int ns = 0;
+      unsigned long long prev_exit = 0;
+      for (unsigned t = 0; t < aSteps; ++t) {
+        unsigned long long e_min = ~0ull, e_max = 0, x_max = 0; double lp = 0, br = 0, ep = 0, lpm = 0; int nw = 0;
+        for (int w = 0; w < n_wg * 4; ++w) {
+          const unsigned long long* s4 = &st[((size_t)t * n_wg * 4 + w) * 4];
+          if (!s4[0] || !s4[3]) continue;
+          e_min = std::min(e_min, s4[0]); e_max = std::max(e_max, s4[0]); x_max = std::max(x_max, s4[3]);
+          lp += (double)(s4[1] - s4[0]); br += (double)(s4[2] - s4[1]); ep += (double)(s4[3] - s4[2]); lpm = std::max(lpm, (double)(s4[1] - s4[0])); ++nw;
+        }
+        if (!nw) continue;
+        if (t >= 8) { span += (double)(x_max - e_min); if (prev_exit) gap += (double)e_min - (double)prev_exit; loop += lp / nw; bar += br / nw; epi += ep / nw; skew_in += (double)(e_max - e_min); loop_max += lpm; ++ns; }
+        prev_exit = x_max;
+      }
+      if (ns) fprintf(stderr, "LSTM_STAMPS rows %d probe %d form %d: per step (us) span %.2f gap %.2f | entry skew %.2f k-loop avg %.2f max %.2f barrier-wait %.2f epilogue %.2f\n", B, tune().lstm_probe,
+                      tune().lstm_form, span / ns / 100, gap / ns / 100, skew_in / ns / 100, loop / ns / 100, loop_max / ns / 100, bar / ns / 100, epi / ns / 100);
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (aElapsedMs) *aElapsedMs = ms;
     return (int)STT_ERR_OK;

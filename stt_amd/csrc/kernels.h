@@ -57,6 +57,8 @@ struct LstmArgs {
   int passes;             // form of the cross-wave reduction: 0 = default, 1 = one pass (64 KiB of LDS), 2 = two passes over the batch
                           // tiles (32 KiB), 3 = owner form (48 KiB, one barrier, cell update on registers); 2, 3: 64-row batches only
   int prio;               // wave priority (s_setprio 0..3) of the step's waves: beats age when other kernels' waves share the SIMDs
+  unsigned long long* stamps;  // STTX_TestLstmSteps only: [steps][workgroups][4 waves][4] REFCLK stamps (null: none)
+  int stamp_step;
   int probe;              // STTX_TestLstmSteps only: honour the tunable lstm_probe (timing probes with wrong results; never set by the engine)
 };
 

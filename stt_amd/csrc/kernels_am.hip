@@ -386,11 +386,26 @@ __device__ __forceinline__ float lstm_cell_(float zf, float c, float zi, float z
 // Every workgroup reads ALL of h (2 * H * 64 bytes at 64 batch rows = 256 KiB) besides its slice of the recurrent matrix, so
 // with 256 workgroups the h re-reads (64 MiB per step) outweigh the weights (33.5 MiB); 128 workgroups halve them, and a
 // workgroup then has a CU to itself (64 KiB reduction buffer, ~230 VGPRs: one wave per SIMD).
+// MFMA with the accumulator tile pinned in the accumulator half of the register file ("a" constraint): left to itself the compiler
+// keeps part of a 128-register accumulator block in VGPRs and shuttles it through AGPRs around the loads (864 v_accvgpr moves per
+// step in the 128-row kernel: 19 us per step with NO operand traffic at all).  Pinned, the VGPR side only holds operands in flight.
+// (The hazard recogniser does not look inside inline asm: lstm_acc_settle() pads the distance between the last MFMA and the
+// first read of its result.)
+template <bool PIN>
+__device__ __forceinline__ void lstm_mfma(f32x4& acc, const f16x8& a, const f16x8& b) {
+  if constexpr (PIN) asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
+template <bool PIN>
+__device__ __forceinline__ void lstm_acc_settle() {
+  if constexpr (PIN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // 32 wait states >= the 8-pass MFMA's result latency
+}
 // DBG (timing probes only, wrong results): bit 0 = every h fragment load reads the wave's first one (h served by the L1: what the
 // step would cost if h were free), bit 1 = the same for the weight fragments (what it would cost if the weight stream were free).
 template <int NT, int G_, int MT, int PHS, int DBG = 0>
 __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
   constexpr bool PF = G_ > 0;
+  constexpr bool PIN = NT == 8;  // accumulators pinned in the accumulator file (lstm_mfma)
   constexpr int UPW = MT * 4;  // hidden units per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
   // The cross-wave reduction goes through LDS in PH passes over the batch tiles (two for 64 rows): 32 KiB instead of 64, so
@@ -403,6 +418,11 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
   if (a.prio) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
   const int wg = blockIdx.x;
+  // timing probe (STTX_TestLstmSteps with the tunable lstm_stamps): REFCLK (100 MHz) at entry / after the k-loop / behind the
+  // reduction barrier / at exit, per (step, workgroup, wave)
+  unsigned long long* const stamp = a.stamps ? a.stamps + (((size_t)a.stamp_step * gridDim.x + wg) * 4 + q) * 4 : nullptr;
+#define LSTM_STAMP(i) do { if (stamp && lane == 0) stamp[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  LSTM_STAMP(0);
   const int H = a.n_hidden;
   const int ksteps = H / 128;  // 32-deep k-steps per wave
   const uint4* wp = reinterpret_cast<const uint4*>(a.whp) + ((size_t)(wg * 4 + q) * ksteps) * MT * 64 + lane;
@@ -460,22 +480,39 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
     _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                              \
       const f16x8 fb = *reinterpret_cast<f16x8*>(&Hh[g][j]);                                      \
       _Pragma("unroll") for (int i = 0; i < MT; ++i)                                              \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&W[g][i]), fb, acc[i][j], 0, 0, 0); \
+        lstm_mfma<PIN>(acc[i][j], *reinterpret_cast<f16x8*>(&W[g][i]), fb);                        \
     }                                                                                             \
   }
+    // (the last pair of groups is peeled: a prefetch condition inside the loop leaves the waitcnt pass with a merge point it can only
+    // resolve with vmcnt(0) -- one group in flight instead of two)
     LSTM_LOAD(wa, ha, 0);
-    for (int s0 = 0; s0 < ksteps; s0 += 2 * G) {
+    int s0 = 0;
+    // (PIN: the asm MFMAs carry no scheduling model, and under the register budget the scheduler sinks each group's loads down to
+    // their first use -- one group in flight again; a scheduling barrier behind every load group keeps the double buffer)
+#define LSTM_FENCE() do { if (PIN) __builtin_amdgcn_sched_barrier(0); } while (0)
+    for (; s0 + 2 * G < ksteps; s0 += 2 * G) {
       LSTM_LOAD(wb, hb, s0 + G);
+      LSTM_FENCE();
       LSTM_MMA(wa, ha);
-      if (s0 + 2 * G < ksteps) { LSTM_LOAD(wa, ha, s0 + 2 * G); }
-      else if (OWN && NT == 8 && ob < B) {  // last group: `wa` / `ha` are free -- the cell-update operands of round 0 take their place in flight
-        const float* xp = a.xproj + ((size_t)a.t * B + ob) * (4 * H) + wg * UPW + ou;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) oxv[g] = *reinterpret_cast<const float4*>(xp + (size_t)g * H);
-        ocv = *reinterpret_cast<const float4*>(a.c + (size_t)ob * H + wg * UPW + ou);
-      }
+      LSTM_FENCE();
+      LSTM_LOAD(wa, ha, s0 + 2 * G);
+      LSTM_FENCE();
       LSTM_MMA(wb, hb);
+      LSTM_FENCE();
     }
+    LSTM_LOAD(wb, hb, s0 + G);
+    LSTM_FENCE();
+    LSTM_MMA(wa, ha);
+    LSTM_FENCE();
+    if (OWN && NT == 8 && ob < B) {  // `wa` / `ha` are free now: the cell-update operands of round 0 take their place in flight
+      const float* xp = a.xproj + ((size_t)a.t * B + ob) * (4 * H) + wg * UPW + ou;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) oxv[g] = *reinterpret_cast<const float4*>(xp + (size_t)g * H);
+      ocv = *reinterpret_cast<const float4*>(a.c + (size_t)ob * H + wg * UPW + ou);
+    }
+    LSTM_FENCE();
+    LSTM_MMA(wb, hb);
+#undef LSTM_FENCE
 #undef LSTM_LOAD
 #undef LSTM_MMA
   } else {
@@ -488,7 +525,7 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
         uint4 hv = hp[(size_t)(s * NT + j) * 64];
         f16x8 fb = *reinterpret_cast<f16x8*>(&hv);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&w[i]), fb, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MT; ++i) lstm_mfma<PIN>(acc[i][j], *reinterpret_cast<f16x8*>(&w[i]), fb);
       }
     }
     if (OWN && NT == 8 && ob < B) {  // (narrow models whose k-loop takes this branch: the cell-update operands of round 0)
@@ -498,6 +535,8 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
       ocv = *reinterpret_cast<const float4*>(a.c + (size_t)ob * H + wg * UPW + ou);
     }
   }
+  lstm_acc_settle<PIN>();
+  LSTM_STAMP(1);
   if (OWN) {
     typedef float OwnT[3][MT][64][4];                    // [writer wave][slot: the writer's foreign tiles in order][gate tile][lane]
     OwnT* park = reinterpret_cast<OwnT*>(lstm_smem);
@@ -524,6 +563,7 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
         ncv = *reinterpret_cast<const float4*>(a.c + (size_t)(obr + 64) * H + wg * UPW + ou);
       }
       __syncthreads();
+      if (rd == 0) LSTM_STAMP(2);
       f32x4 z[MT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -559,6 +599,7 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
       for (int g = 0; g < 4; ++g) oxv[g] = nxv[g];
       ocv = ncv;
     }
+    LSTM_STAMP(3);
     return;
   }
   // cell update: (unit u, batch row b): gate row r = g*UPW+u lives in tile r>>4, lane group (r&15)>>2, reg r&3
@@ -611,6 +652,7 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
   }
 }
 
+#undef LSTM_STAMP
 template <int NT, int G_, int MT, int PHS>
 __global__ __launch_bounds__(256, 2) void lstm_step_kernel(LstmArgs a) {  // (<= 256 registers per lane: two 128-register GEMM waves per SIMD fit beside it)
   lstm_step_body<NT, G_, MT, PHS>(a);
@@ -631,7 +673,7 @@ __global__ __launch_bounds__(256, 2) void lstm_probe4_kernel(LstmArgs a) { lstm_
 template <int DBG>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(LSTM8_VGPRS))) void lstm_probe8_kernel(LstmArgs a) { lstm_step_body<8, 1, 4, 3, DBG>(a); }
 template <int DBG>
-__global__ __launch_bounds__(256, 1) void lstm_probe8g2_kernel(LstmArgs a) { lstm_step_body<8, 2, 4, 3, DBG>(a); }
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(184))) void lstm_probe8g2_kernel(LstmArgs a) { lstm_step_body<8, 2, 4, 3, DBG>(a); }
 
 // h (f32 [B][H]) -> fragment-ordered f16 hp (used once per chunk to seed the recurrence from a carried state)
 __global__ void pack_h_kernel(const float* h, _Float16* hp, int B, int H, int NT) {

@@ -27,6 +27,7 @@
   X(lstm_prefetch, 2, "k-steps per prefetch group of the 64-row recurrent step (1, 2, 4)")                                         \
   X(lstm_prio, 1, "recurrent step's waves at s_setprio 3")                                                                         \
   X(lstm_probe, 0, "STTX_TestLstmSteps only: timing probes of the recurrent step (kernels_am.hip: launch_lstm_probe); wrong results")                                                                         \
+  X(lstm_stamps, 0, "STTX_TestLstmSteps only: in-kernel REFCLK stamps, summary on stderr")                                         \
   X(lstm_upw, 16, "hidden units per recurrent workgroup (16 or 8); read when a model is loaded")                                   \
   X(copy_kernel, 1, "small tables / result blocks through a copy kernel and mapped page-locked memory (0: copy engine)")           \
   X(search_lds_kb, 160, "LDS budget of the search kernel's layout (96..160)")                                                      \
