@@ -47,6 +47,8 @@ def main():
             run(rows, True, lstm_form=3, lstm_probe=probe)
     for probe in (10, 11, 12, 13):
         run(128, True, lstm_probe=probe)
+    for probe in (20, 21, 22):                 # the 64-row step with pinned accumulators, G = 1, 2, 4
+        run(64, True, lstm_probe=probe)
     for rows in (16, 32, 96):
         run(rows, True)
     # where the time of a step goes: in-kernel REFCLK stamps (summary lines on stderr)

@@ -1137,7 +1137,7 @@ int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, 
     HIP_CHECK(hipMemsetAsync(hp1.p, 0, hp_bytes, m->stream));
     LstmArgs l{};
     l.whp = m->whp.as<_Float16>(); l.xproj = xp.as<float>(); l.c = c.as<float>(); l.h_all = hall.as<_Float16>();
-    l.n_hidden = H; l.batch = B; l.passes = 0; l.prio = 0; l.probe = 1;
+    l.n_hidden = H; l.batch = B; l.passes = 0; l.prio = tune().lstm_prio; l.probe = 1;
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
     DevBuf stamps;
@@ -1154,6 +1154,28 @@ int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, 
         launch_lstm_step(l, NT, m->stream);
       }
     };
+    // co-tenant: x-projection GEMMs of a 128-row, 48-frame chunk on a second stream, in the form the batch path runs beside the recurrence
+    DevBuf cx, cy;
+    hipStream_t cst = nullptr;
+    hipEvent_t c0 = nullptr, c1 = nullptr;
+    const int n_co = tune().lstm_cotenant;
+    auto cotenant = [&]() {
+      if (n_co <= 0) return;
+      const int M = 6144;
+      cx.reserve((size_t)M * H * 2); cy.reserve((size_t)M * 4 * H * 4);
+      HIP_CHECK(hipMemsetAsync(cx.p, 0, (size_t)M * H * 2, m->stream));
+      HIP_CHECK(hipStreamSynchronize(m->stream));
+      HIP_CHECK(hipStreamCreateWithFlags(&cst, hipStreamNonBlocking));
+      HIP_CHECK(hipEventCreate(&c0)); HIP_CHECK(hipEventCreate(&c1));
+      DenseArgs d{};
+      d.wt = m->wxt.as<_Float16>(); d.x = cx.as<_Float16>(); d.bias = m->bl.as<float>(); d.y = cy.p; d.M = M; d.N = 4 * H; d.K = H; d.ldx = H; d.ldy = 4 * H;
+      d.relu_clip = 20.0f; d.solo = tune().dense_solo; d.lds_floor = d.solo ? 0 : tune().dense_lds_kb * 1024;
+      launch_dense(d, DENSE_EPI_BIAS_F32, cst);  // (first launch: code object, attributes)
+      HIP_CHECK(hipStreamSynchronize(cst));
+      HIP_CHECK(hipEventRecord(c0, cst));
+      for (int i = 0; i < n_co; ++i) launch_dense(d, DENSE_EPI_BIAS_F32, cst);
+      HIP_CHECK(hipEventRecord(c1, cst));
+    };
     if (aGraph) {
       l.hp_in = hp0.as<_Float16>(); l.hp_out = hp1.as<_Float16>(); l.t = 0; l.h_f32 = nullptr;
       // (first launch of an instantiation sets its function attributes: not inside a capture)
@@ -1169,6 +1191,7 @@ int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, 
       HIP_CHECK(hipStreamEndCapture(m->stream, &graph));
       HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
+      cotenant();
       (void)hipEventRecord(e0, m->stream);
       const hipError_t le = hipGraphLaunch(exec, m->stream);
       (void)hipEventRecord(e1, m->stream);
@@ -1183,9 +1206,18 @@ int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, 
         launch_lstm_step(w, NT, m->stream);
         HIP_CHECK(hipStreamSynchronize(m->stream));
       }
+      cotenant();
       HIP_CHECK(hipEventRecord(e0, m->stream));
       steps();
       HIP_CHECK(hipEventRecord(e1, m->stream));
+    }
+    if (cst) {
+      HIP_CHECK(hipStreamSynchronize(cst));
+      float cms = 0.0f;
+      (void)hipEventElapsedTime(&cms, c0, c1);
+      fprintf(stderr, "LSTM_COTENANT %d GEMMs (6144 x %d x %d, form %d): %.1f us each = %.3f PF/s\n", n_co, 4 * H, H, tune().dense_solo, 1e3 * cms / n_co,
+              2.0 * 6144 * 4.0 * H * H / (1e-3 * cms / n_co) / 1e15);
+      (void)hipEventDestroy(c0); (void)hipEventDestroy(c1); (void)hipStreamDestroy(cst);
     }
     HIP_CHECK(hipMemcpyAsync(aC, c.p, (size_t)B * H * 4, hipMemcpyDeviceToHost, m->stream));
     HIP_CHECK(hipMemcpyAsync(aH, hf.p, (size_t)B * H * 4, hipMemcpyDeviceToHost, m->stream));

@@ -41,7 +41,8 @@ struct DenseArgs {
   int xa, xb;          // tile-grid cut over the 8 XCDs (xa blocks along M x xb along N; filled in by launch_dense)
   int lds_floor;       // ask for at least this much dynamic LDS (bytes; 0 = what the tile needs): > 80 KiB keeps the kernel at ONE
                        // workgroup per CU, so that a recurrent-step workgroup launched beside it always finds room (engine.cpp)
-  int solo;            // 1: the three-stage form of the 128-square tile (96 KiB: one workgroup per CU, two K-tiles in flight); 2: the same on eight waves
+  int solo;            // 1: the three-stage form of the 128-square tile (96 KiB: one workgroup per CU, two K-tiles in flight); 2: the same on eight waves;
+                       // 3: the 128 x 256 eight-wave tile, two stages (96 KiB), where the shape allows (else as 2)
 };
 
 // ---- LSTM ---------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@
   X(pchunk, 48, "batches in flight: frames of the later time-chunks")                                                              \
   X(am_pipe, 1, "acoustic model of the batch path as three engines (0: one stream)")                                               \
   X(dense_lds_kb, 82, "LDS floor of the two-stage GEMM form when it runs beside the recurrence (one workgroup per CU)")            \
-  X(dense_solo, 2, "GEMM form beside the recurrence: 2 = three-stage eight-wave, 1 = three-stage four-wave, 0 = padded two-stage") \
+  X(dense_solo, 2, "GEMM form beside the recurrence: 3 = 128x256 eight-wave, 2 = 128-square three-stage eight-wave, 1 = four-wave, 0 = padded") \
   X(dense_solo_test, -1, "STTX_TestDense: force DenseArgs::solo (-1 = off)")                                                       \
   X(dense_tile, 0, "force the GEMM tile side (128 / 256; 0 = by shape)")                                                           \
   X(dense_big_min, 480, "256-square tiles from this many tiles on")                                                                \
@@ -27,6 +27,7 @@
   X(lstm_prefetch, 2, "k-steps per prefetch group of the 64-row recurrent step (1, 2, 4)")                                         \
   X(lstm_prio, 1, "recurrent step's waves at s_setprio 3")                                                                         \
   X(lstm_probe, 0, "STTX_TestLstmSteps only: timing probes of the recurrent step (kernels_am.hip: launch_lstm_probe); wrong results")                                                                         \
+  X(lstm_cotenant, 0, "STTX_TestLstmSteps only: this many x-projection GEMMs (6144 x 8192 x 2048, form dense_solo) run beside the steps") \
   X(lstm_stamps, 0, "STTX_TestLstmSteps only: in-kernel REFCLK stamps, summary on stderr")                                         \
   X(lstm_upw, 16, "hidden units per recurrent workgroup (16 or 8); read when a model is loaded")                                   \
   X(copy_kernel, 1, "small tables / result blocks through a copy kernel and mapped page-locked memory (0: copy engine)")           \

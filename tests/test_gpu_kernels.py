@@ -82,7 +82,7 @@ def test_dense_kernel(M, N, K, epi):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(300, 256, 512, 0), (129, 128, 2048, 1), (1024, 2048, 2048, 0), (3072, 512, 512, 1),
-                                       (3072, 8192, 2048, 1), (6144, 2048, 2048, 0)])
+                                       (3072, 8192, 2048, 1), (6144, 2048, 2048, 0), (2048, 2048, 512, 1), (130, 768, 64, 0)])
 def test_dense_forms_beside_the_recurrence_are_bit_identical(M, N, K, epi):
     """The three-stage one-per-CU forms of the 128-square tile (four waves; eight waves) that the batch path runs beside the
     recurrence give the bits of the ordinary two-stage form (same k order per output element) -- including the shapes bench.py
@@ -94,7 +94,7 @@ def test_dense_forms_beside_the_recurrence_are_bit_identical(M, N, K, epi):
     outs = []
     try:
         native.set_tuning("dense_tile", 128)
-        for solo in (0, 1, 2):
+        for solo in (0, 1, 2, 3):                       # 3: the 128 x 256 eight-wave tile (where N allows; else the same as 2)
             native.set_tuning("dense_solo_test", solo)
             y = np.zeros((M, N), dtype=np.float32)
             assert native.lib().STTX_TestDense(M, N, K, x.ctypes.data, w.ctypes.data, bias.ctypes.data, 20.0, epi, y.ctypes.data) == 0
@@ -105,7 +105,7 @@ def test_dense_forms_beside_the_recurrence_are_bit_identical(M, N, K, epi):
     if epi == 0:
         ref = np.minimum(np.maximum(ref, 0), 20.0)
     assert (np.abs(outs[0][:len(ref)] - ref) / (1 + np.abs(ref))).max() < 2e-3
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[3])
 
 
 @pytest.mark.parametrize("n", [46797, 0, 100, 512, 832, 16000])
