@@ -307,6 +307,128 @@ __global__ __launch_bounds__(W8 ? 512 : T * T * 64, W8 ? 4 : 1) void dense_kerne
   }
 }
 
+// The 128 (rows) x 256 (features) tile on EIGHT waves, two LDS stages of 48 KiB (96 KiB: one workgroup per CU, like the
+// three-stage forms) -- the co-tenant of the 128-row recurrent step.  Every wave owns 64 features x 64 rows (4 x 4 MFMA tiles,
+// 64 accumulator registers): per K-tile a SIMD's two waves issue 64 MFMAs behind ONE DMA round trip and one barrier, twice the
+// 128-square eight-wave form's, and each operand byte staged feeds 1.33x the flops.  One K-tile of prefetch then covers the
+// landing latency by itself (alone: 0.94 PF/s against 0.74; beside the recurrent step 0.62 against 0.51).  110 registers: two
+// waves per SIMD fit beside the 128-row step's 288.  Same k order per output element as every other form: bit-identical results.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void dense_wide_kernel(DenseArgs a) {
+  constexpr int BM = 128, BN = 256, NTHR = 512, MJ = 4;
+  constexpr int TILE_W = BN * GT_BK * 2, TILE_X = BM * GT_BK * 2, STAGE_BYTES = TILE_W + TILE_X;  // 32 + 16 KiB
+  constexpr int RPI = NTHR / 8;                   // 64 rows staged per DMA instruction of the whole workgroup
+  constexpr int ITW = BN / RPI, ITX = BM / RPI;   // 4 + 2 DMA instructions per thread and stage
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];  // [stage][W | X]
+  lds_u8* const lds = (lds_u8*)lds_raw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wm = wave & 1;        // 4 waves along the features x 2 along the rows
+  const int n_tiles_n = a.N / BN;
+  const int n_tiles_m = (a.M + BM - 1) / BM;
+  int tile_m, tile_n;
+  {  // XCD-aware tile order: see dense_kernel
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int xm = xcd / a.xb, xn = xcd - xm * a.xb;
+    const int Mx = (n_tiles_m + a.xa - 1) / a.xa, Nx = (n_tiles_n + a.xb - 1) / a.xb;
+    const int m_lo = xm * Mx, n_lo = xn * Nx;
+    const int m_cnt = min(Mx, n_tiles_m - m_lo), n_cnt = min(Nx, n_tiles_n - n_lo);
+    if (m_cnt <= 0 || n_cnt <= 0 || idx >= m_cnt * n_cnt) return;
+    const int sbn = min(8, n_cnt), per_strip = m_cnt * sbn, full = n_cnt / sbn;
+    int strip, rem, w;
+    if (idx < full * per_strip) { strip = idx / per_strip; rem = idx - strip * per_strip; w = sbn; }
+    else { strip = full; rem = idx - full * per_strip; w = n_cnt - full * sbn; }
+    const int blk = rem / (8 * w), r2 = rem - blk * 8 * w;
+    const int mh = min(8, m_cnt - blk * 8);
+    const int tn_l = r2 / mh, tm_l = r2 - tn_l * mh;
+    tile_m = m_lo + blk * 8 + tm_l;
+    tile_n = n_lo + strip * sbn + tn_l;
+  }
+  const int n0 = tile_n * BN, m0 = tile_m * BM;
+  const int K = a.K;
+  f32x4 acc[4][MJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int srow = tid >> 3;
+  const int schunk = (tid & 7) ^ (srow & 7);
+  const _Float16* wsrc[ITW];
+  const _Float16* xsrc[ITX];
+#pragma unroll
+  for (int i = 0; i < ITW; ++i) wsrc[i] = a.wt + (size_t)(n0 + srow + RPI * i) * K + schunk * 8;
+#pragma unroll
+  for (int i = 0; i < ITX; ++i) {
+    int mr = m0 + srow + RPI * i;
+    mr = mr < a.M ? mr : a.M - 1;
+    xsrc[i] = a.x + (size_t)mr * a.ldx + schunk * 8;
+  }
+  const unsigned wave_off = (unsigned)wave * 64 * 16;
+#define STAGE_W(buf, k0)                                                                                                 \
+  do {                                                                                                                   \
+    lds_u8* const bw_ = lds + (buf) * STAGE_BYTES + wave_off;                                                            \
+    lds_u8* const bx_ = bw_ + TILE_W;                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < ITW; ++i)                                                                      \
+      __builtin_amdgcn_global_load_lds((gvoid_c*)(wsrc[i] + (k0)), (__attribute__((address_space(3))) void*)(bw_ + i * NTHR * 16), 16, 0, 0); \
+    _Pragma("unroll") for (int i = 0; i < ITX; ++i)                                                                      \
+      __builtin_amdgcn_global_load_lds((gvoid_c*)(xsrc[i] + (k0)), (__attribute__((address_space(3))) void*)(bx_ + i * NTHR * 16), 16, 0, 0); \
+  } while (0)
+  const int frow = lane & 15, fq = lane >> 4;
+  unsigned offw[4], offx[MJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rw = wn * 64 + i * 16 + frow;
+    offw[i] = (unsigned)rw * 128u + (unsigned)((fq ^ (rw & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    const int rx = wm * 64 + j * 16 + frow;
+    offx[j] = (unsigned)rx * 128u + (unsigned)((fq ^ (rx & 7)) << 4);
+  }
+  const int nk = K / GT_BK;
+  STAGE_W(0, 0);
+  __syncthreads();  // (waits for the DMA: vmcnt(0) + barrier)
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) STAGE_W(cur ^ 1, (kt + 1) * GT_BK);
+    const lds_u8* const bw = lds + cur * STAGE_BYTES;
+    const lds_u8* const bx = bw + TILE_W;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 fa[4], fb[MJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(bw + (offw[i] ^ (unsigned)(ks << 6)));
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) fb[j] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(bx + (offx[j] ^ (unsigned)(ks << 6)));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // tile kt+1 has landed; every wave is done reading tile kt
+    cur ^= 1;
+  }
+#undef STAGE_W
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+    const float4 bias = *reinterpret_cast<const float4*>(a.bias + n);
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+      const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+      if (m >= a.M) continue;
+      float v0 = acc[i][j][0] + bias.x, v1 = acc[i][j][1] + bias.y, v2 = acc[i][j][2] + bias.z, v3 = acc[i][j][3] + bias.w;
+      if (EPI == DENSE_EPI_RELU_F16) {
+        v0 = fminf(fmaxf(v0, 0.f), a.relu_clip); v1 = fminf(fmaxf(v1, 0.f), a.relu_clip);
+        v2 = fminf(fmaxf(v2, 0.f), a.relu_clip); v3 = fminf(fmaxf(v3, 0.f), a.relu_clip);
+        f16x4 o = {(_Float16)v0, (_Float16)v1, (_Float16)v2, (_Float16)v3};
+        *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.y) + (size_t)m * a.ldy + n) = o;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + n) = make_float4(v0, v1, v2, v3);
+      }
+    }
+  }
+}
+
 // Skinny form for M <= 16 rows (one stream's 16-frame chunk: STT_FeedAudioContent / STT_SpeechToText): the tiled kernel
 // would run N/128 workgroups through 32 barrier-separated K-tiles.  Here one wave owns 16 output features for the full K
 // with operands straight from L2 into MFMA fragments (weight rows and x rows are both K-contiguous), eight k-steps of loads
@@ -367,10 +489,12 @@ template __global__ void dense_skinny_kernel<DENSE_EPI_BIAS_F32>(DenseArgs);
 // B-fragment order (hp), so the 256 KiB h read is coalesced too.  HBM/L2-bound: 33.5 MB of f16
 // recurrent weights per step for H = 2048, shared by all batch rows.
 // =============================================================================================
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// (v_rcp_f32, 1 ulp, instead of the IEEE division sequence: the cell update of a 128-row step is ~40 quotients per lane, 1.3 us of
+// VALU issue per step as divisions; every kernel form shares these helpers, so all forms still agree bit for bit)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
   const float e = __expf(-2.0f * fabsf(x));
-  const float t = (1.0f - e) / (1.0f + e);
+  const float t = __fmul_rn(1.0f - e, __builtin_amdgcn_rcpf(1.0f + e));
   return copysignf(t, x);
 }
 
@@ -402,10 +526,9 @@ __device__ __forceinline__ void lstm_acc_settle() {
 }
 // DBG (timing probes only, wrong results): bit 0 = every h fragment load reads the wave's first one (h served by the L1: what the
 // step would cost if h were free), bit 1 = the same for the weight fragments (what it would cost if the weight stream were free).
-template <int NT, int G_, int MT, int PHS, int DBG = 0>
+template <int NT, int G_, int MT, int PHS, int DBG = 0, bool PIN = (NT == 8)>   // PIN: accumulators pinned in the accumulator file (lstm_mfma)
 __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
   constexpr bool PF = G_ > 0;
-  constexpr bool PIN = NT == 8;  // accumulators pinned in the accumulator file (lstm_mfma)
   constexpr int UPW = MT * 4;  // hidden units per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char lstm_smem[];
   // The cross-wave reduction goes through LDS in PH passes over the batch tiles (two for 64 rows): 32 KiB instead of 64, so
@@ -446,7 +569,7 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
   constexpr int ROUNDS = OWN ? NT / 4 : 1;
   const int ob = q * 16 + (lane & 15), ou = 4 * (lane >> 4);  // owner form: this lane's batch row (of round 0) and first unit
   float4 oxv[4] = {}, ocv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (OWN && NT == 4 && ob < B) {  // (NT = 8: fetched in the tail of the k-loop, when the operand double buffer has registers to spare)
+  if (OWN && !PIN && ob < B) {  // (pinned form: fetched in the tail of the k-loop, when the operand double buffer has registers to spare)
     const float* xp = a.xproj + ((size_t)a.t * B + ob) * (4 * H) + wg * UPW + ou;
 #pragma unroll
     for (int g = 0; g < 4; ++g) oxv[g] = *reinterpret_cast<const float4*>(xp + (size_t)g * H);
@@ -483,13 +606,22 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
         lstm_mfma<PIN>(acc[i][j], *reinterpret_cast<f16x8*>(&W[g][i]), fb);                        \
     }                                                                                             \
   }
+    if constexpr (!PIN) {
+      LSTM_LOAD(wa, ha, 0);
+      for (int s0 = 0; s0 < ksteps; s0 += 2 * G) {
+        LSTM_LOAD(wb, hb, s0 + G);
+        LSTM_MMA(wa, ha);
+        if (s0 + 2 * G < ksteps) { LSTM_LOAD(wa, ha, s0 + 2 * G); }
+        LSTM_MMA(wb, hb);
+      }
+    } else {
     // (the last pair of groups is peeled: a prefetch condition inside the loop leaves the waitcnt pass with a merge point it can only
     // resolve with vmcnt(0) -- one group in flight instead of two)
     LSTM_LOAD(wa, ha, 0);
     int s0 = 0;
-    // (PIN: the asm MFMAs carry no scheduling model, and under the register budget the scheduler sinks each group's loads down to
+    // (the asm MFMAs carry no scheduling model, and under the register budget the scheduler sinks each group's loads down to
     // their first use -- one group in flight again; a scheduling barrier behind every load group keeps the double buffer)
-#define LSTM_FENCE() do { if (PIN) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LSTM_FENCE() __builtin_amdgcn_sched_barrier(0)
     for (; s0 + 2 * G < ksteps; s0 += 2 * G) {
       LSTM_LOAD(wb, hb, s0 + G);
       LSTM_FENCE();
@@ -504,7 +636,7 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
     LSTM_FENCE();
     LSTM_MMA(wa, ha);
     LSTM_FENCE();
-    if (OWN && NT == 8 && ob < B) {  // `wa` / `ha` are free now: the cell-update operands of round 0 take their place in flight
+    if (OWN && ob < B) {  // `wa` / `ha` are free now: the cell-update operands of round 0 take their place in flight
       const float* xp = a.xproj + ((size_t)a.t * B + ob) * (4 * H) + wg * UPW + ou;
 #pragma unroll
       for (int g = 0; g < 4; ++g) oxv[g] = *reinterpret_cast<const float4*>(xp + (size_t)g * H);
@@ -512,6 +644,7 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
     }
     LSTM_FENCE();
     LSTM_MMA(wb, hb);
+    }
 #undef LSTM_FENCE
 #undef LSTM_LOAD
 #undef LSTM_MMA
@@ -528,7 +661,7 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
         for (int i = 0; i < MT; ++i) lstm_mfma<PIN>(acc[i][j], *reinterpret_cast<f16x8*>(&w[i]), fb);
       }
     }
-    if (OWN && NT == 8 && ob < B) {  // (narrow models whose k-loop takes this branch: the cell-update operands of round 0)
+    if (OWN && PIN && ob < B) {  // (narrow models whose k-loop takes this branch: the cell-update operands of round 0)
       const float* xp = a.xproj + ((size_t)a.t * B + ob) * (4 * H) + wg * UPW + ou;
 #pragma unroll
       for (int g = 0; g < 4; ++g) oxv[g] = *reinterpret_cast<const float4*>(xp + (size_t)g * H);
@@ -672,6 +805,8 @@ template <int DBG>
 __global__ __launch_bounds__(256, 2) void lstm_probe4_kernel(LstmArgs a) { lstm_step_body<4, 2, 4, 3, DBG>(a); }
 template <int DBG>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(LSTM8_VGPRS))) void lstm_probe8_kernel(LstmArgs a) { lstm_step_body<8, 1, 4, 3, DBG>(a); }
+template <int G_>  // the 64-row step with pinned accumulators (64 accumulator registers + operands: G = 2 -> ~150, G = 4 -> ~215 VGPRs)
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void lstm_probe4pin_kernel(LstmArgs a) { lstm_step_body<4, G_, 4, 3, 0, true>(a); }
 template <int DBG>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(184))) void lstm_probe8g2_kernel(LstmArgs a) { lstm_step_body<8, 2, 4, 3, DBG>(a); }
 
@@ -876,6 +1011,30 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
   // CU on it wins -- the long chunks of the pipelined batch path.  Tunables dense_tile = 128 / 256 force a side,
   // dense_big_min moves the threshold)
   const int big_ok = tune().dense_tile, big_min = tune().dense_big_min;
+  if (a.solo >= 3 && a.N % 256 == 0 && a.M >= 128) {  // the 128 x 256 eight-wave co-tenant form
+    DenseArgs b = a;
+    const int ntn = a.N / 256, ntm = (a.M + 127) / 128;
+    int best = 1 << 30;
+    b.xa = 1; b.xb = 8;
+    for (int xa = 1; xa <= 8; xa *= 2) {
+      const int xb = 8 / xa;
+      const int Mx = (ntm + xa - 1) / xa, Nx = (ntn + xb - 1) / xb;
+      const int cost = Mx + 2 * Nx;  // (a block column is a 256-row weight slice: twice the bytes of a block row)
+      if (cost < best || (cost == best && Mx * Nx < ((ntm + b.xa - 1) / b.xa) * ((ntn + b.xb - 1) / b.xb))) { best = cost; b.xa = xa; b.xb = xb; }
+    }
+    const int per_xcd = ((ntm + b.xa - 1) / b.xa) * ((ntn + b.xb - 1) / b.xb);
+    const size_t smem = 96 * 1024;
+    static std::once_flag once[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev & 15], [&]() {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_RELU_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_BIAS_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    if (epi == DENSE_EPI_RELU_F16) hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_RELU_F16>), dim3(8 * per_xcd), dim3(512), smem, st, b);
+    else hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_BIAS_F32>), dim3(8 * per_xcd), dim3(512), smem, st, b);
+    return;
+  }
   const bool big_fits = a.N % 256 == 0 && a.M >= 256;
   const bool big = big_fits && !a.solo && (big_ok >= 256 || (big_ok == 0 && ((a.M + 255) / 256) * (a.N / 256) >= big_min));
   const int side = big ? 256 : 128;
@@ -946,7 +1105,13 @@ static bool launch_lstm_probe(const LstmArgs& a, int NT, hipStream_t st) {
   const size_t smem = (size_t)4 * 3 * 4 * 64 * 16;
   const dim3 grid(a.n_hidden / 16), block(256);
 #define PROBE(K) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); hipLaunchKernelGGL((K), grid, block, smem, st, a); return true; } while (0)
-  if (NT == 4) { switch (pr) { case 1: PROBE(lstm_probe4_kernel<1>); case 2: PROBE(lstm_probe4_kernel<2>); case 3: PROBE(lstm_probe4_kernel<3>); default: return false; } }
+  if (NT == 4) {
+    switch (pr) {
+      case 1: PROBE(lstm_probe4_kernel<1>); case 2: PROBE(lstm_probe4_kernel<2>); case 3: PROBE(lstm_probe4_kernel<3>);
+      case 20: PROBE(lstm_probe4pin_kernel<1>); case 21: PROBE(lstm_probe4pin_kernel<2>); case 22: PROBE(lstm_probe4pin_kernel<4>);
+      default: return false;
+    }
+  }
   switch (pr) {
     case 1: PROBE(lstm_probe8_kernel<1>); case 2: PROBE(lstm_probe8_kernel<2>); case 3: PROBE(lstm_probe8_kernel<3>);
     case 10: PROBE(lstm_probe8g2_kernel<0>); case 11: PROBE(lstm_probe8g2_kernel<1>); case 12: PROBE(lstm_probe8g2_kernel<2>); case 13: PROBE(lstm_probe8g2_kernel<3>);
