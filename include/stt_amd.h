@@ -126,8 +126,8 @@ STTX_EXPORT int STTX_GetDecoderStats(ModelState* aCtx, unsigned long long* aOut4
 /* Shader cycles spent per decoder phase (summed over streams) in the last batch call: emissions + hash, expand
  * prefix-sum, expand items, LM, merge, select, rank + write, end of step. */
 STTX_EXPORT int STTX_GetDecoderPhaseCycles(ModelState* aCtx, unsigned long long* aOut8);
-/* Profiling level 2, fast word-mode search step: shader cycles between the fine-grained stamps of ctc_fast.inc, summed over
- * the streams of the last batch call ([0..31] one expand wave, [32..63] one language-model wave; slot meanings there). */
+/* Profiling level 2: shader cycles between the fine-grained stamps of the search step (ctc.hip: DecParams::stamps), summed over
+ * the streams of the last batch call ([0..15] arrival of each wave at the end of the expand phase, [16..31] its wait there, ...). */
 STTX_EXPORT int STTX_GetDecoderStamps(ModelState* aCtx, unsigned long long* aOut64);
 
 /* ---- stage-level entry points (host buffers in and out) --------------------------------------- */
@@ -195,17 +195,12 @@ STTX_EXPORT int STTX_TestMath(int aOp, const float* aA, const float* aB, float* 
 /* KenLM FullScore (kenlm/lm/model.cc:170-176) over aNumWords words, the state carried from BeginSentence (aBos) or the null
  * context, on a bare KenLM trie binary: aProbs[i] = log10 probability, aLens[i] = matched n-gram length of word i
  * (lm::FullScoreReturn).  aMode 0 = the hashed n-gram index on the host (no GPU needed), 1 = the device trie walk,
- * 2 = the device index lookup (four lanes per query, as in the search kernel). */
+ * 2 = the device index lookup (one lane per query, as in the search kernel). */
 STTX_EXPORT int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* const* aWords, unsigned int aNumWords, int aBos,
                            int aMode, float* aProbs, int* aLens);
 /* Test hook: decoder arenas are sized for aFrames timesteps and never grow (0 = normal sizing), so that the overflow
  * reporting of the decode calls can be exercised. */
 STTX_EXPORT int STTX_DebugLimitArena(int aFrames);
-/* Test hook, word-mode search step: 0 = the generic step everywhere, 1 = the restructured step of ctc_fast.inc, 2 = the generic
- * step with dictionary label bitmaps, two language-model waves and FullScore through the hashed n-gram index (the default
- * wherever it applies: <= 32 classes, no class pruning, beam <= 512), -1 = as the STT_AMD_FAST environment variable says.
- * All three must give identical beams. */
-STTX_EXPORT int STTX_DebugSetFastPath(int aOn);
 /* Host-side packing of the recurrent matrix (no GPU needed): aKernel [2H][4H] f32 -> aOut [4H*H] f16 bits. */
 STTX_EXPORT int STTX_PackLstmRecurrent(const float* aKernel, int aHidden, unsigned short* aOut);
 

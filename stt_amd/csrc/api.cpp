@@ -1292,7 +1292,6 @@ int STTX_ReadModelTensor(const char* aModelBuffer, unsigned int aBufferSize, int
 }
 
 int STTX_DebugLimitArena(int aFrames) { g_debug_arena_frames = aFrames; return STT_ERR_OK; }
-int STTX_DebugSetFastPath(int aOn) { ctc_set_fast_path(aOn); return STT_ERR_OK; }
 
 int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* const* aWords, unsigned int aNumWords, int aBos, int aMode, float* aProbs, int* aLens) {
   return guarded([&]() {

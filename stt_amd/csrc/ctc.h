@@ -147,9 +147,8 @@ struct DecParams {
   unsigned long long wide_stride;
   int wide_max_frames;
   int lds_kb;       // LDS budget of the search kernel's layout in KiB (filled in by launch_ctc_next; host and device carve the same layout)
-  int n_exp_waves;  // fast word path: waves that expand prefixes (one prefix per lane)
-  int n_lm_waves;  // fast word path: waves of the workgroup that only run language-model queries (filled in by launch_ctc_next)
-  unsigned long long* stamps;  // profiling level 2: [n_streams][64] shader cycles between the stamps of ctc_fast.inc (wave 0: 0..31, last wave: 32..63)
+  int n_lm_waves;  // bitmap step: waves of the workgroup that only run language-model queries (0 = by beam width; filled in by launch_ctc_next)
+  unsigned long long* stamps;  // profiling level 2: [n_streams][64] shader cycles between the fine-grained stamps of the step (wave 0: 0..31, last wave: 32..63)
 };
 
 struct DecodeOut {
@@ -169,11 +168,10 @@ void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& 
                      const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st,
                      int max_frames = 0, void* wide_ws = nullptr);
 bool ctc_is_wide(int beam, int C, bool utf8 = false);
-void ctc_set_fast_path(int on);  // test hook: 0 = always the generic search step, 1 = the fast word path where it applies, -1 = environment
 size_t ctc_wide_row_bytes(int C);
 inline bool ctc_sorts_classes(const DecParams& p) { return p.cutoff_prob < 1.0 || p.cutoff_top_n < p.C; }  // :337
-inline size_t ctc_rows_ws_bytes(const DecParams& p, int n_streams, int max_frames) {  // (<= 32 classes: the fast word path reads row records as well)
-  return (ctc_is_wide(p.beam, p.C) || ctc_sorts_classes(p) || p.C <= 32) ? (size_t)n_streams * (size_t)max_frames * ctc_wide_row_bytes(p.C) : 0;
+inline size_t ctc_rows_ws_bytes(const DecParams& p, int n_streams, int max_frames) {
+  return (ctc_is_wide(p.beam, p.C) || ctc_sorts_classes(p)) ? (size_t)n_streams * (size_t)max_frames * ctc_wide_row_bytes(p.C) : 0;
 }
 // All outputs of a decode launch in ONE block (so they come back with one copy): [n_results | errors | lens | confidence | tokens |
 // timesteps]; `view` points a DecodeOut into a block at `base` (device or host).

@@ -29,6 +29,7 @@
 
 #include "ctc.h"
 #include "lmindex.h"
+#include "tuning.h"
 #include "sttmath.h"
 
 using sttm::stt_log_sum_exp;
@@ -60,7 +61,7 @@ struct GStream {
   GLB_AS uint32_t* pq;
   GLB_AS u32x4* be;          // BEntry = 4 x 16 bytes
   GLB_AS float* c_logp; GLB_AS uint32_t* c_pi; GLB_AS int* c_fst; GLB_AS uint64_t* sel_keys;
-  GLB_AS unsigned long long* c_key;  // fast word path: {slot in the segment array, segment} of the elements beyond two per thread
+  GLB_AS unsigned long long* c_key;  // (unused by the present steps; kept in the per-stream slab layout)
   const uint2* pa_generic;   // for the uncached scorer paths
   uint32_t cand_cap, pa_cap, ta_cap, be_cap;
 };
@@ -479,7 +480,7 @@ __device__ __forceinline__ void word_walk(const DevAlphabet& al, const GStream& 
 // fetched one after the other (an order-k entry is verified against the order-(k-1) hit, and most queries end at order 2 or
 // 3), instead of an interpolation search plus child-range reads per order.  Orders <= 5.  Same floats as the trie walk.
 __device__ __forceinline__ float lm_full_score_indexed(const DevScorer& s, const KState& in, uint64_t h, uint32_t wi, const DevVocabSlot& vs, KState& out,
-                                                       unsigned& probes) {
+                                                       unsigned& probes, int* ngram_length = nullptr) {
   const float uprob = wi ? vs.prob : s.unk_prob, uback = wi ? vs.backoff : s.unk_backoff;
   const bool uindep = wi ? (vs.begin == vs.end) : (s.unk_indep != 0);
   const GLB_AS u32x4* tab = (const GLB_AS u32x4*)s.lmi;
@@ -522,7 +523,9 @@ __device__ __forceinline__ float lm_full_score_indexed(const DevScorer& s, const
     }
   }
   int nl;
-  return lmi_combine(s.order, in, wi, uprob, uback, uindep, lv, out, nl);
+  const float r = lmi_combine(s.order, in, wi, uprob, uback, uindep, lv, out, nl);
+  if (ngram_length) *ngram_length = nl;
+  return r;
 }
 
 // FullScore cache (DevScorer::memo).  The key is (the in-state's context words, their count, the word's hash): backoffs
@@ -741,7 +744,7 @@ struct Lds {
   DB<uint32_t> ch, node, ts, bnd;
   DB<int> fst;
   DB<uint32_t> a0; DB<uint16_t> an;    // out-arcs of the prefix's dictionary state: first arc, count (read when the beam is written)
-  DB<uint32_t> sm;                     // fast word path: bitmap of the labels on those arcs (same storage as `an`; a0 = first labelled arc)
+  DB<uint32_t> sm;                     // bitmap step (MODE 4): bitmap of the labels on those arcs (same storage as `an`; a0 = first labelled arc)
   DB<uint64_t> key;
   // word mode, narrow beams: the UTF-8 bytes of the prefix's current (unfinished) word, first byte lowest (wlo = bytes
   // 0..7, whi = 8..15; all ones = longer than 16 bytes), and the BEntry of "prefix + boundary" once scored (STT_NONE before)
@@ -753,9 +756,6 @@ struct Lds {
   LDS_AS uint32_t* bloom;  // utf8 mode: 16384-bit filter over the live keys (one bit per key); null otherwise
   DB<float> pf, lp; LDS_AS float* lps;        // emissions and their logs (double buffered: the next row is prepared one step ahead); lps = by class position when pruning sorts
   LDS_AS double* lbl;                         // [2] log((double)prob[blank])
-  LDS_AS uint32_t* lpm;                       // fast word path: [2][36] bitmap of the k most probable classes of the row
-  LDS_AS float* pbl;                          // [2] prob[blank] (fast word path: the row arrives as a prepared record)
-  LDS_AS uint8_t* wait;                       // fast word path: live prefix whose extension event waits for a score of this step's LM waves
   LDS_AS uint16_t *cls, *pos;
   LDS_AS uint8_t* lab1;                       // [C] the byte of every single-byte label (0 otherwise)
   LDS_AS uint32_t *hist, *cumb;
@@ -781,10 +781,7 @@ enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, 
 // The class-count dependent arrays and the candidate staging area come last.
 // (host: from the environment once; device: the launch is configured with the host's value, and the kernel recomputes the
 // same layout from the same budget passed in DecParams::lds_kb)
-__host__ inline int lds_budget_kb_host() {
-  static const int v = []() { const char* e = getenv("STT_AMD_LDS_KB"); int k = e ? atoi(e) : 160; return k < 96 ? 96 : (k > 160 ? 160 : k); }();
-  return v;
-}
+__host__ inline int lds_budget_kb_host() { const int k = tune().search_lds_kb; return k < 96 ? 96 : (k > 160 ? 160 : k); }
 template <int CAP>
 __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, LDS_AS unsigned char* base, size_t& total, int budget_kb, bool utf8 = false) {
   Lds L{};
@@ -817,13 +814,10 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   offs[k++] = take(64 * 8);                                        // stm
   offs[k++] = take(SC_COUNT * 4);
   offs[k++] = take(16);                                            // lbl[2]
-  offs[k++] = take(2 * 36 * 4);                                    // lpm[2][36]
-  offs[k++] = take(16);                                            // pbl[2]
-  offs[k++] = take(arcs ? cap : 0);                                // wait
   offs[k++] = take(utf8 ? BLOOM_WORDS * 4 : 0);                    // bloom
   // ---- class-count dependent from here on
   for (int a = 0; a < 4; ++a) offs[k++] = take((size_t)(C > 0 && C < 32 ? 32 : C) * 4);  // pf[2], lp[2]
-  offs[k++] = take((size_t)(C > 0 && C <= 32 ? 64 : C) * 4);                            // lps (fast word path: [2][32] sorted log-probs)
+  offs[k++] = take((size_t)C * 4);                                                      // lps
   offs[k++] = take((size_t)C * 2); offs[k++] = take((size_t)C * 2);
   offs[k++] = take((size_t)C);
   // Candidate staging: whatever fits into the CU's 160 KiB, at most 2048 (STT_AMD_LDS_KB: budget in KiB).  Round 1 kept
@@ -863,9 +857,6 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
     l->stm = (LDS_AS unsigned long long*)(base + offs[k++]);
     l->sc = (LDS_AS int*)(base + offs[k++]);
     l->lbl = (LDS_AS double*)(base + offs[k++]);
-    l->lpm = (LDS_AS uint32_t*)(base + offs[k++]);
-    l->pbl = (LDS_AS float*)(base + offs[k++]);
-    l->wait = (LDS_AS uint8_t*)(base + offs[k++]);
     { const size_t ob = offs[k++]; l->bloom = utf8 ? (LDS_AS uint32_t*)(base + ob) : (LDS_AS uint32_t*)nullptr; }
     l->pf.p0 = (LDS_AS float*)(base + offs[k]); l->pf.blk = (uint32_t)(offs[k + 1] - offs[k]); k += 2;
     l->lp.p0 = (LDS_AS float*)(base + offs[k]); l->lp.blk = (uint32_t)(offs[k + 1] - offs[k]); k += 2;
@@ -990,7 +981,7 @@ __device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, co
   const float NEG = STT_NEG_INF;
 #define LSE(x, y) sttm::stt_log_sum_exp_t((x), (y), L.exp_tab, L.log_tab)
   const float e_self = L.ev_self[j], e_blank = L.ev_blank[j], e_ext = L.ev_ext[j];
-  const uint32_t ei = L.ev_exti[j] & 0xFFFFu;  // parent beam index (bits 16..30: the label in the fast word path, bit 31: waits for a score)
+  const uint32_t ei = L.ev_exti[j] & 0xFFFFu;  // parent beam index (bit 31: waits for a score)
   const uint32_t NOUP = 0xFFFFFFFEu;  // "no pending update" (previous_timesteps == nullptr)
   const uint32_t chj = L.ch[cur][j];
   const int kblank = WIDE ? (int)W.pos[p.blank] : (int)L.pos[p.blank];
@@ -1645,10 +1636,8 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   TICK(6);
 }
 
-#include "ctc_fast.inc"
-
-// MODE: 0 = no scorer, 1 = word-level scorer, 2 = utf8 (codepoint-level) scorer, 3 = word-level scorer on the fast path
-// of ctc_fast.inc (<= 32 classes, no class pruning, label bitmaps + hashed n-gram index available, CAP <= 512)
+// MODE: 0 = no scorer, 1 = word-level scorer, 2 = utf8 (codepoint-level) scorer, 4 = word-level scorer with the dictionary's label
+// bitmaps, two language-model waves and FullScore through the hashed n-gram index (<= 32 classes, no class pruning, CAP <= 512)
 template <int MODE, int CAP, bool WIDE>
 __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScorer s, DevAlphabet al, DecStream* streams,
                                                             const float* probs, const int* frame_begin, const int* frame_count) {
@@ -1669,19 +1658,19 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   GLB_AS uint32_t* g_ch = (GLB_AS uint32_t*)G.ch; GLB_AS uint32_t* g_node = (GLB_AS uint32_t*)G.node; GLB_AS uint32_t* g_ts = (GLB_AS uint32_t*)G.ts;
   GLB_AS int* g_fst = (GLB_AS int*)G.fst; GLB_AS uint64_t* g_key = (GLB_AS uint64_t*)G.key; GLB_AS uint32_t* g_bnd = (GLB_AS uint32_t*)G.bnd;
   constexpr bool SC_ON = MODE != 0;
-  constexpr bool FAST = MODE == 3, MASKED = MODE == 4, WORDC = MODE == 1 || MODE == 3 || MODE == 4;
+  constexpr bool MASKED = MODE == 4, WORDC = MODE == 1 || MODE == 4;
   const int tid = threadIdx.x;
   int n = G.n;
   int cur = 0;
   int start_expanding = G.start_expanding;
   int abs_t = G.abs_t;
   const float* row = probs + ((size_t)blockIdx.x * p.t_max + (frame_begin ? frame_begin[blockIdx.x] : p.all_begin)) * p.C;
-  const float v0 = (!WIDE && !FAST && tid < p.C) ? row[tid] : 0.0f;
+  const float v0 = (!WIDE && tid < p.C) ? row[tid] : 0.0f;
   for (int i = tid; i < n; i += NTHREADS) {
     L.score[0][i] = g_score[i]; L.pb[0][i] = g_pb[i]; L.pnb[0][i] = g_pnb[i];
     L.ch[0][i] = g_ch[i]; L.node[0][i] = g_node[i]; L.ts[0][i] = g_ts[i]; const int st = g_fst[i]; L.fst[0][i] = st; L.key[0][i] = g_key[i];
     L.bnd[0][i] = g_bnd[i];
-    if (FAST || MASKED) {
+    if (MASKED) {
       const uint2 rec = s.fst_rec[st];
       L.a0[0][i] = rec.x; L.sm[0][i] = rec.y;
     } else if (SC_ON && L.a0.p0) {
@@ -1689,11 +1678,6 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
       const uint32_t sp = MODE == 1 ? (uint32_t)s.fst_has_space[st] : 0u;
       L.a0[0][i] = f0; L.an[0][i] = (uint16_t)((f1 - f0) | (sp << 15));
     }
-  }
-  if (FAST) {  // what the fast step expects cleared on entry (it clears them again when it writes the new beam)
-    if (tid < CAP) { L.ev_self[tid] = absent(); L.ev_blank[tid] = absent(); L.ev_ext[tid] = absent(); L.ev_exti[tid] = 0; L.wait[tid] = 0; }
-    L.hist[tid] = 0;
-    if (tid == 0) { L.sc[SC_M] = 0; L.sc[SC_LMQ] = 0; L.sc[SC_NQ] = 0; L.sc[SC_PROBES] = 0; L.sc[SC_CLAMP] = 0; L.sc[SC_NA] = 0; L.sc[SC_NB] = 0; }
   }
   for (int c = tid; !WIDE && c < p.C; c += NTHREADS) {
     uint8_t one = 0;
@@ -1708,11 +1692,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   if (tid < 12) L.acc[tid] = 0;
   if (tid < 64) L.stm[tid] = 0;
   __syncthreads();  // the math tables must be in place before the first row is prepared
-  const unsigned char* rec0 = FAST ? p.wide_rows + ((size_t)blockIdx.x * p.wide_max_frames) * p.wide_stride : nullptr;  // this stream's row records
-  if constexpr (FAST) {
-    if (tid < 64) sort_row_classes(L, 0, p.C, tid < p.C ? reinterpret_cast<const float*>(rec0 + sizeof(WideRowHdr))[tid] : 0.0f, tid);
-    else if (tid == 64) { const WideRowHdr* hdr = reinterpret_cast<const WideRowHdr*>(rec0); L.pbl[0] = hdr->pblank; L.lbl[0] = hdr->lbl; }
-  } else if (!WIDE) prep_row(p, L, 0, row, v0);
+  if (!WIDE) prep_row(p, L, 0, row, v0);
   __syncthreads();
   const LDS_AS uint8_t* const lab1 = WIDE ? (const LDS_AS uint8_t*)nullptr : (const LDS_AS uint8_t*)L.lab1;
   if (WORDC && L.pqe.p0) {
@@ -1742,13 +1722,8 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   }
   for (int i = tid; i < n; i += NTHREADS) ht_insert(L, L.key[0][i], i);
   __syncthreads();
-  if constexpr (FAST) {
-    for (int t = 0; t < nfr; ++t)
-      ctc_step_fast<CAP>(p, s, al, GS, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? rec0 + (size_t)(t + 1) * p.wide_stride : nullptr, p.n_lm_waves);
-  } else {
-    for (int t = 0; t < nfr; ++t)
-      ctc_step<MODE, WIDE>(p, s, al, GS, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr, t);
-  }
+  for (int t = 0; t < nfr; ++t)
+    ctc_step<MODE, WIDE>(p, s, al, GS, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr, t);
   for (int i = tid; i < n; i += NTHREADS) {
     g_score[i] = L.score[cur][i]; g_pb[i] = L.pb[cur][i]; g_pnb[i] = L.pnb[cur][i];
     g_ch[i] = L.ch[cur][i]; g_node[i] = L.node[cur][i]; g_ts[i] = L.ts[cur][i]; g_fst[i] = L.fst[cur][i]; g_key[i] = L.key[cur][i];
@@ -1912,23 +1887,10 @@ void launch_scatter_streams(DecStream* const* dst, const DecStream* src, int n, 
 }
 
 // ------------------------------------------------------------------------------------ launchers
-// Fast word path (ctc_fast.inc) when everything it relies on is there; STT_AMD_FAST=0 keeps the generic step (A/B runs).
-// Word-mode step selection: 0 = generic, 1 = restructured step of ctc_fast.inc, 2 = generic step with label bitmaps +
-// two LM waves + indexed FullScore (MODE 4).  -1 = STT_AMD_FAST from the environment.
-static int g_fast_allow = -1;
-void ctc_set_fast_path(int on) { g_fast_allow = on; }
-static int ctc_word_step_choice() {
-  static const int env_allow = []() { const char* e = getenv("STT_AMD_FAST"); return e ? atoi(e) : 2; }();
-  return g_fast_allow >= 0 ? g_fast_allow : env_allow;
-}
+// Word-mode step selection (tunable search_step): 2 = the step with label bitmaps + two LM waves + indexed FullScore (MODE 4) wherever
+// it applies, anything else = the generic step everywhere.  Both give identical beams (tests/test_gpu_decoder.py, test_gpu_fuzz.py).
 static bool ctc_masked_ok(const DecParams& p, const DevScorer& s, const DevAlphabet& al) {
-  return ctc_word_step_choice() == 2 && s.enabled && !s.utf8 && p.C <= 32 && p.C >= 2 && p.blank == p.C - 1 && !ctc_sorts_classes(p) && cap_bucket(p.beam) <= 512 &&
-         s.fst_rec != nullptr && s.lmi != nullptr && s.order <= 5 && s.uni_in_vtab && al.space_id >= 0 && al.space_id < p.C - 1 && al.n_labels == p.C - 1;
-}
-static bool ctc_fast_ok(const DecParams& p, const DevScorer& s, const DevAlphabet& al, bool have_rows) {
-  // Only on request: on the benchmark's near-uniform emissions the restructured step is bit-identical but not faster than the
-  // generic one (5.9 vs 5.3 ms of search per 64 x 5 s batch); STT_AMD_FAST=1 / STTX_DebugSetFastPath(1) select it.
-  return ctc_word_step_choice() == 1 && have_rows && s.enabled && !s.utf8 && p.C <= 32 && p.C >= 2 && p.blank == p.C - 1 && !ctc_sorts_classes(p) && cap_bucket(p.beam) <= 512 &&
+  return tune().search_step == 2 && s.enabled && !s.utf8 && p.C <= 32 && p.C >= 2 && p.blank == p.C - 1 && !ctc_sorts_classes(p) && cap_bucket(p.beam) <= 512 &&
          s.fst_rec != nullptr && s.lmi != nullptr && s.order <= 5 && s.uni_in_vtab && al.space_id >= 0 && al.space_id < p.C - 1 && al.n_labels == p.C - 1;
 }
 static void check_launch(const char* what) {
@@ -1942,31 +1904,15 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
   p.wide_rows = nullptr; p.wide_stride = 0; p.wide_max_frames = 0; p.n_lm_waves = 0;
   if (wide && (!wide_ws || max_frames <= 0 || p.C > STT_MAX_CLASSES)) { fprintf(stderr, "stt_amd: launch_ctc_next: wide alphabet without a row workspace\n"); abort(); }
   const int cb = cap_bucket(p.beam);
-  const bool fast = !wide && ctc_fast_ok(p, s, al, wide_ws != nullptr && max_frames > 0);
-  if (fast) {
-    p.wide_rows = (const unsigned char*)wide_ws; p.wide_stride = ctc_wide_row_bytes(p.C); p.wide_max_frames = max_frames;
-    static const int lmw = []() { const char* e = getenv("STT_AMD_LM_WAVES"); return e ? atoi(e) : 0; }();
-    int nlm = lmw > 0 ? lmw : (cb >= 512 ? 2 : 1);
-    while (nlm > 1 && ((cb / 64) % nlm != 0 || nlm > cb / 64)) --nlm;  // every LM wave scans whole 64-prefix slices of the beam
-    if (nlm > 4) nlm = 4;
-    p.n_lm_waves = nlm;
-    static const int exw = []() { const char* e = getenv("STT_AMD_EXP_WAVES"); return e ? atoi(e) : 0; }();
-    int nexp = exw > 0 ? exw : NWAVES - nlm;
-    if (nexp > NWAVES - nlm) nexp = NWAVES - nlm;
-    if (nexp * 64 < cb) nexp = (cb + 63) / 64;  // a lane owns one prefix
-    p.n_exp_waves = nexp;
-    const int rows = n_streams * max_frames;
-    hipLaunchKernelGGL(ctc_rows_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, p, probs, frame_begin, frame_count, n_streams);
-    check_launch("ctc_rows_kernel");
-  } else if (wide || (ctc_sorts_classes(p) && wide_ws && max_frames > 0 && p.C <= WIDE_SORT_N)) {
+  if (wide || (ctc_sorts_classes(p) && wide_ws && max_frames > 0 && p.C <= WIDE_SORT_N)) {
     p.wide_rows = (const unsigned char*)wide_ws; p.wide_stride = ctc_wide_row_bytes(p.C); p.wide_max_frames = max_frames;
     hipLaunchKernelGGL(ctc_wide_rows_kernel, dim3(n_streams * max_frames), dim3(1024), 0, st, p, probs, frame_begin, frame_count);
     check_launch("ctc_wide_rows_kernel");
   }
-  if (!fast) { static const int lmw2 = []() { const char* e = getenv("STT_AMD_LM_WAVES"); return e ? atoi(e) : 0; }(); p.n_lm_waves = lmw2; }
+  p.n_lm_waves = tune().lm_waves;
   const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : p.C, s.enabled && s.utf8);
   p.lds_kb = lds_budget_kb_host();
-  const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : (fast ? 3 : ((!wide && ctc_masked_ok(p, s, al)) ? 4 : 1)));
+  const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : ((!wide && ctc_masked_ok(p, s, al)) ? 4 : 1));
   const int ci = cb == 64 ? 0 : cb == 128 ? 1 : cb == 256 ? 2 : cb == 512 ? 3 : 4;
   // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: remember what was set per device
   static std::mutex mu;
@@ -1991,7 +1937,6 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
 #define STT_CTC_MODE(M, W) STT_CTC_CASE(M, 0, 64, W) STT_CTC_CASE(M, 1, 128, W) STT_CTC_CASE(M, 2, 256, W) STT_CTC_CASE(M, 3, 512, W) STT_CTC_CASE(M, 4, 1024, W)
   STT_CTC_MODE(0, false) STT_CTC_MODE(1, false) STT_CTC_MODE(2, false)
   STT_CTC_MODE(0, true) STT_CTC_MODE(1, true) STT_CTC_MODE(2, true)
-  STT_CTC_CASE(3, 0, 64, false) STT_CTC_CASE(3, 1, 128, false) STT_CTC_CASE(3, 2, 256, false) STT_CTC_CASE(3, 3, 512, false)
   STT_CTC_CASE(4, 0, 64, false) STT_CTC_CASE(4, 1, 128, false) STT_CTC_CASE(4, 2, 256, false) STT_CTC_CASE(4, 3, 512, false)
 #undef STT_CTC_MODE
 #undef STT_CTC_CASE
@@ -2010,16 +1955,16 @@ __global__ void test_math_kernel(int op, const float* a, const float* b, float* 
   out[i] = op == 0 ? sttm::stt_expf(a[i]) : op == 1 ? sttm::stt_logf(a[i]) : sttm::stt_log_sum_exp(a[i], b[i]);
 }
 // LM test hook: FullScore over a word sequence (state carried from BeginSentence or the null context), through the trie walk
-// (use_index 0, one lane) or through the hashed n-gram index (use_index 1, one quad) -- against answers of the real KenLM.
+// (use_index 0) or through the hashed n-gram index (use_index 1), one lane either way -- against answers of the real KenLM.
 __global__ void test_lm_kernel(DevScorer s, const uint64_t* hashes, int n, int bos, int use_index, float* probs, int* lens) {
-  if (threadIdx.x >= 4) return;
+  if (threadIdx.x >= 1) return;
   KState st[2] = {};
   int cur = 0;
   if (bos) { st[0].length = 1; st[0].words[0] = s.bos_index; st[0].backoff[0] = s.bos_backoff; }
   unsigned probes = 0;
   for (int i = 0; i < n; ++i) {
     float prob; int nl = 0;
-    if (use_index) { uint32_t wi; prob = lm_full_score_quad(s, st[cur], hashes[i], st[cur ^ 1], wi, nl, probes); }
+    if (use_index) { DevVocabSlot vs; const uint32_t wi = vocab_slot(s, hashes[i], vs, probes); prob = lm_full_score_indexed(s, st[cur], hashes[i], wi, vs, st[cur ^ 1], probes, &nl); }
     else { const uint32_t wi = vocab_index(s, hashes[i], probes); prob = kenlm_full_score(s, st[cur], wi, st[cur ^ 1], probes, nullptr, &nl); }
     if (threadIdx.x == 0) { probs[i] = prob; lens[i] = nl; }
     cur ^= 1;

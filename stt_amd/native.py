@@ -51,7 +51,7 @@ STT_AMD_H = [
     "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_GetDecoderStamps", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
     "STTX_DecoderStats", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
-    "STTX_InspectModel", "STTX_ReadModelTensor", "STTX_TestLm", "STTX_DebugLimitArena", "STTX_DebugSetFastPath", "STTX_FleetCreate", "STTX_FleetSize",
+    "STTX_InspectModel", "STTX_ReadModelTensor", "STTX_TestLm", "STTX_DebugLimitArena", "STTX_FleetCreate", "STTX_FleetSize",
     "STTX_FleetEnableExternalScorer", "STTX_FleetSetBeamWidth", "STTX_FleetSpeechToTextBatch", "STTX_FleetFree", "STTX_ShardUtterances", "STTX_TestFleetRecords", "STTX_DebugFleetFailShard",
 ]
 
@@ -141,7 +141,6 @@ def lib():
         "STTX_ReadModelTensor": (ci, [vp, cu, ci, vp, C.c_ulonglong, pp(C.c_ulonglong)]),
         "STTX_TestLm": (ci, [vp, cu, pp(cs), cu, ci, ci, vp, vp]),
         "STTX_DebugLimitArena": (ci, [ci]),
-        "STTX_DebugSetFastPath": (ci, [ci]),
         "STTX_FleetCreate": (ci, [cs, pp(ci), cu, pp(vp)]),
         "STTX_FleetSize": (cu, [vp]),
         "STTX_FleetEnableExternalScorer": (ci, [vp, cs]),

@@ -50,16 +50,16 @@ def _gpu_decode(models, case, probs):
     return res, st, d
 
 
-@pytest.mark.parametrize("fast", [0, 1, 2], ids=["generic-step", "fast-word-step", "bitmap-step"])
-def test_decoder_matches_reference_goldens(models, decoder_cases, fast):
-    """fast = 1: the word-mode cases with a scorer run the restructured step of ctc_fast.inc (label bitmaps, hashed n-gram
-    index, four lanes per LM query); everything else falls back to the generic step either way."""
+@pytest.mark.parametrize("step", [0, 2], ids=["generic-step", "bitmap-step"])
+def test_decoder_matches_reference_goldens(models, decoder_cases, step):
+    """Tunable search_step = 2: the word-mode cases with a scorer run the step with dictionary label bitmaps, two language-model
+    waves and FullScore through the hashed n-gram index; everything else takes the generic step either way."""
     from stt_amd import native
-    native.lib().STTX_DebugSetFastPath(fast)
+    native.set_tuning("search_step", step)
     try:
         _goldens(models, decoder_cases)
     finally:
-        native.lib().STTX_DebugSetFastPath(-1)
+        native.set_tuning("search_step", 2)
 
 
 def _goldens(models, decoder_cases):

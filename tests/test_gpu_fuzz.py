@@ -56,16 +56,16 @@ def _emissions(rng, T, C, blank, kind, vocab, mode):
     return p
 
 
-@pytest.mark.parametrize("mode,lm,fast", [("word", False, 2), ("word", True, 2), ("word", True, 1), ("word", True, 0), ("bytes", False, 2), ("bytes", True, 2)])
-def test_fuzz_decoder_against_port(rigs, port, fix, mode, lm, fast):
-    """Word-mode step selection (STTX_DebugSetFastPath): 0 = generic step, 1 = restructured step of ctc_fast.inc, 2 = generic step
-    with label bitmaps + indexed FullScore (the default where it applies).  The same seeded cases must pass on all three."""
+@pytest.mark.parametrize("mode,lm,step", [("word", False, 2), ("word", True, 2), ("word", True, 0), ("bytes", False, 2), ("bytes", True, 2)])
+def test_fuzz_decoder_against_port(rigs, port, fix, mode, lm, step):
+    """Word-mode step selection (tunable search_step): 0 = generic step, 2 = the step with label bitmaps + indexed FullScore (the
+    default where it applies).  The same seeded cases must pass on both."""
     from stt_amd import native
-    native.lib().STTX_DebugSetFastPath(fast)
+    native.set_tuning("search_step", step)
     try:
         _fuzz(rigs, port, fix, mode, lm)
     finally:
-        native.lib().STTX_DebugSetFastPath(-1)
+        native.set_tuning("search_step", 2)
 
 
 def _fuzz(rigs, port, fix, mode, lm):

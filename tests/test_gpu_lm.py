@@ -1,5 +1,5 @@
-"""KenLM FullScore on the device -- the trie walk (ctc.hip: kenlm_full_score) and the hashed n-gram index with four lanes
-per query (ctc_fast.inc: lm_full_score_quad) -- against the answers of the real KenLM (tests/golden/kenlm_golden.json,
+"""KenLM FullScore on the device -- the trie walk (ctc.hip: kenlm_full_score) and the hashed n-gram index as the search step
+reads it (ctc.hip: lm_full_score_indexed) -- against the answers of the real KenLM (tests/golden/kenlm_golden.json,
 written by the reference library) on all four trie flavours: plain (model type 2), quantised (3), array-compressed (4)
 and quantised + array (5); and against the C port on random word sequences over the shipped scorer's model."""
 import json
