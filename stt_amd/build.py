@@ -43,8 +43,8 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
     objs = [os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o") for src in SOURCES]
-    if jobs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
+    if jobs or not os.path.exists(LIB) or _newer(os.path.join(CSRC, "libstt.map"), LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread", "-Wl,--version-script=" + os.path.join(CSRC, "libstt.map")]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

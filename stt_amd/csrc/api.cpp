@@ -170,9 +170,21 @@ struct BatchPart {
 // `stream`, the beam search of every chunk + the final ranking + the copy of the results to page-locked memory on
 // `stream_dec`, then the slot's `done` event.
 void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::vector<BatchPart>& parts, unsigned num_results, const DevScorer& ds,
-                         bool pipelined, hipEvent_t gate = nullptr) {
+                         bool pipelined, hipEvent_t gate = nullptr, bool optimistic = true) {
   int Bg = 0;
   for (const BatchPart& pt : parts) Bg += (int)pt.idx.size();
+  {  // remember the group (the callers' size arrays do not outlive their call); `parts` may itself be built on a moved-out copy of this
+    std::vector<ModelState::GroupSlot::SavedPart> keep;
+    for (const BatchPart& pt : parts) {
+      ModelState::GroupSlot::SavedPart sp{pt.d_audio, pt.stride, {}, pt.idx};
+      unsigned mx = 0;
+      for (unsigned i : pt.idx) mx = std::max(mx, i);
+      sp.sizes.assign(pt.sizes, pt.sizes + (pt.idx.empty() ? 0 : mx + 1));
+      keep.push_back(std::move(sp));
+    }
+    sl.saved_parts = std::move(keep);
+  }
+  sl.saved_num_results = num_results; sl.saved_pipelined = pipelined; sl.optimistic = optimistic;
   if (gate) HIP_CHECK(hipStreamWaitEvent(sl.stream_dec, gate, 0));  // this group's SEARCH starts behind group g - active; its acoustic model does not wait
   const int which = 1 + (int)(&sl - &m->slots_[0]);  // profiling mark list of this group's search stream
   // small integer tables in one page-locked block: [n_samples | n_frames | audio row | per chunk: begin, count]
@@ -223,7 +235,7 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::ve
     }
   }
   // decoder streams of the group
-  m->decoder_create(sl.dec, Bg, (int)m->beam_width_, t_max, m->scorer_, &sl.h_table);
+  m->decoder_create(sl.dec, Bg, (int)m->beam_width_, t_max, m->scorer_, &sl.h_table, optimistic);
   sl.probs.reserve((size_t)Bg * t_max * m->g.n_classes * 4);
   DecParams p{};
   p.C = m->g.n_classes; p.blank = p.C - 1; p.beam = sl.dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = t_max;
@@ -279,6 +291,22 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::ve
 // Wait for a group and turn its page-locked result block into Output lists: all[idx[i]] = results of the group's stream i.
 void batch_collect_group(ModelState* m, ModelState::GroupSlot& sl, std::vector<std::vector<Output>>& all, Prof& pr) {
   HIP_CHECK(hipEventSynchronize(sl.done));
+  if (sl.optimistic) {  // an arena of the optimistic sizing overflowed (bits 0, 1, 3: flagged by the kernel, nothing written out of bounds): decode the group again with the bound that cannot
+    const DecodeOut h0 = sl.out_layout.view(sl.h_out.p, sl.nr, sl.max_len);
+    int err = 0;
+    for (int i = 0; i < sl.Bg; ++i) err |= h0.errors[i];
+    if (err & 0xB) {
+      ++tune().arena_retries;
+      std::vector<unsigned> keep_idx = sl.idx;
+      const std::vector<ModelState::GroupSlot::SavedPart> saved = std::move(sl.saved_parts);  // (alive while the group is enqueued again)
+      std::vector<BatchPart> parts;
+      for (const auto& sp : saved) parts.push_back(BatchPart{sp.d_audio, sp.stride, sp.sizes.data(), sp.idx});
+      const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->hot_tables_, /*in_flight=*/true);
+      batch_enqueue_group(m, sl, parts, sl.saved_num_results, ds, sl.saved_pipelined, nullptr, /*optimistic=*/false);
+      sl.idx = keep_idx;
+      HIP_CHECK(hipEventSynchronize(sl.done));
+    }
+  }
   const DecodeOut h = sl.out_layout.view(sl.h_out.p, sl.nr, sl.max_len);
   const uint32_t *tok = h.tokens, *ts = h.timesteps;
   const int *lens = h.lens, *nres = h.n_results;
@@ -303,6 +331,11 @@ void batch_collect_group(ModelState* m, ModelState::GroupSlot& sl, std::vector<s
     pr.ms[6] += (float)sl.t_max; pr.ms[7] += (float)sl.t_max * sl.Bg;
     const DecStream* tb = sl.h_prof.as<DecStream>();
     for (int i = 0; i < sl.Bg; ++i) { for (int k = 0; k < 4; ++k) pr.dec_stats[k] += tb[i].stat[k]; for (int k = 0; k < 8; ++k) pr.dec_phase[k] += tb[i].phase[k]; }
+    if (tune().dump_marks) {  // how much of the (worst-case sized) arenas this group really used
+      double fp = 0, ft = 0, fb = 0;
+      for (int i = 0; i < sl.Bg; ++i) { fp = std::max(fp, (double)tb[i].pa_n / tb[i].pa_cap); ft = std::max(ft, (double)tb[i].ta_n / tb[i].ta_cap); fb = std::max(fb, (double)tb[i].be_n / tb[i].be_cap); }
+      fprintf(stderr, "ARENA group of %d streams, t_max %d: max fill path %.3f time %.3f boundary-entries %.3f\n", sl.Bg, sl.t_max, fp, ft, fb);
+    }
     if (sl.prof_stamp_bytes) {
       const unsigned long long* st = reinterpret_cast<const unsigned long long*>((const char*)sl.h_prof.p + sizeof(DecStream) * (size_t)sl.Bg);
       for (int i = 0; i < sl.Bg; ++i) for (int k = 0; k < 64; ++k) pr.dec_stamps[k] += st[(size_t)i * 64 + k];

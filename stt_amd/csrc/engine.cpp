@@ -285,28 +285,35 @@ DevScorer ModelState::current_scorer(std::shared_ptr<ScorerDev> sc, const std::m
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Per-stream slab: [fixed: beam arrays + per-step candidate workspace][path arena][time arena][pq][boundary entries].
-// Arena capacity covers `expected_frames` timesteps (each step appends at most beam path nodes and beam time nodes);
-// boundary entries (one per scored word end) are far rarer than nodes but capped by them, so the same capacity is reserved
-// (address space only: HBM pages the kernel never touches cost nothing).
+// Every timestep appends at most `beam` path nodes, `beam` time nodes and `beam` boundary entries (one per scored word end), so
+// (frames + 2) x beam of each is the bound that can never overflow -- 84 B per node: 40 GB for a group of 64 five-minute
+// utterances at beam 500.  Measured fill of that bound (profiles/r03_arena_fill.txt; 64 x 5 s, the 1-15 s job, byte mode, peaky):
+// time nodes <= 68 %, path nodes <= 14 %, boundary entries <= 8 % (64 B each -- the bulk of the bound).
+//   * a live stream checks before every chunk that the chunk's own worst case fits and grows the arena that does not
+//     (decoder_reserve: capacity doubles) -- it can never overflow and holds about twice what it uses;
+//   * a batch group is enqueued without a host round trip per chunk, so it is sized optimistically (`optimistic`: time nodes in
+//     full, path nodes 1/2, boundary entries 1/4 of the bound: 30 B per node instead of 84) and a group that does overflow --
+//     the search kernel flags it, nothing is written out of bounds -- is decoded again with the full bound (api.cpp).
 namespace {
 struct SlabLayout {
   size_t fixed, o_pa, o_ta, o_pq, o_be, per;
-  uint32_t arena, be_cap;
+  uint32_t pa_cap, ta_cap, be_cap;
 };
-SlabLayout slab_layout(size_t fixed, uint32_t arena) {
+SlabLayout slab_layout(size_t fixed, uint32_t pa_cap, uint32_t ta_cap, uint32_t be_cap) {
   SlabLayout l{};
-  l.fixed = fixed; l.arena = arena; l.be_cap = arena;  // at most one entry per path node
-  l.o_pa = fixed; l.o_ta = l.o_pa + al256((size_t)arena * 8); l.o_pq = l.o_ta + al256((size_t)arena * 8);
-  l.o_be = l.o_pq + al256((size_t)arena * 4); l.per = l.o_be + al256((size_t)l.be_cap * sizeof(BEntry));
+  l.fixed = fixed; l.pa_cap = pa_cap; l.ta_cap = ta_cap; l.be_cap = be_cap;
+  l.o_pa = fixed; l.o_ta = l.o_pa + al256((size_t)pa_cap * 8); l.o_pq = l.o_ta + al256((size_t)ta_cap * 8);
+  l.o_be = l.o_pq + al256((size_t)pa_cap * 4); l.per = l.o_be + al256((size_t)be_cap * sizeof(BEntry));
   return l;
 }
 void point_arenas(DecStream& S, uint8_t* base, const SlabLayout& l) {
   S.pa = (uint2*)(base + l.o_pa); S.ta = (uint2*)(base + l.o_ta); S.pq = (uint32_t*)(base + l.o_pq); S.be = (BEntry*)(base + l.o_be);
-  S.pa_cap = l.arena; S.ta_cap = l.arena; S.be_cap = l.be_cap;
+  S.pa_cap = l.pa_cap; S.ta_cap = l.ta_cap; S.be_cap = l.be_cap;
 }
 }  // namespace
 
-void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc, PinnedBuf* staging) {
+void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc, PinnedBuf* staging,
+                                bool optimistic) {
   const int C = g.n_classes;
   if (beam < 1 || beam > STT_MAX_BEAM) throw std::runtime_error("beam width must be in [1, 1024]");
   db.n_streams = n_streams; db.beam = beam; db.C = C;
@@ -315,11 +322,15 @@ void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int e
   if (g_debug_arena_frames > 0) expected_frames = g_debug_arena_frames;  // test hook: arenas that cannot hold the utterance
   const uint32_t arena = (uint32_t)(expected_frames + 2) * (uint32_t)beam + 2;
   const size_t fixed = al256(cap * 8) + 8 * al256(cap * 4) + al256(cand_cap * 4) * 3 + al256(cand_cap * 8) + al256(((size_t)cap + cand_cap) * 8);
-  const SlabLayout l = slab_layout(fixed, arena);
+  const uint32_t shrink = (uint32_t)std::max(1, tune().arena_shrink);
+  const uint32_t floor_n = (uint32_t)beam * 16u / shrink + 2u;  // (short inputs: never less than 16 frames' worth)
+  const bool opt = optimistic && g_debug_arena_frames <= 0;
+  const SlabLayout l = slab_layout(fixed, opt ? std::min(arena, std::max(arena / 2 / shrink, floor_n)) : arena, arena,
+                                   opt ? std::min(arena, std::max(arena / 4 / shrink, floor_n)) : arena);
   db.per_stream_fixed = fixed;
   db.slab.reserve(l.per * n_streams);
   db.host.assign(n_streams, DecStream{});
-  db.pa_cap.assign(n_streams, arena); db.ta_cap.assign(n_streams, arena);
+  db.pa_cap.assign(n_streams, l.pa_cap); db.ta_cap.assign(n_streams, l.ta_cap);
   uint8_t* base = db.slab.as<uint8_t>();
   for (int i = 0; i < n_streams; ++i) {
     uint8_t* p = base + l.per * i;
@@ -352,15 +363,19 @@ void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_
   HIP_CHECK(hipMemcpyAsync(db.host.data(), db.table.p, sizeof(DecStream) * db.n_streams, hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
   bool grow = false;
-  uint32_t need = 0;
+  uint32_t need_pa = 0, need_ta = 0, need_be = 0;
   for (int i = 0; i < db.n_streams; ++i) {
-    const uint32_t want = std::max(db.host[i].pa_n, db.host[i].ta_n) + (uint32_t)(more_frames[i] + 1) * db.beam + 2;
-    if (want > db.host[i].pa_cap) grow = true;
-    need = std::max(need, want);
+    const uint32_t add = (uint32_t)(more_frames[i] + 1) * db.beam + 2;  // this chunk's worst case, per arena
+    const DecStream& S = db.host[i];
+    if (S.pa_n + add > S.pa_cap || S.ta_n + add > S.ta_cap || S.be_n + add > S.be_cap) grow = true;
+    need_pa = std::max(need_pa, S.pa_n + add); need_ta = std::max(need_ta, S.ta_n + add); need_be = std::max(need_be, S.be_n + add);
   }
   if (!grow) return;
-  const SlabLayout ol = slab_layout(db.per_stream_fixed, db.host[0].pa_cap);
-  const SlabLayout nl = slab_layout(db.per_stream_fixed, need * 2);
+  const DecStream& S0 = db.host[0];
+  const SlabLayout ol = slab_layout(db.per_stream_fixed, S0.pa_cap, S0.ta_cap, S0.be_cap);
+  // only the arena that is short grows (to twice what it needs now); the others keep their size
+  const SlabLayout nl = slab_layout(db.per_stream_fixed, need_pa > S0.pa_cap ? need_pa * 2 : S0.pa_cap, need_ta > S0.ta_cap ? need_ta * 2 : S0.ta_cap,
+                                    need_be > S0.be_cap ? need_be * 2 : S0.be_cap);
   DevBuf ns;
   ns.reserve(nl.per * db.n_streams);
   std::vector<DecStream> nh = db.host;
@@ -449,7 +464,7 @@ std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_
 //   windows_done_  windows already sent through the model in batches of n_steps
 void StreamingState::recycle() {
   scorer_.reset(); hot_words_.clear(); hot_tables_.valid = false; beam_width_ = 0; keep_emissions_ = false;
-  audio_buffer_.clear(); frames_ = 0; windows_done_ = 0; state_nonzero = false; arena_bound_ = 2; probs_.clear();
+  audio_buffer_.clear(); frames_ = 0; windows_done_ = 0; state_nonzero = false; arena_bound_[0] = arena_bound_[1] = arena_bound_[2] = 2; probs_.clear();
 }
 void StreamingState::pushZeroFrames(int n) {
   ModelState& m = *model_;
@@ -550,11 +565,12 @@ void StreamingState::processReady(bool flush_partial, bool final_flush) {
 // at most beam nodes) avoids reading it back on every chunk.
 void StreamingState::reserveArena(int take) {
   const uint32_t add = (uint32_t)(take + 1) * (uint32_t)dec.beam + 2;
-  if (arena_bound_ + add > dec.host[0].pa_cap) {
-    model_->decoder_reserve(dec, std::vector<int>{take});  // reads the table back, grows the slab if needed
-    arena_bound_ = std::max(dec.host[0].pa_n, dec.host[0].ta_n);
+  const DecStream& S = dec.host[0];
+  if (arena_bound_[0] + add > S.pa_cap || arena_bound_[1] + add > S.ta_cap || arena_bound_[2] + add > S.be_cap) {
+    model_->decoder_reserve(dec, std::vector<int>{take});  // reads the table back, grows what is short
+    arena_bound_[0] = dec.host[0].pa_n; arena_bound_[1] = dec.host[0].ta_n; arena_bound_[2] = dec.host[0].be_n;  // (the real fill: far below the bound)
   }
-  arena_bound_ += (uint32_t)take * (uint32_t)dec.beam;
+  for (uint32_t& b : arena_bound_) b += (uint32_t)take * (uint32_t)dec.beam;
 }
 
 // ------------------------------------------------------------------------------------------- batched streaming

@@ -227,6 +227,11 @@ struct ModelState {
     bool part_open[2] = {false, false};          // submitted, not collected yet
     bool prof_enqueued = false;                  // the profiling block rides behind the results of THIS enqueue
     size_t prof_stamp_bytes = 0;
+    // what the group was made of (so that it can be decoded again with full-size arenas if one overflowed) and how it was sized
+    struct SavedPart { const int16_t* d_audio; unsigned stride; std::vector<unsigned> sizes, idx; };
+    std::vector<SavedPart> saved_parts;
+    unsigned saved_num_results = 1;
+    bool saved_pipelined = false, optimistic = false;
     bool results_ready = false;
     std::vector<std::vector<Output>> results;  // unpacked once, handed out per part
     bool busy() const { return part_open[0] || part_open[1]; }
@@ -294,7 +299,9 @@ struct ModelState {
   // ---- decoder ----
   DevScorer current_scorer(std::shared_ptr<ScorerDev> sc, const std::map<std::string, float>& hot, HotTables& ht, bool in_flight = false);
   // `staging`: page-locked room for the stream table; the upload then does not wait for the stream (batch path)
-  void decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc, PinnedBuf* staging = nullptr);
+  // `optimistic`: arenas below the never-overflows bound (engine.cpp); the caller must be prepared to decode again on an overflow flag
+  void decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc, PinnedBuf* staging = nullptr,
+                      bool optimistic = false);
   void decoder_reserve(DecoderBatch& db, const std::vector<int>& more_frames);
 };
 
@@ -314,7 +321,7 @@ struct StreamingState {
   DevBuf d_c, d_h;                            // LSTM state [H] f32
   bool state_nonzero = false;
   DecoderBatch dec;                           // one stream
-  uint32_t arena_bound_ = 2;                  // host-side upper bound of the arena fill (each step appends <= beam nodes)
+  uint32_t arena_bound_[3] = {2, 2, 2};       // host-side upper bounds of the fill of the path / time / boundary-entry arenas (each step appends <= beam to each)
   HotTables hot_tables_;
   std::vector<double> probs_;                 // emissions of the last processed batch (keep_emissions_)
 

@@ -37,6 +37,8 @@
   X(exp_waves, 0, "expand waves of the search step (0 = all the others)")                                                          \
   X(lm_memo, 1, "code-point scorer: FullScore memo table")                                                                         \
   X(lm_index_mb, 4096, "hashed n-gram index: byte cap in MiB (larger models take the trie walk)")                                  \
+  X(arena_shrink, 1, "test hook: divides the optimistic arena sizes of a batch group (forces the overflow -> decode-again path)")        \
+  X(arena_retries, 0, "counter, not a knob: batch groups decoded again with full-size arenas after an overflow flag")                 \
   X(dump_marks, 0, "profiling: raw HIP-event timeline of the batch path on stderr")
 
 struct Tuning {

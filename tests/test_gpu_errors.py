@@ -44,3 +44,39 @@ def test_arena_overflow_is_reported_by_every_decode_path(tmp_path, fix):
         L.STTX_DebugLimitArena(0)
     assert m.stt(a) == good              # streams created afterwards are healthy again
     assert L.STT_SetModelBeamWidth(m._impl, 5000) != 0 and m.beamWidth() == 64   # beyond the LDS beam: refused when set
+
+
+def test_batch_group_with_an_overflowing_optimistic_arena_is_decoded_again(tmp_path, fix):
+    """A batch group's path / boundary-entry arenas are sized below the bound that can never overflow (engine.cpp: measured fill
+    <= 14 % / 8 %); when one does overflow the kernel flags it, and the group is decoded again with the full bound -- same
+    transcripts, blocking call and batches in flight alike."""
+    import os
+
+    import numpy as np
+
+    from stt_amd import Model, modelfile, native, synth
+    from test_gpu_async import _DeviceArray
+    w = synth.synth_weights(21, n_hidden=256)
+    path = str(tmp_path / "m.sttw")
+    modelfile.write_model(path, w, synth.ENGLISH_LABELS, beam_width=64)
+    m = Model(path)
+    m.enableExternalScorer(os.path.join(fix, "pruned_lm.scorer"))
+    lens = [48000 - 1500 * i for i in range(12)]
+    host = np.zeros((len(lens), max(lens)), np.int16)
+    for i, n in enumerate(lens):
+        host[i, :n] = synth.synth_audio(n, seed=60 + i)
+    d = _DeviceArray(host)
+    want = m.sttBatchDevice(d.data_ptr(), host.shape[1], lens)
+    r0 = native.get_tuning("arena_retries")
+    native.set_tuning("arena_shrink", 64)
+    try:
+        got = m.sttBatchDevice(d.data_ptr(), host.shape[1], lens)
+        r1 = native.get_tuning("arena_retries")
+        tk = [m.submitBatchDevice(d.data_ptr(), host.shape[1], lens) for _ in range(2)]
+        got2 = [m.collectBatch(t) for t in tk]
+        r2 = native.get_tuning("arena_retries")
+    finally:
+        native.set_tuning("arena_shrink", 1)
+    assert r1 > r0 and r2 > r1, "the shrunken arenas were expected to overflow"
+    assert got == want and got2 == [want, want]
+    assert any(want)
