@@ -387,12 +387,14 @@ def measure(wl, args, cx, steps, warmup):
             ks = [k for k in pmc if k.startswith(prefix)]
             return pmc[ks[0]] if ks else None
 
+        # per LAUNCH, like `achieved`: a search launch covers one time-chunk of the group's streams (16 + 48 ... frames x 64 or 128 streams)
+        launches = {lstm_name: lstm_launches / K, "ctc_next_kernel": stage["timesteps"] / K / (rows * 250.0) * 6.0 if wl == "batch" else None}
         traffic, traffic_note = None, None
         e = pmc_entry(dom.split("<")[0])
         if e:
             wide = dom.startswith("lstm")   # 16 B/lane coalesced streams: FETCH_SIZE reads 1/2 on gfx950 (MI355X_MICROARCH.md, HBM)
-            traffic = (e["fetch_kb_per_launch"] * (2.0 if wide else 1.0) + e["write_kb_per_launch"]) * 1024.0 * (e["launches_per_batch"] if not wide else 1.0)
-            traffic_note = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE (separate passes, profiles/%s), bytes per %s" % (pmc_file, "launch" if wide else "batch (%d chunk launches)" % round(e["launches_per_batch"]))
+            traffic = (e["fetch_kb_per_launch"] * (2.0 if wide else 1.0) + e["write_kb_per_launch"]) * 1024.0
+            traffic_note = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE (separate passes, profiles/%s), bytes per launch%s" % (pmc_file, " (FETCH_SIZE x2: 16 B/lane streams)" if wide else "")
         # The search kernel is bound by instruction issue and dependent-latency chains inside one CU per stream, not by bytes
         # (DESIGN.md 8.2): shader cycles per stream-timestep is the figure that tracks its speed.
         cyc = sum(v for n_, v in dphase.items() if not n_.startswith("lm_wave")) / steps_total if dphase else None
@@ -407,11 +409,18 @@ def measure(wl, args, cx, steps, warmup):
         if stage.get("features_ms"):
             fg = feat_bytes / (stage["features_ms"] * 1e-3) / 1e9
             allk["mfcc_kernel (+ tables, decoder init on the same stream)"] = {"bound": "hbm", "GB/s": fg, "frac": fg / HBM_PEAK_GBS, "ms_per_step": stage["features_ms"] / K}
-        for name, pref in (("dense_kernel<1, 2, 3, true> (x-projection)", "dense_kernel<1, 2, 3, true>"), ("dense_kernel<0, 2, 3, true> (layers 1-3, 5)", "dense_kernel<0, 2, 3, true>")):
+        # the co-tenant GEMM form of this build (128 x 256 eight-wave tile); algorithmic bytes of a 48-frame chunk of `rows` streams
+        Mc = 48 * rows
+        for name, pref, alg in (("dense_wide_kernel<1> (x-projection)", "dense_wide_kernel<1>", Mc * H * 2 + 4 * H * H * 2 + Mc * 4 * H * 4),
+                                ("dense_wide_kernel<0> (layers 2, 3, 5)", "dense_wide_kernel<0>", Mc * H * 2 + H * H * 2 + Mc * H * 2)):
             e = pmc_entry(pref)
             if e:
-                allk.setdefault("pmc", {})[name] = {"fetch_MB_per_launch_raw": e["fetch_kb_per_launch"] / 1024.0, "write_MB_per_launch": e["write_kb_per_launch"] / 1024.0, "source": "profiles/" + pmc_file}
+                allk.setdefault("pmc", {})[name] = {"fetch_MB_per_launch_raw": e["fetch_kb_per_launch"] / 1024.0, "write_MB_per_launch": e["write_kb_per_launch"] / 1024.0,
+                                                    "algorithmic_MB_per_launch": alg / 1e6, "note": "FETCH_SIZE raw (x2 for 16 B/lane streams on gfx950)", "source": "profiles/" + pmc_file}
+        n_l = launches.get(dom)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "launches_per_step": n_l, "algorithmic_bytes_per_launch": (kernels[dom]["bytes"] / n_l if (n_l and dom != lstm_name) else kernels[dom]["bytes"]),
+                    "avg_launch_ms": (kernels[dom]["avg_ms"] / n_l if (n_l and dom != lstm_name) else kernels[dom]["avg_ms"]),
                     "traffic": traffic, "traffic_note": traffic_note,
                     "search_cycles_per_stream_timestep": cyc, "search_us_per_stream_timestep": 1e3 * dec_ms / T if wl != "ragged" else None,
                     "all": allk}
