@@ -1,0 +1,17 @@
+#!/bin/bash
+cd "$(dirname "$0")/.." && export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_lm.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize.py -q 2>&1 | tail -3
+for t in "pair=1" ; do
+  STT_AMD_TUNING=$t timeout 300 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > gpurun_out/r03_h_bench.json 2> gpurun_out/r03_h_bench.err
+  python - "$t" <<'PY'
+import json,sys
+try:
+    r=json.loads(open('gpurun_out/r03_h_bench.json').read().strip().splitlines()[-1])
+    cp=r['roofline'].get('critical_path',{})
+    print(sys.argv[1], '| ms/step', round(r['ms_per_step'],3), 'RTF', round(r['value']), 'ver', r.get('verified'), '| stages', {k[:-3]: round(v,2) for k,v in r.get('stage_ms_per_step',{}).items()}, '| lstm us', round(cp.get('us_per_launch'),2))
+    print('   cyc', r['roofline'].get('search_cycles_per_stream_timestep'), r.get('decoder_phase_cycles_per_stream_step'))
+except Exception as e:
+    print(sys.argv[1], 'FAILED', e); print(open('gpurun_out/r03_h_bench.err').read()[-800:])
+PY
+done
