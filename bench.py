@@ -437,6 +437,9 @@ def measure(wl, args, cx, steps, warmup):
             "decoder_counters_last_step": dstats,
             # (the LM wave runs beside the expand phases: not part of the serial sum)
             "decoder_phase_cycles_per_stream_step": {k: round(v / steps_total, 1) for k, v in dphase.items()},
+            # profiling level 2 (the extra untimed step): [0..15] arrival of each wave at the end of the expand phase (cycles since the step began),
+            # [16..31] its wait there, [32..47] how often that wave was the last, [48] / [49] last / second-last arrival minus first
+            "decoder_stamp_cycles_per_stream_step": [round(v / steps_total, 1) for v in dstamps[:50]] if any(dstamps) else None,
             "roofline": roofline,
         })
     return res

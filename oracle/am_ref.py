@@ -42,8 +42,10 @@ def n_frames_for(n_samples, win_len=WIN_LEN, win_step=WIN_STEP):
 class MfccSpec:
     """Constant tables of the TF Mfcc op (40 channels, 20 Hz .. sr/2, 26 DCT coefficients)."""
 
-    def __init__(self, sample_rate=SAMPLE_RATE, win_len=WIN_LEN, n_mel=N_MEL, n_coef=N_INPUT, lower=20.0, upper=None):
+    def __init__(self, sample_rate=SAMPLE_RATE, win_len=WIN_LEN, n_mel=N_MEL, n_coef=N_INPUT, lower=20.0, upper=None, win_step=None):
         upper = sample_rate / 2.0 if upper is None else upper
+        self.win_len = win_len
+        self.win_step = WIN_STEP if win_step is None else win_step     # (util/config.py:306-325: 20 ms of the sample rate)
         self.fft_len = 1 << int(np.ceil(np.log2(win_len)))
         self.n_bins = self.fft_len // 2 + 1
         i = np.arange(win_len, dtype=np.float64)
@@ -111,10 +113,11 @@ class MfccSpec:
         """Vectorised version of stt.cc framing + frame() for a whole utterance -> [F, 26] float32.
         Mel/DCT accumulation order differs from frame() only in float64 summation order."""
         n = len(audio_i16)
-        F = n_frames_for(n)
-        x = np.zeros((F - 1) * WIN_STEP + WIN_LEN, dtype=np.float32)
+        WL, WS = self.win_len, self.win_step
+        F = n_frames_for(n, WL, WS)
+        x = np.zeros((F - 1) * WS + WL, dtype=np.float32)
         x[:n] = audio_i16.astype(np.float32) * np.float32(1.0 / 32768.0)
-        idx = np.arange(F)[:, None] * WIN_STEP + np.arange(WIN_LEN)[None, :]
+        idx = np.arange(F)[:, None] * WS + np.arange(WL)[None, :]
         fr = x[idx].astype(np.float64) * self.window[None, :]
         spec = np.fft.rfft(fr, n=self.fft_len, axis=1)
         power = (spec.real ** 2 + spec.imag ** 2).astype(np.float32)
@@ -135,11 +138,12 @@ def mfcc_utterance(audio_i16, spec=None):
     """int16 mono 16 kHz -> [F, 26] float32 following stt.cc's streaming framing exactly."""
     spec = spec or MfccSpec()
     n = len(audio_i16)
-    F = n_frames_for(n)
+    WL, WS = spec.win_len, spec.win_step
+    F = n_frames_for(n, WL, WS)
     x = audio_i16.astype(np.float32) * np.float32(1.0 / 32768.0)  # stt.cc:113-114
     out = np.zeros((F, spec.n_coef), dtype=np.float32)
     for f in range(F):
-        out[f] = spec.frame(x[f * WIN_STEP: f * WIN_STEP + WIN_LEN])  # short tail => zero padded (tflitemodelstate.cc:341-355)
+        out[f] = spec.frame(x[f * WS: f * WS + WL])  # short tail => zero padded (tflitemodelstate.cc:341-355)
     return out
 
 
@@ -209,8 +213,8 @@ def am_forward(windows, w, c0=None, h0=None, dtype=np.float64, relu_clip=RELU_CL
     return probs.astype(np.float32), c, h
 
 
-def utterance_probs(audio_i16, w, **kw):
-    """One-shot STT_SpeechToText acoustic path: audio -> probs [T, C] (float32)."""
-    spec = MfccSpec()
+def utterance_probs(audio_i16, w, spec=None, **kw):
+    """One-shot STT_SpeechToText acoustic path: audio -> probs [T, C] (float32).  `spec`: another feature geometry (8 kHz ...)."""
+    spec = spec or MfccSpec()
     feats = spec.frames_fast(np.asarray(audio_i16, dtype=np.int16))
     return am_forward(context_windows(feats), w, **kw)[0]

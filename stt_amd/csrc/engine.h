@@ -107,6 +107,7 @@ struct Geometry {
   int n_in1() const { return n_input * (2 * n_context + 1); }
   int k1_pad() const { return (n_in1() + 63) / 64 * 64; }
   int c_pad() const { return (n_classes + 127) / 128 * 128; }
+  int fft_len() const { int n = 1; while (n < win_len) n <<= 1; return n; }  // TF AudioSpectrogram: NextPowerOfTwo(window_size)
 };
 
 // What a model file yields, whichever container it came in (model.cpp: "STTAMDW1"; tflite_reader.cpp: ".tflite"):

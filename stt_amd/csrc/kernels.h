@@ -15,9 +15,10 @@ struct MfccArgs {
   int n_max, t_max;
   int all_n_samples, all_n_frames;  // used for every utterance when n_samples / n_frames are null (one stream: no table upload)
   int win_len, win_step, n_coef, n_mel;
+  int fft_len;             // NextPowerOfTwo(win_len): 128, 256, 512 or 1024
   const double* window;    // [win_len]
-  const double2* twiddle;  // [256] (cos, -sin)(2 pi m / 512)
-  const double* mel_w;     // [257]
+  const double2* twiddle;  // [fft_len / 2] (cos, -sin)(2 pi m / fft_len)
+  const double* mel_w;     // [fft_len / 2 + 1]
   const int *mel_lo_begin, *mel_lo_end, *mel_hi_begin, *mel_hi_end;  // [n_mel] bin ranges
   const double* dct;       // [n_coef][n_mel]
 };

@@ -32,14 +32,17 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // =============================================================================================
-// MFCC: one 256-thread workgroup per 512-sample window.  Hann window, 512-point FFT (Stockham
-// radix-2, LDS ping-pong), |X|^2 -> f32 -> sqrt, 40 triangular mel bands, ln, DCT-II -> 26.
+// MFCC: one workgroup of NFFT / 2 threads per window.  Hann window, NFFT-point FFT (Stockham radix-2, LDS ping-pong; NFFT =
+// NextPowerOfTwo(window), as TF's AudioSpectrogram: 512 for 32 ms at 16 kHz, 256 at 8 kHz), |X|^2 -> f32 -> sqrt, 40 triangular
+// mel bands, ln, DCT-II -> 26.
 // Arithmetic is f64 like the TensorFlow ops it restates (oracle/am_ref.py); the explicit
 // __dmul_rn/__dadd_rn keep the accumulation orders of the op (no contraction).
 // =============================================================================================
-__global__ __launch_bounds__(256) void mfcc_kernel(MfccArgs a) {
-  __shared__ double2 buf[2][512];
-  __shared__ double amp[257];
+template <int NFFT>
+__global__ __launch_bounds__(NFFT / 2) void mfcc_kernel(MfccArgs a) {
+  constexpr int HALF = NFFT / 2, NBIN = HALF + 1;  // threads = butterflies per stage; spectrum bins
+  __shared__ double2 buf[2][NFFT];
+  __shared__ double amp[NBIN];
   __shared__ double lmel[40];
   const int frame = blockIdx.x;
   const int b = frame / a.t_max;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccArgs a) {
   }
   const int16_t* au = a.audio + (size_t)(a.rows ? a.rows[b] : b) * a.n_max;
   const int tid = threadIdx.x;
-  for (int i = tid; i < 512; i += 256) {
+  for (int i = tid; i < NFFT; i += HALF) {
     const int s = f * a.win_step + i;
     // stt.cc:113-114: (float)sample * (1.0f / 32768); zero tail = tflitemodelstate.cc:341-355
     const float x = (s < n && i < a.win_len) ? (float)au[s] * (1.0f / 32768.0f) : 0.0f;
@@ -63,12 +66,12 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccArgs a) {
   __syncthreads();
   int cur = 0;
 #pragma unroll 1
-  for (int ns = 1; ns < 512; ns <<= 1) {
+  for (int ns = 1; ns < NFFT; ns <<= 1) {
     const int j = tid;
     const int k = j & (ns - 1);
-    const double2 tw = a.twiddle[k * (256 / ns)];  // (cos, -sin)(2 pi m / 512)
+    const double2 tw = a.twiddle[k * (HALF / ns)];  // (cos, -sin)(2 pi m / NFFT)
     const double2 u = buf[cur][j];
-    const double2 v = buf[cur][j + 256];
+    const double2 v = buf[cur][j + HALF];
     const double vr = __dadd_rn(__dmul_rn(v.x, tw.x), -__dmul_rn(v.y, tw.y));
     const double vi = __dadd_rn(__dmul_rn(v.x, tw.y), __dmul_rn(v.y, tw.x));
     const int j0 = ((j - k) << 1) + k;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccArgs a) {
     cur ^= 1;
     __syncthreads();
   }
-  for (int i = tid; i < 257; i += 256) {
+  for (int i = tid; i < NBIN; i += HALF) {
     const double2 z = buf[cur][i];
     const float p = (float)__dadd_rn(__dmul_rn(z.x, z.x), __dmul_rn(z.y, z.y));  // spectrogram output is float
     amp[i] = sqrt((double)p);
@@ -983,7 +986,13 @@ void launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t st)
   hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, st, (unsigned char*)dst, (const unsigned char*)src, bytes, wide);
 }
 void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st) {
-  hipLaunchKernelGGL(mfcc_kernel, dim3(n_frames_total), dim3(256), 0, st, a);
+  switch (a.fft_len) {
+    case 128: hipLaunchKernelGGL(mfcc_kernel<128>, dim3(n_frames_total), dim3(64), 0, st, a); break;
+    case 256: hipLaunchKernelGGL(mfcc_kernel<256>, dim3(n_frames_total), dim3(128), 0, st, a); break;
+    case 512: hipLaunchKernelGGL(mfcc_kernel<512>, dim3(n_frames_total), dim3(256), 0, st, a); break;
+    case 1024: hipLaunchKernelGGL(mfcc_kernel<1024>, dim3(n_frames_total), dim3(512), 0, st, a); break;
+    default: throw std::runtime_error("launch_mfcc: unsupported FFT length");
+  }
 }
 void launch_context(const ContextArgs& a, int rows, hipStream_t st) {
   hipLaunchKernelGGL(context_kernel, dim3(rows), dim3(256), 0, st, a);

@@ -114,12 +114,10 @@ int parse_model_file(const char* buf, size_t len, ModelTensors& tfl, ModelView& 
     for (int i = 0; i < 12; ++i) { v.t[i] = f; v.count[i] = cnt[i]; f += cnt[i]; }
   }
   const int H = g.n_hidden, C = g.n_classes;
-  // The feature kernel is a 512-point FFT with 257 bins and 40 mel channels.  TF's AudioSpectrogram uses
-  // fft_length = NextPowerOfTwo(window) (util/feeding.py:51-73 -> spectrogram.cc), so only windows of 257..512 samples
-  // (e.g. 32 ms at 16 kHz) give the reference's 257-bin spectrum here; a 256-sample window (32 ms at 8 kHz) would need the
-  // 256-point FFT / 129-bin filterbank and is refused instead of silently producing different features.  The DCT has
-  // 40 mel inputs, so at most 40 coefficients exist.
-  if (H % 128 != 0 || H < 128 || C < 2 || C > STT_MAX_CLASSES || g.win_len > 512 || g.win_len <= 256 || g.win_step < 1 || g.n_input > 40 || g.n_input < 1 ||
+  // The feature kernel takes FFT lengths of 128 .. 1024 (TF's AudioSpectrogram: fft_length = NextPowerOfTwo(window), util/feeding.py:51-73
+  // -> spectrogram.cc): windows of 65 .. 1024 samples -- 32 ms at 8, 16, 22.05 or 32 kHz; longer ones (44.1 / 48 kHz) are refused
+  // rather than silently framed differently.  The DCT has 40 mel inputs, so at most 40 coefficients exist.
+  if (H % 128 != 0 || H < 128 || C < 2 || C > STT_MAX_CLASSES || g.win_len > 1024 || g.win_len <= 64 || g.win_step < 1 || g.sample_rate < 1000 || g.n_input > 40 || g.n_input < 1 ||
       g.n_steps < 1 || g.n_context < 0 || g.beam_width < 1) {
     err = "model geometry outside what the engine supports";
     return STT_ERR_INVALID_SHAPE;
@@ -171,11 +169,11 @@ int ModelState::InitFromBuffer(const char* buf, size_t len) {
   }
   // ---- feature tables (oracle/am_ref.py MfccSpec; upstream tensorflow spectrogram.cc / mfcc_mel_filterbank.cc / mfcc_dct.cc)
   {
-    const int n_mel = 40, n_bins = 257;
+    const int n_mel = 40, nfft = g.fft_len(), n_bins = nfft / 2 + 1;
     std::vector<double> window(g.win_len);
     for (int i = 0; i < g.win_len; ++i) window[i] = 0.5 - 0.5 * cos(2.0 * M_PI * i / g.win_len);
-    std::vector<double2> tw(256);
-    for (int m = 0; m < 256; ++m) tw[m] = make_double2(cos(2.0 * M_PI * m / 512.0), -sin(2.0 * M_PI * m / 512.0));
+    std::vector<double2> tw(nfft / 2);
+    for (int m = 0; m < nfft / 2; ++m) tw[m] = make_double2(cos(2.0 * M_PI * m / nfft), -sin(2.0 * M_PI * m / nfft));
     auto mel = [](double fq) { return 1127.0 * log1p(fq / 700.0); };
     const double lower = 20.0, upper = g.sample_rate / 2.0;
     const double mel_low = mel(lower), mel_hi = mel(upper), spacing = (mel_hi - mel_low) / (n_mel + 1);
@@ -243,7 +241,7 @@ int ModelState::InitFromBuffer(const char* buf, size_t len) {
 
 MfccArgs ModelState::mfcc_args() const {
   MfccArgs a{};
-  a.win_len = g.win_len; a.win_step = g.win_step; a.n_coef = g.n_input; a.n_mel = 40;
+  a.win_len = g.win_len; a.win_step = g.win_step; a.n_coef = g.n_input; a.n_mel = 40; a.fft_len = g.fft_len();
   a.window = t_window.as<double>(); a.twiddle = t_twiddle.as<double2>(); a.mel_w = t_melw.as<double>();
   const int* idx = t_mel_idx.as<int>();
   a.mel_lo_begin = idx; a.mel_lo_end = idx + 40; a.mel_hi_begin = idx + 80; a.mel_hi_end = idx + 120;

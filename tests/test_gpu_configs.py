@@ -130,3 +130,36 @@ def test_config3_many_streams_batched_equal_one_by_one(model):
     assert got_inter == want_inter
     with pytest.raises(RuntimeError):
         streams[0].intermediateDecode()                                    # destroyed by the batch finish
+
+
+@pytest.mark.parametrize("sr,win,step", [(8000, 256, 160), (22050, 705, 441)])
+def test_other_sample_rates_take_the_reference_fft_length(tmp_path, sr, win, step):
+    """util/config.py:306-325: a model trained on 8 kHz audio has 256-sample windows every 160 samples; TF's AudioSpectrogram then
+    runs a 256-point FFT (129 bins), a 22.05 kHz one a 1024-point FFT.  Round 2 refused such models; the reference runs them.
+    Features and probabilities against the restatement at that geometry, streaming == one-shot, frame counts of stt.cc."""
+    import numpy as np
+
+    from oracle import am_ref
+    from stt_amd import Model, modelfile, synth
+    w = synth.synth_weights(31, n_hidden=256)
+    path = str(tmp_path / ("m%d.sttw" % sr))
+    modelfile.write_model(path, w, synth.ENGLISH_LABELS, beam_width=32, sample_rate=sr, win_len=win, win_step=step)
+    m = Model(path)
+    assert m.sampleRate() == sr
+    spec = am_ref.MfccSpec(sample_rate=sr, win_len=win, win_step=step)
+    for n in (3 * sr + 77, win - 1, win, 0):
+        a = synth.synth_audio(n, seed=n + sr, sample_rate=sr)
+        got = m.computeMfcc(a)
+        want = am_ref.mfcc_utterance(a, spec)
+        assert got.shape == want.shape == (am_ref.n_frames_for(n, win, step), 26)
+        assert np.abs(got - want).max() <= 2e-4, (n, np.abs(got - want).max())
+    a = synth.synth_audio(2 * sr + 1234, seed=5, sample_rate=sr)
+    probs = m.acousticProbs([a])[0]
+    want = am_ref.utterance_probs(a, w, spec=spec, weight_round=np.float16)
+    assert probs.shape == want.shape
+    assert np.abs(probs - want).max() < 1e-4 and np.abs(np.log(probs) - np.log(want)).max() < 2e-3
+    text = m.stt(a)
+    s = m.createStream()
+    for k in range(0, len(a), 16 * step):
+        s.feedAudioContent(a[k:k + 16 * step])
+    assert s.finishStream() == text

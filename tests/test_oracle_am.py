@@ -3,6 +3,7 @@ Lite is an un-vendored submodule, SURVEY.md 8c: "parity unpinned"), so these are
 against the reference: the layer stack written a second time with torch's own Linear / LSTMCell kernels (gate order
 re-mapped: TensorFlow i, j, f, o -> torch i, f, g, o), and the spectrogram against a direct FFT (scipy)."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import am_ref
@@ -42,26 +43,34 @@ def test_layer_stack_against_torch_lstmcell():
     assert np.abs(c.numpy()[0] - c_ref).max() < 1e-9 and np.abs(h.numpy()[0] - h_ref).max() < 1e-9
 
 
-def test_power_spectrum_and_frame_count_against_scipy_fft():
+@pytest.mark.parametrize("sr,win,step", [(16000, 512, 320), (8000, 256, 160), (22050, 705, 441)])
+def test_power_spectrum_and_frame_count_against_scipy_fft(sr, win, step):
+    """The feature restatement at the reference's geometries (util/config.py:306-325: 32 ms windows every 20 ms of whatever the
+    sample rate is; TF AudioSpectrogram: fft_length = NextPowerOfTwo(window) -> 512, 256, 1024 points) against scipy's FFT and a
+    hand-written mel / DCT frame."""
     import scipy.fft
     rng = np.random.default_rng(3)
-    audio = (rng.standard_normal(16000) * 3000).astype(np.int16)
-    spec = am_ref.MfccSpec()
-    feats = am_ref.mfcc_utterance(audio)
-    assert feats.shape == (am_ref.n_frames_for(len(audio)), 26)                     # stt.cc frame bookkeeping
-    # frame 5 by hand: periodic Hann, 512-point FFT, |X|^2 as float32, sqrt, mel, ln, DCT-II
+    audio = (rng.standard_normal(sr) * 3000).astype(np.int16)
+    spec = am_ref.MfccSpec(sample_rate=sr, win_len=win, win_step=step)
+    nfft = 1 << int(np.ceil(np.log2(win)))
+    assert spec.fft_len == nfft
+    feats = am_ref.mfcc_utterance(audio, spec)
+    assert feats.shape == (am_ref.n_frames_for(len(audio), win, step), 26)          # stt.cc frame bookkeeping
+    assert np.abs(spec.frames_fast(audio) - feats).max() < 2e-5
+    # frame 5 by hand: periodic Hann, nfft-point FFT, |X|^2 as float32, sqrt, mel, ln, DCT-II
     f = 5
-    x = audio[f * 320:f * 320 + 512].astype(np.float32) * np.float32(1.0 / 32768.0)
-    X = scipy.fft.rfft(x.astype(np.float64) * spec.window)
+    x = np.zeros(nfft)
+    x[:win] = (audio[f * step:f * step + win].astype(np.float32) * np.float32(1.0 / 32768.0)).astype(np.float64) * spec.window
+    X = scipy.fft.rfft(x)
     amp = np.sqrt((X.real ** 2 + X.imag ** 2).astype(np.float32).astype(np.float64))
     mel = np.zeros(40)
-    hz_per_bin = 0.5 * 16000 / 256
+    hz_per_bin = 0.5 * sr / (nfft // 2)
     melf = lambda hz: 1127.0 * np.log1p(hz / 700.0)
-    lo, hi = melf(20.0), melf(8000.0)
+    lo, hi = melf(20.0), melf(sr / 2.0)
     centers = lo + (hi - lo) / 41 * (np.arange(41) + 1)
-    for i in range(int(1.5 + 20.0 / hz_per_bin), int(8000.0 / hz_per_bin) + 1):
+    for i in range(int(1.5 + 20.0 / hz_per_bin), int((sr / 2.0) / hz_per_bin) + 1):
         m = melf(i * hz_per_bin)
-        ch = int(np.searchsorted(centers, m, side="right")) - 1                     # band whose centre is just below the bin
+        ch = int(np.sum(centers[:40] < m)) - 1                                      # band whose centre is just below the bin (mfcc_mel_filterbank.cc: strict <, channel <= 40)
         below = lo if ch < 0 else centers[ch]
         wgt = (centers[ch + 1] - m) / (centers[ch + 1] - below)                     # share of the lower band
         if ch >= 0:
