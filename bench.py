@@ -452,7 +452,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="batch", choices=["batch", "stream", "ragged", "bytes", "peaky"])
     ap.add_argument("--utterances", type=int, default=0, help="stream: utterances per step (default 256); ragged: per rank (default 1250)")
-    ap.add_argument("--streams", type=int, default=64, help="stream: live streams advanced together")
+    ap.add_argument("--streams", type=int, default=128, help="stream: live streams advanced together (one recurrent launch covers 128 rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="batch: do not append the other workloads' sub-lines")
     ap.add_argument("--scorer", default="synthetic", choices=["synthetic", "fixture"])
@@ -507,7 +507,7 @@ def main():
     if rank == 0 and wl == "batch" and world == 1 and not args.no_extras and not args.no_profile:
         # the other configs, same process, same build: short runs (a few seconds each), each with its own roofline
         sub = {}
-        for w, k, wu, kw in (("ragged", 2, 1, {}), ("stream", 1, 1, {"utterances": 128}), ("bytes", 6, 2, {}), ("peaky", 10, 2, {})):
+        for w, k, wu, kw in (("ragged", 2, 1, {}), ("stream", 1, 1, {"utterances": 256}), ("bytes", 6, 2, {}), ("peaky", 10, 2, {})):
             a2 = argparse.Namespace(**vars(args))
             a2.utterances = kw.get("utterances", 0)
             try:

@@ -602,8 +602,9 @@ void streams_process(const std::vector<StreamingState*>& ss, bool flush_partial)
       if (take) { R.push_back(s); takes.push_back(take); }
     }
     if (R.empty()) break;
-    for (size_t g0 = 0; g0 < R.size(); g0 += 64) {
-      const int B = (int)std::min<size_t>(64, R.size() - g0);
+    const size_t rows = (size_t)lstm_max_rows(H);  // streams advanced by one recurrent launch: 128 with 16 units per workgroup, else 64
+    for (size_t g0 = 0; g0 < R.size(); g0 += rows) {
+      const int B = (int)std::min<size_t>(rows, R.size() - g0);
       for (int b = 0; b < B; ++b) {
         StreamingState* s = R[g0 + b];
         s->d_c.reserve((size_t)H * 4); s->d_h.reserve((size_t)H * 4);

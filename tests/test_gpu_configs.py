@@ -98,12 +98,12 @@ def test_config5_bytes_model_beam_1024_with_bytes_scorer(tmp_path, port, fix):
 
 
 def test_config3_many_streams_batched_equal_one_by_one(model):
-    """STTX_FeedAudioContentBatch / IntermediateDecodeBatch / FinishStreamBatch: 70 live streams (more than one 64-group) of
-    different lengths, fed in 320 ms hops together == each stream fed alone through coqui-stt.h (every intermediate result
+    """STTX_FeedAudioContentBatch / IntermediateDecodeBatch / FinishStreamBatch: 140 live streams (more than one group of 128
+    rows -- the recurrent launch covers 128 with 16 units per workgroup) of different lengths, fed in 320 ms hops together == each stream fed alone through coqui-stt.h (every intermediate result
     and the final one)."""
     from stt_amd import model as M
     rng = np.random.RandomState(3)
-    lens = (rng.uniform(0.2, 4.0, size=70) * 16000).astype(int)
+    lens = (rng.uniform(0.2, 4.0, size=140) * 16000).astype(int)
     lens[5] = 100; lens[9] = 5120 * 3                                      # shorter than a window; exact multiple of the hop
     audio = [synth.synth_audio(int(n), seed=900 + i) for i, n in enumerate(lens)]
     # one by one (reference API)
