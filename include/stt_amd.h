@@ -157,6 +157,10 @@ STTX_EXPORT int STTX_DecoderDecode(const STTX_Decoder* aDec, unsigned int aNumRe
 STTX_EXPORT int STTX_DecoderBeam(const STTX_Decoder* aDec, unsigned int aStream, float* aScore, float* aPb, float* aPnb,
                                 int* aChar, unsigned int aCap);
 STTX_EXPORT int STTX_DecoderStats(const STTX_Decoder* aDec, unsigned long long* aOut4);
+/* Profiling of a standalone decoder (benchmarks/search_micro.py): level 1 = HIP-event time of the search launches, 2 = also the
+ * kernel's own phase cycle counters (8, summed over streams) and fine-grained stamps (64).  No equivalent in the reference. */
+STTX_EXPORT int STTX_DecoderSetProfiling(STTX_Decoder* aDec, int aLevel);
+STTX_EXPORT int STTX_DecoderGetProfile(const STTX_Decoder* aDec, unsigned long long* aPhase8, unsigned long long* aStamps64, float* aSearchMs);
 STTX_EXPORT void STTX_DecoderFree(STTX_Decoder* aDec);
 
 /* ---- model files (host only, no GPU needed) ---------------------------------------------------- */

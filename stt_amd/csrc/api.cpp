@@ -1039,8 +1039,10 @@ struct STTX_Decoder {
   std::map<std::string, float> hot;
   DecoderBatch db;
   DecParams p;
-  DevBuf probs, fbegin, fcount, wide;
+  DevBuf probs, fbegin, fcount, wide, stamps;
   HotTables ht;
+  int prof = 0;            // STTX_DecoderSetProfiling
+  float search_ms = 0;     // HIP-event time of the search launches since profiling was switched on
 };
 int STTX_DecoderCreate(ModelState* m, unsigned int aNumStreams, unsigned int aBeamWidth, double aCutoffProb, unsigned int aCutoffTopN, STTX_Decoder** retval) {
   *retval = nullptr;
@@ -1071,9 +1073,13 @@ int STTX_DecoderNext(STTX_Decoder* d, const float* aProbs, unsigned int aStride,
     int max_frames = 1;
     for (int i = 0; i < n; ++i) max_frames = std::max(max_frames, more[i]);
     d->wide.reserve(ctc_rows_ws_bytes(d->p, n, max_frames));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (d->prof) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); HIP_CHECK(hipEventRecord(e0, m->stream)); }
     launch_ctc_next(d->p, ds, m->dev_alphabet, d->db.table.as<DecStream>(), n, d->probs.as<float>(), d->fbegin.as<int>(), d->fcount.as<int>(), m->stream,
                     max_frames, d->wide.p);
+    if (d->prof) HIP_CHECK(hipEventRecord(e1, m->stream));
     HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (d->prof) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1)); d->search_ms += ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     HIP_CHECK(hipGetLastError());
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_RUN_SESS);
@@ -1114,6 +1120,36 @@ int STTX_DecoderBeam(const STTX_Decoder* d, unsigned int aStream, float* aScore,
     return 0;
   }, 0);
   return n;
+}
+int STTX_DecoderSetProfiling(STTX_Decoder* d, int aLevel) {
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(d->m->device));
+    d->prof = aLevel; d->search_ms = 0;
+    d->p.phase_cycles = aLevel >= 2 ? 1 : 0;
+    d->p.stamps = nullptr;
+    if (aLevel >= 2) {
+      d->stamps.reserve((size_t)d->db.n_streams * 64 * 8);
+      HIP_CHECK(hipMemset(d->stamps.p, 0, (size_t)d->db.n_streams * 64 * 8));
+      d->p.stamps = d->stamps.as<unsigned long long>();
+    }
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
+int STTX_DecoderGetProfile(const STTX_Decoder* d, unsigned long long* aPhase8, unsigned long long* aStamps64, float* aSearchMs) {
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(d->m->device));
+    std::vector<DecStream> tb(d->db.n_streams);
+    HIP_CHECK(hipMemcpy(tb.data(), d->db.table.p, sizeof(DecStream) * tb.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) { aPhase8[k] = 0; for (auto& S : tb) aPhase8[k] += S.phase[k]; }
+    for (int k = 0; k < 64; ++k) aStamps64[k] = 0;
+    if (d->p.stamps) {
+      std::vector<unsigned long long> st((size_t)d->db.n_streams * 64);
+      HIP_CHECK(hipMemcpy(st.data(), d->stamps.p, st.size() * 8, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < st.size(); ++i) aStamps64[i & 63] += st[i];
+    }
+    *aSearchMs = d->search_ms;
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
 }
 int STTX_DecoderStats(const STTX_Decoder* d, unsigned long long* aOut4) {
   return guarded([&]() {

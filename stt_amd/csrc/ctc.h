@@ -71,6 +71,7 @@ struct DevScorer {
   // dictionary FST, repacked: state s -> arcs [state_pos[s], state_pos[s+1]); arc = {ilabel, child state} where
   // child state = Start() if the arc's target is final (path_trie.cpp:79-87), else the target
   int fst_start;
+  int fst_tree;                  // the dictionary is a tree in breadth-first order: child along arc k = node k + 1, along a space arc = the root (0)
   const uint32_t* fst_state_pos;
   const uint2* fst_arcs;
   const uint8_t* fst_has_space;  // word mode: state has an out-arc for the space label (a word may end here)

@@ -772,7 +772,7 @@ struct Lds {
 };
 // phase cycle counters (s_memtime is a scalar memory operation with a wait: only on request, DecParams::phase_cycles)
 #define TICK(k) do { if (p.phase_cycles && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); L.acc[4 + (k)] += now_ - tick_; tick_ = now_; } } while (0)
-enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_CLAMP, SC_NA, SC_NB, SC_COUNT = 24 };
+enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_CLAMP, SC_NA, SC_NB, SC_NI, SC_ICUR, SC_FILL, SC_COUNT = 24 };
 #define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
 
@@ -1029,17 +1029,22 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
 #define LP_AT(k, c) (WIDE ? W.lpc[c] : lp[k])
   const LDS_AS uint8_t* const lab1 = WIDE ? (const LDS_AS uint8_t*)nullptr : (const LDS_AS uint8_t*)L.lab1;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform by construction; now the compiler knows it too)
   const int C = p.C, beam = p.beam;
   LDS_AS int* sc = L.sc;
   const float NEG = STT_NEG_INF;
   const LDS_AS float* pf = L.pf[buf];
   LDS_AS float* lp = L.lp[buf];
 
+  // wave-uniform by construction (every thread carries the same values); telling the compiler keeps the control flow that
+  // depends on them scalar -- and loops around wave-level operations (readfirstlane, ballot) MUST be provably uniform: with a
+  // divergent-looking exit the structurizer may send lanes round the loop without the lane the operation relies on
+  n = __builtin_amdgcn_readfirstlane(n); cur = __builtin_amdgcn_readfirstlane(cur);
   unsigned long long tick_ = p.phase_cycles ? __builtin_readcyclecounter() : 0ull;
   float pre = 0.0f;
   if (!WIDE && next_row && tid < C) pre = next_row[tid];  // consumed in P3
   if ((double)(WIDE ? wh.pblank : pf[p.blank]) < 0.999) start_expanding = 1;  // :125-132 (uniform: every thread reads the same value)
+  start_expanding = __builtin_amdgcn_readfirstlane(start_expanding);
   if (!start_expanding) {
     if (!WIDE && next_row) prep_row(p, L, buf ^ 1, next_row, pre);
     abs_t++;
@@ -1048,7 +1053,8 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   }
   // ---- A: clear the per-prefix events and the selection histogram (the hash of the live prefixes was built when the
   // beam was written); class order / cut-off only when pruning is active
-  for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
+  // (bitmap step: every thread clears the events of its own prefix in the pre-pass below -- no barrier in between)
+  if (!MASKED) for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
   L.hist[tid] = 0;
   if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; sc[SC_NQ] = 0; }
   const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
@@ -1093,7 +1099,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     min_cutoff = (float)mc;
     full_beam = (n == beam);
   }
-  __syncthreads();
+  if (!MASKED) __syncthreads();
   TICK(0);
 
   // ---- P2: expand.  Wave w owns prefixes w, w+16, w+32, ...: blank / repeat events per prefix, then one work item per
@@ -1150,17 +1156,24 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     if (lmq) lds_add(&sc[SC_LMQ], (int)lmq);
     if (p.phase_cycles && lane == 0 && wave == NWAVES - 1) L.acc[4 + 7] += __builtin_readcyclecounter() - lmw_t0;  // phase slot 7: the (last) LM wave's own time
     __builtin_amdgcn_s_setprio(0);
-  } else if (MASKED) {
-    // ---- expand with label bitmaps: see the comment above the function
+  }
+  if (MASKED) {
+    // ---- expand with label bitmaps (see the comment above the function), in two halves:
+    // (1) pre-pass, thread i = prefix i (the first n threads; the LM waves are in their queries meanwhile): cut-off mask, blank /
+    //     repeat events, the prefix's work items (one u16 {prefix, label} each) appended to ONE table for the workgroup;
+    // (2) every wave takes chunks of 64 items off the table until it is empty; the LM waves join when their queries are done.
+    // Whoever is free takes the next chunk: the phase ends when the work is done, not when the unluckiest wave is.
     const LDS_AS float* lpv = lp;
     const uint32_t lab_mask = ((1u << (C - 1)) - 1u) & ~(1u << p.blank);  // labels 0 .. C-2, never the blank
-    const uint32_t ppw = pow2_ge((uint32_t)((n + nw_exp - 1) / nw_exp));
-    const int i0 = lane * nw_exp + wave;
-    uint32_t cnt = 0, em = 0;
-    if (lane < (int)ppw && i0 < n) {
-      const float sci = L.score[cur][i0];
+    LDS_AS uint16_t* own = (LDS_AS uint16_t*)L.own;
+    const uint32_t own_n = (L.own_cap * (uint32_t)NWAVES) >> 1;  // items the table holds (more: another pass)
+    uint32_t em = 0;
+    if (tid < n) {
+      const int i = tid;
+      float eb = absent(), es = absent();
+      const float sci = L.score[cur][i];
       if (sci != NEG) {  // :160-162
-        const uint32_t chi = L.ch[cur][i0];
+        const uint32_t chi = L.ch[cur][i];
         uint32_t pm = 0xFFFFFFFFu;  // classes that survive the cut-off for this prefix (bit c)
         if (full_beam) {
           pm = 0;
@@ -1173,64 +1186,91 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
             pm |= (!(__fadd_rn(v.w, sci) < min_cutoff) ? 8u : 0u) << (4 * q4);
           }
         }
-        if ((pm >> p.blank) & 1u) L.ev_blank[i0] = __fadd_rn(lpv[p.blank], sci);                                  // :166-179
-        if (chi != STT_ROOT_CH && ((pm >> chi) & 1u)) L.ev_self[i0] = __fadd_rn(lpv[chi], L.pnb[cur][i0]);        // :182-193
-        em = L.sm[cur][i0] & pm & lab_mask;
-        cnt = (uint32_t)__popc(em);
+        if ((pm >> p.blank) & 1u) eb = __fadd_rn(lpv[p.blank], sci);                                  // :166-179
+        if (chi != STT_ROOT_CH && ((pm >> chi) & 1u)) es = __fadd_rn(lpv[chi], L.pnb[cur][i]);        // :182-193
+        const uint32_t live = L.sm[cur][i] & pm;
+        em = live & lab_mask;
       }
+      L.ev_blank[i] = eb; L.ev_self[i] = es; L.ev_ext[i] = absent(); L.ev_exti[i] = 0;
     }
-    const uint32_t inc = wave_incl_scan(cnt, lane);
-    const uint32_t off = inc - cnt;
-    const uint32_t n_items = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-    const bool use_tab = n_items * 2u <= L.own_cap;  // wave-uniform
-    LDS_AS uint16_t* own = (LDS_AS uint16_t*)(L.own + (uint32_t)wave * L.own_cap);
-    if (use_tab) {  // item -> (owning lane, label)
-      uint32_t mm = em, k = off;
-      while (mm) { const uint32_t c = (uint32_t)__builtin_ctz(mm); mm &= mm - 1u; own[k++] = (uint16_t)((uint32_t)lane | (c << 8)); }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    TICK(1);
+    for (int pass = 0;; ++pass) {
+      if (wave * 64 < n) {
+        const uint32_t cnt = (uint32_t)__popc(em);
+        const uint32_t inc = wave_incl_scan(cnt, lane);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        if (tot) {  // wave-uniform
+          uint32_t b0 = 0;
+          if (lane == 63) b0 = lds_add((LDS_AS uint32_t*)&sc[SC_NI], tot);
+          b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, 63);
+          uint32_t k = b0 + inc - cnt;
+          while (em && k < own_n) { const uint32_t c = (uint32_t)__builtin_ctz(em); em &= em - 1u; own[k++] = (uint16_t)((uint32_t)tid | (c << 9)); }
+        }
+        // "this wave's items are in the table": a counter instead of a barrier, so that the LM waves -- in the middle of their
+        // chain of dependent reads -- are not waited for (LDS operations of a wave are performed in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) lds_add((LDS_AS uint32_t*)&sc[SC_FILL], 1u);
+      }
+      if (pass == 0) TICK(1);
+      {
+        const uint32_t want = (uint32_t)((n + 63) >> 6);
+        int spins = 0;
+        while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((LDS_AS uint32_t*)&sc[SC_FILL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1 << 16)) { lds_or(&sc[SC_ERR], 16); break; }  // (never: the filling waves wait for nobody)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      const uint32_t total_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((LDS_AS uint32_t*)&sc[SC_NI], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      const uint32_t n_items = total_items < own_n ? total_items : own_n;
+      // The loop is controlled by scalars only (the chunk cursor read through lane 0, the item count): a uniform branch.  Lanes past
+      // the end of the last chunk skip the body inside an if-region -- no `continue`, no lane-dependent exit: with those the
+      // compiler may send lanes round the loop on their own, and the wave-level read would then miss lane 0.
+      auto take_chunk = [&]() -> uint32_t {
+        uint32_t v = 0;
+        if (lane == 0) v = lds_add((LDS_AS uint32_t*)&sc[SC_ICUR], 64u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+      };
 #pragma unroll 1
-    for (uint32_t xb = 0; xb < n_items; xb += 64) {
-      const uint32_t x = xb + (uint32_t)lane;
-      const bool v = x < n_items;
-      uint32_t j = 0, c = 0;
-      if (use_tab) { const uint32_t oc = v ? (uint32_t)own[x] : 0u; j = oc & 63u; c = oc >> 8; }
-      else {
-        for (uint32_t step = ppw >> 1; step >= 1; step >>= 1) { const uint32_t v_ = __shfl(off, (int)(j + step)); if (v_ <= x) j += step; }
-        const uint32_t offj = __shfl(off, (int)j);
-        uint32_t emj = __shfl(em, (int)j);
-        if (v) { for (uint32_t kk = x - offj; kk; --kk) emj &= emj - 1u; c = (uint32_t)__builtin_ctz(emj); }
-      }
-      if (!v) continue;
-      const int i = (int)j * nw_exp + wave;
-      const uint32_t smj = L.sm[cur][i];
-      const uint2 arc = s.fst_arcs[L.a0[cur][i] + (uint32_t)__popc(smj & ((1u << c) - 1u))];  // (arc.x == c + 1; arc.y = the child's dictionary state)
-      const float sci = L.score[cur][i];
-      const uint32_t chi = L.ch[cur][i];
-      const float lpc = lpv[c];
-      float log_p = NEG;  // :199-207
-      if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
-      else log_p = __fadd_rn(lpc, sci);
-      const uint32_t needs_lm = c == space_u ? 1u : 0u;
-      const uint64_t ck = child_key(L.key[cur][i], c);
-      const int jj = ht_find(L, ck);
-      if (jj >= 0) {  // the child is a live prefix: one extension event per live prefix per step
-        L.ev_ext[jj] = log_p;
-        L.ev_exti[jj] = (uint32_t)i | (needs_lm << 31);
-        if (needs_lm) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = 0x80000000u | (uint32_t)jj; }
-      } else {
-        const int slot = lds_add(&sc[SC_M], 1);
-        if ((uint32_t)slot < S.cand_cap) {
-          const uint32_t piv = (uint32_t)i | (c << 16) | (needs_lm << 31);  // (class position == class: no pruning in this mode)
-          if ((uint32_t)slot < L.mcap) { L.lc_logp[slot] = log_p; L.lc_pi[slot] = piv; L.lc_fst[slot] = (int)arc.y; }
-          else { S.c_logp[slot] = log_p; S.c_pi[slot] = piv; S.c_fst[slot] = (int)arc.y; }
-          if (needs_lm) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = (uint32_t)slot; }
+      for (uint32_t xb = take_chunk(); xb < n_items; xb = take_chunk()) {
+        const uint32_t x = xb + (uint32_t)lane;
+        if (x < n_items) {
+          const uint32_t oc = (uint32_t)own[x];
+          const int i = (int)(oc & 511u);
+          const uint32_t c = oc >> 9;
+          const uint32_t smj = L.sm[cur][i];
+          const uint32_t aidx = L.a0[cur][i] + (uint32_t)__popc(smj & ((1u << c) - 1u));  // the arc of label c
+          uint32_t child_fst;  // the child's dictionary state: arithmetic in the unfolded tree, the arc's second field otherwise
+          if (s.fst_tree) child_fst = c == space_u ? 0u : aidx + 1u; else child_fst = s.fst_arcs[aidx].y;
+          const float sci = L.score[cur][i];
+          const uint32_t chi = L.ch[cur][i];
+          const float lpc = lpv[c];
+          float log_p = NEG;  // :199-207
+          if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
+          else log_p = __fadd_rn(lpc, sci);
+          const uint32_t needs_lm = c == space_u ? 1u : 0u;
+          const uint64_t ck = child_key(L.key[cur][i], c);
+          const int jj = ht_find(L, ck);
+          if (jj >= 0) {  // the child is a live prefix: one extension event per live prefix per step
+            L.ev_ext[jj] = log_p;
+            L.ev_exti[jj] = (uint32_t)i | (needs_lm << 31);
+            if (needs_lm) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = 0x80000000u | (uint32_t)jj; }
+          } else {
+            const int slot = lds_add(&sc[SC_M], 1);
+            if ((uint32_t)slot < S.cand_cap) {
+              const uint32_t piv = (uint32_t)i | (c << 16) | (needs_lm << 31);  // (class position == class: no pruning in this mode)
+              if ((uint32_t)slot < L.mcap) { L.lc_logp[slot] = log_p; L.lc_pi[slot] = piv; L.lc_fst[slot] = (int)child_fst; }
+              else { S.c_logp[slot] = log_p; S.c_pi[slot] = piv; S.c_fst[slot] = (int)child_fst; }
+              if (needs_lm) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = (uint32_t)slot; }
+            }
+          }
         }
       }
+      if (total_items <= own_n) break;  // (uniform) everything was in the table
+      __syncthreads();
+      if (tid == 0) { sc[SC_NI] = 0; sc[SC_ICUR] = 0; sc[SC_FILL] = 0; }
+      __syncthreads();
     }
-  } else {
+  } else if (!(lm_wave && wave >= nw_exp)) {
     uint32_t ppw = pow2_ge((uint32_t)((n + nw_exp - 1) / nw_exp));  // <= 64 (n <= 64 * 15 when the last wave is set aside: beams <= 512)
     const int i0 = lane * nw_exp + wave;  // interleaved: the beam is sorted by score and good prefixes survive the cut-off for more labels, so every wave gets its share of them
     uint32_t cnt = 0, a0 = 0;
@@ -1362,7 +1402,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     for (int w = 0; w < NWAVES; ++w) { const unsigned long long a = ((LDS_AS unsigned long long*)L.wtot)[w]; if (a > mx) { mx2 = mx; mx = a; who = w; } else if (a > mx2) mx2 = a; if (a < mn) mn = a; }
     L.stm[32 + who] += 1; L.stm[48] += mx - mn; L.stm[49] += mx2 - mn;
   }
-  int m = sc[SC_M];
+  int m = __builtin_amdgcn_readfirstlane(sc[SC_M]);
   if ((uint32_t)m > S.cand_cap) { m = (int)S.cand_cap; if (tid == 0) sc[SC_ERR] |= 4; }
   TICK(2);
 
@@ -1378,7 +1418,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   if (SC_ON) {
     unsigned lmq = 0;
     if (lm_queue) {
-      const int nq = sc[SC_NQ];
+      const int nq = __builtin_amdgcn_readfirstlane(sc[SC_NQ]);
       for (int q = NTHREADS - 1 - tid; q < nq; q += NTHREADS) {
         const uint32_t ent = L.ssrc[q];
         const bool live = (ent >> 31) != 0;
@@ -1479,7 +1519,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   {
     // Scores equal to -NUM_FLT_INF (a repeated label on a prefix whose blank probability is still -inf) would stretch
     // the range over the whole float line; they are re-based right after the worst finite score (monotone, injective).
-    const uint32_t kmin = (uint32_t)sc[SC_KMIN], kmaxf = (uint32_t)sc[SC_KMAX];
+    const uint32_t kmin = (uint32_t)__builtin_amdgcn_readfirstlane(sc[SC_KMIN]), kmaxf = (uint32_t)__builtin_amdgcn_readfirstlane(sc[SC_KMAX]);
     const uint32_t neg_to = (kmaxf >= kmin && kmaxf < NEG_HI) ? kmaxf + 1u : NEG_HI;
 #define REKEY(k) (((uint32_t)((k) >> 32) == NEG_HI) ? (((uint64_t)neg_to << 32) | ((k) & 0xFFFFFFFFull)) : (k))
     uint64_t base = (uint64_t)kmin << 32;
@@ -1506,7 +1546,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       if (tid == 0) L.cumb[NBUCKET] = in_level;
       if (ex < (uint32_t)need && (uint32_t)need <= ex + h) { sc[SC_BT] = tid; sc[SC_BTH] = (int)h; sc[SC_BTCUM] = (int)ex; }
       __syncthreads();
-      const uint32_t bt = (uint32_t)sc[SC_BT], bth = (uint32_t)sc[SC_BTH], btcum = (uint32_t)sc[SC_BTCUM];
+      const uint32_t bt = (uint32_t)__builtin_amdgcn_readfirstlane(sc[SC_BT]), bth = (uint32_t)__builtin_amdgcn_readfirstlane(sc[SC_BTH]), btcum = (uint32_t)__builtin_amdgcn_readfirstlane(sc[SC_BTCUM]);
       const bool last = (bth <= RCAP) || sh == 0;
       for (int e = tid, r = 0; e < total; e += NTHREADS, ++r) {
         const uint64_t k0 = KEY_OF(e, r);
@@ -1627,6 +1667,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
 #undef CLS_AT
 #undef LP_AT
   if (tid == 0) {
+    if (MASKED) { sc[SC_NI] = 0; sc[SC_ICUR] = 0; sc[SC_FILL] = 0; }  // the next step's pre-pass starts without a barrier of its own
     L.acc[0] += 1; L.acc[1] += (unsigned long long)m; L.acc[2] += (unsigned long long)sc[SC_LMQ]; L.acc[3] += (unsigned long long)(unsigned)sc[SC_PROBES];
   }
   abs_t++;
@@ -1688,7 +1729,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
   if (L.bloom) for (uint32_t h = tid; h < BLOOM_WORDS; h += NTHREADS) L.bloom[h] = 0;
   if (tid < 32) { L.exp_tab[tid] = sttm::kExp2Tab[tid]; L.log_tab[tid] = sttm::kLogfTab[tid >> 1][tid & 1]; }
-  if (tid == 0) { L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
+  if (tid == 0) { L.sc[SC_NI] = 0; L.sc[SC_ICUR] = 0; L.sc[SC_FILL] = 0; L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
   if (tid < 12) L.acc[tid] = 0;
   if (tid < 64) L.stm[tid] = 0;
   __syncthreads();  // the math tables must be in place before the first row is prepared

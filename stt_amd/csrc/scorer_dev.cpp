@@ -356,6 +356,51 @@ int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, 
     hs.fst_pos[nstates] = w;
     hs.fst_start = (int)fst_start;
     hs.n_states = (uint64_t)nstates;
+    hs.fst_tree = false;
+    // ---- word mode: the dictionary unfolded into the tree of its word prefixes (the minimised automaton shares suffixes; the
+    // tree has one node per distinct prefix -- at most the number of characters of the vocabulary).  Breadth first, node k + 1 is
+    // the target of arc k and the root is node 0, so the child of a node along its r-th labelled arc is `first arc + r + 1`: the
+    // search kernel needs no arc read to follow the dictionary (an expand item's arc read was a dependent HBM/L2 miss in the
+    // middle of the item).  Same language, same behaviour: the reference only asks "which labels may follow" and "has a word
+    // ended" (path_trie.cpp:54-90).  Taken when every arc into a final state carries the space label and the other way round
+    // (what generate_scorer_package builds) and the tree stays below the `dict_tree_mb` cap; the repacked automaton otherwise.
+    const uint64_t cap_nodes = (uint64_t)std::max(0, tune().dict_tree_mb) * 1024 * 1024 / 21;  // arcs 8 + rec 8 + pos 4 + flag 1 bytes per node
+    if (!hs.utf8 && space_label >= 0 && space_label < 32 && hs.fst_bitmap_ok && cap_nodes > 1) {
+      const uint32_t NONE = 0xFFFFFFFFu;
+      std::vector<uint32_t> node_state(1, (uint32_t)fst_start), t_pos;
+      std::vector<uint2> t_arcs, t_rec;
+      std::vector<uint8_t> t_space;
+      bool ok = true;
+      for (size_t v = 0; v < node_state.size() && ok; ++v) {
+        const uint32_t st = node_state[v];
+        const uint32_t first = (uint32_t)t_arcs.size();
+        t_pos.push_back(first);
+        uint32_t mask = 0; uint8_t sp = 0;
+        if (st != NONE) {
+          for (uint32_t k = hs.fst_pos[st]; k < hs.fst_pos[st + 1]; ++k) {
+            const uint2 a = hs.fst_arcs[k];
+            if (a.x == 0) continue;                                        // epsilon arcs are never matched
+            if (a.x > 32) { ok = false; break; }
+            const uint32_t raw_next = rd32(arcs + 16 * (uint64_t)(rd32(states + 20 * (uint64_t)st + 4) + (k - hs.fst_pos[st])) + 12);
+            const bool to_final = fin[raw_next] != 0, is_space = (int64_t)a.x == (int64_t)space_label + 1;
+            if (to_final != is_space) { ok = false; break; }
+            mask |= 1u << (a.x - 1);
+            if (is_space) sp = 1;
+            t_arcs.push_back(make_uint2(a.x, is_space ? 0u : (uint32_t)t_arcs.size() + 1u));
+            node_state.push_back(is_space ? NONE : raw_next);               // (a space arc's own node is never entered)
+            if (node_state.size() > cap_nodes) { ok = false; break; }
+          }
+        }
+        t_rec.push_back(make_uint2(first, mask));
+        t_space.push_back(sp);
+      }
+      if (ok) {
+        t_pos.push_back((uint32_t)t_arcs.size());
+        t_rec.push_back(make_uint2((uint32_t)t_arcs.size(), 0)); t_space.push_back(0);
+        hs.fst_pos.swap(t_pos); hs.fst_arcs.swap(t_arcs); hs.fst_rec.swap(t_rec); hs.fst_has_space.swap(t_space);
+        hs.fst_start = 0; hs.n_states = (uint64_t)node_state.size(); hs.fst_tree = true;
+      }
+    }
   }
 
   // ---- vocabulary hash table over KenLM's sorted hash array (index = position + 1, vocab.hh:72-83)
@@ -469,7 +514,7 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label, bool lm_on
   ds.prob_bits = hs.prob_bits; ds.backoff_bits = hs.backoff_bits;
   ds.prob_mask = (1u << hs.prob_bits) - 1; ds.backoff_mask = (1u << hs.backoff_bits) - 1;
   ds.bos_index = hs.bos_index; ds.bos_backoff = hs.bos_backoff;
-  ds.fst_start = hs.fst_start;
+  ds.fst_start = hs.fst_start; ds.fst_tree = hs.fst_tree ? 1 : 0;
   if (!lm_only) {
     ds.fst_state_pos = fst_pos_.as<uint32_t>(); ds.fst_arcs = fst_arcs_.as<uint2>(); ds.fst_has_space = fst_space_.as<uint8_t>();
     ds.fst_rec = hs.fst_bitmap_ok ? fst_rec_.as<uint2>() : nullptr;

@@ -34,6 +34,7 @@ struct HostScorer {
   std::vector<uint2> fst_arcs, fst_rec;
   std::vector<uint8_t> fst_has_space;
   bool fst_bitmap_ok = false;
+  bool fst_tree = false;   // the tables hold the dictionary unfolded into a tree (node k + 1 = target of arc k, root 0)
   // vocabulary table, Bhiksha hints
   std::vector<DevVocabSlot> vtab;
   bool uni_ok = false;

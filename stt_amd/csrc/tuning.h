@@ -36,6 +36,7 @@
   X(lm_waves, 0, "language-model waves of the search step (0 = by beam width)")                                                    \
   X(exp_waves, 0, "expand waves of the search step (0 = all the others)")                                                          \
   X(lm_memo, 1, "code-point scorer: FullScore memo table")                                                                         \
+  X(dict_tree_mb, 2048, "dictionary unfolded into a tree (no arc reads in the search): byte cap in MiB, 0 = keep the automaton")           \
   X(lm_index_mb, 4096, "hashed n-gram index: byte cap in MiB (larger models take the trie walk)")                                  \
   X(arena_shrink, 1, "test hook: divides the optimistic arena sizes of a batch group (forces the overflow -> decode-again path)")        \
   X(arena_retries, 0, "counter, not a knob: batch groups decoded again with full-size arenas after an overflow flag")                 \

@@ -417,6 +417,16 @@ class Decoder(object):
         n = native.lib().STTX_DecoderBeam(self._impl, stream, sc.ctypes.data, pb.ctypes.data, pnb.ctypes.data, ch.ctypes.data, cap)
         return sc[:n], pb[:n], pnb[:n], ch[:n]
 
+    def setProfiling(self, level):
+        native.lib().STTX_DecoderSetProfiling(self._impl, int(level))
+
+    def profile(self):
+        """(phase cycles by name, 64 stamps, HIP-event ms of the search launches) since setProfiling()."""
+        ph, st, ms = (C.c_ulonglong * 8)(), (C.c_ulonglong * 64)(), C.c_float(0)
+        native.lib().STTX_DecoderGetProfile(self._impl, ph, st, C.byref(ms))
+        names = ["setup", "expand_events", "expand_items", "lm", "merge", "select", "rank+write", "lm_wave (parallel to expand)"]
+        return dict(zip(names, [int(x) for x in ph])), [int(x) for x in st], float(ms.value)
+
     def stats(self):
         st = (C.c_ulonglong * 4)()
         status = native.lib().STTX_DecoderStats(self._impl, st)
