@@ -772,7 +772,7 @@ struct Lds {
 };
 // phase cycle counters (s_memtime is a scalar memory operation with a wait: only on request, DecParams::phase_cycles)
 #define TICK(k) do { if (p.phase_cycles && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); L.acc[4 + (k)] += now_ - tick_; tick_ = now_; } } while (0)
-enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_CLAMP, SC_NA, SC_NB, SC_NI, SC_ICUR, SC_FILL, SC_COUNT = 24 };
+enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_CLAMP, SC_NA, SC_NB, SC_NI, SC_ICUR, SC_FILL, SC_DONE, SC_LMDONE, SC_COUNT = 24 };
 #define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
 
@@ -1007,6 +1007,22 @@ __device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, co
   return nscore;
 }
 
+// Wait until an LDS counter (bumped once per arriving wave, after a release fence) reaches `want`: a barrier among SOME of the waves
+// of the workgroup (s_barrier always takes all of them).  Scalar loop control (see the note on uniform control flow in ctc_step);
+// bounded, so that a logic error shows up as error bit 16 instead of a hung GPU.
+__device__ __forceinline__ void wait_count(LDS_AS int* ctr, uint32_t want, LDS_AS int* err) {
+  int spins = 0;
+  while ((uint32_t)__builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 17)) { lds_or(err, 16); break; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void signal_count(LDS_AS int* ctr) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & 63) == 0) lds_add(ctr, 1);
+}
+
 // `buf` holds this step's prepared emissions; `next_row` (or null) is prepared into buf^1 while the LM phase runs.
 // MODE: 0 = no scorer, 1 = word-level scorer, 2 = utf8 (codepoint-level) scorer -- separate instantiations, so the
 // hot word-mode kernel does not carry the registers and code of the uncached codepoint paths.
@@ -1156,7 +1172,10 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     if (lmq) lds_add(&sc[SC_LMQ], (int)lmq);
     if (p.phase_cycles && lane == 0 && wave == NWAVES - 1) L.acc[4 + 7] += __builtin_readcyclecounter() - lmw_t0;  // phase slot 7: the (last) LM wave's own time
     __builtin_amdgcn_s_setprio(0);
+    if (MASKED) signal_count(&sc[SC_LMDONE]);
   }
+  const bool lmw_ = lm_wave && wave >= nw_exp;             // this wave is a language-model wave (scalar)
+  const uint32_t n_cons = (uint32_t)(lm_wave ? nw_exp : NWAVES);  // waves that fill the table and take items
   if (MASKED) {
     // ---- expand with label bitmaps (see the comment above the function), in two halves:
     // (1) pre-pass, thread i = prefix i (the first n threads; the LM waves are in their queries meanwhile): cut-off mask, blank /
@@ -1168,8 +1187,13 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     LDS_AS uint16_t* own = (LDS_AS uint16_t*)L.own;
     const uint32_t own_n = (L.own_cap * (uint32_t)NWAVES) >> 1;  // items the table holds (more: another pass)
     uint32_t em = 0;
-    if (tid < n) {
-      const int i = tid;
+    // 64 prefixes per wave: the pre-pass is bound by instruction issue (a CU issues one VALU instruction per cycle over all its
+    // waves), so full waves beat more waves -- 36 lanes of 14 waves measured 9.4 k cycles until the table was complete, 64 lanes
+    // of 8 waves 6.5 k
+    const int i_pre = tid;
+    const bool pre_wave = !lmw_ && wave * 64 < n;        // scalar (an LM wave never is one: n <= 512 < 64 * nw_exp)
+    if (!lmw_ && i_pre < n) {
+      const int i = i_pre;
       float eb = absent(), es = absent();
       const float sci = L.score[cur][i];
       if (sci != NEG) {  // :160-162
@@ -1194,7 +1218,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       L.ev_blank[i] = eb; L.ev_self[i] = es; L.ev_ext[i] = absent(); L.ev_exti[i] = 0;
     }
     for (int pass = 0;; ++pass) {
-      if (wave * 64 < n) {
+      if (pre_wave) {
         const uint32_t cnt = (uint32_t)__popc(em);
         const uint32_t inc = wave_incl_scan(cnt, lane);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -1207,21 +1231,17 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         }
         // "this wave's items are in the table": a counter instead of a barrier, so that the LM waves -- in the middle of their
         // chain of dependent reads -- are not waited for (LDS operations of a wave are performed in order)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) lds_add((LDS_AS uint32_t*)&sc[SC_FILL], 1u);
+        signal_count(&sc[SC_FILL]);
       }
       if (pass == 0) TICK(1);
-      {
-        const uint32_t want = (uint32_t)((n + 63) >> 6);
-        int spins = 0;
-        while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((LDS_AS uint32_t*)&sc[SC_FILL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1 << 16)) { lds_or(&sc[SC_ERR], 16); break; }  // (never: the filling waves wait for nobody)
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      }
+      wait_count(&sc[SC_FILL], (uint32_t)((n + 63) >> 6), &sc[SC_ERR]);
+      const bool stw_ = p.stamps != nullptr && wave == 9;   // profiling level 2: wave 9 (a pure consumer) stamps its item loop
+      unsigned long long ct0_ = 0;
+      if (stw_) { ct0_ = __builtin_readcyclecounter(); if (lane == 0) L.stm[50] += ct0_ - tick_; }   // table complete (since the step began)
       const uint32_t total_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((LDS_AS uint32_t*)&sc[SC_NI], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
       const uint32_t n_items = total_items < own_n ? total_items : own_n;
+      // (Two items per lane -- 128-item chunks, both chains of LDS round trips in flight -- measured SLOWER, 3.92 against 3.81 ms per
+      // 64 x 250 frames: a chunk then took twice as long.  The phase is bound by instruction issue, not by the latency of the chain.)
       // The loop is controlled by scalars only (the chunk cursor read through lane 0, the item count): a uniform branch.  Lanes past
       // the end of the last chunk skip the body inside an if-region -- no `continue`, no lane-dependent exit: with those the
       // compiler may send lanes round the loop on their own, and the wave-level read would then miss lane 0.
@@ -1231,7 +1251,8 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
       };
 #pragma unroll 1
-      for (uint32_t xb = take_chunk(); xb < n_items; xb = take_chunk()) {
+      for (uint32_t xb = lmw_ ? n_items : take_chunk(); xb < n_items; xb = take_chunk()) {   // (the LM waves take no items: they are on their way to the queue of scored extensions)
+        if (stw_) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) { L.stm[51] += t_ - ct0_; L.stm[52] += 1; } ct0_ = t_; }   // 51: taking a chunk (+ the previous body's tail), 52: chunks
         const uint32_t x = xb + (uint32_t)lane;
         if (x < n_items) {
           const uint32_t oc = (uint32_t)own[x];
@@ -1264,6 +1285,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
             }
           }
         }
+        if (stw_) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) L.stm[53] += t_ - ct0_; ct0_ = t_; }   // 53: the chunk's body
       }
       if (total_items <= own_n) break;  // (uniform) everything was in the table
       __syncthreads();
@@ -1394,10 +1416,17 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   // how long did it then wait (slot 16 + wave)
   // ... and which wave was last (slot 32 + wave counts the steps it was; 48: sum of the last wave's arrival, 49: of the second-last)
   unsigned long long arrive_ = 0;
-  if (p.stamps && lane == 0) { arrive_ = __builtin_readcyclecounter(); L.stm[wave] += arrive_ - tick_; ((LDS_AS unsigned long long*)L.wtot)[wave] = arrive_; }
-  __syncthreads();
+  if (p.stamps && lane == 0) { arrive_ = __builtin_readcyclecounter(); L.stm[wave] += arrive_ - tick_; if (!MASKED) ((LDS_AS unsigned long long*)L.wtot)[wave] = arrive_; }
+  if (MASKED) {
+    // The end of the expand phase is a barrier among the item-taking waves only (a counter): the LM waves are still in their
+    // queries -- what the phases after this one need from them (the scores of the queued extensions) is due at the END of the next
+    // phase, and the LM waves' own threads are the ones that put those scores in place, when they and the items are done.
+    if (!lmw_) signal_count(&sc[SC_DONE]);
+    wait_count(&sc[SC_DONE], n_cons, &sc[SC_ERR]);
+    if (lmw_) wait_count(&sc[SC_LMDONE], (uint32_t)nlm, &sc[SC_ERR]);
+  } else __syncthreads();
   if (p.stamps && lane == 0) L.stm[16 + wave] += __builtin_readcyclecounter() - arrive_;
-  if (p.stamps && tid == 0) {
+  if (!MASKED && p.stamps && tid == 0) {
     unsigned long long mx = 0, mx2 = 0, mn = ~0ull; int who = 0;
     for (int w = 0; w < NWAVES; ++w) { const unsigned long long a = ((LDS_AS unsigned long long*)L.wtot)[w]; if (a > mx) { mx2 = mx; mx = a; who = w; } else if (a > mx2) mx2 = a; if (a < mn) mn = a; }
     L.stm[32 + who] += 1; L.stm[48] += mx - mn; L.stm[49] += mx2 - mn;
@@ -1410,7 +1439,8 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   // queued by the expand phase and are taken by the *last* threads of the workgroup, while the first n threads already
   // merge every live prefix that does not wait for a score.  Meanwhile the next row's class log-probs are prepared and
   // the (now dead) hash is cleared for the next beam.
-  for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
+  if (MASKED) { if (!lmw_) for (uint32_t h = tid; h < HTN; h += n_cons * 64u) L.ht_key[h] = 0; }  // (the LM waves come later and go straight to the queue)
+  else for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
   if (L.bloom) for (uint32_t h = tid; h < BLOOM_WORDS; h += NTHREADS) L.bloom[h] = 0;
   if (!WIDE && next_row) prep_row(p, L, buf ^ 1, next_row, pre);
   bool merged = false;
@@ -1419,7 +1449,9 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     unsigned lmq = 0;
     if (lm_queue) {
       const int nq = __builtin_amdgcn_readfirstlane(sc[SC_NQ]);
-      for (int q = NTHREADS - 1 - tid; q < nq; q += NTHREADS) {
+      // (bitmap step with LM waves: their threads only -- every listed query is done by then, LMDONE above)
+      const bool q_all = !(MASKED && lm_wave);
+      for (int q = (q_all || lmw_) ? NTHREADS - 1 - tid : nq; q < nq; q += q_all ? NTHREADS : nlm * 64) {
         const uint32_t ent = L.ssrc[q];
         const bool live = (ent >> 31) != 0;
         const int x = (int)(ent & 0x7FFFFFFFu);  // candidate slot, or live prefix index
@@ -1667,7 +1699,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
 #undef CLS_AT
 #undef LP_AT
   if (tid == 0) {
-    if (MASKED) { sc[SC_NI] = 0; sc[SC_ICUR] = 0; sc[SC_FILL] = 0; }  // the next step's pre-pass starts without a barrier of its own
+    if (MASKED) { sc[SC_NI] = 0; sc[SC_ICUR] = 0; sc[SC_FILL] = 0; sc[SC_DONE] = 0; sc[SC_LMDONE] = 0; }  // the next step's pre-pass starts without a barrier of its own
     L.acc[0] += 1; L.acc[1] += (unsigned long long)m; L.acc[2] += (unsigned long long)sc[SC_LMQ]; L.acc[3] += (unsigned long long)(unsigned)sc[SC_PROBES];
   }
   abs_t++;
@@ -1729,7 +1761,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
   if (L.bloom) for (uint32_t h = tid; h < BLOOM_WORDS; h += NTHREADS) L.bloom[h] = 0;
   if (tid < 32) { L.exp_tab[tid] = sttm::kExp2Tab[tid]; L.log_tab[tid] = sttm::kLogfTab[tid >> 1][tid & 1]; }
-  if (tid == 0) { L.sc[SC_NI] = 0; L.sc[SC_ICUR] = 0; L.sc[SC_FILL] = 0; L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
+  if (tid == 0) { L.sc[SC_NI] = 0; L.sc[SC_ICUR] = 0; L.sc[SC_FILL] = 0; L.sc[SC_DONE] = 0; L.sc[SC_LMDONE] = 0; L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
   if (tid < 12) L.acc[tid] = 0;
   if (tid < 64) L.stm[tid] = 0;
   __syncthreads();  // the math tables must be in place before the first row is prepared
