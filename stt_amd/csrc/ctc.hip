@@ -772,7 +772,7 @@ struct Lds {
 };
 // phase cycle counters (s_memtime is a scalar memory operation with a wait: only on request, DecParams::phase_cycles)
 #define TICK(k) do { if (p.phase_cycles && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); L.acc[4 + (k)] += now_ - tick_; tick_ = now_; } } while (0)
-enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_CLAMP, SC_NA, SC_NB, SC_NI, SC_ICUR, SC_FILL, SC_DONE, SC_LMDONE, SC_COUNT = 24 };
+enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_CLAMP, SC_NA, SC_NB, SC_NI, SC_ICUR, SC_FILL, SC_DONE, SC_COUNT = 24 };
 #define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
 
@@ -1172,7 +1172,6 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     if (lmq) lds_add(&sc[SC_LMQ], (int)lmq);
     if (p.phase_cycles && lane == 0 && wave == NWAVES - 1) L.acc[4 + 7] += __builtin_readcyclecounter() - lmw_t0;  // phase slot 7: the (last) LM wave's own time
     __builtin_amdgcn_s_setprio(0);
-    if (MASKED) signal_count(&sc[SC_LMDONE]);
   }
   const bool lmw_ = lm_wave && wave >= nw_exp;             // this wave is a language-model wave (scalar)
   const uint32_t n_cons = (uint32_t)(lm_wave ? nw_exp : NWAVES);  // waves that fill the table and take items
@@ -1274,14 +1273,13 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
           if (jj >= 0) {  // the child is a live prefix: one extension event per live prefix per step
             L.ev_ext[jj] = log_p;
             L.ev_exti[jj] = (uint32_t)i | (needs_lm << 31);
-            if (needs_lm) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = 0x80000000u | (uint32_t)jj; }
+            // (no queue of scored extensions in this form: bit 31 marks them, the key phase adds the score -- score_ext below)
           } else {
             const int slot = lds_add(&sc[SC_M], 1);
             if ((uint32_t)slot < S.cand_cap) {
               const uint32_t piv = (uint32_t)i | (c << 16) | (needs_lm << 31);  // (class position == class: no pruning in this mode)
               if ((uint32_t)slot < L.mcap) { L.lc_logp[slot] = log_p; L.lc_pi[slot] = piv; L.lc_fst[slot] = (int)child_fst; }
               else { S.c_logp[slot] = log_p; S.c_pi[slot] = piv; S.c_fst[slot] = (int)child_fst; }
-              if (needs_lm) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = (uint32_t)slot; }
             }
           }
         }
@@ -1419,11 +1417,9 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   if (p.stamps && lane == 0) { arrive_ = __builtin_readcyclecounter(); L.stm[wave] += arrive_ - tick_; if (!MASKED) ((LDS_AS unsigned long long*)L.wtot)[wave] = arrive_; }
   if (MASKED) {
     // The end of the expand phase is a barrier among the item-taking waves only (a counter): the LM waves are still in their
-    // queries -- what the phases after this one need from them (the scores of the queued extensions) is due at the END of the next
-    // phase, and the LM waves' own threads are the ones that put those scores in place, when they and the items are done.
-    if (!lmw_) signal_count(&sc[SC_DONE]);
-    wait_count(&sc[SC_DONE], n_cons, &sc[SC_ERR]);
-    if (lmw_) wait_count(&sc[SC_LMDONE], (uint32_t)nlm, &sc[SC_ERR]);
+    // queries, and what the later phases need from them -- the scores of this step's "prefix + space" extensions -- is only read
+    // in the key phase, after the next real barrier (score_ext below); an LM wave goes straight to that barrier when it is done.
+    if (!lmw_) { signal_count(&sc[SC_DONE]); wait_count(&sc[SC_DONE], n_cons, &sc[SC_ERR]); }
   } else __syncthreads();
   if (p.stamps && lane == 0) L.stm[16 + wave] += __builtin_readcyclecounter() - arrive_;
   if (!MASKED && p.stamps && tid == 0) {
@@ -1447,11 +1443,11 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   float my_score = NEG;
   if (SC_ON) {
     unsigned lmq = 0;
-    if (lm_queue) {
+    if (MASKED) {  // no queue in this form; the LM waves (still in their queries, or waiting at the barrier below) have nothing to do here
+      if (!lmw_ && tid < n && !((L.ev_exti[tid] >> 31) && !is_absent(L.ev_ext[tid]))) { my_score = merge_live<WIDE>(p, L, W, cur, tid); merged = true; }
+    } else if (lm_queue) {
       const int nq = __builtin_amdgcn_readfirstlane(sc[SC_NQ]);
-      // (bitmap step with LM waves: their threads only -- every listed query is done by then, LMDONE above)
-      const bool q_all = !(MASKED && lm_wave);
-      for (int q = (q_all || lmw_) ? NTHREADS - 1 - tid : nq; q < nq; q += q_all ? NTHREADS : nlm * 64) {
+      for (int q = NTHREADS - 1 - tid; q < nq; q += NTHREADS) {
         const uint32_t ent = L.ssrc[q];
         const bool live = (ent >> 31) != 0;
         const int x = (int)(ent & 0x7FFFFFFFu);  // candidate slot, or live prefix index
@@ -1512,30 +1508,63 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     if (lmq) lds_add(&sc[SC_LMQ], (int)lmq);
   }
   if (probes) lds_add(&sc[SC_PROBES], (int)probes);
+  if (MASKED && p.stamps && lane == 0) L.stm[32 + wave] += __builtin_readcyclecounter() - tick_;   // profiling level 2: arrival at the end of the score phase (wave 0: since its last TICK)
   __syncthreads();
   TICK(3);
 
   // ---- P4: merge events of live prefixes in the reference's visiting order (class position, then beam index);
   // selection keys of live prefixes and candidates.  Element e (live prefix e < n, else candidate e - n) belongs to
   // thread e % NTHREADS; its first two keys stay in registers, further ones go to the HBM workspace.
+  if (MASKED) {  // (an LM wave passed the end of the expand phase before the items were done: the count is final now)
+    m = __builtin_amdgcn_readfirstlane(sc[SC_M]);
+    if ((uint32_t)m > S.cand_cap) m = (int)S.cand_cap;
+  }
   const int total = n + m;
   uint64_t kreg0 = ~0ULL, kreg1 = ~0ULL;
   uint32_t hmin = 0xFFFFFFFFu, hmax = 0;
+  unsigned lmq4 = 0, probes4 = 0;
+  // bitmap form: log_p of a "prefix i + space" extension with the language-model score of prefix i added (:209-243) -- the score the
+  // LM waves left in pqs during the expand phase, or (no LM waves on the first steps of a stream, n <= 16) one query here
+  auto score_ext = [&](float lp0, int i) -> float {
+    float lms;
+    if (L.pqe[cur][i] != STT_NONE) lms = L.pqs[cur][i];
+    else {
+      const uint32_t bndi = L.bnd[cur][i];
+      double raw = 0.0;
+      if (bndi == STT_NONE) lds_or(&sc[SC_ERR], 8);
+      else {
+        uint32_t ne;
+        raw = lm_word_query_cached<MASKED>(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], L.node[cur][i], bndi, true, L.wlo[cur][i], L.whi[cur][i], ne, probes4);
+        L.pqe[cur][i] = ne; L.pqs[cur][i] = (float)__dmul_rn(raw, s.alpha);
+        ++lmq4;
+      }
+      lms = (float)__dmul_rn(raw, s.alpha);
+    }
+    const float lpv = __fadd_rn(lp0, lms);                  // log_p += score;
+    return (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
+  };
   for (int e = tid, r = 0; e < total; e += NTHREADS, ++r) {
     uint64_t k;
     if (e < n) {  // e == tid: either merged during the LM phase, or it waited for a score
+      if (MASKED && !merged) {
+        const uint32_t xi = L.ev_exti[e];
+        if ((xi >> 31) && !is_absent(L.ev_ext[e])) L.ev_ext[e] = score_ext(L.ev_ext[e], (int)(xi & 0xFFFFu));
+      }
       const float nscore = merged ? my_score : merge_live<WIDE>(p, L, W, cur, e);
       k = sel_key(nscore, L.ch[cur][e], 0, (uint32_t)e);
     } else {
       const int x = e - n;
       const uint32_t pi = CAND_PI(x);
-      k = sel_key(CAND_LOGP(x), CLS_AT((pi >> 16) & 0x7FFFu), 1, pi & 0xFFFFu);
+      float lpx = CAND_LOGP(x);
+      if (MASKED && (pi >> 31)) { lpx = score_ext(lpx, (int)(pi & 0xFFFFu)); if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpx; else S.c_logp[x] = lpx; }
+      k = sel_key(lpx, CLS_AT((pi >> 16) & 0x7FFFu), 1, pi & 0xFFFFu);
     }
     if (r == 0) kreg0 = k; else if (r == 1) kreg1 = k; else S.sel_keys[e] = k;
     const uint32_t kh = (uint32_t)(k >> 32);
     hmin = kh < hmin ? kh : hmin; if (kh != NEG_HI) hmax = kh > hmax ? kh : hmax;
   }
 #define KEY_OF(e, r) ((r) == 0 ? kreg0 : (r) == 1 ? kreg1 : S.sel_keys[e])
+  if (MASKED) { if (lmq4) lds_add(&sc[SC_LMQ], (int)lmq4); if (probes4) lds_add(&sc[SC_PROBES], (int)probes4); }
   hmin = wave_min_u32(hmin); hmax = wave_max_u32(hmax);
   if (lane == 0) { lds_min((LDS_AS uint32_t*)&sc[SC_KMIN], hmin); lds_max((LDS_AS uint32_t*)&sc[SC_KMAX], hmax); }
   __syncthreads();
@@ -1699,7 +1728,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
 #undef CLS_AT
 #undef LP_AT
   if (tid == 0) {
-    if (MASKED) { sc[SC_NI] = 0; sc[SC_ICUR] = 0; sc[SC_FILL] = 0; sc[SC_DONE] = 0; sc[SC_LMDONE] = 0; }  // the next step's pre-pass starts without a barrier of its own
+    if (MASKED) { sc[SC_NI] = 0; sc[SC_ICUR] = 0; sc[SC_FILL] = 0; sc[SC_DONE] = 0; }  // the next step's pre-pass starts without a barrier of its own
     L.acc[0] += 1; L.acc[1] += (unsigned long long)m; L.acc[2] += (unsigned long long)sc[SC_LMQ]; L.acc[3] += (unsigned long long)(unsigned)sc[SC_PROBES];
   }
   abs_t++;
@@ -1761,7 +1790,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
   if (L.bloom) for (uint32_t h = tid; h < BLOOM_WORDS; h += NTHREADS) L.bloom[h] = 0;
   if (tid < 32) { L.exp_tab[tid] = sttm::kExp2Tab[tid]; L.log_tab[tid] = sttm::kLogfTab[tid >> 1][tid & 1]; }
-  if (tid == 0) { L.sc[SC_NI] = 0; L.sc[SC_ICUR] = 0; L.sc[SC_FILL] = 0; L.sc[SC_DONE] = 0; L.sc[SC_LMDONE] = 0; L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
+  if (tid == 0) { L.sc[SC_NI] = 0; L.sc[SC_ICUR] = 0; L.sc[SC_FILL] = 0; L.sc[SC_DONE] = 0; L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
   if (tid < 12) L.acc[tid] = 0;
   if (tid < 64) L.stm[tid] = 0;
   __syncthreads();  // the math tables must be in place before the first row is prepared
