@@ -1072,7 +1072,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   // (bitmap step: every thread clears the events of its own prefix in the pre-pass below -- no barrier in between)
   if (!MASKED) for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
   L.hist[tid] = 0;
-  if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; sc[SC_NQ] = 0; }
+  if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; sc[SC_NQ] = 0; sc[SC_NA] = 0; sc[SC_NB] = 0; }
   const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
   int cutoff_len = WIDE ? wh.cutoff_len : C;
   if (!WIDE && sort_classes && p.wide_rows) {  // class order prepared for all rows of the chunk by ctc_wide_rows_kernel
@@ -1635,18 +1635,69 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     __syncthreads();
     TICK(5);
 
-    // rank inside the segment -> position r in the new beam; write the new beam entry (P6) and hash its key
-    for (uint32_t q = tid; q < placed; q += NTHREADS) {
-      const uint64_t k = L.skey[q];
-      const uint32_t seg = L.sseg[q];
-      const uint32_t seg0 = seg & 0xFFFFu, len = seg >> 16;
-      uint32_t r = seg0;
-      for (uint32_t t = 0; t < len; ++t) r += (L.skey[seg0 + t] < k) ? 1u : 0u;
-      if ((int)r >= keep) continue;
-      const uint32_t x = L.ssrc[q];
+    // rank inside the segment -> position r in the new beam; then write the new beam entry (P6) and hash its key.
+    // A surviving live prefix is a copy of ~20 fields, a new prefix ~3x the work (arena node, dictionary record, word bytes); mixed in
+    // one loop every wave walked through both bodies.  So: (a) rank, and put {source, position} on one of two lists -- live from the
+    // front, new from the back of the (idle) histogram; (b) barrier; (c) the first threads take the live list, the last ones the new
+    // list: a wave runs one body.
+    LDS_AS uint32_t* wl = L.hist;                      // source element (live prefix x < n, else candidate x - n): NBUCKET = 1024 entries >= keep
+    LDS_AS uint16_t* wr = (LDS_AS uint16_t*)L.cumb;    // its position in the new beam (the bucket offsets are dead after the scatter)
+    unsigned long long w6_ = 0;
+#define P6_STAMP(k) do { if (p.stamps && (wave == 0 || wave == NWAVES - 1)) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) L.stm[(wave == 0 ? 56 : 60) + (k)] += t_ - w6_; w6_ = t_; } } while (0)
+    if (p.stamps) w6_ = __builtin_readcyclecounter();
+    uint2 rec_new = make_uint2(0, 0); uint32_t r_rec = 0xFFFFFFFFu;  // bitmap form: dictionary record of a new prefix, fetched early (below)
+    for (uint32_t q0 = 0; q0 < placed; q0 += NTHREADS) {  // (scalar loop control: ballots inside)
+      const uint32_t q = q0 + (uint32_t)tid;
+      bool is_live = false, is_new = false;
+      uint32_t ent = 0, rr = 0;
+      if (q < placed) {
+        const uint64_t k = L.skey[q];
+        const uint32_t seg = L.sseg[q];
+        const uint32_t seg0 = seg & 0xFFFFu, len = seg >> 16;
+        uint32_t r = seg0;
+        // four keys per trip, their reads in flight together: one read per trip made the longest segment of a wave (up to RCAP keys,
+        // an LDS round trip each) the length of this phase -- 5 k cycles on the slowest wave, 2 k on an average one.  (The reads past
+        // the segment's end stay inside the key / segment arrays.)
+        for (uint32_t t = 0; t < len; t += 4) {
+          const uint64_t k0 = L.skey[seg0 + t], k1 = L.skey[seg0 + t + 1], k2 = L.skey[seg0 + t + 2], k3 = L.skey[seg0 + t + 3];
+          r += (k0 < k ? 1u : 0u) + ((t + 1 < len && k1 < k) ? 1u : 0u) + ((t + 2 < len && k2 < k) ? 1u : 0u) + ((t + 3 < len && k3 < k) ? 1u : 0u);
+        }
+        if ((int)r < keep) { const uint32_t x = L.ssrc[q]; ent = x; rr = r; is_live = (int)x < n; is_new = !is_live; }
+      }
+      if (MASKED && is_new) {
+        // {first labelled arc, label bitmap} of the new prefix's dictionary state: a read from a table of tens of MB, i.e. a miss --
+        // started here, consumed after this thread's share of the write phase (stays in flight across the barrier), so nobody waits
+        const int cx = (int)ent - n;
+        rec_new = s.fst_rec[((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst[cx]]; r_rec = rr;
+      }
+      const uint64_t bl = __ballot(is_live), bn = __ballot(is_new);
+      uint32_t base_l = 0, base_n = 0;
+      if (lane == 0) { if (bl) base_l = lds_add((LDS_AS uint32_t*)&sc[SC_NA], (uint32_t)__popcll(bl)); if (bn) base_n = lds_add((LDS_AS uint32_t*)&sc[SC_NB], (uint32_t)__popcll(bn)); }
+      base_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_l); base_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_n);
+      const uint64_t below = (1ull << lane) - 1ull;
+      if (is_live) { const uint32_t at = base_l + (uint32_t)__popcll(bl & below); wl[at] = ent; wr[at] = (uint16_t)rr; }
+      if (is_new) { const uint32_t at = NBUCKET - 1 - (base_n + (uint32_t)__popcll(bn & below)); wl[at] = ent; wr[at] = (uint16_t)rr; }
+    }
+    P6_STAMP(0);   // profiling level 2 (wave 0: slots 56.., last wave: 60..): ranking | wait at the barrier | own list | tail
+    __syncthreads();
+    P6_STAMP(1);
+    const uint32_t n_live = (uint32_t)__builtin_amdgcn_readfirstlane(sc[SC_NA]), n_new = (uint32_t)__builtin_amdgcn_readfirstlane(sc[SC_NB]);
+    if (p.stamps && tid == 0) { L.stm[54] += n_live; L.stm[55] += n_new; }
+    auto finish_entry = [&](uint32_t r, uint64_t nkey, uint32_t pend, uint32_t ts_new) {
+      L.key[nxt][r] = nkey;
+      ht_insert(L, nkey, (int)r);
+      if (pend != 0xFFFFFFFEu) {  // path_trie.cpp:172-184
+        const uint32_t slot = lds_add((LDS_AS uint32_t*)&sc[SC_TAN], 1u);
+        if (slot < S.ta_cap) { store_node(S.ta, slot, pend, (uint32_t)abs_t); ts_new = slot; }
+        else lds_or(&sc[SC_ERR], 2);
+      }
+      L.ts[nxt][r] = ts_new;
+    };
+    for (uint32_t t = tid; t < n_live; t += NTHREADS) {
+      const uint32_t x = wl[t], r = (uint32_t)wr[t];
       uint32_t ts_new, pend;
       uint64_t nkey;
-      if ((int)x < n) {
+      {
         L.score[nxt][r] = L.ev_ext[x]; L.pb[nxt][r] = L.ev_blank[x]; L.pnb[nxt][r] = L.ev_self[x];
         L.ch[nxt][r] = L.ch[cur][x]; L.node[nxt][r] = L.node[cur][x]; L.fst[nxt][r] = L.fst[cur][x];
         if (MASKED) { L.a0[nxt][r] = L.a0[cur][x]; L.sm[nxt][r] = L.sm[cur][x]; }
@@ -1656,7 +1707,14 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         if (MODE == 1 && L.pqe.p0) { L.wlo[nxt][r] = L.wlo[cur][x]; L.whi[nxt][r] = L.whi[cur][x]; L.pqe[nxt][r] = L.pqe[cur][x]; L.pqs[nxt][r] = L.pqs[cur][x]; }
         if (MODE == 2) L.run[nxt][r] = L.run[cur][x];
         pend = L.ev_exti[x]; ts_new = L.ts[cur][x];
-      } else {
+      }
+      finish_entry(r, nkey, pend, ts_new);
+    }
+    for (uint32_t t = NTHREADS - 1 - tid; t < n_new; t += NTHREADS) {
+      const uint32_t x = wl[NBUCKET - 1 - t], r = (uint32_t)wr[NBUCKET - 1 - t];
+      uint32_t ts_new, pend;
+      uint64_t nkey;
+      {
         const int cx = (int)x - n;
         const uint32_t pi = CAND_PI(cx);
         const int i = (int)(pi & 0xFFFFu);
@@ -1666,9 +1724,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
         const int cf = ((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst[cx];
         L.ch[nxt][r] = c; L.fst[nxt][r] = cf;
-        if (MASKED) {  // {first labelled arc, label bitmap} of the child's dictionary state
-          const uint2 rec = s.fst_rec[cf];
-          L.a0[nxt][r] = rec.x; L.sm[nxt][r] = rec.y;
+        if (MASKED) {  // (a0 / sm of the child's dictionary state: written at the end by the thread that ranked this entry)
         } else if (SC_ON && L.a0.p0) {  // arc range of the child's dictionary state; top bit: a word may end here (space arc)
           const uint32_t f0 = s.fst_state_pos[cf], f1 = s.fst_state_pos[cf + 1];
           const uint32_t sp = MODE == 1 ? (uint32_t)s.fst_has_space[cf] : 0u;
@@ -1712,15 +1768,13 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         pend = (NEG < lpv) ? L.ts[cur][i] : 0xFFFFFFFEu;  // :246-251 with log_prob_nb_cur == -inf
         ts_new = STT_ROOT_CH;                              // timesteps == nullptr
       }
-      L.key[nxt][r] = nkey;
-      ht_insert(L, nkey, (int)r);
-      if (pend != 0xFFFFFFFEu) {  // path_trie.cpp:172-184
-        const uint32_t slot = lds_add((LDS_AS uint32_t*)&sc[SC_TAN], 1u);
-        if (slot < S.ta_cap) { store_node(S.ta, slot, pend, (uint32_t)abs_t); ts_new = slot; }
-        else lds_or(&sc[SC_ERR], 2);
-      }
-      L.ts[nxt][r] = ts_new;
+      finish_entry(r, nkey, pend, ts_new);
     }
+    P6_STAMP(2);
+    if (MASKED && r_rec != 0xFFFFFFFFu) { L.a0[nxt][r_rec] = rec_new.x; L.sm[nxt][r_rec] = rec_new.y; }
+    __builtin_amdgcn_s_waitcnt(0);
+    P6_STAMP(3);
+#undef P6_STAMP
   }
 #undef REKEY
 #undef KEY_OF
