@@ -1653,6 +1653,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       if (q < placed) {
         const uint64_t k = L.skey[q];
         const uint32_t seg = L.sseg[q];
+        const uint32_t xsrc = L.ssrc[q];   // (read with the other two: one round trip)
         const uint32_t seg0 = seg & 0xFFFFu, len = seg >> 16;
         uint32_t r = seg0;
         // four keys per trip, their reads in flight together: one read per trip made the longest segment of a wave (up to RCAP keys,
@@ -1662,7 +1663,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
           const uint64_t k0 = L.skey[seg0 + t], k1 = L.skey[seg0 + t + 1], k2 = L.skey[seg0 + t + 2], k3 = L.skey[seg0 + t + 3];
           r += (k0 < k ? 1u : 0u) + ((t + 1 < len && k1 < k) ? 1u : 0u) + ((t + 2 < len && k2 < k) ? 1u : 0u) + ((t + 3 < len && k3 < k) ? 1u : 0u);
         }
-        if ((int)r < keep) { const uint32_t x = L.ssrc[q]; ent = x; rr = r; is_live = (int)x < n; is_new = !is_live; }
+        if ((int)r < keep) { ent = xsrc; rr = r; is_live = (int)xsrc < n; is_new = !is_live; }
       }
       if (MASKED && is_new) {
         // {first labelled arc, label bitmap} of the new prefix's dictionary state: a read from a table of tens of MB, i.e. a miss --
@@ -1671,9 +1672,10 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         rec_new = s.fst_rec[((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst[cx]]; r_rec = rr;
       }
       const uint64_t bl = __ballot(is_live), bn = __ballot(is_new);
-      uint32_t base_l = 0, base_n = 0;
-      if (lane == 0) { if (bl) base_l = lds_add((LDS_AS uint32_t*)&sc[SC_NA], (uint32_t)__popcll(bl)); if (bn) base_n = lds_add((LDS_AS uint32_t*)&sc[SC_NB], (uint32_t)__popcll(bn)); }
-      base_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_l); base_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_n);
+      uint32_t base_ln = 0;   // both list lengths in one word (live low, new high): one atomic round trip per wave
+      if (lane == 0 && (bl | bn)) base_ln = lds_add((LDS_AS uint32_t*)&sc[SC_NA], (uint32_t)__popcll(bl) | ((uint32_t)__popcll(bn) << 16));
+      base_ln = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_ln);
+      const uint32_t base_l = base_ln & 0xFFFFu, base_n = base_ln >> 16;
       const uint64_t below = (1ull << lane) - 1ull;
       if (is_live) { const uint32_t at = base_l + (uint32_t)__popcll(bl & below); wl[at] = ent; wr[at] = (uint16_t)rr; }
       if (is_new) { const uint32_t at = NBUCKET - 1 - (base_n + (uint32_t)__popcll(bn & below)); wl[at] = ent; wr[at] = (uint16_t)rr; }
@@ -1681,7 +1683,8 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     P6_STAMP(0);   // profiling level 2 (wave 0: slots 56.., last wave: 60..): ranking | wait at the barrier | own list | tail
     __syncthreads();
     P6_STAMP(1);
-    const uint32_t n_live = (uint32_t)__builtin_amdgcn_readfirstlane(sc[SC_NA]), n_new = (uint32_t)__builtin_amdgcn_readfirstlane(sc[SC_NB]);
+    const uint32_t n_ln = (uint32_t)__builtin_amdgcn_readfirstlane(sc[SC_NA]);
+    const uint32_t n_live = n_ln & 0xFFFFu, n_new = n_ln >> 16;
     if (p.stamps && tid == 0) { L.stm[54] += n_live; L.stm[55] += n_new; }
     auto finish_entry = [&](uint32_t r, uint64_t nkey, uint32_t pend, uint32_t ts_new) {
       L.key[nxt][r] = nkey;
@@ -1715,6 +1718,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       uint32_t ts_new, pend;
       uint64_t nkey;
       {
+        const uint32_t slot = lds_add((LDS_AS uint32_t*)&sc[SC_PAN], 1u);   // (first: its round trip overlaps the reads below)
         const int cx = (int)x - n;
         const uint32_t pi = CAND_PI(cx);
         const int i = (int)(pi & 0xFFFFu);
@@ -1744,7 +1748,6 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
           }
           L.wlo[nxt][r] = lo; L.whi[nxt][r] = hi; L.pqe[nxt][r] = STT_NONE;
         }
-        const uint32_t slot = lds_add((LDS_AS uint32_t*)&sc[SC_PAN], 1u);
         if (slot < S.pa_cap) { store_node(S.pa, slot, pnode, c); S.pq[slot] = STT_NONE; L.node[nxt][r] = slot; }
         else { L.node[nxt][r] = 0; lds_or(&sc[SC_ERR], 1); }
         if (MODE == 2) {  // utf8 cache: the child's run, and its boundary entry (a new one when it completes a code point)
