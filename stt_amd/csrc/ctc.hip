@@ -973,6 +973,14 @@ __device__ __forceinline__ void prep_row(const DecParams& p, const Lds& L, int b
   }
 }
 
+// The same for an alphabet of at most 64 classes, by whichever threads hold class c's value (c outside 0..C-1: nothing to do)
+__device__ __forceinline__ void prep_row_at(const DecParams& p, const Lds& L, int buf, int c, float x) {
+  if (c < 0 || c >= p.C) return;
+  L.pf[buf][c] = x;
+  L.lp[buf][c] = sttm::stt_logf_t(__fadd_rn(x, STT_FLT_MIN), L.log_tab);
+  if (c == p.blank) L.lbl[buf] = log((double)x);
+}
+
 // Merge the <= 3 events of live prefix j in the reference's visiting order (class position, then beam index; :166-193,
 // :245-253) and leave the results in the event arrays: ev_blank = new log_prob_b, ev_self = new log_prob_nb,
 // ev_ext = new score (iterate_to_vec, path_trie.cpp:170), ev_exti = pending timestep parent.  Returns the new score.
@@ -1058,11 +1066,13 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   n = __builtin_amdgcn_readfirstlane(n); cur = __builtin_amdgcn_readfirstlane(cur);
   unsigned long long tick_ = p.phase_cycles ? __builtin_readcyclecounter() : 0ull;
   float pre = 0.0f;
-  if (!WIDE && next_row && tid < C) pre = next_row[tid];  // consumed in P3
+  // (consumed in P3; bitmap form: by wave 8 -- waves 0..7 have a merge per thread there, wave 0 was the last to arrive with this on top)
+  const int prep_c = MODE_T == 4 ? tid - 512 : tid;
+  if (!WIDE && next_row && prep_c >= 0 && prep_c < C) pre = next_row[prep_c];
   if ((double)(WIDE ? wh.pblank : pf[p.blank]) < 0.999) start_expanding = 1;  // :125-132 (uniform: every thread reads the same value)
   start_expanding = __builtin_amdgcn_readfirstlane(start_expanding);
   if (!start_expanding) {
-    if (!WIDE && next_row) prep_row(p, L, buf ^ 1, next_row, pre);
+    if (!WIDE && next_row) { if (MODE_T == 4) prep_row_at(p, L, buf ^ 1, prep_c, pre); else prep_row(p, L, buf ^ 1, next_row, pre); }
     abs_t++;
     __syncthreads();
     return;
@@ -1264,9 +1274,11 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
           const float sci = L.score[cur][i];
           const uint32_t chi = L.ch[cur][i];
           const float lpc = lpv[c];
-          float log_p = NEG;  // :199-207
-          if (c == chi) { const float pbi = L.pb[cur][i]; if (pbi > NEG) log_p = __fadd_rn(lpc, pbi); }
-          else log_p = __fadd_rn(lpc, sci);
+          // :199-207, without branches (the read of pb is unconditional: one more LDS read, no exec juggling around two of them)
+          const float pbi = L.pb[cur][i];
+          const bool rep = c == chi;
+          float log_p = __fadd_rn(lpc, rep ? pbi : sci);
+          if (rep && !(pbi > NEG)) log_p = NEG;
           const uint32_t needs_lm = c == space_u ? 1u : 0u;
           const uint64_t ck = child_key(L.key[cur][i], c);
           const int jj = ht_find(L, ck);
@@ -1438,7 +1450,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   if (MASKED) { if (!lmw_) for (uint32_t h = tid; h < HTN; h += n_cons * 64u) L.ht_key[h] = 0; }  // (the LM waves come later and go straight to the queue)
   else for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
   if (L.bloom) for (uint32_t h = tid; h < BLOOM_WORDS; h += NTHREADS) L.bloom[h] = 0;
-  if (!WIDE && next_row) prep_row(p, L, buf ^ 1, next_row, pre);
+  if (!WIDE && next_row) { if (MASKED) prep_row_at(p, L, buf ^ 1, prep_c, pre); else prep_row(p, L, buf ^ 1, next_row, pre); }
   bool merged = false;
   float my_score = NEG;
   if (SC_ON) {
