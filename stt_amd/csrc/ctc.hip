@@ -1202,28 +1202,29 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     const int i_pre = tid;
     const bool pre_wave = !lmw_ && wave * 64 < n;        // scalar (an LM wave never is one: n <= 512 < 64 * nw_exp)
     if (!lmw_ && i_pre < n) {
+      // straight-line (selects, not branches: every lane of the wave has a live prefix almost always, and exec juggling around
+      // one or two instructions costs more than they do)
       const int i = i_pre;
-      float eb = absent(), es = absent();
-      const float sci = L.score[cur][i];
-      if (sci != NEG) {  // :160-162
-        const uint32_t chi = L.ch[cur][i];
-        uint32_t pm = 0xFFFFFFFFu;  // classes that survive the cut-off for this prefix (bit c)
-        if (full_beam) {
-          pm = 0;
+      const float sci = L.score[cur][i], pnbi = L.pnb[cur][i];
+      const uint32_t chi = L.ch[cur][i], smi = L.sm[cur][i];
+      uint32_t pm = 0xFFFFFFFFu;  // classes that survive the cut-off for this prefix (bit c)
+      if (full_beam) {   // (scalar)
+        pm = 0;
 #pragma unroll
-          for (int q4 = 0; q4 < 8; ++q4) {
-            const f32x4v v = reinterpret_cast<const LDS_AS f32x4v*>(lpv)[q4];
-            pm |= (!(__fadd_rn(v.x, sci) < min_cutoff) ? 1u : 0u) << (4 * q4);
-            pm |= (!(__fadd_rn(v.y, sci) < min_cutoff) ? 2u : 0u) << (4 * q4);
-            pm |= (!(__fadd_rn(v.z, sci) < min_cutoff) ? 4u : 0u) << (4 * q4);
-            pm |= (!(__fadd_rn(v.w, sci) < min_cutoff) ? 8u : 0u) << (4 * q4);
-          }
+        for (int q4 = 0; q4 < 8; ++q4) {
+          const f32x4v v = reinterpret_cast<const LDS_AS f32x4v*>(lpv)[q4];
+          pm |= (!(__fadd_rn(v.x, sci) < min_cutoff) ? 1u : 0u) << (4 * q4);
+          pm |= (!(__fadd_rn(v.y, sci) < min_cutoff) ? 2u : 0u) << (4 * q4);
+          pm |= (!(__fadd_rn(v.z, sci) < min_cutoff) ? 4u : 0u) << (4 * q4);
+          pm |= (!(__fadd_rn(v.w, sci) < min_cutoff) ? 8u : 0u) << (4 * q4);
         }
-        if ((pm >> p.blank) & 1u) eb = __fadd_rn(lpv[p.blank], sci);                                  // :166-179
-        if (chi != STT_ROOT_CH && ((pm >> chi) & 1u)) es = __fadd_rn(lpv[chi], L.pnb[cur][i]);        // :182-193
-        const uint32_t live = L.sm[cur][i] & pm;
-        em = live & lab_mask;
       }
+      if (!(sci != NEG)) pm = 0;  // :160-162
+      const bool has_ch = chi != STT_ROOT_CH;
+      const float lp_b = lpv[p.blank], lp_s = lpv[has_ch ? chi : 0u];
+      const float eb = ((pm >> p.blank) & 1u) ? __fadd_rn(lp_b, sci) : absent();                        // :166-179
+      const float es = (has_ch && ((pm >> (chi & 31u)) & 1u)) ? __fadd_rn(lp_s, pnbi) : absent();      // :182-193
+      em = smi & pm & lab_mask;
       L.ev_blank[i] = eb; L.ev_self[i] = es; L.ev_ext[i] = absent(); L.ev_exti[i] = 0;
     }
     for (int pass = 0;; ++pass) {
