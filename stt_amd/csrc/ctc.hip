@@ -1021,8 +1021,8 @@ __device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, co
 __device__ __forceinline__ void wait_count(LDS_AS int* ctr, uint32_t want, LDS_AS int* err) {
   int spins = 0;
   while ((uint32_t)__builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1 << 17)) { lds_or(err, 16); break; }
+    __builtin_amdgcn_s_sleep(4);   // (256 cycles: the waiting waves' polls are instructions the working waves cannot issue)
+    if (++spins > (1 << 16)) { lds_or(err, 16); break; }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
