@@ -1457,6 +1457,17 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   if (SC_ON) {
     unsigned lmq = 0;
     if (MASKED) {  // no queue in this form; the LM waves (still in their queries, or waiting at the barrier below) have nothing to do here
+      if (!lm_wave && tid < n) {
+        // no LM waves on the first steps of a stream (n <= 16): every prefix whose word may end gets its score here, whether or not
+        // the extension survives the cut-off (the entry is a cache of what the reference would compute when it needs it)
+        const int i = tid;
+        if (((L.sm[cur][i] >> space_u) & 1u) && L.pqe[cur][i] == STT_NONE && L.bnd[cur][i] != STT_NONE && L.score[cur][i] != NEG) {
+          uint32_t ne;
+          const double raw = lm_word_query_cached<MASKED>(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], L.node[cur][i], L.bnd[cur][i], true, L.wlo[cur][i], L.whi[cur][i], ne, probes);
+          L.pqe[cur][i] = ne; L.pqs[cur][i] = (float)__dmul_rn(raw, s.alpha);
+          ++lmq;
+        }
+      }
       if (!lmw_ && tid < n && !((L.ev_exti[tid] >> 31) && !is_absent(L.ev_ext[tid]))) { my_score = merge_live<WIDE>(p, L, W, cur, tid); merged = true; }
     } else if (lm_queue) {
       const int nq = __builtin_amdgcn_readfirstlane(sc[SC_NQ]);
@@ -1535,24 +1546,11 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   const int total = n + m;
   uint64_t kreg0 = ~0ULL, kreg1 = ~0ULL;
   uint32_t hmin = 0xFFFFFFFFu, hmax = 0;
-  unsigned lmq4 = 0, probes4 = 0;
   // bitmap form: log_p of a "prefix i + space" extension with the language-model score of prefix i added (:209-243) -- the score the
-  // LM waves left in pqs during the expand phase, or (no LM waves on the first steps of a stream, n <= 16) one query here
+  // LM waves (or, without them, the phase above) left in pqs
   auto score_ext = [&](float lp0, int i) -> float {
-    float lms;
-    if (L.pqe[cur][i] != STT_NONE) lms = L.pqs[cur][i];
-    else {
-      const uint32_t bndi = L.bnd[cur][i];
-      double raw = 0.0;
-      if (bndi == STT_NONE) lds_or(&sc[SC_ERR], 8);
-      else {
-        uint32_t ne;
-        raw = lm_word_query_cached<MASKED>(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], L.node[cur][i], bndi, true, L.wlo[cur][i], L.whi[cur][i], ne, probes4);
-        L.pqe[cur][i] = ne; L.pqs[cur][i] = (float)__dmul_rn(raw, s.alpha);
-        ++lmq4;
-      }
-      lms = (float)__dmul_rn(raw, s.alpha);
-    }
+    float lms = 0.0f;
+    if (L.pqe[cur][i] != STT_NONE) lms = L.pqs[cur][i]; else lds_or(&sc[SC_ERR], 8);
     const float lpv = __fadd_rn(lp0, lms);                  // log_p += score;
     return (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
   };
@@ -1577,7 +1575,6 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     hmin = kh < hmin ? kh : hmin; if (kh != NEG_HI) hmax = kh > hmax ? kh : hmax;
   }
 #define KEY_OF(e, r) ((r) == 0 ? kreg0 : (r) == 1 ? kreg1 : S.sel_keys[e])
-  if (MASKED) { if (lmq4) lds_add(&sc[SC_LMQ], (int)lmq4); if (probes4) lds_add(&sc[SC_PROBES], (int)probes4); }
   hmin = wave_min_u32(hmin); hmax = wave_max_u32(hmax);
   if (lane == 0) { lds_min((LDS_AS uint32_t*)&sc[SC_KMIN], hmin); lds_max((LDS_AS uint32_t*)&sc[SC_KMAX], hmax); }
   __syncthreads();
