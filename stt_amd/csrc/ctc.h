@@ -148,6 +148,7 @@ struct DecParams {
   unsigned long long wide_stride;
   int wide_max_frames;
   int lds_kb;       // LDS budget of the search kernel's layout in KiB (filled in by launch_ctc_next; host and device carve the same layout)
+  int item_cap;    // bitmap step, test hook: items the expand table holds per pass (0 = all it has room for; filled in by launch_ctc_next)
   int n_lm_waves;  // bitmap step: waves of the workgroup that only run language-model queries (0 = by beam width; filled in by launch_ctc_next)
   unsigned long long* stamps;  // profiling level 2: [n_streams][64] shader cycles between the fine-grained stamps of the step (wave 0: 0..31, last wave: 32..63)
 };

@@ -1194,7 +1194,8 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     const LDS_AS float* lpv = lp;
     const uint32_t lab_mask = ((1u << (C - 1)) - 1u) & ~(1u << p.blank);  // labels 0 .. C-2, never the blank
     LDS_AS uint16_t* own = (LDS_AS uint16_t*)L.own;
-    const uint32_t own_n = (L.own_cap * (uint32_t)NWAVES) >> 1;  // items the table holds (more: another pass)
+    const uint32_t own_room = (L.own_cap * (uint32_t)NWAVES) >> 1;
+    const uint32_t own_n = (p.item_cap > 0 && (uint32_t)p.item_cap < own_room) ? (uint32_t)p.item_cap : own_room;  // items the table holds (more: another pass)
     uint32_t em = 0;
     // 64 prefixes per wave: the pre-pass is bound by instruction issue (a CU issues one VALU instruction per cycle over all its
     // waves), so full waves beat more waves -- 36 lanes of 14 waves measured 9.4 k cycles until the table was complete, 64 lanes
@@ -2070,7 +2071,7 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
                      const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st, int max_frames, void* wide_ws) {
   DecParams p = p_in;
   const bool wide = ctc_is_wide(p.beam, p.C, s.enabled && s.utf8);
-  p.wide_rows = nullptr; p.wide_stride = 0; p.wide_max_frames = 0; p.n_lm_waves = 0;
+  p.wide_rows = nullptr; p.wide_stride = 0; p.wide_max_frames = 0; p.n_lm_waves = 0; p.item_cap = 0;
   if (wide && (!wide_ws || max_frames <= 0 || p.C > STT_MAX_CLASSES)) { fprintf(stderr, "stt_amd: launch_ctc_next: wide alphabet without a row workspace\n"); abort(); }
   const int cb = cap_bucket(p.beam);
   if (wide || (ctc_sorts_classes(p) && wide_ws && max_frames > 0 && p.C <= WIDE_SORT_N)) {
@@ -2078,7 +2079,7 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
     hipLaunchKernelGGL(ctc_wide_rows_kernel, dim3(n_streams * max_frames), dim3(1024), 0, st, p, probs, frame_begin, frame_count);
     check_launch("ctc_wide_rows_kernel");
   }
-  p.n_lm_waves = tune().lm_waves;
+  p.n_lm_waves = tune().lm_waves; p.item_cap = tune().item_table_cap;
   const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : p.C, s.enabled && s.utf8);
   p.lds_kb = lds_budget_kb_host();
   const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : ((!wide && ctc_masked_ok(p, s, al)) ? 4 : 1));

@@ -35,6 +35,7 @@
   X(search_step, 2, "word-mode search step: 2 = label bitmaps + indexed FullScore where it applies, 0 = generic step")              \
   X(lm_waves, 0, "language-model waves of the search step (0 = by beam width)")                                                    \
   X(exp_waves, 0, "expand waves of the search step (0 = all the others)")                                                          \
+  X(item_table_cap, 0, "test hook: items per pass of the bitmap step's expand table (0 = what fits; small values force the several-pass path)") \
   X(lm_memo, 1, "code-point scorer: FullScore memo table")                                                                         \
   X(dict_tree_mb, 2048, "dictionary unfolded into a tree (no arc reads in the search): byte cap in MiB, 0 = keep the automaton")           \
   X(lm_index_mb, 4096, "hashed n-gram index: byte cap in MiB (larger models take the trie walk)")                                  \

@@ -56,16 +56,21 @@ def _emissions(rng, T, C, blank, kind, vocab, mode):
     return p
 
 
-@pytest.mark.parametrize("mode,lm,step", [("word", False, 2), ("word", True, 2), ("word", True, 0), ("bytes", False, 2), ("bytes", True, 2)])
-def test_fuzz_decoder_against_port(rigs, port, fix, mode, lm, step):
+@pytest.mark.parametrize("mode,lm,step,item_cap", [("word", False, 2, 0), ("word", True, 2, 0), ("word", True, 2, 48), ("word", True, 0, 0), ("bytes", False, 2, 0),
+                                                   ("bytes", True, 2, 0)])
+def test_fuzz_decoder_against_port(rigs, port, fix, mode, lm, step, item_cap):
     """Word-mode step selection (tunable search_step): 0 = generic step, 2 = the step with label bitmaps + indexed FullScore (the
-    default where it applies).  The same seeded cases must pass on both."""
+    default where it applies).  The same seeded cases must pass on both.  item_table_cap = 48: the bitmap step's expand table then
+    holds 48 work items per pass (it has room for ~5900), so a step takes several passes through the table -- the path a real run only
+    sees with thousands of items per step."""
     from stt_amd import native
     native.set_tuning("search_step", step)
+    native.set_tuning("item_table_cap", item_cap)
     try:
         _fuzz(rigs, port, fix, mode, lm)
     finally:
         native.set_tuning("search_step", 2)
+        native.set_tuning("item_table_cap", 0)
 
 
 def _fuzz(rigs, port, fix, mode, lm):
