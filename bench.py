@@ -507,7 +507,7 @@ def main():
     if rank == 0 and wl == "batch" and world == 1 and not args.no_extras and not args.no_profile:
         # the other configs, same process, same build: short runs (a few seconds each), each with its own roofline
         sub = {}
-        for w, k, wu, kw in (("ragged", 2, 1, {}), ("stream", 1, 1, {"utterances": 256}), ("bytes", 6, 2, {}), ("peaky", 10, 2, {})):
+        for w, k, wu, kw in (("ragged", 2, 1, {}), ("stream", 1, 1, {"utterances": 256}), ("bytes", 8, 5, {}), ("peaky", 10, 2, {})):   # (bytes: four batches in flight -- the warm-up covers every slot's first use)
             a2 = argparse.Namespace(**vars(args))
             a2.utterances = kw.get("utterances", 0)
             try:
