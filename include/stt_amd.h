@@ -196,6 +196,10 @@ STTX_EXPORT int STTX_TestLstmSteps(ModelState* aCtx, unsigned int aBatch, unsign
                                   const float* aXproj, float* aC, float* aH, unsigned short* aHAll, float* aElapsedMs);
 /* Device expf/logf/log_sum_exp of sttmath.h over arrays (aOp 0 = expf, 1 = logf, 2 = log_sum_exp(a, b)). */
 STTX_EXPORT int STTX_TestMath(int aOp, const float* aA, const float* aB, float* aOut, unsigned int aCount);
+/* Host only, test hook: label sequences walked through the dictionary tables of a scorer package as the engine parses them (the
+ * minimised automaton of the package, or its unfolding into a tree -- tunable dict_tree_mb).  See stt_amd/csrc/api.cpp. */
+STTX_EXPORT int STTX_TestDictionaryWalk(const char* aScorer, unsigned int aScorerBytes, int aSpaceLabel, const int* aLabels,
+                                        unsigned int aNumSeq, unsigned int aLen, int* aOut);
 /* KenLM FullScore (kenlm/lm/model.cc:170-176) over aNumWords words, the state carried from BeginSentence (aBos) or the null
  * context, on a bare KenLM trie binary: aProbs[i] = log10 probability, aLens[i] = matched n-gram length of word i
  * (lm::FullScoreReturn).  aMode 0 = the hashed n-gram index on the host (no GPU needed), 1 = the device trie walk,

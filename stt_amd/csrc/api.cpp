@@ -1365,6 +1365,40 @@ int STTX_ReadModelTensor(const char* aModelBuffer, unsigned int aBufferSize, int
 
 int STTX_DebugLimitArena(int aFrames) { g_debug_arena_frames = aFrames; return STT_ERR_OK; }
 
+// Host only: walk label sequences through the dictionary tables a scorer package parses into (the repacked automaton, or -- tunable
+// dict_tree_mb -- its unfolding into a tree).  aLabels holds aNumSeq sequences of aLen labels each (label ids, -1 = end of sequence);
+// aOut[seq * aLen + k] = -1 once a label had no arc, else bit 0 = "a word may end after label k" (the state has a space arc) and bit 1 =
+// "the tables are the tree".  What a test compares between the two forms: the language and the word ends are the same.
+int STTX_TestDictionaryWalk(const char* aScorer, unsigned int aScorerBytes, int aSpaceLabel, const int* aLabels, unsigned int aNumSeq, unsigned int aLen, int* aOut) {
+  return guarded([&]() {
+    std::vector<char> copy((size_t)aScorerBytes + 16, 0);
+    memcpy(copy.data(), aScorer, aScorerBytes);
+    HostScorer hs;
+    const int rc = parse_scorer(reinterpret_cast<const uint8_t*>(copy.data()), aScorerBytes, aSpaceLabel, false, hs);
+    if (rc != STT_ERR_OK) return rc;
+    for (unsigned q = 0; q < aNumSeq; ++q) {
+      uint32_t st = (uint32_t)hs.fst_start;
+      bool dead = false;
+      for (unsigned k = 0; k < aLen; ++k) {
+        int& out = aOut[(size_t)q * aLen + k];
+        const int lab = aLabels[(size_t)q * aLen + k];
+        if (lab < 0) dead = true;
+        if (dead) { out = -1; continue; }
+        uint32_t next = 0xFFFFFFFFu;
+        for (uint32_t a = hs.fst_pos[st]; a < hs.fst_pos[st + 1]; ++a) if (hs.fst_arcs[a].x == (uint32_t)lab + 1u) { next = hs.fst_arcs[a].y; break; }
+        if (next == 0xFFFFFFFFu) { dead = true; out = -1; continue; }
+        if (hs.fst_tree && lab != aSpaceLabel) {  // the tree's invariant: the child along arc a is node a + 1
+          uint32_t a = hs.fst_pos[st]; while (hs.fst_arcs[a].x != (uint32_t)lab + 1u) ++a;
+          if (next != a + 1u) return (int)STT_ERR_SCORER_INVALID_TRIE;
+        }
+        st = next;
+        out = (hs.fst_has_space[st] ? 1 : 0) | (hs.fst_tree ? 2 : 0);
+      }
+    }
+    return (int)STT_ERR_OK;
+  }, STT_ERR_SCORER_INVALID_TRIE);
+}
+
 int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* const* aWords, unsigned int aNumWords, int aBos, int aMode, float* aProbs, int* aLens) {
   return guarded([&]() {
     if (aMode == 0) {  // host: parse + hashed index + FullScore chain, no GPU

@@ -51,7 +51,7 @@ STT_AMD_H = [
     "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_GetDecoderStamps", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
     "STTX_DecoderStats", "STTX_DecoderSetProfiling", "STTX_DecoderGetProfile", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
-    "STTX_InspectModel", "STTX_ReadModelTensor", "STTX_TestLm", "STTX_DebugLimitArena", "STTX_FleetCreate", "STTX_FleetSize",
+    "STTX_InspectModel", "STTX_ReadModelTensor", "STTX_TestLm", "STTX_TestDictionaryWalk", "STTX_DebugLimitArena", "STTX_FleetCreate", "STTX_FleetSize",
     "STTX_FleetEnableExternalScorer", "STTX_FleetSetBeamWidth", "STTX_FleetSpeechToTextBatch", "STTX_FleetFree", "STTX_ShardUtterances", "STTX_TestFleetRecords", "STTX_DebugFleetFailShard",
 ]
 
@@ -133,6 +133,7 @@ def lib():
         "STTX_DecoderDecode": (ci, [vp, cu, cu, vp, vp, vp, vp, vp]),
         "STTX_DecoderBeam": (ci, [vp, cu, vp, vp, vp, vp, cu]),
         "STTX_DecoderStats": (ci, [vp, pp(C.c_ulonglong)]),
+        "STTX_TestDictionaryWalk": (ci, [vp, cu, ci, vp, cu, cu, vp]),
         "STTX_DecoderSetProfiling": (ci, [vp, ci]),
         "STTX_DecoderGetProfile": (ci, [vp, pp(C.c_ulonglong), pp(C.c_ulonglong), pp(cf)]),
         "STTX_DecoderFree": (None, [vp]),
