@@ -150,7 +150,11 @@ struct DecParams {
   int lds_kb;       // LDS budget of the search kernel's layout in KiB (filled in by launch_ctc_next; host and device carve the same layout)
   int item_cap;    // bitmap step, test hook: items the expand table holds per pass (0 = all it has room for; filled in by launch_ctc_next)
   int n_lm_waves;  // bitmap step: waves of the workgroup that only run language-model queries (0 = by beam width; filled in by launch_ctc_next)
-  unsigned long long* stamps;  // profiling level 2: [n_streams][64] shader cycles between the fine-grained stamps of the step (wave 0: 0..31, last wave: 32..63)
+  // profiling level 2: [n_streams][64] shader cycles, summed over the steps.  Slots: [w] wave w reaches the end of the expand phase
+  // (since the step began; wave 0: since its last phase tick), [16 + w] its wait there, [32 + w] (bitmap step) arrival at the end of
+  // the score phase; bitmap step, wave 9: [50] item table complete, [51] taking a chunk, [52] chunks, [53] chunk bodies; write phase:
+  // [54] live / [55] new entries, wave 0 [56..59] and the last wave [60..63]: ranking | barrier | own list | tail
+  unsigned long long* stamps;
 };
 
 struct DecodeOut {

@@ -772,7 +772,7 @@ struct Lds {
 };
 // phase cycle counters (s_memtime is a scalar memory operation with a wait: only on request, DecParams::phase_cycles)
 #define TICK(k) do { if (p.phase_cycles && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); L.acc[4 + (k)] += now_ - tick_; tick_ = now_; } } while (0)
-enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_CLAMP, SC_NA, SC_NB, SC_NI, SC_ICUR, SC_FILL, SC_DONE, SC_COUNT = 24 };
+enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_NA, SC_NI, SC_ICUR, SC_FILL, SC_DONE, SC_COUNT = 24 };
 #define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
 
@@ -1038,7 +1038,11 @@ __device__ __forceinline__ void signal_count(LDS_AS int* ctr) {
 // MODE_T 4 = word mode (like 1) with the dictionary's label bitmaps (DevScorer::fst_rec): a prefix's work items are the
 // labels its dictionary state allows AND that survive the score cut-off of :157-159 -- the arcs that would be rejected are
 // never touched (about 5x fewer items on near-uniform emissions) --, two language-model waves, and FullScore through the
-// hashed n-gram index.  <= 32 classes, no class pruning, beam capacity <= 512.
+// hashed n-gram index.  <= 32 classes, no class pruning, beam capacity <= 512.  Its phases differ from the other modes' (DESIGN.md
+// 4.1, "the step of the word-mode kernel as it runs now"): a prefix-per-thread pre-pass fills ONE table of work items which every
+// non-LM wave then empties in chunks; the pre-pass and the items end at counters (wait_count), not at barriers, so the LM waves are
+// waited for only at the end of the score phase; the key phase adds the LM scores; the write phase runs live and new entries on
+// separate waves.  The selection (P5) is the other modes'.
 template <int MODE_T, bool WIDE>
 __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const GStream& S, const Lds& L, int& cur, int& n,
                          int& start_expanding, int& abs_t, int buf, const float* next_row, int t_local) {
@@ -1082,7 +1086,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   // (bitmap step: every thread clears the events of its own prefix in the pre-pass below -- no barrier in between)
   if (!MASKED) for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
   L.hist[tid] = 0;
-  if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; sc[SC_NQ] = 0; sc[SC_NA] = 0; sc[SC_NB] = 0; }
+  if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; sc[SC_NQ] = 0; sc[SC_NA] = 0; }
   const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
   int cutoff_len = WIDE ? wh.cutoff_len : C;
   if (!WIDE && sort_classes && p.wide_rows) {  // class order prepared for all rows of the chunk by ctc_wide_rows_kernel
