@@ -188,3 +188,27 @@ def test_decoder_with_synthetic_order5_scorer(models, port, english, fix, tmp_pa
             n = min(beam, 20)
             assert canon(d.decode(n)[0]) == canon(dp.decode(n)), tag
             assert d.stats()["error"] == 0
+
+
+def test_decoder_profile_counters_do_not_change_results(models, port, english, fix):
+    """STTX_DecoderSetProfiling / STTX_DecoderGetProfile (include/stt_amd.h; benchmarks/search_micro.py): the kernel's phase cycle
+    counters and stamps are a measurement, not a mode -- the same beam comes out with them on, the phases add up to a positive number of
+    cycles and the bitmap step's own stamps (item table complete, chunks taken) are there."""
+    labels, space = english
+    m = models[("word", True)]
+    P = port.Scorer(os.path.join(fix, "pruned_lm.scorer"))
+    rng = np.random.RandomState(77)
+    x = rng.randn(3, 60, 29).astype(np.float32)
+    probs = np.exp(x - x.max(2, keepdims=True)); probs = (probs / probs.sum(2, keepdims=True)).astype(np.float32)
+    plain = m.createDecoder(3, 500); plain.next(probs)
+    want = [canon(r) for r in plain.decode(10)]
+    prof = m.createDecoder(3, 500); prof.setProfiling(2); prof.next(probs)
+    assert [canon(r) for r in prof.decode(10)] == want
+    phases, stamps, ms = prof.profile()
+    steps = prof.stats()["steps"]
+    assert steps == 3 * 60 and ms > 0.0
+    serial = sum(v for k, v in phases.items() if not k.startswith("lm_wave"))
+    assert 1000 * steps < serial < 400000 * steps, serial / steps          # thousands to tens of thousands of cycles per stream-timestep
+    assert stamps[50] > 0 and stamps[52] > 0                                # bitmap step: table-complete time, chunks taken by wave 9
+    o = port.Decoder(labels, space, 500, P); o.next(probs[1])
+    assert want[1] == canon(o.decode(10))
