@@ -59,6 +59,13 @@ STTX_EXPORT int STTX_BatchPipelineDepthFor(ModelState* aCtx);
 STTX_EXPORT int STTX_BatchSubmitDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride,
                                        const unsigned int* aBufferSizes, unsigned int aBatch);
 STTX_EXPORT char** STTX_BatchCollect(ModelState* aCtx, int aTicket, unsigned int* aCount);
+/* ... the same with the best transcript's Metadata (tokens, timesteps, confidence; STT_SpeechToTextWithMetadata with
+ * aNumResults = 1, stt.cc:349-365) per utterance instead of its string: free with STTX_FreeMetadataArray. */
+STTX_EXPORT Metadata** STTX_BatchCollectWithMetadata(ModelState* aCtx, int aTicket, unsigned int* aCount);
+/* ... the strings of STTX_BatchCollect plus, in aConfidence[0 .. *aCount) (room for 64), the best transcript's confidence
+ * (CandidateTranscript::confidence, coqui-stt.h; 0 for an utterance without a result): what a caller needs to compare a
+ * batch with the reference decoder's output without walking 64 Metadata structures. */
+STTX_EXPORT char** STTX_BatchCollectScored(ModelState* aCtx, int aTicket, unsigned int* aCount, double* aConfidence);
 /* Debug / parity hook: the acoustic probabilities of a submitted, not yet collected batch exactly as the pipelined path computed
  * them (three engines, graph-replayed recurrence, ring slots, 64 or 128 rows per recurrent step) -- the block that batch's beam
  * search reads; stands in for the `logits` output of TFLiteModelState::infer (tflitemodelstate.cc:369-405) over the whole

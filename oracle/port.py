@@ -178,6 +178,13 @@ class Decoder:
                                     ln.ctypes.data, cap)
         return sc[:n], pb[:n], pnb[:n], ch[:n], ln[:n]
 
+    def boundary_ties(self):
+        """Steps at which a (score, character) tie straddled the beam boundary: there the reference's choice is libstdc++'s
+        nth_element order (stt_port.c: stat_boundary_ties); 0 = the result is determined by the scores alone."""
+        f = lib().port_decoder_boundary_ties
+        f.restype, f.argtypes = C.c_uint64, [C.c_void_p]
+        return int(f(self.h))
+
     def stats(self):
         out = np.zeros(3, np.uint64)
         lib().port_decoder_stats(self.h, out.ctypes.data)

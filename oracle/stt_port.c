@@ -478,6 +478,11 @@ typedef struct {
   int n_hot; uint64_t* hot_hash; float* hot_boost;
   /* statistics (for the roofline accounting in DESIGN.md) */
   uint64_t stat_lm_queries, stat_candidates, stat_steps;
+  /* Steps at which the last kept and the first dropped prefix compare equal under prefix_compare (same score, same character): the
+   * reference keeps whichever std::nth_element happens to leave in front (libstdc++'s introselect on the trie's iteration order --
+   * unspecified by the standard), this restatement and the kernels keep (live before new, beam index).  From such a step on the two
+   * may hold different -- equally scored -- prefixes; every other step is determined by the scores alone. */
+  uint64_t stat_boundary_ties;
 } PortDecoder;
 
 static inline uint64_t child_key(uint64_t parent_key, uint32_t c) {
@@ -784,6 +789,7 @@ static void step(PortDecoder* d, const double* prob) {
       if (BEFORE(ord[root], ord[child])) { int t2 = ord[root]; ord[root] = ord[child]; ord[child] = t2; root = child; } else break; }
   }
   const int keep = total < beam ? total : beam;
+  if (total > beam && nscore[ord[beam - 1]] == nscore[ord[beam]] && CH_OF(ord[beam - 1]) == CH_OF(ord[beam])) d->stat_boundary_ties++;
 
   /* write the new beam */
   float* o_score = malloc(4 * keep); float* o_pb = malloc(4 * keep); float* o_pnb = malloc(4 * keep);
@@ -873,6 +879,7 @@ int port_decoder_beam(PortDecoder* d, float* score, float* pb, float* pnb, int* 
   }
   return n;
 }
+uint64_t port_decoder_boundary_ties(const PortDecoder* d) { return d->stat_boundary_ties; }
 void port_decoder_stats(PortDecoder* d, uint64_t* out3) { out3[0] = d->stat_steps; out3[1] = d->stat_candidates; out3[2] = d->stat_lm_queries; }
 
 /* test hooks for oracle/glibc_flt.h (tests/test_oracle_math.py) */

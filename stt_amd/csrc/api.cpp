@@ -877,6 +877,35 @@ char** STTX_BatchCollect(ModelState* aCtx, int aTicket, unsigned int* aCount) {
   return res;
 }
 
+char** STTX_BatchCollectScored(ModelState* aCtx, int aTicket, unsigned int* aCount, double* aConfidence) {
+  char** res = nullptr;
+  if (aCount) *aCount = 0;
+  guarded([&]() {
+    auto outs = batch_collect(aCtx, aTicket);
+    res = (char**)malloc(sizeof(char*) * std::max<size_t>(1, outs.size()));
+    for (size_t i = 0; i < outs.size(); ++i) {
+      res[i] = outs[i].empty() ? strdup("") : strdup(aCtx->alphabet_.Decode(outs[i][0].tokens.data(), (int)outs[i][0].tokens.size()).c_str());
+      if (aConfidence) aConfidence[i] = outs[i].empty() ? 0.0 : outs[i][0].confidence;
+    }
+    if (aCount) *aCount = (unsigned)outs.size();
+    return 0;
+  }, 0);
+  return res;
+}
+
+Metadata** STTX_BatchCollectWithMetadata(ModelState* aCtx, int aTicket, unsigned int* aCount) {
+  Metadata** res = nullptr;
+  if (aCount) *aCount = 0;
+  guarded([&]() {
+    auto outs = batch_collect(aCtx, aTicket);
+    res = (Metadata**)malloc(sizeof(Metadata*) * std::max<size_t>(1, outs.size()));
+    for (size_t i = 0; i < outs.size(); ++i) res[i] = make_metadata(aCtx, outs[i]);
+    if (aCount) *aCount = (unsigned)outs.size();
+    return 0;
+  }, 0);
+  return res;
+}
+
 int STTX_DebugBatchProbs(ModelState* aCtx, int aTicket, float* aProbs, unsigned int aMaxFrames, unsigned int* aNumFrames) {
   return guarded([&]() { batch_probs(aCtx, aTicket, aProbs, aMaxFrames, aNumFrames); return (int)STT_ERR_OK; }, STT_ERR_FAIL_RUN_SESS);
 }

@@ -191,6 +191,27 @@ class Model(object):
         native.lib().STTX_FreeStrings(r, n.value)
         return out
 
+    def collectBatchScored(self, ticket):
+        """Wait for a submitted batch; (transcripts, confidences of the best transcripts) (STTX_BatchCollectScored)."""
+        n = C.c_uint(0)
+        conf = (C.c_double * 64)()
+        r = native.lib().STTX_BatchCollectScored(self._impl, int(ticket), C.byref(n), conf)
+        if not r:
+            raise RuntimeError("STTX_BatchCollectScored failed")
+        out = [C.string_at(r[i]).decode("utf-8", "replace") for i in range(n.value)]
+        native.lib().STTX_FreeStrings(r, n.value)
+        return out, list(conf[:n.value])
+
+    def collectBatchWithMetadata(self, ticket):
+        """Wait for a submitted batch; per utterance the best transcript's metadata (STTX_BatchCollectWithMetadata)."""
+        n = C.c_uint(0)
+        r = native.lib().STTX_BatchCollectWithMetadata(self._impl, int(ticket), C.byref(n))
+        if not r:
+            raise RuntimeError("STTX_BatchCollectWithMetadata failed")
+        out = [_metadata_to_py(r[i], free=False) for i in range(n.value)]
+        native.lib().STTX_FreeMetadataArray(r, n.value)
+        return out
+
     def batchProbs(self, ticket, n_utterances):
         """STTX_DebugBatchProbs: the probabilities the pipelined path computed for a submitted, not yet collected batch."""
         g = self.geometry()

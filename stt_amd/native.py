@@ -47,7 +47,7 @@ COQUI_STT_H = [
 ]
 STT_AMD_H = [
     "STTX_SetDevice", "STTX_GetDeviceCount", "STTX_SpeechToTextBatch", "STTX_SpeechToTextBatchWithMetadata",
-    "STTX_SpeechToTextBatchDevice", "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmitDevice", "STTX_BatchCollect", "STTX_DebugBatchProbs", "STTX_SetTuning", "STTX_GetTuning", "STTX_ConfigureRuntime", "STTX_TestLstmSteps", "STTX_FeedAudioContentBatch", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
+    "STTX_SpeechToTextBatchDevice", "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmitDevice", "STTX_BatchCollect", "STTX_BatchCollectWithMetadata", "STTX_BatchCollectScored", "STTX_DebugBatchProbs", "STTX_SetTuning", "STTX_GetTuning", "STTX_ConfigureRuntime", "STTX_TestLstmSteps", "STTX_FeedAudioContentBatch", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
     "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_GetDecoderStamps", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
     "STTX_DecoderStats", "STTX_DecoderSetProfiling", "STTX_DecoderGetProfile", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
@@ -109,6 +109,8 @@ def lib():
         "STTX_BatchPipelineDepthFor": (ci, [vp]),
         "STTX_BatchSubmitDevice": (ci, [vp, vp, cu, pp(cu), cu]),
         "STTX_BatchCollect": (pp(vp), [vp, ci, pp(cu)]),
+        "STTX_BatchCollectWithMetadata": (pp(pp(Metadata)), [vp, ci, pp(cu)]),
+        "STTX_BatchCollectScored": (pp(vp), [vp, ci, pp(cu), pp(cd)]),
         "STTX_DebugBatchProbs": (ci, [vp, ci, vp, cu, pp(cu)]),
         "STTX_SetTuning": (ci, [cs, ci]),
         "STTX_GetTuning": (ci, [cs, pp(ci)]),

@@ -113,3 +113,23 @@ def test_port_vs_live_reference(port, ref, english, fix):
     allblank = np.zeros((5, 29), np.float32); allblank[:, 28] = 1.0
     dr.next(allblank.astype(np.float64)); dp.next(allblank)
     assert canon(dr.decode(3)) == canon(dp.decode(3))
+
+
+def test_boundary_tie_counter_marks_where_the_reference_is_unspecified(port, ref, english, fix):
+    """Two labels with bit-identical probabilities in every frame make sibling prefixes tie on (score, character); with a narrow beam
+    one of such a pair is cut while the other stays.  The restatement counts those steps (stt_port.c: stat_boundary_ties) -- there the
+    reference's choice is libstdc++'s nth_element order, everywhere else the beam is determined by the scores.  bench.py accepts a
+    difference from the reference only in utterances where this counter is non-zero."""
+    labels, space = english
+    rng = np.random.RandomState(11)
+    p = rng.rand(60, 29).astype(np.float32) + 0.05
+    p /= p.sum(1, keepdims=True)
+    tied = p.copy()
+    tied[:, 7] = tied[:, 23]; tied[:, 3] = tied[:, 12]     # 'g' == 'w' and 'c' == 'l', bit for bit: "xga" and "xwa" then tie on (score, character)
+    d = port.Decoder(labels, space, 50, None); d.next(tied)
+    assert d.boundary_ties() > 0
+    d2 = port.Decoder(labels, space, 50, None); d2.next(p)
+    assert d2.boundary_ties() == 0                 # generic emissions: no exact ties
+    A = ref.Alphabet(os.path.join(fix, "alphabet.txt"))
+    dr = ref.Decoder(A, 50, None); dr.next(p.astype(np.float64))
+    assert port.decode_text(labels, d2.decode(1)[0][1]) == A.decode(dr.decode(1)[0][1])
