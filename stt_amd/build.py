@@ -14,6 +14,11 @@ OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libstt.so")
 SOURCES = ["kernels_am.hip", "ctc.hip", "hostutil.cpp", "scorer_dev.cpp", "model.cpp", "tflite_reader.cpp", "engine.cpp", "api.cpp", "fleet.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "hip", "-Wno-unused-result"]
+# ctc.hip: the search kernels run 1024 threads per workgroup (128 registers per lane) through one very long timestep loop.  Machine-level
+# loop-invariant code motion hoists every `thread index * 4 + LDS constant` address and every f64 polynomial coefficient of the bit-exact
+# logf / expf out of that loop and then SPILLS them (scratch loads where one v_add / two v_mov would do): 41 spilled vector registers
+# with it, none without (benchmarks/kernel_resources.sh).
+EXTRA_FLAGS = {"ctc.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
 def _newer(a, b):
@@ -35,7 +40,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -56,29 +56,41 @@ __device__ __forceinline__ uint64_t lds_cas0(LDS_AS uint64_t* p, uint64_t desire
 #define GLB_AS __attribute__((address_space(1)))
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+// The stream's pointers and capacities are NOT copied into registers when the kernel starts (26 scalar registers live from the first
+// instruction to the last were the larger half of the kernel's 256 spilled scalars): they are read from the DecStream itself --
+// through the constant address space, i.e. with scalar loads -- where they are used.  The kernel never writes these fields.
+#define CONST_AS __attribute__((address_space(4)))
+template <class T> __device__ __forceinline__ const CONST_AS T* launder(const CONST_AS T* q) { asm volatile("" : "+s"(q)); return q; }
 struct GStream {
-  GLB_AS uint64_t *pa, *ta;  // {parent (low word), character / timestep (high word)}
-  GLB_AS uint32_t* pq;
-  GLB_AS u32x4* be;          // BEntry = 4 x 16 bytes
-  GLB_AS float* c_logp; GLB_AS uint32_t* c_pi; GLB_AS int* c_fst; GLB_AS uint64_t* sel_keys;
-  GLB_AS unsigned long long* c_key;  // (unused by the present steps; kept in the per-stream slab layout)
-  const uint2* pa_generic;   // for the uncached scorer paths
-  uint32_t cand_cap, pa_cap, ta_cap, be_cap;
+  const CONST_AS DecStream* g;
+  __device__ __forceinline__ GLB_AS uint64_t* pa() const { return (GLB_AS uint64_t*)g->pa; }   // {parent (low word), character / timestep (high word)}
+  __device__ __forceinline__ GLB_AS uint64_t* ta() const { return (GLB_AS uint64_t*)g->ta; }
+  __device__ __forceinline__ GLB_AS uint32_t* pq() const { return (GLB_AS uint32_t*)g->pq; }
+  __device__ __forceinline__ GLB_AS u32x4* be() const { return (GLB_AS u32x4*)g->be; }         // BEntry = 4 x 16 bytes
+  __device__ __forceinline__ GLB_AS float* c_logp() const { return (GLB_AS float*)g->c_logp; }
+  __device__ __forceinline__ GLB_AS uint32_t* c_pi() const { return (GLB_AS uint32_t*)g->c_pi; }
+  __device__ __forceinline__ GLB_AS int* c_fst() const { return (GLB_AS int*)g->c_fst; }
+  __device__ __forceinline__ GLB_AS uint64_t* sel_keys() const { return (GLB_AS uint64_t*)g->sel_keys; }
+  __device__ __forceinline__ const uint2* pa_generic() const { return g->pa; }                  // for the uncached scorer paths
+  __device__ __forceinline__ uint32_t cand_cap() const { return g->cand_cap; }
+  __device__ __forceinline__ uint32_t pa_cap() const { return g->pa_cap; }
+  __device__ __forceinline__ uint32_t ta_cap() const { return g->ta_cap; }
+  __device__ __forceinline__ uint32_t be_cap() const { return g->be_cap; }
 };
 union BEntryBits { BEntry e; u32x4 q[4]; __device__ BEntryBits() {} };
 __device__ __forceinline__ BEntry load_be(const GStream& S, uint32_t idx) {
   BEntryBits b;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) b.q[i] = S.be[(size_t)idx * 4 + i];
+  for (int i = 0; i < 4; ++i) b.q[i] = S.be()[(size_t)idx * 4 + i];
   return b.e;
 }
 __device__ __forceinline__ void store_be(const GStream& S, uint32_t idx, const BEntry& e) {
   BEntryBits b; b.e = e;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) S.be[(size_t)idx * 4 + i] = b.q[i];
+  for (int i = 0; i < 4; ++i) S.be()[(size_t)idx * 4 + i] = b.q[i];
 }
 __device__ __forceinline__ double load_be_raw(const GStream& S, uint32_t idx) {  // BEntry::raw is the first 8 bytes
-  const GLB_AS double* p = (const GLB_AS double*)(S.be + (size_t)idx * 4);
+  const GLB_AS double* p = (const GLB_AS double*)(S.be() + (size_t)idx * 4);
   return *p;
 }
 __device__ __forceinline__ uint2 load_node(const GLB_AS uint64_t* a, uint32_t idx) { const uint64_t v = a[idx]; return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
@@ -450,7 +462,7 @@ __device__ __forceinline__ void word_walk(const DevAlphabet& al, const GStream& 
   lo = 0; hi = 0;
   int nbytes = 0;
   for (uint32_t cur = node; cur != STT_ROOT_CH;) {
-    const uint2 pn = load_node(S.pa, cur);
+    const uint2 pn = load_node(S.pa(), cur);
     ++probes;
     if (pn.y == (uint32_t)al.space_id || pn.y == STT_ROOT_CH) break;
     const uint8_t one = lab1 ? lab1[pn.y] : (uint8_t)0;  // LDS copy of single-byte labels (0 / no table = read the label from HBM)
@@ -469,6 +481,45 @@ __device__ __forceinline__ void word_walk(const DevAlphabet& al, const GStream& 
     cur = pn.x;
   }
   if (nbytes > 16) { lo = ~0ULL; hi = ~0ULL; }
+}
+
+// MurmurHash64A (seed 0) of the word that ends at path node `node` (back to the previous space / the root), for words the packed
+// 16-byte form does not hold.  The path is a backward-linked list and the hash eats 8-byte blocks from the front; instead of a label
+// buffer on the stack (256 bytes of scratch memory per lane in a kernel that otherwise has none) every block walks the word again --
+// a long word costs len^2 / 8 node reads, and dictionaries hold few of them.
+__device__ __forceinline__ uint64_t murmur_path_word(const DevAlphabet& al, const GStream& S, uint32_t node, unsigned& probes) {
+  const uint64_t m = 0xc6a4a7935bd1e995ULL;
+  const int r = 47;
+  uint32_t len = 0;
+  for (uint32_t cur = node; cur != STT_ROOT_CH;) {
+    const uint2 pn = load_node(S.pa(), cur);
+    ++probes;
+    if (pn.y == (uint32_t)al.space_id || pn.y == STT_ROOT_CH) break;
+    len += (uint32_t)(al.label_off[pn.y] - (pn.y ? al.label_off[pn.y - 1] : 0));
+    cur = pn.x;
+  }
+  uint64_t h = 0 ^ ((uint64_t)len * m);
+  for (uint32_t b0 = 0; b0 < len; b0 += 8) {   // bytes [b0, b0 + 8) of the word, first byte lowest
+    uint64_t k = 0;
+    uint32_t end = len;                         // the current label's bytes are [end - ll, end)
+    for (uint32_t cur = node; cur != STT_ROOT_CH && end > b0;) {
+      const uint2 pn = load_node(S.pa(), cur);
+      ++probes;
+      if (pn.y == (uint32_t)al.space_id || pn.y == STT_ROOT_CH) break;
+      const int l0 = pn.y ? al.label_off[pn.y - 1] : 0, l1 = al.label_off[pn.y];
+      const uint32_t beg = end - (uint32_t)(l1 - l0);
+      for (int q = l0; q < l1; ++q) {
+        const uint32_t at = beg + (uint32_t)(q - l0);
+        if (at >= b0 && at < b0 + 8) k |= (uint64_t)al.label_bytes[q] << (8 * (at - b0));
+      }
+      end = beg;
+      cur = pn.x;
+    }
+    if (len - b0 >= 8) { k *= m; k ^= k >> r; k *= m; h ^= k; h *= m; }
+    else { h ^= k; h *= m; }                    // the tail: remaining bytes little-endian, then one multiply
+  }
+  h ^= h >> r; h *= m; h ^= h >> r;
+  return h;
 }
 
 // Score "prefix X, then a word boundary" for a live word-mode prefix X whose last label is neither space nor root,
@@ -575,20 +626,8 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
   // 16 bytes take the generic label-array path.
   if (!have_word) word_walk(al, S, lab1, node, lo, hi, probes);
   uint64_t h;
-  if ((lo & hi) != ~0ULL) {
-    h = murmur_packed(lo, hi, word_nbytes(lo, hi));
-  } else {
-    uint32_t labs[MAX_UNIT_LABELS];
-    int nl = 0;
-    for (uint32_t cur = node; cur != STT_ROOT_CH;) {
-      const uint2 pn = load_node(S.pa, cur);
-      ++probes;
-      if (pn.y == (uint32_t)al.space_id || pn.y == STT_ROOT_CH) break;
-      if (nl < MAX_UNIT_LABELS) labs[nl++] = pn.y;
-      cur = pn.x;
-    }
-    h = hash_labels_reversed(al, labs, nl);
-  }
+  if ((lo & hi) != ~0ULL) h = murmur_packed(lo, hi, word_nbytes(lo, hi));
+  else h = murmur_path_word(al, S, node, probes);   // a word of more than 16 bytes
   const BEntry ep = load_be(S, e_prev);  // issued before the vocabulary probe: the two reads are independent
   ++probes;
   BEntry en;
@@ -630,7 +669,7 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
   out_entry = STT_NONE;
   if (be_n) {  // (null: a read-only caller -- DecoderState::decode -- only wants the value)
     const uint32_t idx = lds_add(be_n, 1u);  // LDS copy of the arena fill (written back when the launch ends)
-    if (idx < S.be_cap) { store_be(S, idx, en); S.pq[node] = idx; out_entry = idx; }
+    if (idx < S.be_cap()) { store_be(S, idx, en); S.pq()[node] = idx; out_entry = idx; }
   }
   return en.raw;
 }
@@ -776,6 +815,12 @@ enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, 
 #define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
 
+// The layout starts at LDS address LDS_ORIGIN, not at the address of an `extern __shared__` array: the kernel has no static LDS, so its
+// dynamic LDS begins at address 0 (checked when the kernel starts), and with literal addresses every array of the layout is a compile-time
+// constant folded into the ds_* instructions.  Relative to the array's symbol each base was `symbol + constant` -- a value the compiler
+// materialised in a scalar register, hoisted out of the timestep loop and, there being forty of them, spilled: every LDS access in a
+// step began with a v_readlane.  (Address 0 itself is skipped: an integer 0 converts to the null pointer of the LDS address space.)
+#define LDS_ORIGIN 16
 // Layout for a beam capacity CAP (a compile-time constant: every array that only depends on CAP sits at a constant LDS
 // address, which the compiler folds into the ds_* instructions instead of keeping ~50 pointers alive in registers).
 // The class-count dependent arrays and the candidate staging area come last.
@@ -826,7 +871,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   // key and write phases.  The recurrence's 256 workgroups fit two per CU on the 192 CUs the search does not occupy.
   uint32_t mcap = 0;
   {
-    const size_t budget = (size_t)budget_kb * 1024;
+    const size_t budget = (size_t)budget_kb * 1024 - LDS_ORIGIN;
     if (o + 256 * 12 <= budget) { mcap = (uint32_t)((budget - o) / 12) & ~63u; if (mcap > 2048) mcap = 2048; }
   }
   const size_t o_lc = o;
@@ -880,7 +925,7 @@ size_t ctc_next_lds_bytes(int beam, int C, bool utf8) {
     case 512: (void)lds_carve<512>(C, nullptr, t, lds_budget_kb_host(), utf8); break;
     default: (void)lds_carve<1024>(C, nullptr, t, lds_budget_kb_host(), utf8); break;
   }
-  return t;
+  return t + LDS_ORIGIN;
 }
 
 #define STT_LDS_MAX (160 * 1024)
@@ -945,8 +990,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-#define CAND_PI(x) (((uint32_t)(x) < L.mcap) ? L.lc_pi[x] : S.c_pi[x])
-#define CAND_LOGP(x) (((uint32_t)(x) < L.mcap) ? L.lc_logp[x] : S.c_logp[x])
+// Everything the search kernel is launched with, as ONE by-value kernel parameter: it sits at offset 0 of the kernel-argument segment,
+// and the kernel reads it through __builtin_amdgcn_kernarg_segment_ptr() -- constant address space, scalar loads at the point of use.
+// (Named by-value parameters are loaded into scalar registers in the prologue and stay live to the end: DevScorer alone is 76 of them.)
+struct NextArgs {
+  DecParams p; DevScorer s; DevAlphabet al;
+  DecStream* streams; const float* probs; const int* frame_begin; const int* frame_count;
+};
+
+#define CAND_PI(x) (((uint32_t)(x) < L.mcap) ? L.lc_pi[x] : S.c_pi()[x])
+#define CAND_LOGP(x) (((uint32_t)(x) < L.mcap) ? L.lc_logp[x] : S.c_logp()[x])
 
 // ------------------------------------------------------------------------------------ one timestep
 // LDS hash insert of a live prefix key (value = beam index)
@@ -1044,8 +1097,20 @@ __device__ __forceinline__ void signal_count(LDS_AS int* ctr) {
 // waited for only at the end of the score phase; the key phase adds the LM scores; the write phase runs live and new entries on
 // separate waves.  The selection (P5) is the other modes'.
 template <int MODE_T, bool WIDE>
-__device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s, const DevAlphabet& al, const GStream& S, const Lds& L, int& cur, int& n,
+__device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONST_AS DecStream* gq, const Lds& L, int& cur, int& n,
                          int& start_expanding, int& abs_t, int buf, const float* next_row, int t_local) {
+  // Parameters, scorer description and stream pointers are read where they are used (scalar loads from the kernel-argument segment /
+  // the DecStream), not carried in registers from the kernel's first instruction: the pointers are made opaque once per step, so the
+  // loads cannot be hoisted out of the timestep loop and kept alive across it (NextArgs, GStream).
+  // Inside this function `p`, `s`, `al` and `S` are not variables but views of whatever `ka` / `gq` are NOW (macros, undefined again
+  // below the function): STEP_FENCE() at a phase boundary makes the two pointers opaque again, so a field read in one phase is read
+  // again in the next instead of being held in a scalar register in between.
+#define STEP_FENCE() do { ka = launder(ka); gq = launder(gq); } while (0)
+#define p (*(const DecParams*)&ka->p)
+#define s (*(const DevScorer*)&ka->s)
+#define al (*(const DevAlphabet*)&ka->al)
+#define S (GStream{gq})
+  STEP_FENCE();
   constexpr int MODE = MODE_T == 4 ? 1 : MODE_T;
   constexpr bool MASKED = MODE_T == 4;
   constexpr bool SC_ON = MODE != 0, SC_UTF8 = MODE == 2;
@@ -1131,6 +1196,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   }
   if (!MASKED) __syncthreads();
   TICK(0);
+  STEP_FENCE();
 
   // ---- P2: expand.  Wave w owns prefixes w, w+16, w+32, ...: blank / repeat events per prefix, then one work item per
   // (prefix, candidate label) -- with a dictionary only the out-arcs of the prefix's FST state can succeed
@@ -1294,10 +1360,10 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
             // (no queue of scored extensions in this form: bit 31 marks them, the key phase adds the score -- score_ext below)
           } else {
             const int slot = lds_add(&sc[SC_M], 1);
-            if ((uint32_t)slot < S.cand_cap) {
+            if ((uint32_t)slot < S.cand_cap()) {
               const uint32_t piv = (uint32_t)i | (c << 16) | (needs_lm << 31);  // (class position == class: no pruning in this mode)
               if ((uint32_t)slot < L.mcap) { L.lc_logp[slot] = log_p; L.lc_pi[slot] = piv; L.lc_fst[slot] = (int)child_fst; }
-              else { S.c_logp[slot] = log_p; S.c_pi[slot] = piv; S.c_fst[slot] = (int)child_fst; }
+              else { S.c_logp()[slot] = log_p; S.c_pi()[slot] = piv; S.c_fst()[slot] = (int)child_fst; }
             }
           }
         }
@@ -1399,7 +1465,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         if (SC_ON) {
           if (SC_UTF8) {
             if (al.byte_labels) needs_lm = utf8_completes(L.run[cur][i], (uint8_t)(c + 1)) ? 1u : 0u;  // (UTF8Alphabet: label c is byte c + 1)
-            else needs_lm = is_scoring_boundary(s, al, S.pa_generic, L.node[cur][i], c, c, probes) ? 1u : 0u;
+            else needs_lm = is_scoring_boundary(s, al, S.pa_generic(), L.node[cur][i], c, c, probes) ? 1u : 0u;
           } else needs_lm = (int)c == al.space_id ? 1u : 0u;
         }
         const uint64_t ck = child_key(L.key[cur][i], c);
@@ -1416,10 +1482,10 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
           if (needs_lm && lm_queue) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = 0x80000000u | (uint32_t)jj; }
         } else {
           const int slot = lds_add(&sc[SC_M], 1);
-          if ((uint32_t)slot < S.cand_cap) {
+          if ((uint32_t)slot < S.cand_cap()) {
             const uint32_t piv = (uint32_t)i | ((uint32_t)k << 16) | (needs_lm << 31);
             if ((uint32_t)slot < L.mcap) { L.lc_logp[slot] = log_p; L.lc_pi[slot] = piv; L.lc_fst[slot] = child_fst; }
-            else { S.c_logp[slot] = log_p; S.c_pi[slot] = piv; S.c_fst[slot] = child_fst; }
+            else { S.c_logp()[slot] = log_p; S.c_pi()[slot] = piv; S.c_fst()[slot] = child_fst; }
             if (needs_lm && lm_queue) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = (uint32_t)slot; }
           }
         }
@@ -1446,8 +1512,9 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     L.stm[32 + who] += 1; L.stm[48] += mx - mn; L.stm[49] += mx2 - mn;
   }
   int m = __builtin_amdgcn_readfirstlane(sc[SC_M]);
-  if ((uint32_t)m > S.cand_cap) { m = (int)S.cand_cap; if (tid == 0) sc[SC_ERR] |= 4; }
+  if ((uint32_t)m > S.cand_cap()) { m = (int)S.cand_cap(); if (tid == 0) sc[SC_ERR] |= 4; }
   TICK(2);
+  STEP_FENCE();
 
   // ---- P3: language model on scoring boundaries (:209-243).  Word mode: the few scored extensions of this step were
   // queued by the expand phase and are taken by the *last* threads of the workgroup, while the first n threads already
@@ -1492,7 +1559,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         double raw = 0.0;
         float lms_cached = 0.0f;
         const bool in_lds = L.pqe.p0 != nullptr;
-        const uint32_t e = in_lds ? L.pqe[cur][i] : S.pq[nodei];
+        const uint32_t e = in_lds ? L.pqe[cur][i] : S.pq()[nodei];
         const bool cached_f = in_lds && e != STT_NONE;  // scored earlier (or by the LM wave during expand): alpha-scaled score is in LDS
         if (cached_f) lms_cached = L.pqs[cur][i];
         else if (e != STT_NONE) raw = load_be_raw(S, e);
@@ -1510,7 +1577,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         const float lms = cached_f ? lms_cached : (float)__dmul_rn(raw, s.alpha);
         float lpv = __fadd_rn(lp0, lms);                       // log_p += score;
         lpv = (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
-        if (!live) { if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpv; else S.c_logp[x] = lpv; } else L.ev_ext[x] = lpv;
+        if (!live) { if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpv; else S.c_logp()[x] = lpv; } else L.ev_ext[x] = lpv;
       }
       if (tid < n && !((L.ev_exti[tid] >> 31) && !is_absent(L.ev_ext[tid]))) { my_score = merge_live<WIDE>(p, L, W, cur, tid); merged = true; }
     } else {
@@ -1526,12 +1593,12 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         if (al.byte_labels && bndi != STT_NONE && utf8_step_clean(L.run[cur][i], L.ch[cur][i] == STT_ROOT_CH, (uint8_t)(first + 1), unit)) {
           uint32_t ne;  // one FullScore from the state after the previous code point
           raw = lm_word_query_cached<false>(s, al, S, lab1, (LDS_AS uint32_t*)nullptr, 0u, bndi, true, (uint64_t)unit, 0ULL, ne, probes);
-        } else raw = lm_score(s, al, S.pa_generic, L.node[cur][i], first, true, probes);
+        } else raw = lm_score(s, al, S.pa_generic(), L.node[cur][i], first, true, probes);
         ++lmq;
         const float lms = (float)__dmul_rn(raw, s.alpha);
         float lpv = __fadd_rn(lp0, lms);
         lpv = (float)__dadd_rn((double)lpv, s.beta);
-        if (x < m) { if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpv; else S.c_logp[x] = lpv; } else L.ev_ext[x - m] = lpv;
+        if (x < m) { if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpv; else S.c_logp()[x] = lpv; } else L.ev_ext[x - m] = lpv;
       }
     }
     if (lmq) lds_add(&sc[SC_LMQ], (int)lmq);
@@ -1540,13 +1607,14 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   if (MASKED && p.stamps && lane == 0) L.stm[32 + wave] += __builtin_readcyclecounter() - tick_;   // profiling level 2: arrival at the end of the score phase (wave 0: since its last TICK)
   __syncthreads();
   TICK(3);
+  STEP_FENCE();
 
   // ---- P4: merge events of live prefixes in the reference's visiting order (class position, then beam index);
   // selection keys of live prefixes and candidates.  Element e (live prefix e < n, else candidate e - n) belongs to
   // thread e % NTHREADS; its first two keys stay in registers, further ones go to the HBM workspace.
   if (MASKED) {  // (an LM wave passed the end of the expand phase before the items were done: the count is final now)
     m = __builtin_amdgcn_readfirstlane(sc[SC_M]);
-    if ((uint32_t)m > S.cand_cap) m = (int)S.cand_cap;
+    if ((uint32_t)m > S.cand_cap()) m = (int)S.cand_cap();
   }
   const int total = n + m;
   uint64_t kreg0 = ~0ULL, kreg1 = ~0ULL;
@@ -1572,18 +1640,19 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       const int x = e - n;
       const uint32_t pi = CAND_PI(x);
       float lpx = CAND_LOGP(x);
-      if (MASKED && (pi >> 31)) { lpx = score_ext(lpx, (int)(pi & 0xFFFFu)); if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpx; else S.c_logp[x] = lpx; }
+      if (MASKED && (pi >> 31)) { lpx = score_ext(lpx, (int)(pi & 0xFFFFu)); if ((uint32_t)x < L.mcap) L.lc_logp[x] = lpx; else S.c_logp()[x] = lpx; }
       k = sel_key(lpx, CLS_AT((pi >> 16) & 0x7FFFu), 1, pi & 0xFFFFu);
     }
-    if (r == 0) kreg0 = k; else if (r == 1) kreg1 = k; else S.sel_keys[e] = k;
+    if (r == 0) kreg0 = k; else if (r == 1) kreg1 = k; else S.sel_keys()[e] = k;
     const uint32_t kh = (uint32_t)(k >> 32);
     hmin = kh < hmin ? kh : hmin; if (kh != NEG_HI) hmax = kh > hmax ? kh : hmax;
   }
-#define KEY_OF(e, r) ((r) == 0 ? kreg0 : (r) == 1 ? kreg1 : S.sel_keys[e])
+#define KEY_OF(e, r) ((r) == 0 ? kreg0 : (r) == 1 ? kreg1 : S.sel_keys()[e])
   hmin = wave_min_u32(hmin); hmax = wave_max_u32(hmax);
   if (lane == 0) { lds_min((LDS_AS uint32_t*)&sc[SC_KMIN], hmin); lds_max((LDS_AS uint32_t*)&sc[SC_KMAX], hmax); }
   __syncthreads();
   TICK(4);
+  STEP_FENCE();
 
   // ---- P5: keep the best beam_size (nth_element + resize, :263-274) in sorted order.  Keys are unique, so the rank of
   // a key is its position in the new beam.  Bucket the keys over their live range (NBUCKET bins of 2^sh), prefix-sum the
@@ -1649,6 +1718,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     }
     __syncthreads();
     TICK(5);
+    STEP_FENCE();
 
     // rank inside the segment -> position r in the new beam; then write the new beam entry (P6) and hash its key.
     // A surviving live prefix is a copy of ~20 fields, a new prefix ~3x the work (arena node, dictionary record, word bytes); mixed in
@@ -1684,7 +1754,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         // {first labelled arc, label bitmap} of the new prefix's dictionary state: a read from a table of tens of MB, i.e. a miss --
         // started here, consumed after this thread's share of the write phase (stays in flight across the barrier), so nobody waits
         const int cx = (int)ent - n;
-        rec_new = s.fst_rec[((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst[cx]]; r_rec = rr;
+        rec_new = s.fst_rec[((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst()[cx]]; r_rec = rr;
       }
       const uint64_t bl = __ballot(is_live), bn = __ballot(is_new);
       uint32_t base_ln = 0;   // both list lengths in one word (live low, new high): one atomic round trip per wave
@@ -1698,6 +1768,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
     P6_STAMP(0);   // profiling level 2 (wave 0: slots 56.., last wave: 60..): ranking | wait at the barrier | own list | tail
     __syncthreads();
     P6_STAMP(1);
+    STEP_FENCE();
     const uint32_t n_ln = (uint32_t)__builtin_amdgcn_readfirstlane(sc[SC_NA]);
     const uint32_t n_live = n_ln & 0xFFFFu, n_new = n_ln >> 16;
     if (p.stamps && tid == 0) { L.stm[54] += n_live; L.stm[55] += n_new; }
@@ -1706,7 +1777,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
       ht_insert(L, nkey, (int)r);
       if (pend != 0xFFFFFFFEu) {  // path_trie.cpp:172-184
         const uint32_t slot = lds_add((LDS_AS uint32_t*)&sc[SC_TAN], 1u);
-        if (slot < S.ta_cap) { store_node(S.ta, slot, pend, (uint32_t)abs_t); ts_new = slot; }
+        if (slot < S.ta_cap()) { store_node(S.ta(), slot, pend, (uint32_t)abs_t); ts_new = slot; }
         else lds_or(&sc[SC_ERR], 2);
       }
       L.ts[nxt][r] = ts_new;
@@ -1741,7 +1812,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         const float lpv = CAND_LOGP(cx);
         const uint32_t pnode = L.node[cur][i];
         L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
-        const int cf = ((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst[cx];
+        const int cf = ((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst()[cx];
         L.ch[nxt][r] = c; L.fst[nxt][r] = cf;
         if (MASKED) {  // (a0 / sm of the child's dictionary state: written at the end by the thread that ranked this entry)
         } else if (SC_ON && L.a0.p0) {  // arc range of the child's dictionary state; top bit: a word may end here (space arc)
@@ -1751,7 +1822,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
         }
         nkey = child_key(L.key[cur][i], c);
         uint32_t b = L.bnd[cur][i];
-        if (MODE == 1 && (int)c == al.space_id) b = L.pqe.p0 ? L.pqe[cur][i] : S.pq[pnode];  // the boundary entry scored in P3 (or earlier)
+        if (MODE == 1 && (int)c == al.space_id) b = L.pqe.p0 ? L.pqe[cur][i] : S.pq()[pnode];  // the boundary entry scored in P3 (or earlier)
         L.bnd[nxt][r] = b;
         if (MODE == 1 && L.pqe.p0) {
           uint64_t lo = 0, hi = 0;
@@ -1763,7 +1834,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
           }
           L.wlo[nxt][r] = lo; L.whi[nxt][r] = hi; L.pqe[nxt][r] = STT_NONE;
         }
-        if (slot < S.pa_cap) { store_node(S.pa, slot, pnode, c); S.pq[slot] = STT_NONE; L.node[nxt][r] = slot; }
+        if (slot < S.pa_cap()) { store_node(S.pa(), slot, pnode, c); S.pq()[slot] = STT_NONE; L.node[nxt][r] = slot; }
         else { L.node[nxt][r] = 0; lds_or(&sc[SC_ERR], 1); }
         if (MODE == 2) {  // utf8 cache: the child's run, and its boundary entry (a new one when it completes a code point)
           const uint8_t byte = (uint8_t)(c + 1);
@@ -1774,7 +1845,7 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
             L.run[nxt][r] = utf8_child_run(prun, byte);
             if (b != STT_NONE && utf8_step_clean(prun, L.ch[cur][i] == STT_ROOT_CH, byte, unit)) {
               if (pi >> 31) {
-                if (slot < S.pa_cap) {
+                if (slot < S.pa_cap()) {
                   lm_word_query_cached<false>(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], slot, b, true, (uint64_t)unit, 0ULL, nb, probes6);
                   if (nb == STT_NONE) lds_or(&sc[SC_ERR], 8);
                 }
@@ -1808,26 +1879,33 @@ __device__ __forceinline__ void ctc_step(const DecParams& p, const DevScorer& s,
   n = keep;
   __syncthreads();
   TICK(6);
+  STEP_FENCE();
+#undef p
+#undef s
+#undef al
+#undef S
+#undef STEP_FENCE
 }
 
 // MODE: 0 = no scorer, 1 = word-level scorer, 2 = utf8 (codepoint-level) scorer, 4 = word-level scorer with the dictionary's label
 // bitmaps, two language-model waves and FullScore through the hashed n-gram index (<= 32 classes, no class pruning, CAP <= 512)
 template <int MODE, int CAP, bool WIDE>
-__global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScorer s, DevAlphabet al, DecStream* streams,
-                                                            const float* probs, const int* frame_begin, const int* frame_count) {
+__global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(NextArgs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const CONST_AS NextArgs* ka = (const CONST_AS NextArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  const DecParams& p = *(const DecParams*)&ka->p;
+  const DevScorer& s = *(const DevScorer*)&ka->s;
+  const DevAlphabet& al = *(const DevAlphabet*)&ka->al;
+  const float* probs = ka->probs; const int* frame_begin = ka->frame_begin; const int* frame_count = ka->frame_count;
   size_t lds_total;
-  const Lds L = lds_carve<CAP>(WIDE ? 0 : p.C, (LDS_AS unsigned char*)smem, lds_total, p.lds_kb, MODE == 2);
-  DecStream& G = streams[blockIdx.x];
+  // (bitmap step: <= 32 classes -- the layout is carved for 32, so every LDS address but the candidate staging capacity is a constant)
+  if ((uint32_t)(uintptr_t)(LDS_AS unsigned char*)smem != 0u) __builtin_trap();   // (no static LDS in this kernel: see LDS_ORIGIN)
+  const Lds L = lds_carve<CAP>(WIDE ? 0 : (MODE == 4 ? 32 : p.C), (LDS_AS unsigned char*)(uintptr_t)LDS_ORIGIN, lds_total, p.lds_kb, MODE == 2);
+  DecStream& G = ka->streams[blockIdx.x];
+  const CONST_AS DecStream* gq = (const CONST_AS DecStream*)&G;
   const int nfr = frame_count ? frame_count[blockIdx.x] : p.all_count;
   if (nfr <= 0) return;
-  // the stream's pointers and capacities, read once into registers (field by field: a struct copy indexed in a loop would
-  // live in scratch memory)
-  GStream GS;
-  GS.pa = (GLB_AS uint64_t*)G.pa; GS.ta = (GLB_AS uint64_t*)G.ta; GS.pq = (GLB_AS uint32_t*)G.pq; GS.be = (GLB_AS u32x4*)G.be;
-  GS.c_logp = (GLB_AS float*)G.c_logp; GS.c_pi = (GLB_AS uint32_t*)G.c_pi; GS.c_fst = (GLB_AS int*)G.c_fst; GS.sel_keys = (GLB_AS uint64_t*)G.sel_keys;
-  GS.c_key = (GLB_AS unsigned long long*)G.c_key;
-  GS.pa_generic = G.pa; GS.cand_cap = G.cand_cap; GS.pa_cap = G.pa_cap; GS.ta_cap = G.ta_cap; GS.be_cap = G.be_cap;
+  const GStream GS{gq};
   GLB_AS float* g_score = (GLB_AS float*)G.score; GLB_AS float* g_pb = (GLB_AS float*)G.pb; GLB_AS float* g_pnb = (GLB_AS float*)G.pnb;
   GLB_AS uint32_t* g_ch = (GLB_AS uint32_t*)G.ch; GLB_AS uint32_t* g_node = (GLB_AS uint32_t*)G.node; GLB_AS uint32_t* g_ts = (GLB_AS uint32_t*)G.ts;
   GLB_AS int* g_fst = (GLB_AS int*)G.fst; GLB_AS uint64_t* g_key = (GLB_AS uint64_t*)G.key; GLB_AS uint32_t* g_bnd = (GLB_AS uint32_t*)G.bnd;
@@ -1875,7 +1953,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
       const uint32_t nd = L.node[0][i];
       uint64_t lo, hi;
       word_walk(al, GS, lab1, nd, lo, hi, pr);
-      const uint32_t e0 = GS.pq[nd];
+      const uint32_t e0 = GS.pq()[nd];
       L.wlo[0][i] = lo; L.whi[0][i] = hi; L.pqe[0][i] = e0;
       L.pqs[0][i] = e0 != STT_NONE ? (float)__dmul_rn(load_be_raw(GS, e0), s.alpha) : 0.0f;
     }
@@ -1884,7 +1962,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
     for (int i = tid; i < n; i += NTHREADS) {
       uint64_t acc = 0; uint32_t len = 0; bool found = false;
       for (uint32_t nd = L.node[0][i]; nd != STT_ROOT_CH;) {
-        const uint2 pn = load_node(GS.pa, nd);
+        const uint2 pn = load_node(GS.pa(), nd);
         if (pn.y == STT_ROOT_CH) break;
         const uint8_t byte = (uint8_t)(pn.y + 1);
         acc = (acc << 8) | byte; len = len < 255u ? len + 1u : 255u;  // (newest byte first: the start byte ends up lowest)
@@ -1897,7 +1975,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(DecParams p, DevScor
   for (int i = tid; i < n; i += NTHREADS) ht_insert(L, L.key[0][i], i);
   __syncthreads();
   for (int t = 0; t < nfr; ++t)
-    ctc_step<MODE, WIDE>(p, s, al, GS, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr, t);
+    ctc_step<MODE, WIDE>(ka, gq, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr, t);
   for (int i = tid; i < n; i += NTHREADS) {
     g_score[i] = L.score[cur][i]; g_pb[i] = L.pb[cur][i]; g_pnb[i] = L.pnb[cur][i];
     g_ch[i] = L.ch[cur][i]; g_node[i] = L.node[cur][i]; g_ts[i] = L.ts[cur][i]; g_fst[i] = L.fst[cur][i]; g_key[i] = L.key[cur][i];
@@ -1927,10 +2005,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevSc
   const int n = S.n;
   const uint32_t sortn = pow2_ge((uint32_t)(n > 0 ? n : 1));
   unsigned probes = 0;
-  GStream GS;
-  GS.pa = (GLB_AS uint64_t*)S.pa; GS.ta = (GLB_AS uint64_t*)S.ta; GS.pq = (GLB_AS uint32_t*)S.pq; GS.be = (GLB_AS u32x4*)S.be;
-  GS.c_logp = nullptr; GS.c_pi = nullptr; GS.c_fst = nullptr; GS.sel_keys = nullptr;
-  GS.pa_generic = S.pa; GS.cand_cap = 0; GS.pa_cap = S.pa_cap; GS.ta_cap = S.ta_cap; GS.be_cap = S.be_cap;
+  const GStream GS{(const CONST_AS DecStream*)&S};
   if (tid < 256) {  // single-byte labels (the word walk reads them); labels >= 256 are looked up in HBM
     uint8_t one = 0;
     if (tid < al.n_labels) { const int b0 = tid ? al.label_off[tid - 1] : 0; if (al.label_off[tid] - b0 == 1) one = al.label_bytes[b0]; }
@@ -1991,7 +2066,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevSc
     int k = 0;
     if ((q & 1) == 0) {
       for (uint32_t x = S.node[i]; x != STT_ROOT_CH;) {
-        const uint2 pn = load_node(GS.pa, x);
+        const uint2 pn = load_node(GS.pa(), x);
         if (pn.y == STT_ROOT_CH) break;
         out.tokens[ob * out.max_len + (k % out.max_len)] = pn.y;
         ++k; x = pn.x;
@@ -2000,7 +2075,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_decode_kernel(DecParams p, DevSc
       out.confidence[ob] = (double)sscore[i];
     } else {
       for (uint32_t x = S.ts[i]; x != STT_ROOT_CH && x != 0;) {
-        const uint2 tn = load_node(GS.ta, x);
+        const uint2 tn = load_node(GS.ta(), x);
         out.timesteps[ob * out.max_len + (k % out.max_len)] = tn.y;
         ++k; x = tn.x;
       }
@@ -2084,9 +2159,11 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
     check_launch("ctc_wide_rows_kernel");
   }
   p.n_lm_waves = tune().lm_waves; p.item_cap = tune().item_table_cap;
-  const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : p.C, s.enabled && s.utf8);
-  p.lds_kb = lds_budget_kb_host();
   const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : ((!wide && ctc_masked_ok(p, s, al)) ? 4 : 1));
+  const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : (mode == 4 ? 32 : p.C), s.enabled && s.utf8);   // (mode 4: the kernel carves its layout for 32 classes)
+  p.lds_kb = lds_budget_kb_host();
+  NextArgs na;
+  na.p = p; na.s = s; na.al = al; na.streams = streams; na.probs = probs; na.frame_begin = frame_begin; na.frame_count = frame_count;
   const int ci = cb == 64 ? 0 : cb == 128 ? 1 : cb == 256 ? 2 : cb == 512 ? 3 : 4;
   // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: remember what was set per device
   static std::mutex mu;
@@ -2104,14 +2181,18 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
         configured[di][W][M][CI] = lds;                                                                                      \
       }                                                                                                                      \
     }                                                                                                                        \
-    hipLaunchKernelGGL((ctc_next_kernel<M, CAPV, W>), dim3(n_streams), dim3(NTHREADS), lds, st, p, s, al, streams, probs, frame_begin, frame_count); \
+    hipLaunchKernelGGL((ctc_next_kernel<M, CAPV, W>), dim3(n_streams), dim3(NTHREADS), lds, st, na);                          \
     check_launch("ctc_next_kernel");                                                                                         \
     return;                                                                                                                  \
   }
 #define STT_CTC_MODE(M, W) STT_CTC_CASE(M, 0, 64, W) STT_CTC_CASE(M, 1, 128, W) STT_CTC_CASE(M, 2, 256, W) STT_CTC_CASE(M, 3, 512, W) STT_CTC_CASE(M, 4, 1024, W)
+#ifdef STT_CTC_PROBE   // code-generation experiments (benchmarks/kernel_resources.sh): only the two instantiations the bench's headline and bytes workloads run
+  STT_CTC_CASE(4, 3, 512, false) STT_CTC_CASE(2, 4, 1024, false)
+#else
   STT_CTC_MODE(0, false) STT_CTC_MODE(1, false) STT_CTC_MODE(2, false)
   STT_CTC_MODE(0, true) STT_CTC_MODE(1, true) STT_CTC_MODE(2, true)
   STT_CTC_CASE(4, 0, 64, false) STT_CTC_CASE(4, 1, 128, false) STT_CTC_CASE(4, 2, 256, false) STT_CTC_CASE(4, 3, 512, false)
+#endif
 #undef STT_CTC_MODE
 #undef STT_CTC_CASE
   throw std::runtime_error("launch_ctc_next: no kernel instance for this configuration");
