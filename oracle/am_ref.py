@@ -18,7 +18,8 @@ CPU restatement (numpy, float64 internally) of SURVEY.md section 8a rows a2-a6:
 PARITY UNPINNED for this half: no TensorFlow/TFLite runtime and no model file exist in
 /root/reference or in this image, and the reference has no test that pins these stages with
 in-tree data.  The HIP kernels are compared against this restatement with the
-tolerances written in tests/test_gpu_am.py; the restatement itself cannot be checked against
+tolerances written in tests/test_gpu_kernels.py, test_gpu_benchshape.py and test_gpu_timedpath.py (and, for the reference's
+hybrid-int8 arithmetic, oracle/am_hybrid.py + tests/test_gpu_hybrid.py); the restatement itself cannot be checked against
 the reference binary.
 """
 import numpy as np

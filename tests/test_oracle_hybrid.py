@@ -1,0 +1,60 @@
+"""oracle/am_hybrid.py (TFLite's hybrid int8 FULLY_CONNECTED restated) against first principles: no GPU."""
+import numpy as np
+
+from oracle import am_hybrid, am_ref
+from stt_amd import synth, tflitefile
+
+
+def test_symmetric_quantize_rows_follows_the_published_kernel():
+    x = np.array([[0.0, 0.0, 0.0], [1.0, -2.0, 0.5], [127.0, 63.5, -0.5], [1e-3, 2.5e-4, -7.5e-4]], dtype=np.float32)
+    q, sf = am_hybrid.symmetric_quantize_rows(x)
+    assert np.array_equal(q[0], [0, 0, 0]) and sf[0] == 1.0                       # range 0: zeros, scaling factor 1
+    assert np.array_equal(q[1], [64, -127, 32]) and sf[1] == np.float32(2.0 / 127.0)   # 63.5 -> 64, 31.75 -> 32 (round half away from zero)
+    assert np.array_equal(q[2], [127, 64, -1])                                    # 63.5 -> 64, -0.5 -> -1
+    assert np.array_equal(q[3], [127, 32, -95])                                   # 31.75 -> 32, -95.25 -> -95
+
+
+def test_hybrid_fully_connected_is_exact_integer_arithmetic():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((5, 300)).astype(np.float32)
+    w = rng.standard_normal((300, 40)).astype(np.float32)
+    b = rng.standard_normal(40).astype(np.float32)
+    for per_channel in (False, True):
+        wq, ws = am_hybrid.quantize_weights(w, per_channel)
+        got = am_hybrid.fully_connected_hybrid(x, wq, ws, b)
+        q, sf = am_hybrid.symmetric_quantize_rows(x)
+        want = np.zeros((5, 40), np.float32)
+        for i in range(5):
+            for r in range(40):
+                dot = int(np.sum(q[i].astype(np.int64) * wq[r].astype(np.int64)))       # int32 accumulate
+                want[i, r] = np.float32(b[r]) + np.float32(np.float32(dot) * np.float32(sf[i] * (ws[r] if per_channel else ws[0])))
+        assert np.array_equal(got, want)
+    assert np.array_equal(am_hybrid.fully_connected_hybrid(np.zeros((2, 300), np.float32), wq, ws, b), np.broadcast_to(b, (2, 40)))
+
+
+def test_quantised_weights_are_the_tflite_writers():
+    """The int8 matrices and scales the restatement computes with are the ones stt_amd/tflitefile.py stores in a quantised .tflite (and
+    the engine de-quantises): the two describe the same model."""
+    w = synth.synth_weights(2, n_hidden=64)
+    for per_channel in (False, True):
+        _, eff = tflitefile.tflite_bytes(w, synth.ENGLISH_LABELS, quantize=True, per_channel=per_channel)
+        mine = am_hybrid.HybridModel(w, per_channel).effective_weights()
+        for k in eff:
+            assert np.array_equal(np.asarray(eff[k], np.float32), mine[k]), k
+
+
+def test_hybrid_model_stays_near_the_float_graph_of_the_same_weights():
+    """Activation quantisation is noise of about 1/254 of a row's range per element: the softmax outputs of the hybrid graph stay
+    within a few 1e-3 (absolute) of the float graph evaluated with the de-quantised weights -- and are not equal to it."""
+    w = synth.synth_weights(1, n_hidden=128)
+    a = synth.synth_audio(12000, seed=3)
+    M = am_hybrid.HybridModel(w)
+    win = am_ref.context_windows(am_ref.MfccSpec().frames_fast(a))[None]
+    ph = M.forward_batch(win)[0]
+    pf = am_ref.am_forward(win[0], M.effective_weights())[0]
+    d = np.abs(ph - pf).max()
+    assert 0 < d < 5e-3, d
+    assert np.allclose(ph.sum(1), 1.0, atol=1e-5)
+    # batching changes nothing: rows are quantised one by one
+    two = M.forward_batch(np.concatenate([win, win[:, ::-1]]))
+    assert np.array_equal(two[0], ph)
