@@ -70,6 +70,17 @@ def synth_scorer(scorer_dir):
     return path, desc
 
 
+def synth_codepoint_scorer(scorer_dir):
+    """configs[4]'s scorer (SURVEY.md 8d Config 5): a code-point level language model in bytes-output mode -- 6000 three-byte units
+    (Mandarin-shaped: doc/DECODER.rst:193), order 5, KenLM `-a 255 -q 8 trie` layout, packaged with --force_bytes_output_mode."""
+    from stt_amd import scorertools
+    lm, vocab = os.path.join(scorer_dir, "cp.lm.binary"), os.path.join(scorer_dir, "cp.vocab.txt")
+    path = os.path.join(scorer_dir, "synthetic_codepoints.scorer")
+    scorertools.synth_lm(lm, vocab, words=6000, order=5, seed=9, avg={2: 300, 3: 2.0, 4: 1.0, 5: 0.7}, codepoints=True)
+    scorertools.generate_scorer_package(lm, vocab, path, force_bytes_output_mode=True, default_alpha=0.931289039105002, default_beta=1.1834137581510284)
+    return path, "synthetic code-point scorer (6000 three-byte units, order 5, quant-array-trie, bytes-output mode, %.0f MB)" % (os.path.getsize(path) / 1e6)
+
+
 def cpu_baseline(model, weights, audio, scorer_path):
     """SURVEY.md 8d "CPU baseline timed beside it" on the GPU box's host cores, a bounded sample of the timed workload:
     (3) the evaluate_export.py:65-80 pattern -- worker processes over ALL 64 utterances of the batch, each running the whole CPU
@@ -189,7 +200,7 @@ def measure(wl, args, cx, steps, warmup):
         if cx.bytes_model is None:
             cx.bytes_model, _ = make_model(256, 1024, [bytes([i + 1]) for i in range(255)])   # UTF8Alphabet (alphabet.h:83-91)
             cx.bytes_model.enableExternalScorer(cx.bytes_scorer_path)
-        model, scorer_desc = cx.bytes_model, "pruned_lm.bytes.scorer (codepoint-level, order 2)"
+        model, scorer_desc = cx.bytes_model, cx.bytes_scorer_desc
     else:
         model, scorer_desc = cx.model, cx.scorer_desc
     hop_lat, extra = [], {}
@@ -658,7 +669,11 @@ def main():
     native.lib().STTX_SetDevice(local_rank)
     wl = args.workload
     cx.bytes_model = None
-    cx.bytes_scorer_path = os.path.join(FIX, "pruned_lm.bytes.scorer")
+    cx.bytes_scorer_path, cx.bytes_scorer_desc = os.path.join(FIX, "pruned_lm.bytes.scorer"), "pruned_lm.bytes.scorer fixture (code-point level, order 2)"
+    cx.tmpdirs = []
+    if args.scorer == "synthetic" and (wl == "bytes" or (wl == "batch" and not args.no_extras)):
+        cx.tmpdirs.append(tempfile.TemporaryDirectory())
+        cx.bytes_scorer_path, cx.bytes_scorer_desc = synth_codepoint_scorer(cx.tmpdirs[-1].name)
     cx.model, cx.scorer_path, cx.scorer_desc, weights = None, None, None, None
     scorer_dir = None
     if wl != "bytes" or not args.no_extras:

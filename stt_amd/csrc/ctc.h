@@ -89,6 +89,11 @@ struct DevScorer {
   // over key and value, which rejects an entry torn between two concurrent writers.  null = none.
   uint32_t* memo;
   uint32_t memo_mask;
+  // utf8 mode: cp_ub[u] >= get_log_cond_prob() of ANY n-gram that ends with code point u (U+0000 .. U+FFFF; -1000 = not in the
+  // vocabulary), cp_ub_max = the largest entry; null = no table (scorer_dev.cpp: build_unit_bounds)
+  const float* cp_ub;
+  float cp_ub_max;
+  int cp_ub_on;   // cp_ub_max is valid
   // hot words (murmur hashes of the words)
   int n_hot;
   const uint64_t* hot_hash;

@@ -71,6 +71,7 @@ struct GStream {
   __device__ __forceinline__ GLB_AS uint32_t* c_pi() const { return (GLB_AS uint32_t*)g->c_pi; }
   __device__ __forceinline__ GLB_AS int* c_fst() const { return (GLB_AS int*)g->c_fst; }
   __device__ __forceinline__ GLB_AS uint64_t* sel_keys() const { return (GLB_AS uint64_t*)g->sel_keys; }
+  __device__ __forceinline__ GLB_AS uint32_t* c_elem() const { return (GLB_AS uint32_t*)g->c_key; }   // code-point step: element ids of the candidates that reach the selection
   __device__ __forceinline__ const uint2* pa_generic() const { return g->pa; }                  // for the uncached scorer paths
   __device__ __forceinline__ uint32_t cand_cap() const { return g->cand_cap; }
   __device__ __forceinline__ uint32_t pa_cap() const { return g->pa_cap; }
@@ -811,7 +812,7 @@ struct Lds {
 };
 // phase cycle counters (s_memtime is a scalar memory operation with a wait: only on request, DecParams::phase_cycles)
 #define TICK(k) do { if (p.phase_cycles && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); L.acc[4 + (k)] += now_ - tick_; tick_ = now_; } } while (0)
-enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_NA, SC_NI, SC_ICUR, SC_FILL, SC_DONE, SC_COUNT = 24 };
+enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_NA, SC_NI, SC_ICUR, SC_FILL, SC_DONE, SC_NS, SC_THB, SC_COUNT = 24 };
 #define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
 
@@ -1151,7 +1152,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
   // (bitmap step: every thread clears the events of its own prefix in the pre-pass below -- no barrier in between)
   if (!MASKED) for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
   L.hist[tid] = 0;
-  if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; sc[SC_NQ] = 0; sc[SC_NA] = 0; }
+  if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; sc[SC_NQ] = 0; sc[SC_NA] = 0; sc[SC_NS] = 0; sc[SC_THB] = 0; }
   const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
   int cutoff_len = WIDE ? wh.cutoff_len : C;
   if (!WIDE && sort_classes && p.wide_rows) {  // class order prepared for all rows of the chunk by ctc_wide_rows_kernel
@@ -1194,6 +1195,27 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
     min_cutoff = (float)mc;
     full_beam = (n == beam);
   }
+  // Code-point scorer: a score that `beam` prefixes of the next beam are KNOWN to reach before anything is expanded.  Every live prefix
+  // i whose blank event is not cut off ends the step with log_sum_exp(b, nb) >= b = lp[blank] + score[i] (log_sum_exp never returns less
+  // than its larger operand), the beam is sorted, so with a full beam all `beam` of them reach thr = lp[blank] + score[n - 1].  A NEW
+  // prefix whose final log-probability is below thr -- or whose log-probability plus an UPPER BOUND of its language-model score is
+  // (DevScorer::cp_ub) -- cannot be among the best `beam` of this step: it is dropped where it is made, or its FullScore is skipped
+  // and it is parked at -inf.  The surviving beam is the reference's, entry for entry (bytes goldens, bytes fuzz, test_gpu_configs).
+  // (-inf = no such statement this step.  Hot words add to the score and are not in the bound: no pruning with them.)
+  float thr = NEG;
+  if (SC_UTF8 && full_beam && s.n_hot == 0 && s.alpha >= 0.0) {
+    const int kb = POS_OF(p.blank);
+    const float sw = L.score[cur][n - 1];
+    if (kb != 0xFFFF && sw != NEG) {
+      const float bw = __fadd_rn(LP_AT(kb, p.blank), sw);
+      if (!(bw < min_cutoff)) thr = bw;
+    }
+  }
+  // the same with the bound: log_p + (bound * alpha) + beta, rounded as the reference rounds the score itself (monotone in the bound)
+  auto lm_bound = [&](float lp0, float ub) -> float {
+    const float lpv = __fadd_rn(lp0, (float)__dmul_rn((double)ub, s.alpha));
+    return (float)__dadd_rn((double)lpv, s.beta);
+  };
   if (!MASKED) __syncthreads();
   TICK(0);
   STEP_FENCE();
@@ -1470,6 +1492,10 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
         }
         const uint64_t ck = child_key(L.key[cur][i], c);
         if (p.stamps && wave == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) { L.stm[51] += t_ - xt0_; L.stm[54] += 1; } xt0_ = t_; }
+        // (code-point scorer, see `thr`: a new prefix that cannot reach the beam even with the best language-model score any code point
+        // has is not made; one without a score to come is compared as it is.  Extensions into LIVE prefixes are events of prefixes
+        // that stay: they are never dropped -- decided below, once the hash has been asked)
+        const bool hopeless = SC_UTF8 && thr != NEG && (needs_lm == 0 || s.cp_ub_on != 0) && ((needs_lm ? lm_bound(log_p, s.cp_ub_max) : log_p) < thr);
         int jj = -1;
         {  // (utf8 mode: a one-bit filter first -- a wave pays for its slowest lane's probe sequence, and ~97 % of the lookups miss)
           const uint32_t fb = (uint32_t)(ck >> 28) & (BLOOM_WORDS * 32 - 1);
@@ -1480,7 +1506,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
           L.ev_ext[jj] = log_p;
           L.ev_exti[jj] = (uint32_t)i | (needs_lm << 31);
           if (needs_lm && lm_queue) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = 0x80000000u | (uint32_t)jj; }
-        } else {
+        } else if (!hopeless) {
           const int slot = lds_add(&sc[SC_M], 1);
           if ((uint32_t)slot < S.cand_cap()) {
             const uint32_t piv = (uint32_t)i | ((uint32_t)k << 16) | (needs_lm << 31);
@@ -1515,6 +1541,40 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
   if ((uint32_t)m > S.cand_cap()) { m = (int)S.cand_cap(); if (tid == 0) sc[SC_ERR] |= 4; }
   TICK(2);
   STEP_FENCE();
+
+  // ---- code-point scorer: where will the cut fall?  (`thr` above is the weakest such statement: the WORST live prefix's blank event.)
+  // Every live prefix ends the step at or above max(blank event, repeat event), every new prefix WITHOUT a language-model score to
+  // come ends it exactly at its log-probability: a histogram of these values over [thr - 4, best score] and a count from the top
+  // give a bin below which `beam` entries are already known to lie above -- theta, its lower edge less one bin for the rounding of
+  // the bin arithmetic.  Whatever ends below theta is not in the next beam: new prefixes below it are left out of the selection, and a
+  // new prefix that waits for a language-model score is not scored when log-probability + the best score any code point can have
+  // (DevScorer::cp_ub / cp_ub_max) + beta stays below it.  With near-uniform emissions that is 95 % of the FullScores of a step.
+  float theta = NEG;
+  if (SC_UTF8 && thr != NEG && n + m > beam) {   // (uniform)
+    const float hi = L.score[cur][0], lo = __fsub_rn(thr, 4.0f);
+    const float scale = hi > lo ? 1023.0f / (hi - lo) : 0.0f;
+    auto bin_of = [&](float v) -> uint32_t { if (!(v > lo)) return 0u; const float t_ = (v - lo) * scale; return t_ >= 1023.0f ? 1023u : (uint32_t)t_; };
+    if (tid < n) {
+      const float eb = L.ev_blank[tid], es = L.ev_self[tid];
+      float v = NEG;
+      if (!is_absent(eb)) v = eb;
+      if (!is_absent(es) && es > v) v = es;
+      if (v != NEG) lds_add(&L.hist[bin_of(v)], 1u);
+    }
+    for (int x = tid; x < m; x += NTHREADS) {
+      const uint32_t pi = CAND_PI(x);
+      if (!(pi >> 31)) lds_add(&L.hist[bin_of(CAND_LOGP(x))], 1u);
+    }
+    __syncthreads();
+    const uint32_t hb = L.hist[1023 - tid];   // thread t: bin 1023 - t, so that the scan counts from the top
+    uint32_t all_;
+    const uint32_t above = block_excl_scan(hb, L.wtot, all_);
+    if (above < (uint32_t)beam && (uint32_t)beam <= above + hb) sc[SC_THB] = 1023 - tid;
+    __syncthreads();
+    const int tb = __builtin_amdgcn_readfirstlane(sc[SC_THB]);
+    if (tb >= 2 && scale > 0.0f) theta = lo + (float)(tb - 1) / scale;
+    L.hist[tid] = 0;   // (the selection starts from an empty histogram; a barrier follows before it is used)
+  }
 
   // ---- P3: language model on scoring boundaries (:209-243).  Word mode: the few scored extensions of this step were
   // queued by the expand phase and are taken by the *last* threads of the workgroup, while the first n threads already
@@ -1591,6 +1651,21 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
         uint32_t unit = 0;
         const uint32_t bndi = L.bnd[cur][i];
         if (al.byte_labels && bndi != STT_NONE && utf8_step_clean(L.run[cur][i], L.ch[cur][i] == STT_ROOT_CH, (uint8_t)(first + 1), unit)) {
+          if (theta != NEG && s.cp_ub_on != 0 && x < m) {   // (a NEW prefix only: an extension into a live prefix is an event of a prefix that stays)
+            bool dead = lm_bound(lp0, s.cp_ub_max) < theta;      // no read needed for this one
+            if (!dead && s.cp_ub != nullptr) {
+              const uint32_t b0 = unit & 0xFFu, nbytes = utf8_unit_len(b0);
+              uint32_t cp = 0xFFFFFFFFu;   // the code point these bytes spell (an over-long form lands on the entry of the proper one: a larger bound, still one)
+              if (nbytes == 1) cp = b0;
+              else if (nbytes == 2) cp = ((b0 & 0x1Fu) << 6) | ((unit >> 8) & 0x3Fu);
+              else if (nbytes == 3) cp = ((b0 & 0x0Fu) << 12) | (((unit >> 8) & 0x3Fu) << 6) | ((unit >> 16) & 0x3Fu);
+              if (cp < 65536u) dead = lm_bound(lp0, s.cp_ub[cp]) < theta;
+            }
+            if (dead) {
+              if ((uint32_t)x < L.mcap) L.lc_logp[x] = NEG; else S.c_logp()[x] = NEG;
+              continue;
+            }
+          }
           uint32_t ne;  // one FullScore from the state after the previous code point
           raw = lm_word_query_cached<false>(s, al, S, lab1, (LDS_AS uint32_t*)nullptr, 0u, bndi, true, (uint64_t)unit, 0ULL, ne, probes);
         } else raw = lm_score(s, al, S.pa_generic(), L.node[cur][i], first, true, probes);
@@ -1616,7 +1691,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
     m = __builtin_amdgcn_readfirstlane(sc[SC_M]);
     if ((uint32_t)m > S.cand_cap()) m = (int)S.cand_cap();
   }
-  const int total = n + m;
+  int total = n + m;
   uint64_t kreg0 = ~0ULL, kreg1 = ~0ULL;
   uint32_t hmin = 0xFFFFFFFFu, hmax = 0;
   // bitmap form: log_p of a "prefix i + space" extension with the language-model score of prefix i added (:209-243) -- the score the
@@ -1627,6 +1702,27 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
     const float lpv = __fadd_rn(lp0, lms);                  // log_p += score;
     return (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
   };
+  if (SC_UTF8) {
+    // code-point step: the live prefix's key stays in a register; the new prefixes that can still reach the beam (log-probability at or
+    // above theta) put {key, element} on ONE compact list in the stream's workspace -- with theta in force a few thousand of the ~60 k
+    // a step makes -- and the selection below walks that list instead of every candidate
+    if (tid < n) {
+      const float nscore = merged ? my_score : merge_live<WIDE>(p, L, W, cur, tid);
+      kreg0 = sel_key(nscore, L.ch[cur][tid], 0, (uint32_t)tid);
+      const uint32_t kh = (uint32_t)(kreg0 >> 32);
+      hmin = kh; if (kh != NEG_HI) hmax = kh;
+    }
+    for (int x = tid; x < m; x += NTHREADS) {
+      const float lpx = CAND_LOGP(x);
+      if (lpx < theta) continue;   // (also the new prefixes parked at -inf above; theta == -inf: nothing is left out)
+      const uint32_t pi = CAND_PI(x);
+      const uint64_t k = sel_key(lpx, CLS_AT((pi >> 16) & 0x7FFFu), 1, pi & 0xFFFFu);
+      const uint32_t at = lds_add((LDS_AS uint32_t*)&sc[SC_NS], 1u);
+      S.sel_keys()[at] = k; S.c_elem()[at] = (uint32_t)(n + x);
+      const uint32_t kh = (uint32_t)(k >> 32);
+      hmin = kh < hmin ? kh : hmin; if (kh != NEG_HI) hmax = kh > hmax ? kh : hmax;
+    }
+  } else
   for (int e = tid, r = 0; e < total; e += NTHREADS, ++r) {
     uint64_t k;
     if (e < n) {  // e == tid: either merged during the LM phase, or it waited for a score
@@ -1647,12 +1743,16 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
     const uint32_t kh = (uint32_t)(k >> 32);
     hmin = kh < hmin ? kh : hmin; if (kh != NEG_HI) hmax = kh > hmax ? kh : hmax;
   }
-#define KEY_OF(e, r) ((r) == 0 ? kreg0 : (r) == 1 ? kreg1 : S.sel_keys()[e])
+  // element q of the selection: its key / which prefix it is (live prefix e < n, else candidate slot e - n).  Code-point step: q < n is
+  // the live prefix q (key in kreg0 of thread q), q >= n entry q - n of the compact list; everywhere else q IS the element.
+#define KEY_OF(e, r) (SC_UTF8 ? ((e) < n ? kreg0 : S.sel_keys()[(e) - n]) : ((r) == 0 ? kreg0 : (r) == 1 ? kreg1 : S.sel_keys()[e]))
+#define ELEM_OF(e) (SC_UTF8 ? ((e) < n ? (uint32_t)(e) : S.c_elem()[(e) - n]) : (uint32_t)(e))
   hmin = wave_min_u32(hmin); hmax = wave_max_u32(hmax);
   if (lane == 0) { lds_min((LDS_AS uint32_t*)&sc[SC_KMIN], hmin); lds_max((LDS_AS uint32_t*)&sc[SC_KMAX], hmax); }
   __syncthreads();
   TICK(4);
   STEP_FENCE();
+  if (SC_UTF8) total = n + (int)__builtin_amdgcn_readfirstlane(sc[SC_NS]);
 
   // ---- P5: keep the best beam_size (nth_element + resize, :263-274) in sorted order.  Keys are unique, so the rank of
   // a key is its position in the new beam.  Bucket the keys over their live range (NBUCKET bins of 2^sh), prefix-sum the
@@ -1704,7 +1804,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
           const uint32_t seg0 = (uint32_t)off + L.cumb[b];
           const uint32_t len = L.cumb[b + 1] - L.cumb[b];
           const uint32_t at = seg0 + (lds_sub(&L.hist[b], 1u) - 1u);
-          L.skey[at] = k; L.ssrc[at] = (uint32_t)e; L.sseg[at] = seg0 | (len << 16);
+          L.skey[at] = k; L.ssrc[at] = ELEM_OF(e); L.sseg[at] = seg0 | (len << 16);
         }
       }
       if (last) { placed = (uint32_t)off + btcum + bth; break; }
@@ -1867,6 +1967,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
   }
 #undef REKEY
 #undef KEY_OF
+#undef ELEM_OF
 #undef POS_OF
 #undef CLS_AT
 #undef LP_AT

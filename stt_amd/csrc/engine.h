@@ -96,7 +96,7 @@ class ScorerDev {
 
  private:
   int Parse(const uint8_t* buf, size_t len, int space_label, bool lm_only);
-  DevBuf blob_, fst_pos_, fst_arcs_, fst_space_, fst_rec_, vtab_, hint_, lmi_, memo_;
+  DevBuf blob_, fst_pos_, fst_arcs_, fst_space_, fst_rec_, vtab_, hint_, lmi_, memo_, cp_ub_;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -186,6 +186,77 @@ static bool build_lm_index(HostScorer& hs) {
   return true;
 }
 
+// Code-point scorers: how good can the language-model score of a candidate that completes code point u possibly be?
+// GenericModel::FullScore (lm/model.cc:170-176) returns the probability of the LONGEST stored n-gram that ends with u -- an entry of
+// u's sub-trie in the reverse trie -- plus the backoffs of the context n-grams that were too long to match (:312-338).  So
+//     log10 P(u | any history) <= max over u's sub-trie of prob  +  sum over orders k < order of max(0, largest backoff of order k)
+// whatever the history is.  The search kernel compares this bound with a score that 'beam' other prefixes are already known to reach
+// and skips the FullScore (three to four dependent reads) of every candidate that cannot make it (ctc.hip, P3 of the code-point step).
+// The table is indexed by code point (one read, no vocabulary probe); a code point the model does not know carries OOV_SCORE.
+static void build_unit_bounds(HostScorer& hs) {
+  const int ord = hs.order;
+  const uint64_t n1 = hs.counts[0];
+  const uint8_t* buf = hs.buf;
+  std::vector<float> ub(n1);
+  float bplus = 0.0f;
+  { float mb = 0.0f; for (uint64_t w = 0; w < n1; ++w) { ub[w] = rdf(buf + hs.unigram_off + 16 * w); mb = std::max(mb, rdf(buf + hs.unigram_off + 16 * w + 4)); } bplus += mb; }
+  std::vector<uint32_t> root_prev(n1), root_cur;
+  for (uint64_t w = 0; w < n1; ++w) root_prev[w] = (uint32_t)w;
+  std::vector<uint64_t> next_prev(n1 + 1), next_cur;
+  for (uint64_t w = 0; w <= n1; ++w) next_prev[w] = rd64(buf + hs.unigram_off + 16 * w + 8);
+  for (int level = 2; level <= ord; ++level) {
+    const bool is_longest = level == ord;
+    const int om2 = level - 2;
+    const HostBitPacked& bp = is_longest ? hs.lon : hs.mid[om2];
+    const uint64_t cnt = hs.counts[level - 1];
+    const uint8_t* base = buf + bp.base_off;
+    const uint64_t next_mask = bp.next_bits >= 64 ? ~0ULL : (1ULL << bp.next_bits) - 1;
+    if (next_prev.back() != cnt) { hs.cp_ub.clear(); return; }
+    if (!is_longest) {
+      next_cur.assign(cnt + 1, 0);
+      const uint64_t* offs = bp.off_begin_off ? reinterpret_cast<const uint64_t*>(buf + bp.off_begin_off) : nullptr;
+      const uint32_t ocnt = bp.off_count;
+      uint64_t bi = 0;
+      for (uint64_t c = 0; c <= cnt; ++c) {
+        const uint64_t lo = rd57(base, c * bp.total_bits + bp.word_bits + bp.quant_bits, next_mask);
+        if (offs) { while (bi + 1 < ocnt && offs[bi + 1] <= c) ++bi; next_cur[c] = (bi << bp.next_bits) | lo; }
+        else next_cur[c] = lo;
+      }
+    }
+    root_cur.assign(cnt, 0);
+    float mb = 0.0f;
+    for (uint64_t pnt = 0; pnt < root_prev.size(); ++pnt) {
+      const uint64_t cb = next_prev[pnt], ce = next_prev[pnt + 1];
+      if (cb > ce || ce > cnt) { hs.cp_ub.clear(); return; }
+      for (uint64_t c = cb; c < ce; ++c) {
+        root_cur[c] = root_prev[pnt];
+        const float pr = is_longest ? hs.longest_prob(c) : hs.middle_prob(om2, c);
+        float& u = ub[root_prev[pnt]];
+        if (pr > u) u = pr;
+        if (!is_longest) mb = std::max(mb, hs.middle_backoff(om2, c));
+      }
+    }
+    bplus += mb;
+    root_prev.swap(root_cur); next_prev.swap(next_cur);
+  }
+  auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; };
+  hs.cp_ub.assign(65536, -1000.0f);   // OOV_SCORE (scorer.h:16)
+  float mx = -1000.0f;                // (over EVERY unit of the vocabulary, also those beyond U+FFFF that have no table entry)
+  for (uint64_t w = 0; w < n1; ++w) mx = std::max(mx, up(((double)ub[w] + (double)bplus) / (double)0.4342944819f));
+  for (uint32_t cp = 1; cp < 65536; ++cp) {
+    unsigned char u[3]; size_t n;
+    if (cp < 0x80) { u[0] = (unsigned char)cp; n = 1; }
+    else if (cp < 0x800) { u[0] = (unsigned char)(0xC0 | (cp >> 6)); u[1] = (unsigned char)(0x80 | (cp & 0x3F)); n = 2; }
+    else { u[0] = (unsigned char)(0xE0 | (cp >> 12)); u[1] = (unsigned char)(0x80 | ((cp >> 6) & 0x3F)); u[2] = (unsigned char)(0x80 | (cp & 0x3F)); n = 3; }
+    const uint32_t w = hs.vocab_index(murmur64a(u, n, 0));
+    if (w == 0 || w >= n1) continue;
+    // get_log_cond_prob: cond_prob / NUM_FLT_LOGE (scorer.cpp:344), the constant being the float 0.4342944819
+    const float v = up(((double)ub[w] + (double)bplus) / (double)0.4342944819f);
+    hs.cp_ub[cp] = v;
+  }
+  hs.cp_ub_max = mx;
+}
+
 // SortedVocabulary::Index (lm/vocab.hh:72-83): binary search over the sorted hashes (host side)
 uint32_t HostScorer::vocab_index(uint64_t h) const {
   uint64_t lo = 0, hi = vocab_n;
@@ -446,6 +517,7 @@ int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, 
   try { hs.lmi_ok = index_usable && build_lm_index(hs); }
   catch (const std::bad_alloc&) { hs.lmi_ok = false; }  // no memory for the table: the scorer still loads (trie walk), as it does in the reference
   if (!hs.lmi_ok) { hs.lmi.clear(); hs.lmi.shrink_to_fit(); hs.lmi_buckets = 0; }
+  if (hs.utf8 && !lm_only && tune().unit_bounds != 0) build_unit_bounds(hs);
   return STT_ERR_OK;
 }
 
@@ -521,6 +593,12 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label, bool lm_on
   }
   ds.lmi = hs.lmi_ok ? lmi_.as<LmiEntry>() : nullptr; ds.lmi_buckets = hs.lmi_buckets;
   ds.unk_prob = hs.unk_prob; ds.unk_backoff = hs.unk_backoff; ds.unk_indep = hs.unk_indep ? 1 : 0;
+  // (unit_bounds 1: only the largest bound is used -- a comparison, no read; 2: the per-code-point table as well: one more read per
+  // candidate, worth it only where the bounds differ from unit to unit; measured a loss on both benchmark scorers)
+  if (!hs.cp_ub.empty()) {
+    ds.cp_ub_max = hs.cp_ub_max; ds.cp_ub_on = 1;
+    if (tune().unit_bounds >= 2) { cp_ub_.upload(hs.cp_ub.data(), hs.cp_ub.size() * 4); ds.cp_ub = cp_ub_.as<float>(); }
+  }
   const bool memo_on = tune().lm_memo != 0;  // (0: measure without)
   if (hs.utf8 && ord <= 5 && !lm_only && memo_on) {  // FullScore cache of the code-point search (ctc.h: DevScorer::memo)
     const size_t n = (size_t)1 << 18;

@@ -47,6 +47,10 @@ struct HostScorer {
   uint32_t lmi_buckets = 0;
   float unk_prob = 0.0f, unk_backoff = 0.0f;
   bool unk_indep = true;
+  // code-point scorers: an upper bound of get_log_cond_prob() (natural log, rounded up to float) of any n-gram that ENDS with the
+  // code point, indexed by code point (U+0000 .. U+FFFF); empty = none (scorer_dev.cpp: build_unit_bounds)
+  std::vector<float> cp_ub;
+  float cp_ub_max = 0.0f;
 
   float middle_prob(int om2, uint64_t at) const;
   float middle_backoff(int om2, uint64_t at) const;

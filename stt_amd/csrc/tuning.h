@@ -37,6 +37,7 @@
   X(exp_waves, 0, "expand waves of the search step (0 = all the others)")                                                          \
   X(item_table_cap, 0, "test hook: items per pass of the bitmap step's expand table (0 = what fits; small values force the several-pass path)") \
   X(lm_memo, 1, "code-point scorer: FullScore memo table")                                                                         \
+  X(unit_bounds, 1, "code-point scorer: upper bounds of the LM score (candidates that cannot reach the beam skip FullScore): 1 = the largest over all units, 2 = also a table by code point; read when a scorer is loaded") \
   X(dict_tree_mb, 2048, "dictionary unfolded into a tree (no arc reads in the search): byte cap in MiB, 0 = keep the automaton")           \
   X(lm_index_mb, 4096, "hashed n-gram index: byte cap in MiB (larger models take the trie walk)")                                  \
   X(arena_shrink, 1, "test hook: divides the optimistic arena sizes of a batch group (forces the overflow -> decode-again path)")        \

@@ -23,9 +23,12 @@ def generate_scorer_package(lm, vocab, package, alphabet=None, force_bytes_outpu
     return package
 
 
-def synth_lm(out, vocab_out, words=100000, order=5, seed=1, avg=None):
+def synth_lm(out, vocab_out, words=100000, order=5, seed=1, avg=None, codepoints=False):
+    """codepoints=True: the units are `words` distinct three-byte code points (a code-point level LM for a bytes-output scorer)."""
     cmd = [_tool(), "synth-lm", "--words", str(int(words)), "--order", str(int(order)), "--seed", str(int(seed)),
            "--out", out, "--vocab-out", vocab_out]
+    if codepoints:
+        cmd += ["--codepoints", "1"]
     for n, v in (avg or {}).items():
         cmd += ["--avg%d" % int(n), repr(float(v))]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)

@@ -8,7 +8,9 @@
 //       that is minimised by merging identical sub-trees, which yields the same minimal deterministic acceptor
 //       (state numbering differs; the decoder only follows arcs).
 //
-//   stt_scorer_tools synth-lm --words N --order K --seed S --out lm.binary --vocab-out vocab.txt
+//   stt_scorer_tools synth-lm --words N --order K --seed S --out lm.binary --vocab-out vocab.txt [--codepoints 1]
+//       (--codepoints: the "words" are N distinct three-byte UTF-8 code points from U+4E00 on -- the units of a code-point level
+//        language model for a bytes-output scorer, doc/DECODER.rst:193; package the result with `package --bytes`)
 //                             [--avg2 a --avg3 b --avg4 c --avg5 d]
 //       Writes a synthetic KenLM language model directly in the binary format KenLM's `build_binary -a 255 -q 8 -v trie`
 //       produces (model type QUANT_ARRAY_TRIE, no vocabulary strings): the benchmark needs a huge-vocabulary scorer and
@@ -111,10 +113,18 @@ int synth_lm(const std::map<std::string, std::string>& a) {
   if (out.empty() || order < 2 || order > 6) { std::cerr << "synth-lm: need --out and 2 <= --order <= 6\n"; return 2; }
   double avg[7] = {0, 0, std::stod(get("avg2", "8")), std::stod(get("avg3", "1.0")), std::stod(get("avg4", "0.6")), std::stod(get("avg5", "0.5")), std::stod(get("avg6", "0.4"))};
   std::mt19937_64 rng(seed);
+  const bool codepoints = get("codepoints", "0") != "0";
+  if (codepoints && n_words > 20000) { std::cerr << "synth-lm: --codepoints takes at most 20000 units (U+4E00 .. U+9C1F)\n"; return 2; }
 
   // ---- vocabulary: distinct pronounceable pseudo-words; index = rank of the MurmurHash64A + 1 (lm/vocab.hh:72-83)
   std::unordered_set<std::string> seen = {"<s>", "</s>"};
   std::vector<std::string> words = {"<s>", "</s>"};
+  if (codepoints) {   // unit i = U+4E00 + i as UTF-8 (three bytes: E4 B8 80 ...), in a seeded random order so that the Zipfian ranks are spread over the block
+    std::vector<uint32_t> cps(n_words);
+    for (uint32_t i = 0; i < n_words; ++i) cps[i] = 0x4E00u + i;
+    std::shuffle(cps.begin(), cps.end(), rng);
+    for (uint32_t cp : cps) { const char u[4] = {(char)(0xE0 | (cp >> 12)), (char)(0x80 | ((cp >> 6) & 0x3F)), (char)(0x80 | (cp & 0x3F)), 0}; words.push_back(std::string(u, 3)); }
+  }
   while (words.size() < n_words + 2) { std::string w = make_word(rng); if (w.size() <= 15 && seen.insert(w).second) words.push_back(w); }
   const uint64_t V = words.size() + 1;  // + <unk> (index 0)
   std::vector<std::pair<uint64_t, uint32_t>> hashed(words.size());

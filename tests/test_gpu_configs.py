@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+from conftest import canon
 from stt_amd import dist, modelfile, synth
 
 pytestmark = pytest.mark.gpu
@@ -163,3 +164,42 @@ def test_other_sample_rates_take_the_reference_fft_length(tmp_path, sr, win, ste
     for k in range(0, len(a), 16 * step):
         s.feedAudioContent(a[k:k + 16 * step])
     assert s.finishStream() == text
+
+
+def test_config5_code_point_scorer_with_three_byte_units(tmp_path, port, ref):
+    """configs[4] on the scorer SURVEY.md 8d names: a code-point level LM (three-byte units, `synth-lm --codepoints`) in bytes-output
+    mode.  A full beam takes the code-point step's pruning (ctc.hip: `thr` / `theta` -- new prefixes that provably cannot reach the beam
+    are left out of the selection and are not scored): complete N-best lists, scores and timesteps must still be the REAL reference
+    decoder's, on near-uniform emissions (everything is a candidate) and on peaky ones, beams 64 / 1024, in one piece and in chunks."""
+    from stt_amd import Model, scorertools
+    lm, vocab, pkg = str(tmp_path / "cp.binary"), str(tmp_path / "cp.vocab"), str(tmp_path / "cp.scorer")
+    scorertools.synth_lm(lm, vocab, words=6000, order=5, seed=9, avg={2: 60, 3: 2.0, 4: 1.0, 5: 0.7}, codepoints=True)
+    scorertools.generate_scorer_package(lm, vocab, pkg, force_bytes_output_mode=True, default_alpha=0.93, default_beta=1.18)
+    units = open(vocab, encoding="utf-8").read().split()
+    ulabels, uspace = port.utf8_alphabet()
+    w = synth.synth_weights(44, n_hidden=128, n_classes=256)
+    path = str(tmp_path / "bytes.sttw")
+    modelfile.write_model(path, w, ulabels, beam_width=1024)
+    m = Model(path)
+    m.enableExternalScorer(pkg)
+    A = ref.Alphabet(None)
+    S = ref.Scorer(pkg, A)
+    rng = np.random.RandomState(5)
+    cases = []
+    logits = rng.randn(40, 256) * 0.5
+    pu = np.exp(logits); cases.append(("near-uniform", (pu / pu.sum(1, keepdims=True)).astype(np.float32)))
+    text = "".join(rng.choice(units, size=8)).encode("utf-8")
+    cases.append(("peaky", synth.peaky_emissions([b - 1 for b in text], 30 + 5 * len(text), 256, 255, seed=3, noise=0.2)))
+    for name, p in cases:
+        for beam in (64, 1024):
+            for chunk in (0, 7):
+                dr = ref.Decoder(A, beam, S); dr.next(p.astype(np.float64))
+                d = m.createDecoder(1, beam)
+                if chunk:
+                    for i in range(0, len(p), chunk):
+                        d.next(p[i:i + chunk])
+                else:
+                    d.next(p)
+                assert d.stats()["error"] == 0
+                k = min(beam, 20)
+                assert canon(d.decode(k)[0]) == canon(dr.decode(k)), (name, beam, chunk)

@@ -99,3 +99,34 @@ def test_synth_lm_against_real_kenlm_reader(port, ref, english, synth_scorer, fi
             dr = ref.Decoder(A, beam, S); dp = port.Decoder(labels, space, beam, P)
             dr.next(p.astype(np.float64)); dp.next(p)
             assert canon(dr.decode(beam)) == canon(dp.decode(beam)), (it, beam)
+
+
+def test_synth_code_point_lm_packaged_in_bytes_mode(port, ref, tmp_path):
+    """`synth-lm --codepoints`: the units are three-byte code points (the scorer SURVEY.md 8d Config 5 names: a code-point level LM in
+    bytes-output mode).  The REAL KenLM + OpenFst read the package, agree with the port on random n-grams, and the two decoders agree
+    on byte-alphabet emissions that spell units of the vocabulary."""
+    lm, vocab, pkg = str(tmp_path / "cp.binary"), str(tmp_path / "cp.vocab"), str(tmp_path / "cp.scorer")
+    scorertools.synth_lm(lm, vocab, words=500, order=4, seed=3, avg={2: 40, 3: 2.0, 4: 1.0}, codepoints=True)
+    scorertools.generate_scorer_package(lm, vocab, pkg, force_bytes_output_mode=True, default_alpha=0.9, default_beta=1.1)
+    units = open(vocab, encoding="utf-8").read().split()
+    assert len(units) == 500 and all(len(u) == 1 and len(u.encode("utf-8")) == 3 for u in units)
+    A = ref.Alphabet(None)
+    S = ref.Scorer(pkg, A)
+    P = port.Scorer(pkg)
+    assert S.utf8 and S.order == 4 and (P.utf8, P.order) == (True, 4)
+    rng = np.random.RandomState(1)
+    for it in range(600):
+        ws = [units[min(len(units) - 1, int(rng.zipf(1.4)) - 1)] for _ in range(rng.randint(1, 6))]
+        if rng.rand() < 0.05:
+            ws[0] = "Ж"                                   # a two-byte code point the model does not know
+        bos = bool(it & 1)
+        assert S.log_cond_prob(ws, bos) == P.log_cond_prob(ws, bos), (ws, bos)
+    ulabels, uspace = port.utf8_alphabet()
+    for it, noise in enumerate((0.02, 0.3)):
+        text = "".join(rng.choice(units, size=6)).encode("utf-8")
+        lab = [b - 1 for b in text]                            # UTF8Alphabet: label = byte - 1
+        p = synth.peaky_emissions(lab, 30 + 5 * len(lab), 256, 255, seed=60 + it, noise=noise)
+        for beam in (40, 200):
+            dr = ref.Decoder(A, beam, S); dp = port.Decoder(ulabels, uspace, beam, P)
+            dr.next(p.astype(np.float64)); dp.next(p)
+            assert canon(dr.decode(min(beam, 20))) == canon(dp.decode(min(beam, 20))), (it, beam)
