@@ -51,7 +51,9 @@ STTX_EXPORT char** STTX_SpeechToTextBatchDevice(ModelState* aCtx, const short* a
  * the groups in flight run one after the other, each group's beam search beside the acoustic model and the searches of its
  * neighbours.  Where the recurrent kernel covers 128 rows, two consecutive submits form ONE group (the recurrent matrix is
  * streamed once per step for both): the first of the two is enqueued together with the second -- or alone, when it is collected
- * first.  Transcripts never depend on how batches were grouped. */
+ * first.  Transcripts never depend on how batches were grouped.  Collect batches in the order they were submitted: slots are taken
+ * round-robin, and a submit whose slot still holds an uncollected batch is refused ("the pipeline is full") even if another slot is
+ * free.  A first half of a pair starts no GPU work until its partner is submitted or it is collected. */
 STTX_EXPORT int STTX_BatchPipelineDepth(void);
 /* ... for THIS model as configured now: a search-bound setup (code-point scorer, beam width beyond 512) takes four slots and
  * runs their searches side by side, everything else two. */

@@ -170,7 +170,8 @@ struct BatchPart {
 // `stream`, the beam search of every chunk + the final ranking + the copy of the results to page-locked memory on
 // `stream_dec`, then the slot's `done` event.
 void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::vector<BatchPart>& parts, unsigned num_results, const DevScorer& ds,
-                         bool pipelined, hipEvent_t gate = nullptr, bool optimistic = true) {
+                         bool pipelined, hipEvent_t gate = nullptr, bool optimistic = true, const std::shared_ptr<ScorerDev>* scorer_then = nullptr) {
+  const std::shared_ptr<ScorerDev> scorer = scorer_then ? *scorer_then : m->scorer_;   // (a retry: the scorer of the first attempt)
   int Bg = 0;
   for (const BatchPart& pt : parts) Bg += (int)pt.idx.size();
   {  // remember the group (the callers' size arrays do not outlive their call); `parts` may itself be built on a moved-out copy of this
@@ -185,6 +186,7 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::ve
     sl.saved_parts = std::move(keep);
   }
   sl.saved_num_results = num_results; sl.saved_pipelined = pipelined; sl.optimistic = optimistic;
+  sl.saved_ds = ds; sl.saved_scorer = scorer;
   if (gate) HIP_CHECK(hipStreamWaitEvent(sl.stream_dec, gate, 0));  // this group's SEARCH starts behind group g - active; its acoustic model does not wait
   const int which = 1 + (int)(&sl - &m->slots_[0]);  // profiling mark list of this group's search stream
   // small integer tables in one page-locked block: [n_samples | n_frames | audio row | per chunk: begin, count]
@@ -235,7 +237,7 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::ve
     }
   }
   // decoder streams of the group
-  m->decoder_create(sl.dec, Bg, (int)m->beam_width_, t_max, m->scorer_, &sl.h_table, optimistic);
+  m->decoder_create(sl.dec, Bg, (int)m->beam_width_, t_max, scorer, &sl.h_table, optimistic);
   sl.probs.reserve((size_t)Bg * t_max * m->g.n_classes * 4);
   DecParams p{};
   p.C = m->g.n_classes; p.blank = p.C - 1; p.beam = sl.dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = t_max;
@@ -296,13 +298,16 @@ void batch_collect_group(ModelState* m, ModelState::GroupSlot& sl, std::vector<s
     int err = 0;
     for (int i = 0; i < sl.Bg; ++i) err |= h0.errors[i];
     if (err & 0xB) {
-      ++tune().arena_retries;
+      __atomic_fetch_add(&tune().arena_retries, 1, __ATOMIC_RELAXED);   // (a fleet collects on one thread per device)
       std::vector<unsigned> keep_idx = sl.idx;
       const std::vector<ModelState::GroupSlot::SavedPart> saved = std::move(sl.saved_parts);  // (alive while the group is enqueued again)
       std::vector<BatchPart> parts;
       for (const auto& sp : saved) parts.push_back(BatchPart{sp.d_audio, sp.stride, sp.sizes.data(), sp.idx});
-      const DevScorer ds = m->current_scorer(m->scorer_, m->hot_words_, m->hot_tables_, /*in_flight=*/true);
-      batch_enqueue_group(m, sl, parts, sl.saved_num_results, ds, sl.saved_pipelined, nullptr, /*optimistic=*/false);
+      // under the scorer, hot words and alpha / beta the group was SUBMITTED with -- not what the model holds now (STT_AddHotWord or a
+      // scorer swap between submit and collect must not change a batch only when its arenas happened to overflow)
+      const DevScorer ds = sl.saved_ds;
+      const std::shared_ptr<ScorerDev> scorer_then = sl.saved_scorer;
+      batch_enqueue_group(m, sl, parts, sl.saved_num_results, ds, sl.saved_pipelined, nullptr, /*optimistic=*/false, &scorer_then);
       sl.idx = keep_idx;
       HIP_CHECK(hipEventSynchronize(sl.done));
     }

@@ -114,7 +114,7 @@ struct DecStream {
   int abs_t;            // abs_time_step_
   int start_expanding;  // ctc_beam_search_decoder.cpp:125-132
   int error;            // bit0: path arena full, bit1: time arena full, bit2: candidate workspace full, bit3: scorer cache state lost /
-                        // boundary-entry arena full, bit4: a path-hash hit was not the child it stood for.  Sticky; every decode call
+                        // boundary-entry arena full, bit4: an intra-workgroup counter wait of the bitmap step timed out.  Sticky; every decode call
                         // reports it (STT_* return NULL / STT_ERR_FAIL_RUN_SESS instead of a transcript from a damaged beam)
   uint32_t pa_n, ta_n, pa_cap, ta_cap;
   // beam arrays [beam_cap]
@@ -154,6 +154,7 @@ struct DecParams {
   int wide_max_frames;
   int lds_kb;       // LDS budget of the search kernel's layout in KiB (filled in by launch_ctc_next; host and device carve the same layout)
   int item_cap;    // bitmap step, test hook: items the expand table holds per pass (0 = all it has room for; filled in by launch_ctc_next)
+  int wait_spins;  // bitmap step: polls a counter wait may take before it gives up with error bit 0x10 (filled in by launch_ctc_next)
   int n_lm_waves;  // bitmap step: waves of the workgroup that only run language-model queries (0 = by beam width; filled in by launch_ctc_next)
   // profiling level 2: [n_streams][64] shader cycles, summed over the steps.  Slots: [w] wave w reaches the end of the expand phase
   // (since the step began; wave 0: since its last phase tick), [16 + w] its wait there, [32 + w] (bitmap step) arrival at the end of

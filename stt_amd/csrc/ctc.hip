@@ -1072,13 +1072,19 @@ __device__ __forceinline__ float merge_live(const DecParams& p, const Lds& L, co
 // Wait until an LDS counter (bumped once per arriving wave, after a release fence) reaches `want`: a barrier among SOME of the waves
 // of the workgroup (s_barrier always takes all of them).  Scalar loop control (see the note on uniform control flow in ctc_step);
 // bounded, so that a logic error shows up as error bit 16 instead of a hung GPU.
-__device__ __forceinline__ void wait_count(LDS_AS int* ctr, uint32_t want, LDS_AS int* err) {
+// Returns false when it gave up: the caller must then NOT consume what the counter stands for (an item table that is not complete
+// holds whatever the selection left there -- indices that lead out of every table).
+__device__ __forceinline__ bool wait_count(LDS_AS int* ctr, uint32_t want, LDS_AS int* err, int max_spins) {
   int spins = 0;
+  bool ok = true;
   while ((uint32_t)__builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) {
     __builtin_amdgcn_s_sleep(4);   // (256 cycles: the waiting waves' polls are instructions the working waves cannot issue)
-    if (++spins > (1 << 16)) { lds_or(err, 16); break; }
+    // (the bound is there so that a logic error ends as an error bit, not as a hung GPU: 4 M polls are half a second -- a correct run
+    // under a serialising profiler or starved by priority-3 co-tenants stays far below it)
+    if (++spins > max_spins) { lds_or(err, 16); ok = false; break; }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return ok;
 }
 __device__ __forceinline__ void signal_count(LDS_AS int* ctr) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1337,12 +1343,12 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
         signal_count(&sc[SC_FILL]);
       }
       if (pass == 0) TICK(1);
-      wait_count(&sc[SC_FILL], (uint32_t)((n + 63) >> 6), &sc[SC_ERR]);
+      const bool filled = wait_count(&sc[SC_FILL], (uint32_t)((n + 63) >> 6), &sc[SC_ERR], p.wait_spins);
       const bool stw_ = p.stamps != nullptr && wave == 9;   // profiling level 2: wave 9 (a pure consumer) stamps its item loop
       unsigned long long ct0_ = 0;
       if (stw_) { ct0_ = __builtin_readcyclecounter(); if (lane == 0) L.stm[50] += ct0_ - tick_; }   // table complete (since the step began)
       const uint32_t total_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((LDS_AS uint32_t*)&sc[SC_NI], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-      const uint32_t n_items = total_items < own_n ? total_items : own_n;
+      const uint32_t n_items = !filled ? 0u : (total_items < own_n ? total_items : own_n);   // (a wait that gave up: this wave takes no items)
       // (Two items per lane -- 128-item chunks, both chains of LDS round trips in flight -- measured SLOWER, 3.92 against 3.81 ms per
       // 64 x 250 frames: a chunk then took twice as long.  The phase is bound by instruction issue, not by the latency of the chain.)
       // The loop is controlled by scalars only (the chunk cursor read through lane 0, the item count): a uniform branch.  Lanes past
@@ -1529,7 +1535,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
     // The end of the expand phase is a barrier among the item-taking waves only (a counter): the LM waves are still in their
     // queries, and what the later phases need from them -- the scores of this step's "prefix + space" extensions -- is only read
     // in the key phase, after the next real barrier (score_ext below); an LM wave goes straight to that barrier when it is done.
-    if (!lmw_) { signal_count(&sc[SC_DONE]); wait_count(&sc[SC_DONE], n_cons, &sc[SC_ERR]); }
+    if (!lmw_) { signal_count(&sc[SC_DONE]); (void)wait_count(&sc[SC_DONE], n_cons, &sc[SC_ERR], p.wait_spins); }
   } else __syncthreads();
   if (p.stamps && lane == 0) L.stm[16 + wave] += __builtin_readcyclecounter() - arrive_;
   if (!MASKED && p.stamps && tid == 0) {
@@ -2260,6 +2266,7 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
     check_launch("ctc_wide_rows_kernel");
   }
   p.n_lm_waves = tune().lm_waves; p.item_cap = tune().item_table_cap;
+  p.wait_spins = tune().wait_spins > 0 ? tune().wait_spins : (1 << 22);
   const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : ((!wide && ctc_masked_ok(p, s, al)) ? 4 : 1));
   const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : (mode == 4 ? 32 : p.C), s.enabled && s.utf8);   // (mode 4: the kernel carves its layout for 32 classes)
   p.lds_kb = lds_budget_kb_host();

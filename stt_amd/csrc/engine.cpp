@@ -409,7 +409,7 @@ void check_decoder_errors(const int* errors, int n) {
   if (err) {
     char hex[16];
     snprintf(hex, sizeof(hex), "0x%x", (unsigned)err);
-    throw std::runtime_error(std::string("decoder state error bits ") + hex + " (0x1 path arena, 0x2 time arena, 0x4 candidates, 0x8 scorer cache, 0x10 path hash)");
+    throw std::runtime_error(std::string("decoder state error bits ") + hex + " (0x1 path arena, 0x2 time arena, 0x4 candidates, 0x8 scorer cache, 0x10 intra-workgroup counter wait timed out)");
   }
 }
 

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "ctc.h"
+#include "tuning.h"
 #include "kernels.h"
 
 #define HIP_CHECK(expr)                                                                                   \
@@ -231,6 +232,8 @@ struct ModelState {
     // what the group was made of (so that it can be decoded again with full-size arenas if one overflowed) and how it was sized
     struct SavedPart { const int16_t* d_audio; unsigned stride; std::vector<unsigned> sizes, idx; };
     std::vector<SavedPart> saved_parts;
+    DevScorer saved_ds{};                       // the scorer description the group was enqueued with (its tables stay alive while the
+    std::shared_ptr<ScorerDev> saved_scorer;    // group is in flight: retired_bufs_ / this reference): a retry decodes under the SAME scorer
     unsigned saved_num_results = 1;
     bool saved_pipelined = false, optimistic = false;
     bool results_ready = false;
@@ -282,6 +285,7 @@ struct ModelState {
   // chunk [t0, t0+T) of a batch through the three engines; `done` is recorded on stream_o behind the softmax
   void run_acoustic_chunk_piped(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs, hipEvent_t done);
 
+  ModelState() { tuning_model_count(+1); }   // (tuning.h: load-time knobs are frozen while a model is alive)
   ~ModelState();
   int InitFromBuffer(const char* buf, size_t len);  // STT_ERR_* code
   MfccArgs mfcc_args() const;

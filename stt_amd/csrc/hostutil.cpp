@@ -1,4 +1,5 @@
 // stt_amd/csrc/hostutil.cpp -- device buffers, Alphabet (native_client/alphabet.{h,cc}).
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,8 +18,13 @@ const TuneEntry kTune[] = {
 #undef X
 };
 }  // namespace
+static std::atomic<int> g_models_alive{0};
+void tuning_model_count(int delta) { g_models_alive += delta; }
 int tuning_set(const char* name, int value) {
   if (!name) return -1;
+  // lstm_upw decides how the recurrent matrix is PACKED when a model is loaded, and every recurrent launch reads it again: changed
+  // under a live model the kernel shape would no longer match the packed matrix (wrong probabilities, silently).  Refused.
+  if (!strcmp(name, "lstm_upw") && g_models_alive.load() > 0 && value != tune().lstm_upw) return -1;
   for (const TuneEntry& e : kTune)
     if (!strcmp(e.name, name)) { tune().*(e.field) = value; return 0; }
   return -1;

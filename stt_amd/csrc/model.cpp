@@ -70,6 +70,7 @@ void pack_lstm_recurrent_host(const float* kernel, int H, _Float16* out) {
 }
 
 ModelState::~ModelState() {
+  tuning_model_count(-1);
   for (StreamingState* s : stream_pool_) delete s;
   if (stream) (void)hipStreamDestroy(stream);
   if (stream_dec) (void)hipStreamDestroy(stream_dec);

@@ -35,6 +35,7 @@
   X(search_step, 2, "word-mode search step: 2 = label bitmaps + indexed FullScore where it applies, 0 = generic step")              \
   X(lm_waves, 0, "language-model waves of the search step (0 = by beam width)")                                                    \
   X(exp_waves, 0, "expand waves of the search step (0 = all the others)")                                                          \
+  X(wait_spins, 0, "test hook: polls (of 256 cycles) an intra-workgroup counter wait of the search step may take before it gives up with error bit 0x10 (0 = 4 M, about half a second)") \
   X(item_table_cap, 0, "test hook: items per pass of the bitmap step's expand table (0 = what fits; small values force the several-pass path)") \
   X(lm_memo, 1, "code-point scorer: FullScore memo table")                                                                         \
   X(unit_bounds, 1, "code-point scorer: upper bounds of the LM score (candidates that cannot reach the beam skip FullScore): 1 = the largest over all units, 2 = also a table by code point; read when a scorer is loaded") \
@@ -50,5 +51,6 @@ struct Tuning {
 #undef X
 };
 Tuning& tune();                                // the table (seeded from STT_AMD_TUNING on first use)
+void tuning_model_count(int delta);            // models alive: the knobs that are read when a model / scorer is loaded cannot change under one
 int tuning_set(const char* name, int value);   // 0 = ok, -1 = no such name
 int tuning_get(const char* name, int* value);

@@ -219,6 +219,7 @@ std::string run_one(ModelState* ctx, const Options& o, const std::vector<short>&
 int main(int argc, char** argv) {
   Options o;
   if (!parse(argc, argv, o)) return 1;
+  STTX_ConfigureRuntime();   // before the first HIP call: a hardware queue for each of the engine's streams (include/stt_amd.h)
   ModelState* ctx = nullptr;
   std::string model_bytes, scorer_bytes;  // must outlive the model when created from buffers (client.cc:491,519)
   int status;

@@ -212,3 +212,34 @@ def test_decoder_profile_counters_do_not_change_results(models, port, english, f
     assert stamps[50] > 0 and stamps[52] > 0                                # bitmap step: table-complete time, chunks taken by wave 9
     o = port.Decoder(labels, space, 500, P); o.next(probs[1])
     assert want[1] == canon(o.decode(10))
+
+
+def test_a_counter_wait_that_times_out_ends_as_an_error_not_as_a_transcript(models, port, english, fix):
+    """ctc.hip: wait_count -- the bitmap step's waits on LDS counters are bounded (a logic error must not hang the GPU); a wait that
+    gives up sets error bit 0x10 and the beam may be anything.  Every decode path reports the bit instead of a result
+    (check_decoder_errors: STT_* return NULL, STTX_DecoderDecode fails).  Tunable wait_spins = 1 forces the time-out."""
+    from stt_amd import native
+    p = synth.peaky_emissions([8, 5, 12, 12, 15, 0, 23, 15, 18, 12, 4], 120, 29, 28, seed=1, noise=0.8)
+    m = models[("word", True)]
+    native.set_tuning("wait_spins", 1)
+    try:
+        d = m.createDecoder(4, 500)
+        d.next(np.stack([p] * 4))
+        st = d.stats()
+        assert st["error"] != 0, st                      # (STT_ERR_FAIL_RUN_SESS: some stream carries an error bit -- the waves did overtake a counter)
+        with pytest.raises(RuntimeError):
+            d.decode(1)
+    finally:
+        native.set_tuning("wait_spins", 0)
+    d = m.createDecoder(1, 500); d.next(p)              # ... and with the default bound the same input decodes
+    assert d.stats()["error"] == 0 and d.decode(1)[0]
+
+
+def test_load_time_tunables_are_frozen_while_a_model_is_alive(models):
+    """lstm_upw decides how the recurrent matrix is packed at load: changing it under a live model is refused (STT_ERR_INVALID_SHAPE)."""
+    from stt_amd import native
+    cur = native.get_tuning("lstm_upw")
+    with pytest.raises(Exception):
+        native.set_tuning("lstm_upw", 8 if cur != 8 else 16)
+    native.set_tuning("lstm_upw", cur)                   # the same value is fine
+    assert native.get_tuning("lstm_upw") == cur
