@@ -79,7 +79,7 @@ STTX_EXPORT int STTX_DebugBatchProbs(ModelState* aCtx, int aTicket, float* aProb
 STTX_EXPORT int STTX_SetTuning(const char* aName, int aValue);
 STTX_EXPORT int STTX_GetTuning(const char* aName, int* aValue);
 /* Call once BEFORE the process makes its first HIP call (before STT_CreateModel): asks the HIP runtime for 8 hardware queues
- * (GPU_MAX_HW_QUEUES, unless the caller set it), so that the batch path's streams do not share queues.  Without it everything
+ * (GPU_MAX_HW_QUEUES, unless the caller set it), so that the streams of the batch path and of streaming replicas do not share queues.  Without it everything
  * still works; streams that share a queue run one after the other. */
 STTX_EXPORT void STTX_ConfigureRuntime(void);
 STTX_EXPORT void STTX_FreeStrings(char** aStrings, unsigned int aCount);
@@ -118,6 +118,13 @@ STTX_EXPORT int STTX_ShardUtterances(const unsigned int* aSizes, unsigned int aC
  * are processed one by one. */
 STTX_EXPORT void STTX_FeedAudioContentBatch(StreamingState* const* aStreams, const short* const* aBuffers, const unsigned int* aBufferSizes,
                                            unsigned int aCount);
+/* ... the same, and for every stream with aLast[i] != 0 this buffer is the stream's FINAL audio: what STT_FinishStream's flush does in
+ * an acoustic pass of its own (the partial window, the trailing context frames, the last partial batch of windows: stt.cc:236-254)
+ * goes through the model in the SAME launches as the other streams' hop.  STT_FinishStream / STT_FinishStreamWithMetadata /
+ * STTX_FinishStreamBatch on such a stream then only rank and back-track.  (A server that keeps a fixed number of streams live finishes a
+ * few of them in every hop; their flushes cost a whole pass each otherwise.)  aLast may be NULL (= STTX_FeedAudioContentBatch). */
+STTX_EXPORT void STTX_FeedAudioContentBatchEx(StreamingState* const* aStreams, const short* const* aBuffers, const unsigned int* aBufferSizes,
+                                              const unsigned char* aLast, unsigned int aCount);
 /* aCount malloc'd strings (free with STTX_FreeStrings), or NULL on error. */
 STTX_EXPORT char** STTX_IntermediateDecodeBatch(StreamingState* const* aStreams, unsigned int aCount);
 /* Like STT_FinishStream on every stream: the streams are destroyed. */

@@ -735,6 +735,16 @@ void STTX_FeedAudioContentBatch(StreamingState* const* aStreams, const short* co
     return 0;
   }, 0);
 }
+void STTX_FeedAudioContentBatchEx(StreamingState* const* aStreams, const short* const* aBuffers, const unsigned int* aBufferSizes, const unsigned char* aLast, unsigned int aCount) {
+  guarded([&]() {
+    if (!aCount) return 0;
+    std::vector<StreamingState*> ss(aStreams, aStreams + aCount);
+    HIP_CHECK(hipSetDevice(ss[0]->model_->device));
+    if (streams_batchable(ss)) streams_feed_batch(ss, aBuffers, aBufferSizes, aLast);
+    else for (unsigned i = 0; i < aCount; ++i) { ss[i]->feedAudioContent(aBuffers[i], aBufferSizes[i]); if (aLast && aLast[i]) ss[i]->flushBuffers(true); }
+    return 0;
+  }, 0);
+}
 char** STTX_IntermediateDecodeBatch(StreamingState* const* aStreams, unsigned int aCount) {
   char** r = nullptr;
   guarded([&]() {
@@ -921,7 +931,10 @@ void STTX_ConfigureRuntime(void) {
   // HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that share a queue run
   // one after the other -- a group's output layers behind another group's 0.8 ms search launch.  The runtime reads the flag at
   // the first HIP call of the process, so this must run before it; a value the caller set stays.
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  // Sixteen, not eight: a process that also keeps streaming cohorts on model replicas (two more streams each) ran them on shared
+  // queues at eight -- the cohorts' passes serialised: 15.8 k x real time and 13 ms hop outliers against 23.2 k x and 4.6 ms at
+  // sixteen, the batch path unchanged (profiles/r04_hw_queues.txt).
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);
 }
 
 static void upload_batch_audio(ModelState* m, const short* const* bufs, const unsigned* sizes, unsigned B, unsigned& stride) {

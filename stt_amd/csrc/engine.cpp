@@ -325,8 +325,13 @@ void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int e
   const uint32_t shrink = (uint32_t)std::max(1, tune().arena_shrink);
   const uint32_t floor_n = (uint32_t)beam * 16u / shrink + 2u;  // (short inputs: never less than 16 frames' worth)
   const bool opt = optimistic && g_debug_arena_frames <= 0;
-  const SlabLayout l = slab_layout(fixed, opt ? std::min(arena, std::max(arena / 2 / shrink, floor_n)) : arena, arena,
-                                   opt ? std::min(arena, std::max(arena / 4 / shrink, floor_n)) : arena);
+  uint32_t want_pa = opt ? std::min(arena, std::max(arena / 2 / shrink, floor_n)) : arena, want_ta = arena,
+           want_be = opt ? std::min(arena, std::max(arena / 4 / shrink, floor_n)) : arena;
+  if (!opt && db.keep_n == n_streams && db.keep_fixed == fixed && g_debug_arena_frames <= 0) {   // (see DecoderBatch::keep_*)
+    want_pa = std::max(want_pa, db.keep_pa); want_ta = std::max(want_ta, db.keep_ta); want_be = std::max(want_be, db.keep_be);
+  }
+  const SlabLayout l = slab_layout(fixed, want_pa, want_ta, want_be);
+  db.keep_pa = l.pa_cap; db.keep_ta = l.ta_cap; db.keep_be = l.be_cap; db.keep_fixed = fixed; db.keep_n = n_streams;
   db.per_stream_fixed = fixed;
   db.slab.reserve(l.per * n_streams);
   db.host.assign(n_streams, DecStream{});
@@ -371,6 +376,7 @@ void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_
     need_pa = std::max(need_pa, S.pa_n + add); need_ta = std::max(need_ta, S.ta_n + add); need_be = std::max(need_be, S.be_n + add);
   }
   if (!grow) return;
+  if (tune().dump_marks) fprintf(stderr, "ARENA GROW %d streams: need path %u time %u entries %u (caps %u %u %u)\n", db.n_streams, need_pa, need_ta, need_be, db.host[0].pa_cap, db.host[0].ta_cap, db.host[0].be_cap);
   const DecStream& S0 = db.host[0];
   const SlabLayout ol = slab_layout(db.per_stream_fixed, S0.pa_cap, S0.ta_cap, S0.be_cap);
   // only the arena that is short grows (to twice what it needs now); the others keep their size
@@ -397,6 +403,7 @@ void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   std::swap(db.slab.p, ns.p); std::swap(db.slab.cap, ns.cap);
+  db.keep_pa = nl.pa_cap; db.keep_ta = nl.ta_cap; db.keep_be = nl.be_cap;
   db.host = nh;
   db.table.upload(db.host.data(), sizeof(DecStream) * db.n_streams, stream);
 }
@@ -464,7 +471,7 @@ std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_
 //   windows_done_  windows already sent through the model in batches of n_steps
 void StreamingState::recycle() {
   scorer_.reset(); hot_words_.clear(); hot_tables_.valid = false; beam_width_ = 0; keep_emissions_ = false;
-  audio_buffer_.clear(); frames_ = 0; windows_done_ = 0; state_nonzero = false; arena_bound_[0] = arena_bound_[1] = arena_bound_[2] = 2; probs_.clear();
+  audio_buffer_.clear(); frames_ = 0; windows_done_ = 0; state_nonzero = false; flushed_ = false; arena_bound_[0] = arena_bound_[1] = arena_bound_[2] = 2; probs_.clear();
 }
 void StreamingState::pushZeroFrames(int n) {
   ModelState& m = *model_;
@@ -514,6 +521,8 @@ void StreamingState::feedAudioContent(const short* buffer, unsigned int buffer_s
 }
 
 void StreamingState::flushBuffers(bool addZeroMfccVectors) {
+  if (addZeroMfccVectors && flushed_) return;   // its last audio came through STTX_FeedAudioContentBatchEx with the last flag: already flushed
+  if (addZeroMfccVectors) flushed_ = true;
   // stt.cc:236-254: the partial audio window goes through the feature graph as is (zero padded), audio_buffer_ is kept
   pushFrames(audio_buffer_.data(), (int)audio_buffer_.size(), 1);
   if (addZeroMfccVectors) pushZeroFrames(model_->g.n_context);
@@ -587,8 +596,40 @@ bool streams_batchable(const std::vector<StreamingState*>& ss) {
 }
 
 namespace {
-// runs every batch of n_steps windows that is ready in any of the streams (and the partial ones when flushing)
-void streams_process(const std::vector<StreamingState*>& ss, bool flush_partial) {
+// One read-back for ALL streams whose host-side arena bound says "may not fit" (the bound adds `beam` nodes per step, the real fill
+// is a fraction of it): their DecStream entries are gathered into one block and copied with one transfer.  Stream by stream
+// (StreamingState::reserveArena) this was a table read-back + synchronisation EACH -- 128 streams that started together all reach
+// their bound in the same hop: 8 ms in one hop of a 128-stream set (benchmarks/stream_rolling.py).
+void streams_check_arenas(ModelState& m, const std::vector<StreamingState*>& R, const std::vector<int>& takes) {
+  std::vector<int> idx;
+  for (size_t i = 0; i < R.size(); ++i) {
+    StreamingState* s = R[i];
+    const uint32_t add = (uint32_t)(takes[i] + 1) * (uint32_t)s->dec.beam + 2;
+    const DecStream& S = s->dec.host[0];
+    if (s->arena_bound_[0] + add > S.pa_cap || s->arena_bound_[1] + add > S.ta_cap || s->arena_bound_[2] + add > S.be_cap) idx.push_back((int)i);
+  }
+  if (idx.empty()) return;
+  if (tune().dump_marks) fprintf(stderr, "ARENA CHECK %zu of %zu streams\n", idx.size(), R.size());
+  const size_t n = idx.size();
+  m.sb_htab3.reserve(n * 8); m.sb_tab3.reserve(n * 8);
+  void** hp = m.sb_htab3.as<void*>();
+  for (size_t k = 0; k < n; ++k) hp[k] = R[idx[k]]->dec.table.p;
+  HIP_CHECK(hipMemcpyAsync(m.sb_tab3.p, hp, n * 8, hipMemcpyHostToDevice, m.stream));
+  m.sb_table.reserve(sizeof(DecStream) * n);
+  launch_gather_streams(reinterpret_cast<const DecStream* const*>(m.sb_tab3.p), m.sb_table.as<DecStream>(), (int)n, m.stream);
+  std::vector<DecStream> fill(n);
+  HIP_CHECK(hipMemcpyAsync(fill.data(), m.sb_table.p, sizeof(DecStream) * n, hipMemcpyDeviceToHost, m.stream));
+  HIP_CHECK(hipStreamSynchronize(m.stream));
+  for (size_t k = 0; k < n; ++k) {
+    StreamingState* s = R[idx[k]];
+    s->arena_bound_[0] = fill[k].pa_n; s->arena_bound_[1] = fill[k].ta_n; s->arena_bound_[2] = fill[k].be_n;   // the real fill
+  }
+}
+
+// runs every batch of n_steps windows that is ready in any of the streams (and the partial ones of the streams that flush);
+// returns whether the stream was synchronised after the last launch (the page-locked staging of the caller is then free again)
+bool streams_process(const std::vector<StreamingState*>& ss, bool flush_partial, const std::vector<uint8_t>* flush_each = nullptr) {
+  bool synced = false;
   ModelState& m = *ss[0]->model_;
   const Geometry& g = m.g;
   const int H = g.n_hidden, C = g.n_classes, kp = g.k1_pad(), kw = g.n_in1(), T = g.n_steps;
@@ -596,12 +637,15 @@ void streams_process(const std::vector<StreamingState*>& ss, bool flush_partial)
   for (;;) {
     std::vector<StreamingState*> R;
     std::vector<int> takes;
-    for (StreamingState* s : ss) {
+    for (size_t si = 0; si < ss.size(); ++si) {
+      StreamingState* s = ss[si];
+      const bool fl = flush_partial || (flush_each && (*flush_each)[si]);
       const int ready = std::max(0, s->frames_ - 2 * g.n_context) - s->windows_done_;
-      const int take = ready >= T ? T : ((flush_partial && ready > 0) ? ready : 0);
+      const int take = ready >= T ? T : ((fl && ready > 0) ? ready : 0);
       if (take) { R.push_back(s); takes.push_back(take); }
     }
     if (R.empty()) break;
+    streams_check_arenas(m, R, takes);
     const size_t rows = (size_t)lstm_max_rows(H);  // streams advanced by one recurrent launch: 128 with 16 units per workgroup, else 64
     for (size_t g0 = 0; g0 < R.size(); g0 += rows) {
       const int B = (int)std::min<size_t>(rows, R.size() - g0);
@@ -648,9 +692,11 @@ void streams_process(const std::vector<StreamingState*>& ss, bool flush_partial)
       launch_ctc_next(p, ds, m.dev_alphabet, m.sb_table.as<DecStream>(), B, m.ws_probs.as<float>(), d_int + 2 * B, d_int + B, m.stream, T, m.ws_wide.p);
       launch_scatter_streams(d_tp, m.sb_table.as<DecStream>(), B, m.stream);
       HIP_CHECK(hipStreamSynchronize(m.stream));  // the page-locked table is reused by the next group
+      synced = true;
       for (int b = 0; b < B; ++b) { R[g0 + b]->windows_done_ += takes[g0 + b]; R[g0 + b]->state_nonzero = true; }
     }
   }
+  return synced;
 }
 
 // MFCC of the new windows of every stream in one launch, written straight behind each stream's frame list
@@ -671,38 +717,51 @@ void streams_push_frames(const std::vector<StreamingState*>& ss, const std::vect
   memset(ha, 0, (size_t)n * max_span * 2);
   for (int i = 0; i < n; ++i) if (!spans[i].empty()) memcpy(ha + (size_t)i * max_span, spans[i].data(), spans[i].size() * 2);
   HIP_CHECK(hipMemcpyAsync(m.sb_audio.p, ha, (size_t)n * max_span * 2, hipMemcpyHostToDevice, m.stream));
+  // (its own table: the acoustic pass that follows fills sb_htab / sb_tab while this one may still be in flight -- the caller
+  // synchronises once, behind that pass)
   const size_t bytes = (size_t)n * 8 + (size_t)2 * n * 4;
-  m.sb_htab.reserve(bytes); m.sb_tab.reserve(bytes);
-  uint8_t* hb = m.sb_htab.as<uint8_t>();
+  m.sb_htab2.reserve(bytes); m.sb_tab2.reserve(bytes);
+  uint8_t* hb = m.sb_htab2.as<uint8_t>();
   void** hp = reinterpret_cast<void**>(hb);
   int* hi = reinterpret_cast<int*>(hb + (size_t)n * 8);
   for (int i = 0; i < n; ++i) {
     hp[i] = ss[i]->d_frames.as<float>() + (size_t)ss[i]->frames_ * g.n_input;
     hi[i] = (int)spans[i].size(); hi[n + i] = n_frames[i];
   }
-  HIP_CHECK(hipMemcpyAsync(m.sb_tab.p, hb, bytes, hipMemcpyHostToDevice, m.stream));
+  HIP_CHECK(hipMemcpyAsync(m.sb_tab2.p, hb, bytes, hipMemcpyHostToDevice, m.stream));
   MfccArgs a = m.mfcc_args();
   a.audio = m.sb_audio.as<int16_t>(); a.n_max = max_span; a.t_max = max_w;
-  a.feats = nullptr; a.feats_ptrs = reinterpret_cast<float* const*>(m.sb_tab.p);
-  a.n_samples = reinterpret_cast<const int*>(m.sb_tab.as<uint8_t>() + (size_t)n * 8); a.n_frames = a.n_samples + n;
+  a.feats = nullptr; a.feats_ptrs = reinterpret_cast<float* const*>(m.sb_tab2.p);
+  a.n_samples = reinterpret_cast<const int*>(m.sb_tab2.as<uint8_t>() + (size_t)n * 8); a.n_frames = a.n_samples + n;
   launch_mfcc(a, n * max_w, m.stream);
-  HIP_CHECK(hipStreamSynchronize(m.stream));  // page-locked staging is reused by the next call
   for (int i = 0; i < n; ++i) ss[i]->frames_ += n_frames[i];
 }
 }  // namespace
 
-void streams_feed_batch(const std::vector<StreamingState*>& ss, const short* const* buffers, const unsigned int* sizes) {
-  const Geometry& g = ss[0]->model_->g;
+// `last` (or null): last[i] != 0 = this is the final audio of stream i -- what StreamingState::flushBuffers(true) would do in an acoustic
+// pass of its own (the partial window as one more frame, n_context zero frames, the partial batch of windows: stt.cc:236-254) rides in
+// THIS pass, beside the live streams' rows; the stream is marked flushed and its finish only decodes.
+void streams_feed_batch(const std::vector<StreamingState*>& ss, const short* const* buffers, const unsigned int* sizes, const unsigned char* last) {
+  ModelState& m = *ss[0]->model_;
+  const Geometry& g = m.g;
   const int n = (int)ss.size();
   std::vector<std::vector<int16_t>> spans(n);
   std::vector<int> nf(n, 0);
+  std::vector<uint8_t> fl(n, 0);
+  bool any_last = false;
   for (int i = 0; i < n; ++i) {  // the window arithmetic of StreamingState::feedAudioContent, per stream
     StreamingState* s = ss[i];
     std::vector<int16_t> all(s->audio_buffer_);
     all.insert(all.end(), buffers[i], buffers[i] + sizes[i]);
     const int len = (int)all.size();
     const int W = len >= g.win_len ? (len - g.win_len) / g.win_step + 1 : 0;
-    if (W > 0) {
+    const bool is_last = last && last[i] && !s->flushed_;
+    if (is_last) {   // W full windows and the partial one behind them (zero padded by the feature kernel), from one span
+      fl[i] = 1; any_last = true;
+      spans[i] = all;
+      s->audio_buffer_.assign(all.begin() + std::min((size_t)len, (size_t)W * g.win_step), all.end());   // (flushBuffers keeps it: stt.cc:236-254)
+      nf[i] = W + 1;
+    } else if (W > 0) {
       spans[i].assign(all.begin(), all.begin() + (size_t)(W - 1) * g.win_step + g.win_len);
       s->audio_buffer_.assign(all.begin() + (size_t)W * g.win_step, all.end());
       nf[i] = W;
@@ -711,17 +770,22 @@ void streams_feed_batch(const std::vector<StreamingState*>& ss, const short* con
     }
   }
   streams_push_frames(ss, spans, nf);
-  streams_process(ss, false);
+  if (any_last)
+    for (int i = 0; i < n; ++i) if (fl[i]) { ss[i]->pushZeroFrames(g.n_context); ss[i]->flushed_ = true; }
+  if (!streams_process(ss, false, any_last ? &fl : nullptr)) HIP_CHECK(hipStreamSynchronize(m.stream));   // page-locked staging is reused by the next call
 }
 
-void streams_flush_batch(const std::vector<StreamingState*>& ss, bool addZeroMfccVectors) {
+void streams_flush_batch(const std::vector<StreamingState*>& ss_all, bool addZeroMfccVectors) {
+  std::vector<StreamingState*> ss;
+  for (StreamingState* s : ss_all) if (!(addZeroMfccVectors && s->flushed_)) ss.push_back(s);   // (flushed with its last audio: streams_feed_batch)
+  if (ss.empty()) return;
   const int n = (int)ss.size();
   std::vector<std::vector<int16_t>> spans(n);
   std::vector<int> nf(n, 1);
   for (int i = 0; i < n; ++i) spans[i] = ss[i]->audio_buffer_;  // stt.cc:236-254: the partial window as is (zero padded)
   streams_push_frames(ss, spans, nf);
-  if (addZeroMfccVectors) for (StreamingState* s : ss) s->pushZeroFrames(s->model_->g.n_context);
-  streams_process(ss, true);
+  if (addZeroMfccVectors) for (StreamingState* s : ss) { s->pushZeroFrames(s->model_->g.n_context); s->flushed_ = true; }
+  if (!streams_process(ss, true)) HIP_CHECK(hipStreamSynchronize(ss[0]->model_->stream));
 }
 
 std::vector<std::vector<Output>> streams_decode_batch(const std::vector<StreamingState*>& ss, unsigned num_results) {

@@ -140,6 +140,12 @@ struct DecoderBatch {
   DevBuf slab;                  // all per-stream arrays
   std::vector<uint32_t> pa_cap, ta_cap;
   size_t per_stream_fixed = 0;
+  // the arena capacities the slab was last laid out / grown for: a batch that is created again on the same slab (a parked stream taken
+  // from ModelState::stream_pool_) keeps what it grew to instead of starting at the default again and growing in the same hop as
+  // every other stream that started with it
+  uint32_t keep_pa = 0, keep_ta = 0, keep_be = 0;
+  size_t keep_fixed = 0;
+  int keep_n = 0;
 };
 
 // Hot-word table of a scorer view in HBM, uploaded when the words change, not at every launch (STT_AddHotWord & co.: stt.cc:451-497;
@@ -252,8 +258,8 @@ struct ModelState {
   bool async_pair_ = false;  // ... and whether they were submitted as pairs
   bool async_any() const { if (pending_.valid) return true; for (const GroupSlot& s : slots_) if (s.busy()) return true; return false; }
   // scratch of the batched streaming calls (STTX_FeedAudioContentBatch & co.)
-  DevBuf sb_audio, sb_tab, sb_c, sb_h, sb_table;
-  PinnedBuf sb_haudio, sb_htab;
+  DevBuf sb_audio, sb_tab, sb_tab2, sb_tab3, sb_c, sb_h, sb_table;
+  PinnedBuf sb_haudio, sb_htab, sb_htab2, sb_htab3;   // (…2: the feature pass's table -- the acoustic pass behind it fills sb_htab while that one is in flight; …3: the arena check's)
   hipEvent_t ev_chunk[2] = {};  // chunk hand-over acoustic stream -> decoder stream (alternating)
   // The acoustic model of the batch path as three engines (STT_AMD_AM_PIPE=0: one stream, as the streaming path runs it):
   // `stream` = features, context windows, layers 1-3 and the x-projection of chunk k+1, k+2; `stream_l` = the recurrence of
@@ -326,6 +332,7 @@ struct StreamingState {
   DevBuf d_c, d_h;                            // LSTM state [H] f32
   bool state_nonzero = false;
   DecoderBatch dec;                           // one stream
+  bool flushed_ = false;                       // the final flush (partial window + trailing context frames) has gone through the model
   uint32_t arena_bound_[3] = {2, 2, 2};       // host-side upper bounds of the fill of the path / time / boundary-entry arenas (each step appends <= beam to each)
   HotTables hot_tables_;
   std::vector<double> probs_;                 // emissions of the last processed batch (keep_emissions_)
@@ -348,7 +355,7 @@ std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_
 // what STT_FeedAudioContent / STT_IntermediateDecode / flushBuffers do, with the ready windows of all streams pushed through
 // the acoustic model and the beam search as one batch.
 bool streams_batchable(const std::vector<StreamingState*>& ss);
-void streams_feed_batch(const std::vector<StreamingState*>& ss, const short* const* buffers, const unsigned int* sizes);
+void streams_feed_batch(const std::vector<StreamingState*>& ss, const short* const* buffers, const unsigned int* sizes, const unsigned char* last = nullptr);
 void streams_flush_batch(const std::vector<StreamingState*>& ss, bool addZeroMfccVectors);
 std::vector<std::vector<Output>> streams_decode_batch(const std::vector<StreamingState*>& ss, unsigned num_results);
 int n_frames_for(const Geometry& g, int n_samples);

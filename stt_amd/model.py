@@ -312,13 +312,19 @@ def _stream_ptrs(streams):
     return (C.c_void_p * len(streams))(*[st._impl for st in streams])
 
 
-def feedAudioContentBatch(streams, audio_buffers):
-    """STTX_FeedAudioContentBatch: stream i receives audio_buffers[i]; the ready windows of all streams run as one batch."""
+def feedAudioContentBatch(streams, audio_buffers, last=None):
+    """STTX_FeedAudioContentBatch: stream i receives audio_buffers[i]; the ready windows of all streams run as one batch.
+    last (optional, one flag per stream): this is the stream's final audio -- its flush rides in the same pass
+    (STTX_FeedAudioContentBatchEx) and finishStream() / finishStreamBatch() then only decode."""
     arrs = [np.ascontiguousarray(a, dtype=np.int16) for a in audio_buffers]
     n = len(streams)
     ptrs = (C.c_void_p * n)(*[a.ctypes.data if a.size else 0 for a in arrs])
     sizes = (C.c_uint * n)(*[a.shape[0] for a in arrs])
-    native.lib().STTX_FeedAudioContentBatch(_stream_ptrs(streams), ptrs, sizes, n)
+    if last is None:
+        native.lib().STTX_FeedAudioContentBatch(_stream_ptrs(streams), ptrs, sizes, n)
+    else:
+        flags = (C.c_ubyte * n)(*[1 if f else 0 for f in last])
+        native.lib().STTX_FeedAudioContentBatchEx(_stream_ptrs(streams), ptrs, sizes, flags, n)
 
 
 def intermediateDecodeBatch(streams):

@@ -203,3 +203,37 @@ def test_config5_code_point_scorer_with_three_byte_units(tmp_path, port, ref):
                 assert d.stats()["error"] == 0
                 k = min(beam, 20)
                 assert canon(d.decode(k)[0]) == canon(dr.decode(k)), (name, beam, chunk)
+
+
+def test_config3_last_audio_carries_the_flush(model):
+    """STTX_FeedAudioContentBatchEx: a stream whose final audio is flagged has its flush (partial window, trailing context frames, last
+    partial batch: stt.cc:236-254) done in the same pass as the other streams' hop; its finish only decodes.  A rolling live set --
+    streams end in different hops, new ones take their place -- gives the transcripts of STT_SpeechToText on every utterance, also
+    for utterances shorter than a window / an exact multiple of the hop, and a flagged stream finished through plain coqui-stt.h."""
+    from stt_amd import model as M
+    rng = np.random.RandomState(8)
+    lens = (rng.uniform(0.1, 3.0, size=40) * 16000).astype(int)
+    lens[3] = 100; lens[7] = 5120 * 2; lens[11] = 5120 * 2 + 1; lens[13] = 512
+    audio = [synth.synth_audio(int(n), seed=1500 + i) for i, n in enumerate(lens)]
+    want = [model.stt(a) for a in audio]
+    got = [None] * len(audio)
+    S, nxt, live = 9, 0, []
+    while nxt < len(audio) or live:
+        while len(live) < S and nxt < len(audio):
+            live.append([nxt, model.createStream(), 0]); nxt += 1
+        M.feedAudioContentBatch([s for _, s, _ in live], [audio[u][k:k + 5120] for u, _, k in live], last=[k + 5120 >= len(audio[u]) for u, _, k in live])
+        inter = M.intermediateDecodeBatch([s for _, s, _ in live])
+        for e in live:
+            e[2] += 5120
+        done = [e for e in live if e[2] >= len(audio[e[0]])]
+        for (u, s, _), t_inter in zip(live, inter):
+            if any(u == d[0] for d in done):
+                assert t_inter == want[u], u                 # everything has gone through the model: the intermediate result is the final one
+        if done:
+            if len(done) == 1:
+                got[done[0][0]] = done[0][1].finishStream()  # plain STT_FinishStream on a flagged stream: no second flush
+            else:
+                for e, t in zip(done, M.finishStreamBatch([e[1] for e in done])):
+                    got[e[0]] = t
+            live = [e for e in live if e[2] < len(audio[e[0]])]
+    assert got == want
