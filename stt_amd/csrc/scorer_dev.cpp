@@ -601,7 +601,8 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label, bool lm_on
   }
   const bool memo_on = tune().lm_memo != 0;  // (0: measure without)
   if (hs.utf8 && ord <= 5 && !lm_only && memo_on) {  // FullScore cache of the code-point search (ctc.h: DevScorer::memo)
-    const size_t n = (size_t)1 << 18;
+    const int lg = tune().lm_memo >= 10 && tune().lm_memo <= 26 ? tune().lm_memo : 24;   // (lm_memo 1 = the default 2^24 entries = 512 MB of the 288 GB, 10..26 = log2 of the entry count)
+    const size_t n = (size_t)1 << lg;
     memo_.reserve(n * 32);
     HIP_CHECK(hipMemset(memo_.p, 0, n * 32));
     ds.memo = memo_.as<uint32_t>(); ds.memo_mask = (uint32_t)n - 1;
