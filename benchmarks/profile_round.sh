@@ -6,9 +6,9 @@
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 TAG=${1:-r03_x}
 OUT=gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-extras > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-extras --no-reference-check > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C -d $OUT/pmc_$C -o pmc --output-format csv -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C -d $OUT/pmc_$C -o pmc --output-format csv -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras --no-reference-check > $OUT/pmc_$C.log 2>&1
 done
 python - "$TAG" "$OUT" <<'PY'
 import csv, glob, json, collections, sys, shutil
@@ -23,10 +23,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
             acc[(k, r["Counter_Name"])] += float(r["Counter_Value"]); calls[(k, r["Counter_Name"])] += 1
-steps = 8.0   # --steps 4 --warmup 2 + the untimed phase-counter step + the blocking verification call bench.py appends (batches of 64)
+steps = 11.0   # --steps 4 --warmup 2 + the untimed phase-counter step + one blocking verification call per distinct timed batch (4): batches of 64
 kern = {}
 with open("gpurun_out/%s_pmc_per_kernel.csv" % tag, "w") as o:
-    o.write("# rocprofv3 --pmc FETCH_SIZE (pass 1) and --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras; values in KB as reported by rocprofv3\n")
+    o.write("# rocprofv3 --pmc FETCH_SIZE (pass 1) and --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras --no-reference-check; values in KB as reported by rocprofv3\n")
     o.write("Kernel,Counter,Calls,SumKB,AvgKBPerCall\n")
     for (k, c), v in sorted(acc.items()):
         n = calls[(k, c)]

@@ -131,3 +131,26 @@ def test_search_bound_setup_takes_four_slots(tmp_path):
     m.setBeamWidth(100)                                  # nothing in flight: the depth follows the configuration
     assert m.pipelineDepth() == (4 if native.get_tuning("pair") else 2)   # two slots, two batches per slot when batches pair up
 
+
+
+def test_collect_with_confidence_and_with_metadata(model):
+    """STTX_BatchCollectScored / STTX_BatchCollectWithMetadata: a submitted batch comes back with the confidence (and tokens, timesteps)
+    STT_SpeechToTextWithMetadata reports for the same audio (stt.cc:349-365), whichever way it is collected."""
+    batches = _device_batches(4, 6, seed=77)
+    hosts = []
+    for k in range(4):
+        lens = [8000 + 1777 * ((i * 7 + k) % 9) for i in range(6)]
+        hosts.append([synth.synth_audio(n, seed=77 + 100 * k + i) for i, n in enumerate(lens)])
+    want = [[model.sttWithMetadata(a, 1)["transcripts"][0] for a in utts] for utts in hosts]
+    tickets = [model.submitBatchDevice(d.data_ptr(), stride, lens) for d, stride, lens in batches]
+    for k, t in enumerate(tickets):
+        if k % 2 == 0:
+            texts, conf = model.collectBatchScored(t)
+            assert texts == [w["text"] for w in want[k]]
+            assert conf == [w["confidence"] for w in want[k]]
+        else:
+            md = model.collectBatchWithMetadata(t)
+            got = [m["transcripts"][0] for m in md]
+            assert [g["text"] for g in got] == [w["text"] for w in want[k]]
+            assert [g["confidence"] for g in got] == [w["confidence"] for w in want[k]]
+            assert [[tk[1] for tk in g["tokens"]] for g in got] == [[tk[1] for tk in w["tokens"]] for w in want[k]]
