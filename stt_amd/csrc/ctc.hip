@@ -1248,7 +1248,8 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
   const int nw_exp = NWAVES - nlm;
   const uint32_t space_u = (uint32_t)al.space_id;
   if (lm_wave && wave >= nw_exp) {
-    __builtin_amdgcn_s_setprio(3);  // the chain of dependent reads is the critical path of the phase: issue it first
+    // (the chain of dependent reads was the critical path of the phase when the phase ended at a barrier: issue it first)
+    if (p.lm_prio >= 3) __builtin_amdgcn_s_setprio(3); else if (p.lm_prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.lm_prio == 1) __builtin_amdgcn_s_setprio(1);
     const unsigned long long lmw_t0 = p.phase_cycles ? __builtin_readcyclecounter() : 0ull;
     const int ksp = POS_OF(al.space_id);
     const int lw = wave - nw_exp;
@@ -2274,6 +2275,7 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
   }
   p.n_lm_waves = tune().lm_waves; p.item_cap = tune().item_table_cap;
   p.wait_spins = tune().wait_spins > 0 ? tune().wait_spins : (1 << 22);
+  p.lm_prio = tune().lm_prio;
   const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : ((!wide && ctc_masked_ok(p, s, al)) ? 4 : 1));
   const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : (mode == 4 ? 32 : p.C), s.enabled && s.utf8);   // (mode 4: the kernel carves its layout for 32 classes)
   p.lds_kb = lds_budget_kb_host();

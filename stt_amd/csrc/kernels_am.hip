@@ -528,7 +528,9 @@ __device__ __forceinline__ void lstm_acc_settle() {
   if constexpr (PIN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // 32 wait states >= the 8-pass MFMA's result latency
 }
 // DBG (timing probes only, wrong results): bit 0 = every h fragment load reads the wave's first one (h served by the L1: what the
-// step would cost if h were free), bit 1 = the same for the weight fragments (what it would cost if the weight stream were free).
+// step would cost if h were free), bit 1 = the same for the weight fragments (what it would cost if the weight stream were free),
+// bit 2 = no cross-wave reduction (every wave settles its tile from its own partial sums: no parking in LDS, no barrier -- what a form
+// that needs no reduction, e.g. waves that split the batch rows instead of K, could save at most).
 template <int NT, int G_, int MT, int PHS, int DBG = 0, bool PIN = (NT == 8)>   // PIN: accumulators pinned in the accumulator file (lstm_mfma)
 __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
   constexpr bool PF = G_ > 0;
@@ -679,10 +681,10 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
       const int obr = ob + rd * 64;                      // this lane's batch row in this round
-      if (rd) __syncthreads();                           // every wave has read the previous round's partials
+      if (rd && !(DBG & 4)) __syncthreads();             // every wave has read the previous round's partials
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (j == q) continue;                            // (wave-uniform)
+        if (j == q || (DBG & 4)) continue;               // (wave-uniform)
         const int sl = j - (j > q ? 1 : 0);
 #pragma unroll
         for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4*>(&park[q][sl][i][lane][0]) = acc[i][rd * 4 + j];
@@ -698,7 +700,7 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
         for (int g = 0; g < 4; ++g) nxv[g] = *reinterpret_cast<const float4*>(xp + (size_t)g * H);
         ncv = *reinterpret_cast<const float4*>(a.c + (size_t)(obr + 64) * H + wg * UPW + ou);
       }
-      __syncthreads();
+      if (!(DBG & 4)) __syncthreads();
       if (rd == 0) LSTM_STAMP(2);
       f32x4 z[MT];
 #pragma unroll
@@ -707,7 +709,7 @@ __device__ __forceinline__ void lstm_step_body(const LstmArgs& a) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const int sl = q - (q > w ? 1 : 0);            // where writer w parked tile q (unused for w == q)
-          v[w] = (w == q) ? own[i] : *reinterpret_cast<const f32x4*>(&park[w][sl < 3 ? sl : 2][i][lane][0]);
+          v[w] = (w == q || (DBG & 4)) ? own[i] : *reinterpret_cast<const f32x4*>(&park[w][sl < 3 ? sl : 2][i][lane][0]);
         }
         z[i] = ((v[0] + v[1]) + v[2]) + v[3];
       }
@@ -1123,6 +1125,7 @@ static bool launch_lstm_probe(const LstmArgs& a, int NT, hipStream_t st) {
   }
   switch (pr) {
     case 1: PROBE(lstm_probe8_kernel<1>); case 2: PROBE(lstm_probe8_kernel<2>); case 3: PROBE(lstm_probe8_kernel<3>);
+    case 4: PROBE(lstm_probe8_kernel<4>); case 7: PROBE(lstm_probe8_kernel<7>);
     case 10: PROBE(lstm_probe8g2_kernel<0>); case 11: PROBE(lstm_probe8g2_kernel<1>); case 12: PROBE(lstm_probe8g2_kernel<2>); case 13: PROBE(lstm_probe8g2_kernel<3>);
     default: return false;
   }

@@ -33,6 +33,7 @@
   X(copy_kernel, 1, "small tables / result blocks through a copy kernel and mapped page-locked memory (0: copy engine)")           \
   X(search_lds_kb, 160, "LDS budget of the search kernel's layout (96..160)")                                                      \
   X(search_step, 2, "word-mode search step: 2 = label bitmaps + indexed FullScore where it applies, 0 = generic step")              \
+  X(lm_prio, 3, "s_setprio of the search step's language-model waves during their queries (0..3)")                               \
   X(lm_waves, 0, "language-model waves of the search step (0 = by beam width)")                                                    \
   X(exp_waves, 0, "expand waves of the search step (0 = all the others)")                                                          \
   X(wait_spins, 0, "test hook: polls (of 256 cycles) an intra-workgroup counter wait of the search step may take before it gives up with error bit 0x10 (0 = 4 M, about half a second)") \
