@@ -91,3 +91,50 @@ def test_config0_ldc93s1_no_scorer_beam_1(big, ref, port, english, fix):
         assert s.finishStream() == text
     finally:
         model.setBeamWidth(500)
+
+
+def test_bench_shape_and_scorer_against_the_real_reference_decoder_all_64(big, ref, port, english, fix, tmp_path):
+    """configs[1] as bench.py times it -- 64 x 5 s, beam 500, the synthetic 500 k-word order-5 scorer -- through the library's pipelined
+    path (STTX_BatchSubmitDevice / STTX_BatchCollectScored, two batches sharing one recurrence), EVERY utterance against the REAL reference
+    decoder (oracle/_ref: ctc_beam_search_decoder_batch on the GPU's emissions): transcript and confidence equal, or the utterance is one in
+    which a (score, character) tie straddles the beam boundary -- the reference's choice there is libstdc++'s nth_element order -- and
+    then the C restatement, whose tie rule the kernels share, must agree instead.  bench.py makes the same check on every
+    timed batch; this is its test-suite twin."""
+    import ctypes
+    from test_gpu_async import _DeviceArray       # int16 rows in HBM through the HIP runtime libstt.so is bound to (not torch's)
+    from stt_amd import scorertools
+    model, w = big
+    lm, vocab, pkg = str(tmp_path / "lm.binary"), str(tmp_path / "vocab.txt"), str(tmp_path / "s500k.scorer")
+    scorertools.synth_lm(lm, vocab, words=500000, order=5, seed=7, avg={2: 24, 3: 1.2, 4: 0.7, 5: 0.5})
+    scorertools.generate_scorer_package(lm, vocab, pkg, alphabet=os.path.join(fix, "alphabet.txt"),
+                                        default_alpha=0.931289039105002, default_beta=1.1834137581510284)
+    model.enableExternalScorer(pkg)
+    try:
+        batches = [synth.synth_audio_batch(64, 80000, seed=9000 + k) for k in range(2)]
+        dev = [_DeviceArray(b) for b in batches]
+        sizes = (ctypes.c_uint * 64)(*([80000] * 64))
+        tickets = [model.submitBatchDevice(d.data_ptr(), 80000, sizes) for d in dev]
+        got = [model.collectBatchScored(t) for t in tickets]
+        A = ref.Alphabet(os.path.join(fix, "alphabet.txt"))
+        S = ref.Scorer(pkg, A)
+        labels, space = english
+        P = port.Scorer(pkg)
+        n_equal = n_tie = 0
+        for k, host in enumerate(batches):
+            probs = model.acousticProbs(list(host))
+            res = ref.decode_batch(np.stack(probs).astype(np.float64), [250] * 64, A, 500, os.cpu_count() or 1, S)
+            for b in range(64):
+                want_t, want_c = A.decode(res[b][1]).decode("utf-8", "replace"), float(res[b][0])
+                if got[k][0][b] == want_t and got[k][1][b] == want_c:
+                    n_equal += 1
+                    continue
+                d = port.Decoder(labels, space, 500, P)
+                d.next(probs[b])
+                r = d.decode(1)[0]
+                assert d.boundary_ties() > 0, (k, b, got[k][0][b], want_t)                       # a difference without a tie is a bug
+                assert got[k][0][b] == port.decode_text(labels, r[1]).decode() and got[k][1][b] == float(r[0]), (k, b)
+                n_tie += 1
+        print("bench shape vs the real reference: %d of 128 equal, %d tie-affected and equal to the restatement" % (n_equal, n_tie))
+        assert n_equal >= 100
+    finally:
+        model.disableExternalScorer()
