@@ -135,6 +135,12 @@ struct DecStream {
   uint64_t* c_key;
   uint64_t* sel_keys;  // [beam_cap + cand_cap]
   uint32_t cand_cap;
+  // Incremental back-tracking (streams only; null = none): a decode with one result walks the best prefix's path back only to where
+  // it meets the path the PREVIOUS decode of this stream walked (ctc_decode_kernel).  dpd[node] / dtd[time node] = depth of a node that
+  // was on a decoded chain (0 = unknown; the depth of a node never changes), chain = [token count | timestep count | tokens of the last
+  // decoded best prefix [chain_cap] | their path nodes | its timesteps | their time nodes | scratch 4 x chain_cap]
+  uint32_t *dpd, *dtd, *chain;
+  uint32_t chain_cap, pad_;
   // statistics (DESIGN.md roofline accounting): steps, candidates, lm queries, lm memory probes
   unsigned long long stat[4];
   // shader cycles (s_memtime, thread 0; profiling level 2) per phase: [0] setup, [1] expand: events, [2] expand: items, [3] LM

@@ -298,22 +298,32 @@ namespace {
 struct SlabLayout {
   size_t fixed, o_pa, o_ta, o_pq, o_be, per;
   uint32_t pa_cap, ta_cap, be_cap;
+  size_t o_dpd, o_dtd, o_chain;   // incremental back-tracking (chain_cap > 0): ctc.h, DecStream::dpd / dtd / chain
+  uint32_t chain_cap;
 };
-SlabLayout slab_layout(size_t fixed, uint32_t pa_cap, uint32_t ta_cap, uint32_t be_cap) {
+// chain_cap = tokens / timesteps the cached best path may hold: one per frame the time arena was sized for (0 = no cache)
+SlabLayout slab_layout(size_t fixed, uint32_t pa_cap, uint32_t ta_cap, uint32_t be_cap, uint32_t chain_cap = 0) {
   SlabLayout l{};
-  l.fixed = fixed; l.pa_cap = pa_cap; l.ta_cap = ta_cap; l.be_cap = be_cap;
+  l.fixed = fixed; l.pa_cap = pa_cap; l.ta_cap = ta_cap; l.be_cap = be_cap; l.chain_cap = chain_cap;
   l.o_pa = fixed; l.o_ta = l.o_pa + al256((size_t)pa_cap * 8); l.o_pq = l.o_ta + al256((size_t)ta_cap * 8);
   l.o_be = l.o_pq + al256((size_t)pa_cap * 4); l.per = l.o_be + al256((size_t)be_cap * sizeof(BEntry));
+  if (chain_cap) {
+    l.o_dpd = l.per; l.o_dtd = l.o_dpd + al256((size_t)pa_cap * 4); l.o_chain = l.o_dtd + al256((size_t)ta_cap * 4);
+    l.per = l.o_chain + al256(((size_t)8 * chain_cap + 2) * 4);
+  }
   return l;
 }
+uint32_t chain_cap_for(uint32_t ta_cap, int beam) { return ta_cap / (uint32_t)std::max(1, beam) + 8u; }
 void point_arenas(DecStream& S, uint8_t* base, const SlabLayout& l) {
   S.pa = (uint2*)(base + l.o_pa); S.ta = (uint2*)(base + l.o_ta); S.pq = (uint32_t*)(base + l.o_pq); S.be = (BEntry*)(base + l.o_be);
   S.pa_cap = l.pa_cap; S.ta_cap = l.ta_cap; S.be_cap = l.be_cap;
+  S.dpd = l.chain_cap ? (uint32_t*)(base + l.o_dpd) : nullptr; S.dtd = l.chain_cap ? (uint32_t*)(base + l.o_dtd) : nullptr;
+  S.chain = l.chain_cap ? (uint32_t*)(base + l.o_chain) : nullptr; S.chain_cap = l.chain_cap; S.pad_ = 0;
 }
 }  // namespace
 
 void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc, PinnedBuf* staging,
-                                bool optimistic) {
+                                bool optimistic, bool decode_cache) {
   const int C = g.n_classes;
   if (beam < 1 || beam > STT_MAX_BEAM) throw std::runtime_error("beam width must be in [1, 1024]");
   db.n_streams = n_streams; db.beam = beam; db.C = C;
@@ -330,8 +340,10 @@ void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int e
   if (!opt && db.keep_n == n_streams && db.keep_fixed == fixed && g_debug_arena_frames <= 0) {   // (see DecoderBatch::keep_*)
     want_pa = std::max(want_pa, db.keep_pa); want_ta = std::max(want_ta, db.keep_ta); want_be = std::max(want_be, db.keep_be);
   }
-  const SlabLayout l = slab_layout(fixed, want_pa, want_ta, want_be);
+  decode_cache = decode_cache && !optimistic && tune().decode_cache != 0;
+  const SlabLayout l = slab_layout(fixed, want_pa, want_ta, want_be, decode_cache ? chain_cap_for(want_ta, beam) : 0u);
   db.keep_pa = l.pa_cap; db.keep_ta = l.ta_cap; db.keep_be = l.be_cap; db.keep_fixed = fixed; db.keep_n = n_streams;
+  db.decode_cache = decode_cache;
   db.per_stream_fixed = fixed;
   db.slab.reserve(l.per * n_streams);
   db.host.assign(n_streams, DecStream{});
@@ -349,6 +361,8 @@ void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int e
     S.c_key = (uint64_t*)take(cand_cap * 8); S.sel_keys = (uint64_t*)take(((size_t)cap + cand_cap) * 8);
     point_arenas(S, base + l.per * i, l);
     S.cand_cap = cand_cap;
+    // no node has been on a decoded path yet, the cached path is empty (the slab may be a parked stream's: whatever it holds is stale)
+    if (l.chain_cap) HIP_CHECK(hipMemsetAsync(base + l.per * i + l.o_dpd, 0, l.per - l.o_dpd, stream));
   }
   if (staging) {
     staging->reserve(sizeof(DecStream) * n_streams);
@@ -378,10 +392,11 @@ void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_
   if (!grow) return;
   if (tune().dump_marks) fprintf(stderr, "ARENA GROW %d streams: need path %u time %u entries %u (caps %u %u %u)\n", db.n_streams, need_pa, need_ta, need_be, db.host[0].pa_cap, db.host[0].ta_cap, db.host[0].be_cap);
   const DecStream& S0 = db.host[0];
-  const SlabLayout ol = slab_layout(db.per_stream_fixed, S0.pa_cap, S0.ta_cap, S0.be_cap);
+  const SlabLayout ol = slab_layout(db.per_stream_fixed, S0.pa_cap, S0.ta_cap, S0.be_cap, db.decode_cache ? S0.chain_cap : 0u);
   // only the arena that is short grows (to twice what it needs now); the others keep their size
-  const SlabLayout nl = slab_layout(db.per_stream_fixed, need_pa > S0.pa_cap ? need_pa * 2 : S0.pa_cap, need_ta > S0.ta_cap ? need_ta * 2 : S0.ta_cap,
-                                    need_be > S0.be_cap ? need_be * 2 : S0.be_cap);
+  const uint32_t new_ta = need_ta > S0.ta_cap ? need_ta * 2 : S0.ta_cap;
+  const SlabLayout nl = slab_layout(db.per_stream_fixed, need_pa > S0.pa_cap ? need_pa * 2 : S0.pa_cap, new_ta,
+                                    need_be > S0.be_cap ? need_be * 2 : S0.be_cap, db.decode_cache ? std::max(S0.chain_cap, chain_cap_for(new_ta, db.beam)) : 0u);
   DevBuf ns;
   ns.reserve(nl.per * db.n_streams);
   std::vector<DecStream> nh = db.host;
@@ -400,6 +415,14 @@ void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_
     HIP_CHECK(hipMemcpyAsync(S.ta, O.ta, (size_t)std::min(O.ta_n, O.ta_cap) * 8, hipMemcpyDeviceToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(S.pq, O.pq, (size_t)std::min(O.pa_n, O.pa_cap) * 4, hipMemcpyDeviceToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(S.be, O.be, (size_t)std::min(O.be_n, O.be_cap) * sizeof(BEntry), hipMemcpyDeviceToDevice, stream));
+    if (nl.chain_cap) {   // the cached best path and the depths of the nodes on it move along (new room: no node seen yet)
+      HIP_CHECK(hipMemsetAsync(nb + nl.o_dpd, 0, nl.per - nl.o_dpd, stream));
+      HIP_CHECK(hipMemcpyAsync(S.dpd, O.dpd, (size_t)std::min(O.pa_n, O.pa_cap) * 4, hipMemcpyDeviceToDevice, stream));
+      HIP_CHECK(hipMemcpyAsync(S.dtd, O.dtd, (size_t)std::min(O.ta_n, O.ta_cap) * 4, hipMemcpyDeviceToDevice, stream));
+      HIP_CHECK(hipMemcpyAsync(S.chain, O.chain, 8, hipMemcpyDeviceToDevice, stream));                     // the two lengths
+      for (int a4 = 0; a4 < 4; ++a4)   // tokens, their nodes, timesteps, their nodes (the scratch quarter-blocks hold nothing between decodes)
+        HIP_CHECK(hipMemcpyAsync(S.chain + 2 + (size_t)a4 * nl.chain_cap, O.chain + 2 + (size_t)a4 * ol.chain_cap, (size_t)ol.chain_cap * 4, hipMemcpyDeviceToDevice, stream));
+    }
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   std::swap(db.slab.p, ns.p); std::swap(db.slab.cap, ns.cap);

@@ -146,6 +146,7 @@ struct DecoderBatch {
   uint32_t keep_pa = 0, keep_ta = 0, keep_be = 0;
   size_t keep_fixed = 0;
   int keep_n = 0;
+  bool decode_cache = false;    // the slab carries the arrays of the incremental back-tracking (DecStream::dpd / dtd / chain)
 };
 
 // Hot-word table of a scorer view in HBM, uploaded when the words change, not at every launch (STT_AddHotWord & co.: stt.cc:451-497;
@@ -311,8 +312,9 @@ struct ModelState {
   DevScorer current_scorer(std::shared_ptr<ScorerDev> sc, const std::map<std::string, float>& hot, HotTables& ht, bool in_flight = false);
   // `staging`: page-locked room for the stream table; the upload then does not wait for the stream (batch path)
   // `optimistic`: arenas below the never-overflows bound (engine.cpp); the caller must be prepared to decode again on an overflow flag
+  // decode_cache: lay out (and clear) the arrays of the incremental back-tracking -- streams that are decoded hop after hop
   void decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc, PinnedBuf* staging = nullptr,
-                      bool optimistic = false);
+                      bool optimistic = false, bool decode_cache = false);
   void decoder_reserve(DecoderBatch& db, const std::vector<int>& more_frames);
 };
 
