@@ -196,6 +196,8 @@ def stream_pass(cx, args, utts, hop_lat):
     import threading
     from stt_amd import model as M
     S, nco = args.streams, max(1, args.cohorts)
+    from stt_amd import native
+    native.set_tuning("stream_frames", 768)      # the workload's longest utterance (15 s): no stream grows its arenas in the middle of a hop
     while len(cx.stream_models) < nco:           # replicas: same weights, same scorer
         m2, _ = make_model(29, BEAM, __import__("stt_amd").synth.ENGLISH_LABELS)
         m2.enableExternalScorer(cx.scorer_path)

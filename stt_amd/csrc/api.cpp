@@ -138,7 +138,7 @@ int create_stream(ModelState* aCtx, StreamingState** retval, bool keep_emissions
     ctx->d_c.reserve((size_t)aCtx->g.n_hidden * 4); ctx->d_h.reserve((size_t)aCtx->g.n_hidden * 4);
     HIP_CHECK(hipMemsetAsync(ctx->d_c.p, 0, (size_t)aCtx->g.n_hidden * 4, aCtx->stream));  // stt.cc:535-536
     HIP_CHECK(hipMemsetAsync(ctx->d_h.p, 0, (size_t)aCtx->g.n_hidden * 4, aCtx->stream));
-    aCtx->decoder_create(ctx->dec, 1, (int)aCtx->beam_width_, 256, ctx->scorer_, nullptr, false, /*decode_cache=*/true);  // arenas sized for 256 frames up front (11 MB at beam 500); cutoff_top_n = 40, cutoff_prob = 1.0 fixed (stt.cc:539-540)
+    aCtx->decoder_create(ctx->dec, 1, (int)aCtx->beam_width_, std::max(16, tune().stream_frames), ctx->scorer_, nullptr, false, /*decode_cache=*/true);  // arenas sized for `stream_frames` (256: 11 MB at beam 500) up front; cutoff_top_n = 40, cutoff_prob = 1.0 fixed (stt.cc:539-540)
     *retval = ctx.release();
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_CREATE_STREAM);

@@ -38,6 +38,7 @@
   X(exp_waves, 0, "expand waves of the search step (0 = all the others)")                                                          \
   X(wait_spins, 0, "test hook: polls (of 256 cycles) an intra-workgroup counter wait of the search step may take before it gives up with error bit 0x10 (0 = 4 M, about half a second)") \
   X(item_table_cap, 0, "test hook: items per pass of the bitmap step's expand table (0 = what fits; small values force the several-pass path)") \
+  X(stream_frames, 256, "frames (20 ms each) a new stream's search arenas are laid out for; longer utterances grow them (an allocation and a copy in the middle of a hop): a server sets its longest expected utterance") \
   X(decode_cache, 1, "streams: a decode with one result walks the best path back only to where it meets the previously decoded one (0: the whole path every time); read when a stream is created") \
   X(lm_memo, 1, "code-point scorer: FullScore memo table (0 off, 1 = 2^24 entries of 32 B -- measured on the code-point bench scorer: 2^18 66.4 ms per batch, 2^22 54.1, 2^24 49.3 --, 10..26 = log2 of the entry count); read when a scorer is loaded")                                                                         \
   X(unit_bounds, 1, "code-point scorer: upper bounds of the LM score (candidates that cannot reach the beam skip FullScore): 1 = the largest over all units, 2 = also a table by code point; read when a scorer is loaded") \
