@@ -11,8 +11,9 @@ workload batch  (default, the driver's line) configs[1]: 64 synthetic 5 s 16 kHz
                 a DIFFERENT seeded batch every step (up to 32 distinct batches, then they repeat)
          stream configs[2]: synthetic utterances of 1-15 s fed in 320 ms hops with an intermediate decode of every live stream after
                 every hop; a ROLLING live set: --streams streams are live at all times per cohort (a stream that has consumed its
-                utterance is finished, the next utterance takes its place; its last hop carries its flush:
-                STTX_FeedAudioContentBatchEx), --cohorts independent live sets, each on its own model replica and host thread
+                utterance is finished, the next utterance takes its place; its last hop carries its flush and the
+                few windows the flush leaves ride in the next hop's pass -- STTX_FeedAudioContentBatchEx, aLast = 2 -- so a
+                cohort's --streams open streams are ~123 live + ~5 in that last hop), --cohorts independent live sets, each on its own model replica and host thread
                 (one cohort's beam search overlaps the other's acoustic pass on the GPU); a step = one pass over --utterances
          ragged configs[3]: ONE seeded LibriSpeech-shaped list (--utterances per rank x ranks: 1250 x 8 = the 10 k of configs[3];
                 lengths U(1,15) s) dealt longest-processing-time-first over the ranks (stt_amd.dist.shard_utterances); rank 0 puts the
@@ -209,21 +210,25 @@ def stream_pass(cx, args, utts, hop_lat):
 
     def cohort(c):
         try:
-            model, mine, nxt, live = cx.stream_models[c], parts[c], 0, []
-            while nxt < len(mine) or live:
-                while len(live) < S and nxt < len(mine):
+            model, mine, nxt, live, drain = cx.stream_models[c], parts[c], 0, [], []
+            empty = np.zeros(0, dtype=np.int16)
+            while nxt < len(mine) or live or drain:
+                # S open streams: the live ones and those whose last audio went in with the previous hop (aLast = 2: the few windows
+                # their flush left ride in this hop's pass instead of costing a pass of their own; then they are finished)
+                while len(live) + len(drain) < S and nxt < len(mine):
                     live.append([mine[nxt], model.createStream(), 0]); nxt += 1
                 t0 = time.perf_counter()
-                M.feedAudioContentBatch([s for _, s, _ in live], [utts[u][k:k + 5120] for u, _, k in live], last=[k + 5120 >= len(utts[u]) for u, _, k in live])
+                M.feedAudioContentBatch([s for _, s, _ in live] + [s for _, s, _ in drain], [utts[u][k:k + 5120] for u, _, k in live] + [empty] * len(drain),
+                                        last=[2 if k + 5120 >= len(utts[u]) else 0 for u, _, k in live] + [0] * len(drain))
                 M.intermediateDecodeBatch([s for _, s, _ in live])
                 lats[c].append(time.perf_counter() - t0)
+                if drain:
+                    for e, t in zip(drain, M.finishStreamBatch([e[1] for e in drain])):
+                        texts[e[0]] = t
                 for e in live:
                     e[2] += 5120
-                done = [e for e in live if e[2] >= len(utts[e[0]])]
-                if done:
-                    for e, t in zip(done, M.finishStreamBatch([e[1] for e in done])):
-                        texts[e[0]] = t
-                    live = [e for e in live if e[2] < len(utts[e[0]])]
+                drain = [e for e in live if e[2] >= len(utts[e[0]])]
+                live = [e for e in live if e[2] < len(utts[e[0]])]
         except Exception as ex:
             errs.append(ex)
     import gc

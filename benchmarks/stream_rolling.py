@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
+DEFER = True  # ... and what the flush leaves behind the hop's pass rides in the next hop (aLast = 2); --no-defer: a pass of its own
 FOLD = True   # a stream's last hop carries its flush (STTX_FeedAudioContentBatchEx); --no-fold: the flush is finishStreamBatch's own pass
 
 
@@ -27,25 +28,29 @@ def run(model, utts, S, M):
     texts = [None] * len(utts)
     nxt = 0
     live = []      # [utterance index, stream, samples consumed]
+    drain = []     # DEFER: streams whose last audio went in with the previous hop (aLast = 2); the rest of their flush rides in this hop
     recs = []
-    while nxt < len(utts) or live:
+    empty = np.zeros(0, dtype=np.int16)
+    while nxt < len(utts) or live or drain:
         t0 = time.perf_counter()
         n_created = 0
-        while len(live) < S and nxt < len(utts):
+        while len(live) + len(drain) < S and nxt < len(utts):
             live.append([nxt, model.createStream(), 0]); nxt += 1; n_created += 1
         t1 = time.perf_counter()
-        M.feedAudioContentBatch([s for _, s, _ in live], [utts[u][k:k + 5120] for u, _, k in live],
-                                last=([k + 5120 >= len(utts[u]) for u, _, k in live] if FOLD else None))
+        code = 2 if DEFER else 1
+        M.feedAudioContentBatch([s for _, s, _ in live] + [s for _, s, _ in drain], [utts[u][k:k + 5120] for u, _, k in live] + [empty] * len(drain),
+                                last=([code if k + 5120 >= len(utts[u]) else 0 for u, _, k in live] + [0] * len(drain) if FOLD else None))
         t2 = time.perf_counter()
         M.intermediateDecodeBatch([s for _, s, _ in live])
         t3 = time.perf_counter()
         for e in live:
             e[2] += 5120
-        done = [e for e in live if e[2] >= len(utts[e[0]])]
+        done = drain if DEFER else [e for e in live if e[2] >= len(utts[e[0]])]
         if done:
             for e, t in zip(done, M.finishStreamBatch([e[1] for e in done])):
                 texts[e[0]] = t
-            live = [e for e in live if e[2] < len(utts[e[0]])]
+        drain = [e for e in live if e[2] >= len(utts[e[0]])] if DEFER else []
+        live = [e for e in live if e[2] < len(utts[e[0]])]
         t4 = time.perf_counter()
         recs.append((t2 - t1, t3 - t2, t4 - t3, t1 - t0, len(live) + len(done), len(done), n_created))
     return texts, recs
@@ -59,10 +64,12 @@ def main():
     ap.add_argument("--scorer", default="synthetic", choices=["synthetic", "fixture"])
     ap.add_argument("--set", default="")
     ap.add_argument("--no-fold", action="store_true")
+    ap.add_argument("--no-defer", action="store_true")
     ap.add_argument("--cohorts", type=int, default=1, help="independent live sets of --streams streams, each on its own Model replica and host thread (their passes overlap on the GPU)")
     a = ap.parse_args()
-    global FOLD
+    global FOLD, DEFER
     FOLD = not a.no_fold
+    DEFER = FOLD and not a.no_defer
     from stt_amd import model as M
     from stt_amd import native, synth
     native.lib()

@@ -122,7 +122,10 @@ STTX_EXPORT void STTX_FeedAudioContentBatch(StreamingState* const* aStreams, con
  * an acoustic pass of its own (the partial window, the trailing context frames, the last partial batch of windows: stt.cc:236-254)
  * goes through the model in the SAME launches as the other streams' hop.  STT_FinishStream / STT_FinishStreamWithMetadata /
  * STTX_FinishStreamBatch on such a stream then only rank and back-track.  (A server that keeps a fixed number of streams live finishes a
- * few of them in every hop; their flushes cost a whole pass each otherwise.)  aLast may be NULL (= STTX_FeedAudioContentBatch). */
+ * few of them in every hop; their flushes cost a whole pass each otherwise.)  aLast[i] == 2: the same, but whatever the flush leaves
+ * after the call's first pass (at most n_steps - 1 windows: the flush adds n_context + 1 frames to a full hop) is not given a pass of
+ * its own: it rides in the stream's NEXT STTX_FeedAudioContentBatch(Ex) call (pass the stream with an empty buffer, beside the live
+ * streams' hop) or is processed by its finish.  aLast may be NULL (= STTX_FeedAudioContentBatch). */
 STTX_EXPORT void STTX_FeedAudioContentBatchEx(StreamingState* const* aStreams, const short* const* aBuffers, const unsigned int* aBufferSizes,
                                               const unsigned char* aLast, unsigned int aCount);
 /* aCount malloc'd strings (free with STTX_FreeStrings), or NULL on error. */

@@ -544,7 +544,10 @@ void StreamingState::feedAudioContent(const short* buffer, unsigned int buffer_s
 }
 
 void StreamingState::flushBuffers(bool addZeroMfccVectors) {
-  if (addZeroMfccVectors && flushed_) return;   // its last audio came through STTX_FeedAudioContentBatchEx with the last flag: already flushed
+  if (addZeroMfccVectors && flushed_) {   // its last audio came through STTX_FeedAudioContentBatchEx with the last flag: already flushed ...
+    processReady(true, true);              // ... except for a tail that was deferred and has not ridden along yet
+    return;
+  }
   if (addZeroMfccVectors) flushed_ = true;
   // stt.cc:236-254: the partial audio window goes through the feature graph as is (zero padded), audio_buffer_ is kept
   pushFrames(audio_buffer_.data(), (int)audio_buffer_.size(), 1);
@@ -657,12 +660,15 @@ bool streams_process(const std::vector<StreamingState*>& ss, bool flush_partial,
   const Geometry& g = m.g;
   const int H = g.n_hidden, C = g.n_classes, kp = g.k1_pad(), kw = g.n_in1(), T = g.n_steps;
   DevScorer ds = m.current_scorer(ss[0]->scorer_, ss[0]->hot_words_, ss[0]->hot_tables_);
-  for (;;) {
+  for (int pass = 0;; ++pass) {
     std::vector<StreamingState*> R;
     std::vector<int> takes;
     for (size_t si = 0; si < ss.size(); ++si) {
       StreamingState* s = ss[si];
-      const bool fl = flush_partial || (flush_each && (*flush_each)[si]);
+      // flush_each: 1 = this stream's partial batch of windows goes through as well; 2 = only in the first pass of this call -- what
+      // is left after it waits for the stream's next call (or its finish): no pass of its own for a handful of rows
+      const uint8_t fe = flush_each ? (*flush_each)[si] : 0;
+      const bool fl = flush_partial || fe == 1 || (fe == 2 && pass == 0);
       const int ready = std::max(0, s->frames_ - 2 * g.n_context) - s->windows_done_;
       const int take = ready >= T ? T : ((fl && ready > 0) ? ready : 0);
       if (take) { R.push_back(s); takes.push_back(take); }
@@ -779,8 +785,9 @@ void streams_feed_batch(const std::vector<StreamingState*>& ss, const short* con
     const int len = (int)all.size();
     const int W = len >= g.win_len ? (len - g.win_len) / g.win_step + 1 : 0;
     const bool is_last = last && last[i] && !s->flushed_;
+    if (s->flushed_) { fl[i] = 2; any_last = true; }   // flushed by an earlier call that deferred its tail (last = 2): the tail rides in this pass
     if (is_last) {   // W full windows and the partial one behind them (zero padded by the feature kernel), from one span
-      fl[i] = 1; any_last = true;
+      fl[i] = last[i] == 2 ? 2 : 1; any_last = true;
       spans[i] = all;
       s->audio_buffer_.assign(all.begin() + std::min((size_t)len, (size_t)W * g.win_step), all.end());   // (flushBuffers keeps it: stt.cc:236-254)
       nf[i] = W + 1;
@@ -794,13 +801,17 @@ void streams_feed_batch(const std::vector<StreamingState*>& ss, const short* con
   }
   streams_push_frames(ss, spans, nf);
   if (any_last)
-    for (int i = 0; i < n; ++i) if (fl[i]) { ss[i]->pushZeroFrames(g.n_context); ss[i]->flushed_ = true; }
+    for (int i = 0; i < n; ++i) if (fl[i] && !ss[i]->flushed_) { ss[i]->pushZeroFrames(g.n_context); ss[i]->flushed_ = true; }
   if (!streams_process(ss, false, any_last ? &fl : nullptr)) HIP_CHECK(hipStreamSynchronize(m.stream));   // page-locked staging is reused by the next call
 }
 
 void streams_flush_batch(const std::vector<StreamingState*>& ss_all, bool addZeroMfccVectors) {
-  std::vector<StreamingState*> ss;
-  for (StreamingState* s : ss_all) if (!(addZeroMfccVectors && s->flushed_)) ss.push_back(s);   // (flushed with its last audio: streams_feed_batch)
+  std::vector<StreamingState*> ss, left;
+  for (StreamingState* s : ss_all) {
+    if (!(addZeroMfccVectors && s->flushed_)) ss.push_back(s);   // (else: flushed with its last audio, streams_feed_batch ...
+    else if (std::max(0, s->frames_ - 2 * s->model_->g.n_context) - s->windows_done_ > 0) left.push_back(s);   // ... but its tail was deferred and never rode along)
+  }
+  if (!left.empty() && !streams_process(left, true)) HIP_CHECK(hipStreamSynchronize(left[0]->model_->stream));
   if (ss.empty()) return;
   const int n = (int)ss.size();
   std::vector<std::vector<int16_t>> spans(n);

@@ -323,12 +323,14 @@ def feedAudioContentBatch(streams, audio_buffers, last=None):
     if last is None:
         native.lib().STTX_FeedAudioContentBatch(_stream_ptrs(streams), ptrs, sizes, n)
     else:
-        flags = (C.c_ubyte * n)(*[1 if f else 0 for f in last])
+        flags = (C.c_ubyte * n)(*[int(f) if f else 0 for f in last])   # 1 = final audio, flush now; 2 = final audio, the flush's tail rides in the next call
         native.lib().STTX_FeedAudioContentBatchEx(_stream_ptrs(streams), ptrs, sizes, flags, n)
 
 
 def intermediateDecodeBatch(streams):
     n = len(streams)
+    if n == 0:
+        return []
     r = native.lib().STTX_IntermediateDecodeBatch(_stream_ptrs(streams), n)
     if not r:
         raise RuntimeError("STTX_IntermediateDecodeBatch failed")
@@ -339,6 +341,8 @@ def intermediateDecodeBatch(streams):
 
 def finishStreamBatch(streams):
     n = len(streams)
+    if n == 0:
+        return []
     r = native.lib().STTX_FinishStreamBatch(_stream_ptrs(streams), n)
     for st in streams:
         st._impl = None   # destroyed by the call, like STT_FinishStream

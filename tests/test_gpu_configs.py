@@ -237,3 +237,37 @@ def test_config3_last_audio_carries_the_flush(model):
                     got[e[0]] = t
             live = [e for e in live if e[2] < len(audio[e[0]])]
     assert got == want
+
+
+def test_config3_deferred_flush_tail(model):
+    """aLast == 2: the flagged stream's flush leaves a handful of windows behind the call's first pass; they ride in the stream's next
+    batched call (empty buffer, beside the live streams' hop) or -- if none comes -- are processed by its finish, batched or plain.
+    Same transcripts as STT_SpeechToText either way."""
+    from stt_amd import model as M
+    rng = np.random.RandomState(9)
+    lens = (rng.uniform(0.1, 4.0, size=48) * 16000).astype(int)
+    lens[2] = 100; lens[5] = 5120 * 3; lens[6] = 5120 * 3 + 1; lens[9] = 512; lens[10] = 5120 * 3 - 1
+    audio = [synth.synth_audio(int(n), seed=1700 + i) for i, n in enumerate(lens)]
+    want = [model.stt(a) for a in audio]
+    got = [None] * len(audio)
+    S, nxt, live, drain, hop = 9, 0, [], [], 0
+    empty = np.zeros(0, dtype=np.int16)
+    while nxt < len(audio) or live or drain:
+        while len(live) + len(drain) < S and nxt < len(audio):
+            live.append([nxt, model.createStream(), 0]); nxt += 1
+        ride = drain if hop % 3 else []              # every third hop the drained streams go straight to their finish: it does the tail
+        M.feedAudioContentBatch([s for _, s, _ in live] + [s for _, s, _ in ride], [audio[u][k:k + 5120] for u, _, k in live] + [empty] * len(ride),
+                                last=[2 if k + 5120 >= len(audio[u]) else 0 for u, _, k in live] + [0] * len(ride))
+        M.intermediateDecodeBatch([s for _, s, _ in live])
+        if len(drain) == 1:
+            got[drain[0][0]] = drain[0][1].finishStream()
+        elif drain:
+            for e, t in zip(drain, M.finishStreamBatch([e[1] for e in drain])):
+                got[e[0]] = t
+        for e in live:
+            e[2] += 5120
+        drain = [e for e in live if e[2] >= len(audio[e[0]])]
+        live = [e for e in live if e[2] < len(audio[e[0]])]
+        hop += 1
+    assert got == want
+
