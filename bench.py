@@ -220,11 +220,10 @@ def stream_pass(cx, args, utts, hop_lat):
                 t0 = time.perf_counter()
                 M.feedAudioContentBatch([s for _, s, _ in live] + [s for _, s, _ in drain], [utts[u][k:k + 5120] for u, _, k in live] + [empty] * len(drain),
                                         last=[2 if k + 5120 >= len(utts[u]) else 0 for u, _, k in live] + [0] * len(drain))
-                M.intermediateDecodeBatch([s for _, s, _ in live])
+                out = M.decodeStreamsBatch([s for _, s, _ in live] + [s for _, s, _ in drain], [False] * len(live) + [True] * len(drain))   # the hop's intermediate results and the finishes: one launch
                 lats[c].append(time.perf_counter() - t0)
-                if drain:
-                    for e, t in zip(drain, M.finishStreamBatch([e[1] for e in drain])):
-                        texts[e[0]] = t
+                for e, t in zip(drain, out[len(live):]):
+                    texts[e[0]] = t
                 for e in live:
                     e[2] += 5120
                 drain = [e for e in live if e[2] >= len(utts[e[0]])]

@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
+ONE_DECODE = True   # STTX_DecodeStreamsBatch; --two-decodes: STTX_IntermediateDecodeBatch + STTX_FinishStreamBatch
 DEFER = True  # ... and what the flush leaves behind the hop's pass rides in the next hop (aLast = 2); --no-defer: a pass of its own
 FOLD = True   # a stream's last hop carries its flush (STTX_FeedAudioContentBatchEx); --no-fold: the flush is finishStreamBatch's own pass
 
@@ -41,12 +42,17 @@ def run(model, utts, S, M):
         M.feedAudioContentBatch([s for _, s, _ in live] + [s for _, s, _ in drain], [utts[u][k:k + 5120] for u, _, k in live] + [empty] * len(drain),
                                 last=([code if k + 5120 >= len(utts[u]) else 0 for u, _, k in live] + [0] * len(drain) if FOLD else None))
         t2 = time.perf_counter()
-        M.intermediateDecodeBatch([s for _, s, _ in live])
+        if DEFER and ONE_DECODE:   # the hop's intermediate results and the finishes of the drained streams in one launch
+            out = M.decodeStreamsBatch([s for _, s, _ in live] + [s for _, s, _ in drain], [False] * len(live) + [True] * len(drain))
+            for e, t in zip(drain, out[len(live):]):
+                texts[e[0]] = t
+        else:
+            M.intermediateDecodeBatch([s for _, s, _ in live])
         t3 = time.perf_counter()
         for e in live:
             e[2] += 5120
         done = drain if DEFER else [e for e in live if e[2] >= len(utts[e[0]])]
-        if done:
+        if done and not (DEFER and ONE_DECODE):
             for e, t in zip(done, M.finishStreamBatch([e[1] for e in done])):
                 texts[e[0]] = t
         drain = [e for e in live if e[2] >= len(utts[e[0]])] if DEFER else []
@@ -65,9 +71,11 @@ def main():
     ap.add_argument("--set", default="")
     ap.add_argument("--no-fold", action="store_true")
     ap.add_argument("--no-defer", action="store_true")
+    ap.add_argument("--two-decodes", action="store_true")
     ap.add_argument("--cohorts", type=int, default=1, help="independent live sets of --streams streams, each on its own Model replica and host thread (their passes overlap on the GPU)")
     a = ap.parse_args()
-    global FOLD, DEFER
+    global FOLD, DEFER, ONE_DECODE
+    ONE_DECODE = not a.two_decodes
     FOLD = not a.no_fold
     DEFER = FOLD and not a.no_defer
     from stt_amd import model as M

@@ -132,6 +132,9 @@ STTX_EXPORT void STTX_FeedAudioContentBatchEx(StreamingState* const* aStreams, c
 STTX_EXPORT char** STTX_IntermediateDecodeBatch(StreamingState* const* aStreams, unsigned int aCount);
 /* Like STT_FinishStream on every stream: the streams are destroyed. */
 STTX_EXPORT char** STTX_FinishStreamBatch(StreamingState* const* aStreams, unsigned int aCount);
+/* Both in one ranking + back-tracking launch: STT_IntermediateDecode for the streams with aFinish[i] == 0, STT_FinishStream (the
+ * stream is destroyed, also on error) for those with aFinish[i] != 0 -- a server's hop has some of each.  aCount strings or NULL. */
+STTX_EXPORT char** STTX_DecodeStreamsBatch(StreamingState* const* aStreams, const unsigned char* aFinish, unsigned int aCount);
 
 /* Per-stage GPU time of the last batch call, measured with HIP events on the engine's own stream.
  * aMs receives up to aCap floats: [0] features, [1] dense layers 1-3 + x-projection, [2] LSTM recurrence,

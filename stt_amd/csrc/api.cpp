@@ -757,6 +757,25 @@ char** STTX_IntermediateDecodeBatch(StreamingState* const* aStreams, unsigned in
   }, 0);
   return r;
 }
+char** STTX_DecodeStreamsBatch(StreamingState* const* aStreams, const unsigned char* aFinish, unsigned int aCount) {
+  char** r = nullptr;
+  guarded([&]() {
+    if (!aCount) return 0;
+    std::vector<StreamingState*> ss(aStreams, aStreams + aCount), fin;
+    for (unsigned i = 0; i < aCount; ++i) if (aFinish && aFinish[i]) fin.push_back(ss[i]);
+    HIP_CHECK(hipSetDevice(ss[0]->model_->device));
+    if (streams_batchable(ss)) {
+      if (!fin.empty()) streams_flush_batch(fin, true);        // (nothing left to do for streams whose last audio carried the flush)
+      r = strings_of(ss[0]->model_, streams_decode_batch(ss, 1));   // ONE ranking + back-tracking launch: the hop's intermediate results and the finishes'
+    } else {
+      r = (char**)malloc(sizeof(char*) * aCount);
+      for (unsigned i = 0; i < aCount; ++i) { if (aFinish && aFinish[i]) ss[i]->flushBuffers(true); r[i] = decode_string(ss[i]); }
+    }
+    return 0;
+  }, 0);
+  for (unsigned i = 0; i < aCount; ++i) if (aFinish && aFinish[i]) STT_FreeStream(aStreams[i]);   // like STT_FinishStream: also when the decode failed
+  return r;
+}
 char** STTX_FinishStreamBatch(StreamingState* const* aStreams, unsigned int aCount) {
   char** r = nullptr;
   guarded([&]() {

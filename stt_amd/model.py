@@ -339,6 +339,23 @@ def intermediateDecodeBatch(streams):
     return out
 
 
+def decodeStreamsBatch(streams, finish):
+    """STTX_DecodeStreamsBatch: one launch for a hop's intermediate results (finish[i] false) and its finishes (true: stream destroyed)."""
+    n = len(streams)
+    if n == 0:
+        return []
+    flags = (C.c_ubyte * n)(*[1 if f else 0 for f in finish])
+    r = native.lib().STTX_DecodeStreamsBatch(_stream_ptrs(streams), flags, n)
+    for st, f in zip(streams, finish):
+        if f:
+            st._impl = None
+    if not r:
+        raise RuntimeError("STTX_DecodeStreamsBatch failed")
+    out = [C.string_at(r[i]).decode("utf-8", "replace") for i in range(n)]
+    native.lib().STTX_FreeStrings(r, n)
+    return out
+
+
 def finishStreamBatch(streams):
     n = len(streams)
     if n == 0:

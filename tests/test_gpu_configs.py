@@ -258,12 +258,21 @@ def test_config3_deferred_flush_tail(model):
         ride = drain if hop % 3 else []              # every third hop the drained streams go straight to their finish: it does the tail
         M.feedAudioContentBatch([s for _, s, _ in live] + [s for _, s, _ in ride], [audio[u][k:k + 5120] for u, _, k in live] + [empty] * len(ride),
                                 last=[2 if k + 5120 >= len(audio[u]) else 0 for u, _, k in live] + [0] * len(ride))
-        M.intermediateDecodeBatch([s for _, s, _ in live])
-        if len(drain) == 1:
-            got[drain[0][0]] = drain[0][1].finishStream()
-        elif drain:
-            for e, t in zip(drain, M.finishStreamBatch([e[1] for e in drain])):
+        if hop % 2:                                  # STTX_DecodeStreamsBatch: the hop's intermediate results and the finishes in one launch
+            inter = M.intermediateDecodeBatch([s for _, s, _ in live]) if hop % 4 == 1 else None
+            out = M.decodeStreamsBatch([s for _, s, _ in live] + [s for _, s, _ in drain], [False] * len(live) + [True] * len(drain))
+            assert inter is None or out[:len(live)] == inter
+            for e, t in zip(drain, out[len(live):]):
                 got[e[0]] = t
+                with pytest.raises(RuntimeError):
+                    e[1].intermediateDecode()        # destroyed
+        else:
+            M.intermediateDecodeBatch([s for _, s, _ in live])
+            if len(drain) == 1:
+                got[drain[0][0]] = drain[0][1].finishStream()
+            elif drain:
+                for e, t in zip(drain, M.finishStreamBatch([e[1] for e in drain])):
+                    got[e[0]] = t
         for e in live:
             e[2] += 5120
         drain = [e for e in live if e[2] >= len(audio[e[0]])]
