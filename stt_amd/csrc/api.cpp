@@ -136,8 +136,9 @@ int create_stream(ModelState* aCtx, StreamingState** retval, bool keep_emissions
     HIP_CHECK(hipSetDevice(aCtx->device));
     ctx->pushZeroFrames(aCtx->g.n_context);                         // stt.cc:533
     ctx->d_c.reserve((size_t)aCtx->g.n_hidden * 4); ctx->d_h.reserve((size_t)aCtx->g.n_hidden * 4);
-    HIP_CHECK(hipMemsetAsync(ctx->d_c.p, 0, (size_t)aCtx->g.n_hidden * 4, aCtx->stream));  // stt.cc:535-536
-    HIP_CHECK(hipMemsetAsync(ctx->d_h.p, 0, (size_t)aCtx->g.n_hidden * 4, aCtx->stream));
+    // stt.cc:535-536 (previous_state_c / _h = 0): nothing is written here -- a stream whose state_nonzero is false enters its first pass
+    // with a zero state by construction (acoustic_rows: carry 0 clears the cell state and the h fragments; the batched pass gathers
+    // zeros for such a row), and a recycled stream's flag was reset (StreamingState::recycle)
     aCtx->decoder_create(ctx->dec, 1, (int)aCtx->beam_width_, std::max(16, tune().stream_frames), ctx->scorer_, nullptr, false, /*decode_cache=*/true);  // arenas sized for `stream_frames` (256: 11 MB at beam 500) up front; cutoff_top_n = 40, cutoff_prob = 1.0 fixed (stt.cc:539-540)
     *retval = ctx.release();
     return (int)STT_ERR_OK;
