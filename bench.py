@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's metric on BASELINE.json's config, one process per GPU.
 
-    python bench.py --gpus 1 --steps K --warmup W [--workload batch|stream|ragged|bytes|peaky]
+    python bench.py --gpus 1 --steps K --warmup W [--workload batch|stream|ragged|bytes|peaky|peaky_bytes]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 metric   audio-seconds per wall-second (RTF x), whole job, audio already resident in HBM when the clock starts
@@ -22,7 +22,9 @@ workload batch  (default, the driver's line) configs[1]: 64 synthetic 5 s 16 kHz
          peaky  configs[1]'s decoder stage alone on peaky synthetic emissions (SURVEY.md 8d Config 2: blank ~0.9, labels held two
                 frames) of sentences drawn from vocab.pruned.txt, 64 streams x 250 frames: DecoderState::next + decode, state
                 slabs allocated before the clock starts
-         The default run (batch, one GPU) appends the other four as `workloads` sub-lines, measured in the same process on the
+         peaky_bytes  configs[4]'s decoder stage alone on peaky byte emissions of code-point sentences (what a trained byte-output
+                model emits; `bytes` runs a random-init one: near-uniform over 256 classes), 64 streams x 250 frames, beam 1024
+         The default run (batch, one GPU) appends the other five as `workloads` sub-lines, measured in the same process on the
          same build (--no-extras skips them).
 weights  seeded random init of the reference architecture (no checkpoint exists offline); scorer = a synthetic
          huge-vocabulary package written at start-up by stt_amd/tools (500 k pseudo-words, order 5, 30 M n-grams, KenLM
@@ -254,9 +256,10 @@ def measure(wl, args, cx, steps, warmup):
     from stt_amd import model as M
     from stt_amd import native, synth
     rank, world, dev, cdev, dist = cx.rank, cx.world, cx.dev, cx.cdev, cx.dist
-    C = 256 if wl == "bytes" else 29
-    beam = 1024 if wl == "bytes" else BEAM
-    if wl == "bytes":
+    byte_mode = wl in ("bytes", "peaky_bytes")
+    C = 256 if byte_mode else 29
+    beam = 1024 if byte_mode else BEAM
+    if byte_mode:
         if cx.bytes_model is None:
             cx.bytes_model, _ = make_model(256, 1024, [bytes([i + 1]) for i in range(255)])   # UTF8Alphabet (alphabet.h:83-91)
             cx.bytes_model.enableExternalScorer(cx.bytes_scorer_path)
@@ -308,6 +311,24 @@ def measure(wl, args, cx, steps, warmup):
                 "rolling live set of %d streams x %d cohort(s) (model replicas on their own host threads), English geometry, beam_width=500, scorer = %s"
                 % (nu, args.streams, max(1, args.cohorts), scorer_desc))
         gbatch = world * nu
+    elif wl == "peaky_bytes":
+        # configs[4]'s decoder stage as a TRAINED byte-output model would drive it: peaky emissions of sentences of three-byte code
+        # points (the scorer's units, U+4E00 ...), every byte held two frames; the `bytes` workload's random-init model is the other
+        # extreme (near-uniform over 256 classes: every prefix has 64 scored children per step)
+        rng = np.random.RandomState(11 + rank)
+        T = 250
+        em = []
+        for i in range(BATCH):
+            lab = []
+            for cp in 0x4E00 + rng.randint(0, 6000, size=19):
+                lab += [(0xE0 | (cp >> 12)) - 1, (0x80 | ((cp >> 6) & 0x3F)) - 1, (0x80 | (cp & 0x3F)) - 1]   # UTF8Alphabet: label = byte - 1 (alphabet.h:83-91)
+            em.append(synth.peaky_emissions(lab, T, 256, 255, seed=int(rng.randint(1 << 30)), noise=0.02 * 29 / 256, lead=10))
+        em = np.stack(em).astype(np.float32)
+        audio_s_step = BATCH * SECONDS
+        desc = ("configs[4] decoder stage on peaky synthetic byte emissions (blank ~0.9, every byte of 19 three-byte code points held 2 frames, noise mass as "
+                "the word-mode peaky workload): 64 streams x 250 frames, 256 classes, beam_width=1024, scorer = " + scorer_desc)
+        gbatch = world * BATCH
+        decoders = [model.createDecoder(BATCH, beam) for _ in range(steps + warmup)]
     else:  # peaky
         vocab = open(os.path.join(FIX, "vocab.pruned.txt")).read().split()
         rng = np.random.RandomState(7 + rank)
@@ -345,7 +366,10 @@ def measure(wl, args, cx, steps, warmup):
             td = time.perf_counter()
             for k_, v_ in (("next_ms", tc - tb), ("decode_ms", td - tc)):
                 extra[k_] = extra.get(k_, 0.0) + 1e3 * v_
-            texts = ["".join(" " if t == 0 else ("'" if t == 27 else chr(ord("a") + int(t) - 1)) for t in r[0][1]) if r else "" for r in res]
+            if wl == "peaky_bytes":
+                texts = [bytes(int(t) + 1 for t in r[0][1]).decode("utf-8", "replace") if r else "" for r in res]
+            else:
+                texts = ["".join(" " if t == 0 else ("'" if t == 27 else chr(ord("a") + int(t) - 1)) for t in r[0][1]) if r else "" for r in res]
         return sdist.gather_transcripts(texts, device=cdev) if world > 1 else [texts]
 
     pipelined = wl in ("batch", "bytes") and not args.no_pipeline
@@ -494,9 +518,13 @@ def measure(wl, args, cx, steps, warmup):
         verified_against = "blocking"
         verified_what = ("final transcripts of the %d streamed utterances of every timed pass == the one-shot batch path on the whole utterances "
                          "(stt.cc:641-688: one-shot = create stream, feed everything, finish); %d non-empty" % (len(utts), sum(1 for t in want_s if t)))
-    elif wl == "peaky":
+    elif wl in ("peaky", "peaky_bytes"):
         verified = all(t for _, t in timed_texts) and len({tuple(t) for _, t in timed_texts}) == 1
         verified_what = "all timed steps give the same non-empty transcripts"
+        if wl == "peaky_bytes":   # ... and they are the sentences the emissions were drawn from (3 bytes per code point, nothing lost or split)
+            n_cp = [len(t) for t in timed_texts[0][1]]
+            verified = verified and all(15 <= n <= 21 for n in n_cp)   # (noise can add a code point the LM likes; none may vanish wholesale)
+            verified_what += "; code points per transcript %d-%d of 19 drawn" % (min(n_cp), max(n_cp))
     dstats, dphase, dstamps = {}, {}, []
     if profiled:
         model.setProfiling(2)            # one extra, untimed step with the search kernel's phase cycle counters on
@@ -509,9 +537,10 @@ def measure(wl, args, cx, steps, warmup):
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if wl == "peaky":
+    if wl in ("peaky", "peaky_bytes"):
         for d in decoders:
             d.close()
+    if wl == "peaky":
         model.disableExternalScorer(); model.enableExternalScorer(cx.scorer_path)
     if rank != 0:
         return None
@@ -555,11 +584,11 @@ def measure(wl, args, cx, steps, warmup):
         res["roofline"] = {"kernel": "one 320 ms hop of all live streams (16 x lstm_step_kernel + dense + ctc_next_kernel + ctc_decode_kernel)", "bound": "hbm",
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                            "note": "host-timed whole hop, not a single kernel: launch-bound (about 45 kernels per hop)"}
-    elif wl == "peaky":
+    elif wl in ("peaky", "peaky_bytes"):
         ms = extra.get("next_ms", 0.0) / K      # DecoderState::next alone: H2D of 1.9 MB of emissions + the search launch, host-timed
         res["stage_ms_per_step"] = {k_: v_ / K for k_, v_ in extra.items()}
-        by = BATCH * 250 * (29 * 4 + 2 * BEAM * 40)
-        res["roofline"] = {"kernel": "ctc_next_kernel (+ H2D of 1.9 MB emissions)", "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        by = BATCH * 250 * (C * 4 + 2 * beam * 40)
+        res["roofline"] = {"kernel": "ctc_next_kernel (+ H2D of %.1f MB emissions)" % (BATCH * 250 * C * 4 / 1e6), "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "us_per_stream_timestep": 1e3 * ms / 250.0,
                            "note": "host-timed STTX_DecoderNext of 64 streams x 250 frames (state slabs allocated before the clock)"}
     else:
@@ -664,7 +693,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", default="batch", choices=["batch", "stream", "ragged", "bytes", "peaky"])
+    ap.add_argument("--workload", default="batch", choices=["batch", "stream", "ragged", "bytes", "peaky", "peaky_bytes"])
     ap.add_argument("--utterances", type=int, default=0, help="stream: utterances per step (default 1000); ragged: per rank (default 1250; the list holds this x ranks)")
     ap.add_argument("--streams", type=int, default=128, help="stream: live streams per cohort, advanced together (one recurrent launch covers 128 rows)")
     ap.add_argument("--cohorts", type=int, default=2, help="stream: independent live sets, each on its own model replica and host thread")
@@ -730,12 +759,12 @@ def main():
     cx.stream_models = []
     cx.bytes_scorer_path, cx.bytes_scorer_desc = os.path.join(FIX, "pruned_lm.bytes.scorer"), "pruned_lm.bytes.scorer fixture (code-point level, order 2)"
     cx.tmpdirs = []
-    if args.scorer == "synthetic" and (wl == "bytes" or (wl == "batch" and not args.no_extras)):
+    if args.scorer == "synthetic" and (wl in ("bytes", "peaky_bytes") or (wl == "batch" and not args.no_extras)):
         cx.tmpdirs.append(tempfile.TemporaryDirectory())
         cx.bytes_scorer_path, cx.bytes_scorer_desc = synth_codepoint_scorer(cx.tmpdirs[-1].name)
     cx.model, cx.scorer_path, cx.scorer_desc, weights = None, None, None, None
     scorer_dir = None
-    if wl != "bytes" or not args.no_extras:
+    if wl not in ("bytes", "peaky_bytes") or not args.no_extras:
         cx.model, weights = make_model(29, BEAM, synth.ENGLISH_LABELS)
         if args.scorer == "synthetic":
             scorer_dir = tempfile.TemporaryDirectory()
@@ -748,7 +777,7 @@ def main():
     if rank == 0 and wl == "batch" and world == 1 and not args.no_extras and not args.no_profile:
         # the other configs, same process, same build: short runs (a few seconds each), each with its own roofline
         sub = {}
-        for w, k, wu, kw in (("ragged", 2, 1, {}), ("stream", 3, 1, {"utterances": 1000}), ("bytes", 8, 5, {}), ("peaky", 10, 2, {})):   # (bytes: four batches in flight -- the warm-up covers every slot's first use)
+        for w, k, wu, kw in (("ragged", 2, 1, {}), ("stream", 3, 1, {"utterances": 1000}), ("bytes", 8, 5, {}), ("peaky", 10, 2, {}), ("peaky_bytes", 6, 2, {})):   # (bytes: four batches in flight -- the warm-up covers every slot's first use)
             a2 = argparse.Namespace(**vars(args))
             a2.utterances = kw.get("utterances", 0)
             try:

@@ -624,7 +624,15 @@ __device__ __forceinline__ void lm_memo_store(const DevScorer& s, const LmMemoKe
 }
 
 // IDX: FullScore through the hashed n-gram index (the scorer must have one: orders <= 5), else the trie walk
-template <bool IDX>
+// the trie walk as a real call: the cold side of the code-point step's FullScore (a scorer without the index), kept out of its registers
+__device__ __noinline__ float kenlm_full_score_call(const DevScorer& s, const KState* in, uint32_t wi, KState* out, unsigned* probes, const DevVocabSlot* uni) {
+  unsigned pr = 0;
+  const float r = kenlm_full_score(s, *in, wi, *out, pr, uni);
+  *probes += pr;
+  return r;
+}
+// RT_IDX (code-point step): the index if the scorer has one (decided per scorer at load time: a run-time test), else the trie walk
+template <bool IDX, bool RT_IDX = false>
 __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al, const GStream& S, const LDS_AS uint8_t* lab1, LDS_AS uint32_t* be_n, uint32_t node, uint32_t e_prev,
                                        bool have_word, uint64_t lo, uint64_t hi, uint32_t& out_entry, unsigned& probes) {
   // The word's bytes come from the beam state (have_word) or from a walk back to the previous boundary; words longer than
@@ -649,6 +657,8 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
     DevVocabSlot vs;
     const uint32_t wi = vocab_slot(s, h, vs, probes);
     if constexpr (IDX) prob = lm_full_score_indexed(s, ep.st, h, wi, vs, en.st, probes);  // (the launcher picks IDX only when the index exists)
+    else if (RT_IDX && s.lmi != nullptr && s.uni_in_vtab) prob = lm_full_score_indexed(s, ep.st, h, wi, vs, en.st, probes);
+    else if (RT_IDX) prob = kenlm_full_score_call(s, &ep.st, wi, &en.st, &probes, (wi != 0 && s.uni_in_vtab) ? &vs : nullptr);
     else prob = kenlm_full_score(s, ep.st, wi, en.st, probes, (wi != 0 && s.uni_in_vtab) ? &vs : nullptr);
     word_oov = wi == 0;
     if (use_memo) lm_memo_store(s, mk, prob, word_oov);
@@ -1681,7 +1691,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
             }
           }
           uint32_t ne;  // one FullScore from the state after the previous code point
-          raw = lm_word_query_cached<false>(s, al, S, lab1, (LDS_AS uint32_t*)nullptr, 0u, bndi, true, (uint64_t)unit, 0ULL, ne, probes);
+          raw = lm_word_query_cached<false, true>(s, al, S, lab1, (LDS_AS uint32_t*)nullptr, 0u, bndi, true, (uint64_t)unit, 0ULL, ne, probes);
         } else raw = lm_score(s, al, S.pa_generic(), L.node[cur][i], first, true, probes);
         ++lmq;
         const float lms = (float)__dmul_rn(raw, s.alpha);
@@ -1960,7 +1970,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
             if (b != STT_NONE && utf8_step_clean(prun, L.ch[cur][i] == STT_ROOT_CH, byte, unit)) {
               if (pi >> 31) {
                 if (slot < S.pa_cap()) {
-                  lm_word_query_cached<false>(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], slot, b, true, (uint64_t)unit, 0ULL, nb, probes6);
+                  lm_word_query_cached<false, true>(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], slot, b, true, (uint64_t)unit, 0ULL, nb, probes6);
                   if (nb == STT_NONE) lds_or(&sc[SC_ERR], 8);
                 }
               } else nb = b;

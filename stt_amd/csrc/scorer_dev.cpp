@@ -511,9 +511,10 @@ int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, 
   // <s> index and backoff (lm/model.cc:115-124)
   hs.bos_index = hs.vocab_index(murmur64a("<s>", 3, 0));
   hs.bos_backoff = rdf(buf + unigram_off + 16 * (uint64_t)hs.bos_index + 4);
-  // The index is read by the word-mode search step with label bitmaps (ctc.hip: ctc_masked_ok) and by the LM test hooks; code-point
-  // scorers, order-6 models and dictionaries without bitmaps never touch it: do not build what cannot be used.
-  const bool index_usable = lm_only || (!hs.utf8 && ord <= 5 && hs.fst_bitmap_ok && hs.uni_ok);
+  // The index is read by the word-mode search step with label bitmaps (ctc.hip: ctc_masked_ok), by the code-point step on a miss of its
+  // FullScore memo (tunable cp_index) and by the LM test hooks; order-6 models and word dictionaries without bitmaps never touch it: do
+  // not build what cannot be used.
+  const bool index_usable = lm_only || (ord <= 5 && hs.uni_ok && (hs.utf8 ? tune().cp_index != 0 : hs.fst_bitmap_ok));
   try { hs.lmi_ok = index_usable && build_lm_index(hs); }
   catch (const std::bad_alloc&) { hs.lmi_ok = false; }  // no memory for the table: the scorer still loads (trie walk), as it does in the reference
   if (!hs.lmi_ok) { hs.lmi.clear(); hs.lmi.shrink_to_fit(); hs.lmi_buckets = 0; }
