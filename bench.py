@@ -667,6 +667,17 @@ def measure(wl, args, cx, steps, warmup):
                     "traffic": traffic, "traffic_note": traffic_note,
                     "search_cycles_per_stream_timestep": cyc, "search_us_per_stream_timestep": 1e3 * dec_ms / T if wl != "ragged" else None,
                     "all": allk}
+        if wl == "bytes" and dstats.get("lm_probes"):
+            # The code-point step is bound by scattered reads (memo entries, index buckets, dictionary arcs), not by bytes or lanes
+            # (DESIGN.md 9.3): its roofline is the chip's rate of dependent scattered 32-byte record reads, measured with nothing else
+            # around them by benchmarks/gather_probe.hip (profiles/r04_q_gather_probe.jsonl: 256 workgroups x 1024 lanes, 512 MB table).
+            reads = float(dstats["lm_probes"]) * (BATCH * 250.0 / steps_total)      # counted reads of the LM phase, per batch
+            rate = reads / (elapsed / K) / 1e9
+            roofline["gather"] = {"kernel": "ctc_next_kernel<2, 1024, false>", "bound": "scattered record reads", "achieved": rate, "peak": 55.0, "unit": "G records/s",
+                                  "frac": rate / 55.0, "reads_per_stream_timestep": float(dstats["lm_probes"]) / steps_total,
+                                  "note": "language-model phase reads per batch / time per batch; peak = gather_probe's scattered rate from a 512 MB table "
+                                          "(80 from a cache-resident one, 233 when a wave's 64 lanes read one 2 KB slice): many of the step's reads hit in L2, "
+                                          "so a fraction near or above 1 says the phase runs at what scattered reads allow -- fewer or contiguous reads is what is left"}
         if pipelined:
             # With batches in flight the searches of neighbouring groups overlap, the recurrences cannot: the stream that is busy for
             # most of a step is the recurrence's.  Its roofline is the one that bounds the step.
