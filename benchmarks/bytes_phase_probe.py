@@ -56,7 +56,11 @@ def main():
                     n = max(1, s["steps"])
                     print(json.dumps({"emissions": name, "ms_profiled": round(ms, 2), "search_ms": round(kms, 2), "per_stream_timestep": {
                         "phase_cycles": {k: int(v / n) for k, v in ph.items()}, "candidates": round(s["candidates"] / n, 1), "lm_queries": round(s["lm_queries"] / n, 1),
-                        "memo_probes": round(s["lm_probes"] / n, 1)}, "error": s["error"], "non_empty": sum(1 for r in res if r and len(r[0][1]))}), flush=True)
+                        "memo_probes": round(s["lm_probes"] / n, 1),
+                        # wave 0's share of the expand loop (cycles per stream-timestep): locating the item + issuing its arc read | waiting for the arc,
+                        # class position, log-probability, key | filter + path hash | event or candidate record; [54] = items wave 0 took
+                        "expand_wave0": {"locate": int(st[50] / n), "arc_to_key": int(st[51] / n), "hash": int(st[52] / n), "record": int(st[53] / n), "items": round(st[54] / n, 1)}},
+                        "error": s["error"], "non_empty": sum(1 for r in res if r and len(r[0][1]))}), flush=True)
                 else:
                     print(json.dumps({"emissions": name, "ms": round(ms, 2)}), flush=True)
                 dec.close()
