@@ -208,6 +208,13 @@ STTX_EXPORT int STTX_ReadModelTensor(const char* aModelBuffer, unsigned int aBuf
  * ReLU (y rounded to f16, returned as f32), 1 = bias only (f32). */
 STTX_EXPORT int STTX_TestDense(int aM, int aN, int aK, const float* aX, const float* aW, const float* aBias, float aClip,
                               int aEpilogue, float* aY);
+/* Test hook: TensorFlow Lite's hybrid FULLY_CONNECTED (what the reference's CPU path runs for the released, dynamic-range quantised
+ * models: tflitemodelstate.cc:200, tensorflow/lite/kernels/fully_connected.cc EvalHybrid) on the int8 matrix cores -- every row of aX
+ * (f32 [aM][aK]) quantised with its own scale max|x| / 127, int8 x int8 -> int32, aY = aBias + float(sum) * (row scale x weight scale);
+ * aWq int8 [aN][aK], aWScale [aNScales = 1 or aN].  aQ / aRowScale (optional): the quantised rows and their scales.  aReps > 0: that many
+ * timed repetitions, *aElapsedMs per repetition.  aK a multiple of 128, aN of 256.  Not yet a model path. */
+STTX_EXPORT int STTX_TestDenseHybridI8(const float* aX, unsigned int aM, unsigned int aK, const signed char* aWq, const float* aWScale, unsigned int aNScales,
+                                      const float* aBias, unsigned int aN, float* aY, signed char* aQ, float* aRowScale, unsigned int aReps, float* aElapsedMs);
 /* The recurrent step kernel alone (deepspeech_model.py:144-168, one LSTMCell step per launch) on the model's packed recurrent
  * matrix: aSteps steps from a zero state, step t adding x-projection block t % aPeriod (aXproj [aPeriod * aBatch][4 * n_hidden] f32,
  * row = block * aBatch + b).  aC, aH [aBatch][n_hidden]: the final state; aHAll (may be NULL) [aPeriod * aBatch][n_hidden] f16 bits:

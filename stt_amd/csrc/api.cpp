@@ -1261,6 +1261,41 @@ int STTX_TestDense(int M, int N, int K, const float* aX, const float* aW, const 
   }, STT_ERR_FAIL_RUN_SESS);
 }
 
+// TFLite's hybrid FULLY_CONNECTED on the int8 MFMA path (kernels.h: launch_quantize_rows + launch_dense_hybrid_i8), as a test hook:
+// x f32 [M][K], wq int8 [N][K], wscale [n_scales = 1 or N], bias [N] -> y f32 [M][N] (and, if asked for, the quantised rows and their
+// scales); aReps timed repetitions of quantisation + product (HIP events) -> *aElapsedMs per repetition.
+int STTX_TestDenseHybridI8(const float* aX, unsigned int aM, unsigned int aK, const signed char* aWq, const float* aWScale, unsigned int aNScales, const float* aBias,
+                           unsigned int aN, float* aY, signed char* aQ, float* aRowScale, unsigned int aReps, float* aElapsedMs) {
+  return guarded([&]() {
+    const size_t M = aM, K = aK, N = aN;
+    if (!M || K % 128 != 0 || N % 256 != 0 || (aNScales != 1 && aNScales != aN)) return (int)STT_ERR_INVALID_SHAPE;
+    hipStream_t st = nullptr;
+    DevBuf x, q, rs, wq, ws, b, y;
+    x.upload(aX, M * K * 4, st); wq.upload(aWq, N * K, st); ws.upload(aWScale, (size_t)aNScales * 4, st); b.upload(aBias, N * 4, st);
+    q.reserve(M * K); rs.reserve(M * 4); y.reserve(M * N * 4);
+    auto once = [&]() {
+      launch_quantize_rows(x.as<float>(), q.as<signed char>(), rs.as<float>(), (int)M, (int)K, st);
+      launch_dense_hybrid_i8(q.as<signed char>(), rs.as<float>(), wq.as<signed char>(), ws.as<float>(), (int)aNScales, b.as<float>(), y.as<float>(), (int)M, (int)N, (int)K, st);
+    };
+    once();
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (aReps && aElapsedMs) {
+      hipEvent_t e0, e1;
+      HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+      HIP_CHECK(hipEventRecord(e0, st));
+      for (unsigned r = 0; r < aReps; ++r) once();
+      HIP_CHECK(hipEventRecord(e1, st));
+      HIP_CHECK(hipEventSynchronize(e1));
+      float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      *aElapsedMs = ms / (float)aReps;
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    HIP_CHECK(hipMemcpy(aY, y.p, M * N * 4, hipMemcpyDeviceToHost));
+    if (aQ) HIP_CHECK(hipMemcpy(aQ, q.p, M * K, hipMemcpyDeviceToHost));
+    if (aRowScale) HIP_CHECK(hipMemcpy(aRowScale, rs.p, M * 4, hipMemcpyDeviceToHost));
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
 int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, unsigned int aPeriod, int aGraph, const float* aXproj, float* aC, float* aH,
                        unsigned short* aHAll, float* aElapsedMs) {
   return guarded([&]() {

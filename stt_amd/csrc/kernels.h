@@ -31,7 +31,7 @@ struct ContextArgs {
 };
 
 // ---- dense --------------------------------------------------------------------------------------
-enum { DENSE_EPI_RELU_F16 = 0, DENSE_EPI_BIAS_F32 = 1 };
+enum { DENSE_EPI_RELU_F16 = 0, DENSE_EPI_BIAS_F32 = 1, DENSE_EPI_I8_F32 = 2 };   // I8: TFLite's hybrid FULLY_CONNECTED (launch_dense_hybrid_i8)
 struct DenseArgs {
   const _Float16* wt;  // [N][K]
   const _Float16* x;   // [M][ldx]
@@ -42,9 +42,21 @@ struct DenseArgs {
   int xa, xb;          // tile-grid cut over the 8 XCDs (xa blocks along M x xb along N; filled in by launch_dense)
   int lds_floor;       // ask for at least this much dynamic LDS (bytes; 0 = what the tile needs): > 80 KiB keeps the kernel at ONE
                        // workgroup per CU, so that a recurrent-step workgroup launched beside it always finds room (engine.cpp)
+  const float* row_scale;  // DENSE_EPI_I8_F32: the activation rows' scaling factors [M] (quantize_rows) ...
+  const float* col_scale;  // ... and the weight scale(s): [N] per output row, or [1] per tensor (col_scale_n)
+  int col_scale_n;
   int solo;            // 1: the three-stage form of the 128-square tile (96 KiB: one workgroup per CU, two K-tiles in flight); 2: the same on eight waves;
                        // 3: the 128 x 256 eight-wave tile, two stages (96 KiB), where the shape allows (else as 2)
 };
+
+// TFLite's hybrid FULLY_CONNECTED (tensorflow/lite/kernels/fully_connected.cc EvalHybrid, restated in oracle/am_hybrid.py): every row of the
+// f32 input quantised to int8 with its own scale max|x| / 127 (PortableSymmetricQuantizeFloats), int8 x int8 -> int32 dot products on
+// v_mfma_i32_16x16x64_i8, y = bias + float(acc) * (row scale * weight scale).  The integer sums are exact, so the result differs from the
+// reference CPU kernel only where float rounding of the rescale could (it cannot: same operations, same order).  x f32 [M][K] -> q int8
+// [M][K] + scale f32 [M]; wq int8 [N][K]; y f32 [M][N].  K a multiple of 128, N of 256.  (Round 4: a tested kernel, not yet a model path.)
+void launch_quantize_rows(const float* x, signed char* q, float* scale, int M, int K, hipStream_t st);
+void launch_dense_hybrid_i8(const signed char* q, const float* row_scale, const signed char* wq, const float* col_scale, int col_scale_n, const float* bias, float* y,
+                            int M, int N, int K, hipStream_t st);
 
 // ---- LSTM ---------------------------------------------------------------------------------------
 struct LstmArgs {

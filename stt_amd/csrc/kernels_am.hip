@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <mutex>
 #include <stdexcept>
+#include <type_traits>
 
 #include "kernels.h"
 #include "tuning.h"
@@ -348,11 +349,14 @@ __global__ __launch_bounds__(512, 2) void dense_wide_kernel(DenseArgs a) {
   }
   const int n0 = tile_n * BN, m0 = tile_m * BM;
   const int K = a.K;
-  f32x4 acc[4][MJ];
+  constexpr bool I8 = EPI == DENSE_EPI_I8_F32;   // int8 operands: a row of a K-tile is the same 128 bytes (128 k-values instead of 64), K counts 2-byte units
+  typedef int i32x4_ __attribute__((ext_vector_type(4)));
+  typedef typename std::conditional<I8, i32x4_, f32x4>::type acc_t;
+  acc_t acc[4][MJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MJ; ++j) acc[i][j] = (acc_t){0, 0, 0, 0};
   const int srow = tid >> 3;
   const int schunk = (tid & 7) ^ (srow & 7);
   const _Float16* wsrc[ITW];
@@ -405,12 +409,42 @@ __global__ __launch_bounds__(512, 2) void dense_wide_kernel(DenseArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MJ; ++j) {
+          if constexpr (I8) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_, fa[i]), __builtin_bit_cast(i32x4_, fb[j]), acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
     }
     __syncthreads();  // tile kt+1 has landed; every wave is done reading tile kt
     cur ^= 1;
   }
 #undef STAGE_W
+  if constexpr (I8) {
+    // y = bias + float(acc) * (row scale * weight scale): portable_tensor_utils.cc MatrixBatchVectorMultiplyAccumulate (int8), in its order,
+    // every operation rounded on its own as the portable x86-64 build does (no fused multiply-add)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+      const float4 bias = *reinterpret_cast<const float4*>(a.bias + n);
+      float cs[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[r] = a.col_scale[a.col_scale_n > 1 ? n + r : 0];
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+        if (m >= a.M) continue;
+        const float rs = a.row_scale[m];
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float prod;   // (an instruction of its own: the compiler contracts a * b + c into v_fma_f32 whatever the pragma says for inlined operators)
+          asm volatile("v_mul_f32 %0, %1, %2" : "=v"(prod) : "v"((float)acc[i][j][r]), "v"(__fmul_rn(rs, cs[r])));
+          v[r] = (&bias.x)[r] + prod;
+        }
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
@@ -430,6 +464,33 @@ __global__ __launch_bounds__(512, 2) void dense_wide_kernel(DenseArgs a) {
       }
     }
   }
+}
+
+// PortableSymmetricQuantizeFloats per row (tensorflow/lite/kernels/internal/reference/portable_tensor_utils.cc): range = max |x|;
+// range == 0 -> zeros, scale 1; else q = clamp(round(x * (127 / range)), -127, 127) (std::round: half away from zero), scale = range / 127.
+// One wave per row.
+__global__ __launch_bounds__(256) void quantize_rows_kernel(const float* __restrict__ x, signed char* __restrict__ q, float* __restrict__ scale, int M, int K) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * K;
+  float mx = 0.0f;
+  for (int k = lane * 4; k < K; k += 256) { const float4 v = *reinterpret_cast<const float4*>(xr + k); mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+  const float inv = mx > 0.0f ? __fdiv_rn(127.0f, mx) : 0.0f;
+  if (lane == 0) scale[row] = mx > 0.0f ? __fdiv_rn(mx, 127.0f) : 1.0f;
+  signed char* qr = q + (size_t)row * K;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + k);
+    char4 o;
+    o.x = (signed char)fminf(fmaxf(roundf(__fmul_rn(v.x, inv)), -127.0f), 127.0f); o.y = (signed char)fminf(fmaxf(roundf(__fmul_rn(v.y, inv)), -127.0f), 127.0f);
+    o.z = (signed char)fminf(fmaxf(roundf(__fmul_rn(v.z, inv)), -127.0f), 127.0f); o.w = (signed char)fminf(fmaxf(roundf(__fmul_rn(v.w, inv)), -127.0f), 127.0f);
+    *reinterpret_cast<char4*>(qr + k) = o;
+  }
+}
+void launch_quantize_rows(const float* x, signed char* q, float* scale, int M, int K, hipStream_t st) {
+  if (K % 4 != 0) throw std::runtime_error("launch_quantize_rows: K must be a multiple of 4");
+  hipLaunchKernelGGL(quantize_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, q, scale, M, K);
 }
 
 // Skinny form for M <= 16 rows (one stream's 16-frame chunk: STT_FeedAudioContent / STT_SpeechToText): the tiled kernel
@@ -986,6 +1047,27 @@ void launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t st)
   const size_t items = wide ? (bytes + 15) / 16 : bytes;
   const int blocks = (int)std::min<size_t>(64, (items + 255) / 256);
   hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, st, (unsigned char*)dst, (const unsigned char*)src, bytes, wide);
+}
+void launch_dense_hybrid_i8(const signed char* q, const float* row_scale, const signed char* wq, const float* col_scale, int col_scale_n, const float* bias, float* y,
+                            int M, int N, int K, hipStream_t st) {
+  if (K % 128 != 0 || N % 256 != 0 || M < 1) throw std::runtime_error("launch_dense_hybrid_i8: K must be a multiple of 128, N of 256");
+  DenseArgs b{};
+  b.wt = reinterpret_cast<const _Float16*>(wq); b.x = reinterpret_cast<const _Float16*>(q); b.bias = bias; b.y = y;
+  b.M = M; b.N = N; b.K = K / 2; b.ldx = K / 2; b.ldy = N;   // (K and ldx in 2-byte units: the tile loops of the f16 form, unchanged)
+  b.row_scale = row_scale; b.col_scale = col_scale; b.col_scale_n = col_scale_n;
+  const int ntn = N / 256, ntm = (M + 127) / 128;
+  int best = 1 << 30;
+  b.xa = 1; b.xb = 8;
+  for (int xa = 1; xa <= 8; xa *= 2) {
+    const int xb = 8 / xa;
+    const int Mx = (ntm + xa - 1) / xa, Nx = (ntn + xb - 1) / xb;
+    const int cost = Mx + 2 * Nx;
+    if (cost < best) { best = cost; b.xa = xa; b.xb = xb; }
+  }
+  const int per_xcd = ((ntm + b.xa - 1) / b.xa) * ((ntn + b.xb - 1) / b.xb);
+  const size_t smem = 96 * 1024;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_I8_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_I8_F32>), dim3(8 * per_xcd), dim3(512), smem, st, b);
 }
 void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st) {
   switch (a.fft_len) {

@@ -1,0 +1,74 @@
+"""TensorFlow Lite's hybrid FULLY_CONNECTED on the int8 matrix cores (kernels.h: launch_quantize_rows + launch_dense_hybrid_i8, through the
+STTX_TestDenseHybridI8 hook) against its restatement oracle/am_hybrid.py (fully_connected.cc EvalHybrid; portable_tensor_utils.cc
+PortableSymmetricQuantizeFloats / MatrixBatchVectorMultiplyAccumulate).  Integer dot products are exact and the float operations around
+them are the reference's, in its order: the bar is BIT EQUALITY of the quantised rows, their scales and the f32 outputs."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import am_hybrid
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(x, wq, wscale, bias, reps=0):
+    from stt_amd import native
+    L = native.lib()
+    M, K = x.shape
+    N = wq.shape[0]
+    x = np.ascontiguousarray(x, dtype=np.float32); wq = np.ascontiguousarray(wq, dtype=np.int8)
+    wscale = np.ascontiguousarray(wscale, dtype=np.float32); bias = np.ascontiguousarray(bias, dtype=np.float32)
+    y = np.zeros((M, N), dtype=np.float32); q = np.zeros((M, K), dtype=np.int8); rs = np.zeros(M, dtype=np.float32)
+    ms = C.c_float(0)
+    rc = L.STTX_TestDenseHybridI8(x.ctypes.data, M, K, wq.ctypes.data, wscale.ctypes.data, len(wscale), bias.ctypes.data, N, y.ctypes.data, q.ctypes.data, rs.ctypes.data,
+                                  reps, C.byref(ms))
+    assert rc == 0, hex(rc)
+    return y, q, rs, float(ms.value)
+
+
+@pytest.mark.parametrize("per_channel", [False, True])
+def test_hybrid_fully_connected_is_bit_equal_to_the_restatement(per_channel):
+    rng = np.random.default_rng(21)
+    M, K, N = 300, 2048, 512                      # (M not a multiple of the 128-row tile)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.01, 6.0, size=(M, 1))).astype(np.float32)
+    x[7] = 0.0                                    # IsZeroVector / range == 0: zeros, scale 1 -> the output row is the bias
+    x[11, 5] = 20.0                               # layer outputs are clipped at 20 (relu_clip)
+    x[13] = np.round(x[13] * 4) / 4               # many exact .5 products: round half away from zero, not to even
+    x[13, 0] = 127.0 / 4
+    w = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)
+    wq, wscale = am_hybrid.quantize_weights(w, per_channel)
+    bias = rng.standard_normal(N).astype(np.float32)
+    y, q, rs, _ = _run(x, wq, wscale, bias)
+    q_ref, sf_ref = am_hybrid.symmetric_quantize_rows(x)
+    assert np.array_equal(q.astype(np.float64), q_ref)
+    assert np.array_equal(rs, sf_ref)
+    want = am_hybrid.fully_connected_hybrid(x, wq, wscale, bias)
+    assert np.array_equal(y[7], bias)
+    assert np.array_equal(y, want), float(np.abs(y - want).max())
+
+
+def test_hybrid_gemm_at_the_bench_shape():
+    """The x-projection of one 48-frame chunk of 128 rows (M = 6144, K = 2048, N = 8192), int32 sums beyond 2^24 included (the
+    int -> float conversion rounds like the reference's); timed, and written beside the f16 form's figure for DESIGN.md 7.1."""
+    rng = np.random.default_rng(22)
+    M, K, N = 6144, 2048, 8192
+    x = np.minimum(np.maximum(rng.standard_normal((M, K)) * 3.0, 0.0), 20.0).astype(np.float32)     # what layer 3 hands on: clipped ReLU
+    x[:64] = 20.0 * (rng.random((64, K)) > 0.02)                                                      # nearly saturated rows: |sum| > 2^24
+    w = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)
+    w[:, :64] = 0.2 + 0.01 * rng.standard_normal((K, 64))          # quantised to ~100 of 127: sums of 2048 x 127 x 100 = 2.6e7 > 2^24
+    wq, wscale = am_hybrid.quantize_weights(w, False)
+    bias = rng.standard_normal(N).astype(np.float32)
+    y, q, rs, ms = _run(x, wq, wscale, bias, reps=20)
+    rows = np.r_[0:96, rng.choice(M, 160, replace=False)]
+    want = am_hybrid.fully_connected_hybrid(x[rows], wq, wscale, bias)
+    acc = am_hybrid.symmetric_quantize_rows(x[:64])[0] @ wq[:64].astype(np.float64).T
+    assert np.abs(acc).max() > 2 ** 24
+    assert np.array_equal(y[rows], want), float(np.abs(y[rows] - want).max())
+    out = {"M": M, "K": K, "N": N, "ms_quantise_plus_product": ms, "int8_TOP_s": 2.0 * M * K * N / (ms * 1e-3) / 1e12,
+           "note": "row quantisation + 128 x 256 tile on v_mfma_i32_16x16x64_i8, alone on the chip; the f16 form of the same product: benchmarks / DESIGN.md 8.3 (0.94 PF/s alone)"}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "hybrid_i8_gemm.json"), "w"))
