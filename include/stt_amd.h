@@ -213,7 +213,7 @@ STTX_EXPORT int STTX_TestDense(int aM, int aN, int aK, const float* aX, const fl
  * (f32 [aM][aK]) quantised with its own scale max|x| / 127, int8 x int8 -> int32, aY = aBias + float(sum) * (row scale x weight scale);
  * aWq int8 [aN][aK], aWScale [aNScales = 1 or aN].  aQ / aRowScale (optional): the quantised rows and their scales.  aReps > 0: that many
  * timed repetitions, *aElapsedMs per repetition.  aK a multiple of 128, aN of 256.  Not yet a model path. */
-STTX_EXPORT int STTX_TestDenseHybridI8(const float* aX, unsigned int aM, unsigned int aK, const signed char* aWq, const float* aWScale, unsigned int aNScales,
+STTX_EXPORT int STTX_TestDenseHybrid(const float* aX, unsigned int aM, unsigned int aK, const signed char* aWq, const float* aWScale, unsigned int aNScales,
                                       const float* aBias, unsigned int aN, float* aY, signed char* aQ, float* aRowScale, unsigned int aReps, float* aElapsedMs);
 /* The recurrent step kernel alone (deepspeech_model.py:144-168, one LSTMCell step per launch) on the model's packed recurrent
  * matrix: aSteps steps from a zero state, step t adding x-projection block t % aPeriod (aXproj [aPeriod * aBatch][4 * n_hidden] f32,

@@ -1264,7 +1264,7 @@ int STTX_TestDense(int M, int N, int K, const float* aX, const float* aW, const 
 // TFLite's hybrid FULLY_CONNECTED on the int8 MFMA path (kernels.h: launch_quantize_rows + launch_dense_hybrid_i8), as a test hook:
 // x f32 [M][K], wq int8 [N][K], wscale [n_scales = 1 or N], bias [N] -> y f32 [M][N] (and, if asked for, the quantised rows and their
 // scales); aReps timed repetitions of quantisation + product (HIP events) -> *aElapsedMs per repetition.
-int STTX_TestDenseHybridI8(const float* aX, unsigned int aM, unsigned int aK, const signed char* aWq, const float* aWScale, unsigned int aNScales, const float* aBias,
+int STTX_TestDenseHybrid(const float* aX, unsigned int aM, unsigned int aK, const signed char* aWq, const float* aWScale, unsigned int aNScales, const float* aBias,
                            unsigned int aN, float* aY, signed char* aQ, float* aRowScale, unsigned int aReps, float* aElapsedMs) {
   return guarded([&]() {
     const size_t M = aM, K = aK, N = aN;

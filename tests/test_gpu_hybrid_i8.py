@@ -1,5 +1,5 @@
 """TensorFlow Lite's hybrid FULLY_CONNECTED on the int8 matrix cores (kernels.h: launch_quantize_rows + launch_dense_hybrid_i8, through the
-STTX_TestDenseHybridI8 hook) against its restatement oracle/am_hybrid.py (fully_connected.cc EvalHybrid; portable_tensor_utils.cc
+STTX_TestDenseHybrid hook) against its restatement oracle/am_hybrid.py (fully_connected.cc EvalHybrid; portable_tensor_utils.cc
 PortableSymmetricQuantizeFloats / MatrixBatchVectorMultiplyAccumulate).  Integer dot products are exact and the float operations around
 them are the reference's, in its order: the bar is BIT EQUALITY of the quantised rows, their scales and the f32 outputs."""
 import ctypes as C
@@ -24,7 +24,7 @@ def _run(x, wq, wscale, bias, reps=0):
     wscale = np.ascontiguousarray(wscale, dtype=np.float32); bias = np.ascontiguousarray(bias, dtype=np.float32)
     y = np.zeros((M, N), dtype=np.float32); q = np.zeros((M, K), dtype=np.int8); rs = np.zeros(M, dtype=np.float32)
     ms = C.c_float(0)
-    rc = L.STTX_TestDenseHybridI8(x.ctypes.data, M, K, wq.ctypes.data, wscale.ctypes.data, len(wscale), bias.ctypes.data, N, y.ctypes.data, q.ctypes.data, rs.ctypes.data,
+    rc = L.STTX_TestDenseHybrid(x.ctypes.data, M, K, wq.ctypes.data, wscale.ctypes.data, len(wscale), bias.ctypes.data, N, y.ctypes.data, q.ctypes.data, rs.ctypes.data,
                                   reps, C.byref(ms))
     assert rc == 0, hex(rc)
     return y, q, rs, float(ms.value)
