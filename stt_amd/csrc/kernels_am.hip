@@ -1066,7 +1066,10 @@ void launch_dense_hybrid_i8(const signed char* q, const float* row_scale, const 
   }
   const int per_xcd = ((ntm + b.xa - 1) / b.xa) * ((ntn + b.xb - 1) / b.xb);
   const size_t smem = 96 * 1024;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_I8_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  static std::once_flag once[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::call_once(once[dev & 15], [&]() { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_I8_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
   hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_I8_F32>), dim3(8 * per_xcd), dim3(512), smem, st, b);
 }
 void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st) {
