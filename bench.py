@@ -770,7 +770,7 @@ def main():
     cx.stream_models = []
     cx.bytes_scorer_path, cx.bytes_scorer_desc = os.path.join(FIX, "pruned_lm.bytes.scorer"), "pruned_lm.bytes.scorer fixture (code-point level, order 2)"
     cx.tmpdirs = []
-    if args.scorer == "synthetic" and (wl in ("bytes", "peaky_bytes") or (wl == "batch" and not args.no_extras)):
+    if args.scorer == "synthetic" and (wl in ("bytes", "peaky_bytes") or (wl == "batch" and not args.no_extras and world == 1)):   # (the side workloads run on one rank only)
         cx.tmpdirs.append(tempfile.TemporaryDirectory())
         cx.bytes_scorer_path, cx.bytes_scorer_desc = synth_codepoint_scorer(cx.tmpdirs[-1].name)
     cx.model, cx.scorer_path, cx.scorer_desc, weights = None, None, None, None
