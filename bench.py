@@ -213,18 +213,24 @@ def stream_pass(cx, args, utts, hop_lat):
     def cohort(c):
         try:
             model, mine, nxt, live, drain = cx.stream_models[c], parts[c], 0, [], []
-            empty = np.zeros(0, dtype=np.int16)
+            call = M.StreamBatchCall(S)
+            base = {u: utts[u].ctypes.data for u in mine}   # (the utterances are contiguous int16 arrays that outlive the pass)
             while nxt < len(mine) or live or drain:
                 # S open streams: the live ones and those whose last audio went in with the previous hop (aLast = 2: the few windows
                 # their flush left ride in this hop's pass instead of costing a pass of their own; then they are finished)
                 while len(live) + len(drain) < S and nxt < len(mine):
                     live.append([mine[nxt], model.createStream(), 0]); nxt += 1
                 t0 = time.perf_counter()
-                M.feedAudioContentBatch([s for _, s, _ in live] + [s for _, s, _ in drain], [utts[u][k:k + 5120] for u, _, k in live] + [empty] * len(drain),
-                                        last=[2 if k + 5120 >= len(utts[u]) else 0 for u, _, k in live] + [0] * len(drain))
-                out = M.decodeStreamsBatch([s for _, s, _ in live] + [s for _, s, _ in drain], [False] * len(live) + [True] * len(drain))   # the hop's intermediate results and the finishes: one launch
+                nl = len(live)
+                for i, (u, st, k) in enumerate(live):
+                    left = len(utts[u]) - k
+                    call.set(i, st, base[u] + 2 * k, min(5120, left), last=2 if left <= 5120 else 0)
+                for i, (u, st, k) in enumerate(drain):
+                    call.set(nl + i, st, 0, 0, finish=1)
+                call.feed(nl + len(drain))
+                out = call.decode(nl + len(drain), [e[1] for e in drain])   # the hop's intermediate results and the finishes: one launch
                 lats[c].append(time.perf_counter() - t0)
-                for e, t in zip(drain, out[len(live):]):
+                for e, t in zip(drain, out[nl:]):
                     texts[e[0]] = t
                 for e in live:
                     e[2] += 5120

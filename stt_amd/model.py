@@ -327,6 +327,46 @@ def feedAudioContentBatch(streams, audio_buffers, last=None):
         native.lib().STTX_FeedAudioContentBatchEx(_stream_ptrs(streams), ptrs, sizes, flags, n)
 
 
+class StreamBatchCall(object):
+    """Preallocated argument tables for the batched stream calls of a server's hop loop (a cohort of at most `capacity` streams): the caller
+    fills streams / audio addresses / sizes / flags by index and calls feed() and decode() -- no per-stream numpy or ctypes objects per hop
+    (128 streams: 0.24 ms of Python per hop with feedAudioContentBatch's conveniences, a seventh of the hop)."""
+
+    def __init__(self, capacity):
+        self.capacity = capacity
+        self.streams = (C.c_void_p * capacity)()
+        self.audio = (C.c_void_p * capacity)()
+        self.sizes = (C.c_uint * capacity)()
+        self.last = (C.c_ubyte * capacity)()
+        self.finish = (C.c_ubyte * capacity)()
+
+    def set(self, i, stream, audio_address, n_samples, last=0, finish=0):
+        """row i: `stream` (a Stream) gets n_samples int16 samples at audio_address (0 / None with n_samples 0: nothing) in feed();
+        last as STTX_FeedAudioContentBatchEx's aLast; finish != 0: decode() finishes (destroys) the stream"""
+        stream._check()
+        self.streams[i] = stream._impl
+        self.audio[i] = audio_address if n_samples else None
+        self.sizes[i] = n_samples
+        self.last[i] = last
+        self.finish[i] = finish
+
+    def feed(self, n):
+        native.lib().STTX_FeedAudioContentBatchEx(self.streams, self.audio, self.sizes, self.last, n)
+
+    def decode(self, n, finished_streams=()):
+        """STTX_DecodeStreamsBatch over rows [0, n): -> n strings; pass the Stream objects of the rows flagged finish so that they are marked destroyed"""
+        if n == 0:
+            return []
+        r = native.lib().STTX_DecodeStreamsBatch(self.streams, self.finish, n)
+        for st in finished_streams:
+            st._impl = None
+        if not r:
+            raise RuntimeError("STTX_DecodeStreamsBatch failed")
+        out = [C.string_at(r[i]).decode("utf-8", "replace") for i in range(n)]
+        native.lib().STTX_FreeStrings(r, n)
+        return out
+
+
 def intermediateDecodeBatch(streams):
     n = len(streams)
     if n == 0:
