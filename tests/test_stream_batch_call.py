@@ -67,3 +67,51 @@ def test_rows_name_the_right_audio_and_flags(monkeypatch):
     assert out == ["s1002", "s1000", "s1001"] and fake.decoded[0] == [(1002, 0), (1000, 1), (1001, 1)] and fake.freed == 1
     assert streams[0]._impl is None and streams[1]._impl is None and streams[2]._impl
     assert call.decode(0) == []
+
+
+def test_bench_stream_pass_feeds_every_utterance_once_and_keeps_the_cohort_size(monkeypatch):
+    """bench.py: stream_pass (configs[2]'s hop loop) against the stand-in library: every utterance's audio goes in exactly once and in
+    order, no hop has more rows than --streams (live + draining), every utterance comes back with a transcript."""
+    import argparse
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Lib(_FakeLib):
+        def STTX_SetTuning(self, *a):
+            return 0
+
+    fake = Lib()
+    monkeypatch.setattr(native, "lib", lambda: fake)
+    monkeypatch.setattr(native, "set_tuning", lambda *a: None)
+
+    class FakeModel(object):
+        n = 0
+
+        def createStream(self):
+            FakeModel.n += 1
+            return _FakeStream(FakeModel.n)
+
+    class Cx(object):
+        pass
+    cx = Cx()
+    cx.stream_models = [FakeModel(), FakeModel()]
+    rng = np.random.RandomState(1)
+    utts = [np.arange(int(rng.uniform(1, 4) * 16000), dtype=np.int16) + 7 * u for u in range(40)]
+    utts[5] = utts[5][:5120 * 3].copy()                     # an exact multiple of the hop
+    lat = []
+    texts = bench.stream_pass(cx, argparse.Namespace(streams=8, cohorts=2), utts, lat)
+    assert all(t is not None for t in texts)
+    assert max(len(rows) for rows in fake.fed) <= 8 and len(lat) == len(fake.fed)
+    by_stream = {}
+    for rows in fake.fed:
+        for h, a, last in rows:
+            by_stream.setdefault(h, []).append((a, last))
+    got = sorted((np.concatenate([a for a, _ in v]).tobytes() for v in by_stream.values()), key=len)
+    want = sorted((u.tobytes() for u in utts), key=len)
+    assert sorted(got) == sorted(want)
+    for v in by_stream.values():                            # the last audio carries the flag, once; what follows is the empty ride-along row
+        flags = [l for _, l in v]
+        assert flags.count(2) == 1 and all(a.size == 0 for a, _ in v[flags.index(2) + 1:])
