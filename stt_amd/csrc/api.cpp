@@ -1503,7 +1503,7 @@ int STTX_TestDictionaryWalk(const char* aScorer, unsigned int aScorerBytes, int 
 
 int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* const* aWords, unsigned int aNumWords, int aBos, int aMode, float* aProbs, int* aLens) {
   return guarded([&]() {
-    if (aMode == 0) {  // host: parse + hashed index + FullScore chain, no GPU
+    if (aMode == 0 || aMode == 3) {  // host: parse + hashed index (3: + the code-point blocks) + FullScore chain, no GPU
       std::vector<char> copy((size_t)aLmBytes + 16, 0);
       memcpy(copy.data(), aLm, aLmBytes);
       HostScorer hs;
@@ -1515,6 +1515,17 @@ int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* const* aWord
       if (aBos) { st[0].length = 1; st[0].words[0] = hs.bos_index; st[0].backoff[0] = hs.bos_backoff; }
       for (unsigned i = 0; i < aNumWords; ++i) {
         int nl = 0; uint32_t wi = 0;
+        if (aMode == 3) {   // every word must be ONE code point of the BMP (UTF-8); the blocks must exist (tunable cp_blocks)
+          if (!hs.cpb_ok) return (int)STT_ERR_SCORER_INVALID_LM;
+          const unsigned char* w = reinterpret_cast<const unsigned char*>(aWords[i]);
+          const size_t wl = strlen(aWords[i]);
+          uint32_t cp = 0;
+          if (wl == 1 && w[0] < 0x80) cp = w[0];
+          else if (wl == 2 && (w[0] & 0xE0) == 0xC0) cp = ((uint32_t)(w[0] & 0x1F) << 6) | (w[1] & 0x3F);
+          else if (wl == 3 && (w[0] & 0xF0) == 0xE0) cp = ((uint32_t)(w[0] & 0x0F) << 12) | ((uint32_t)(w[1] & 0x3F) << 6) | (w[2] & 0x3F);
+          else return (int)STT_ERR_INVALID_SHAPE;
+          aProbs[i] = hs.full_score_blocks(st[cur], cp, st[cur ^ 1], nl, wi);
+        } else
         aProbs[i] = hs.full_score_indexed(st[cur], aWords[i], strlen(aWords[i]), st[cur ^ 1], nl, wi);
         aLens[i] = nl;
         cur ^= 1;

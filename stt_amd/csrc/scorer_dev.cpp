@@ -257,6 +257,129 @@ static void build_unit_bounds(HostScorer& hs) {
   hs.cp_ub_max = mx;
 }
 
+static size_t utf8_of(uint32_t cp, unsigned char* u) {   // U+0001 .. U+FFFF (surrogates have no encoding: 0)
+  if (cp >= 0xD800 && cp < 0xE000) return 0;
+  if (cp < 0x80) { u[0] = (unsigned char)cp; return 1; }
+  if (cp < 0x800) { u[0] = (unsigned char)(0xC0 | (cp >> 6)); u[1] = (unsigned char)(0x80 | (cp & 0x3F)); return 2; }
+  u[0] = (unsigned char)(0xE0 | (cp >> 12)); u[1] = (unsigned char)(0x80 | ((cp >> 6) & 0x3F)); u[2] = (unsigned char)(0x80 | (cp & 0x3F)); return 3;
+}
+static inline uint32_t cpb_hash(uint32_t w1, uint32_t block) {
+  uint64_t a = ((uint64_t)w1 << 32 | block) * 0x9E3779B97F4A7C15ULL;
+  a ^= a >> 29;
+  return (uint32_t)(a * 0xD6E8FEB86659FD93ULL >> 32);
+}
+
+// The bigram blocks of scorer_host.h.  Needs the hashed index (the records carry their slots: orders >= 3 continue there).
+static bool build_cp_blocks(HostScorer& hs) {
+  hs.cpb_ok = false; hs.cpt.clear(); hs.cpb_tab.clear(); hs.cpb_rec.clear();
+  if (!hs.lmi_ok || hs.order < 2) return false;
+  const uint8_t* buf = hs.buf;
+  const uint64_t n1 = hs.counts[0], n2 = hs.counts[1];
+  // code point <-> vocabulary index (a word of the model that is not ONE code point of the BMP has no block: it takes the index alone)
+  hs.cpt.assign(65536, HostScorer::CptEntry{0u, 0.0f, 0.0f, 0u});
+  std::vector<uint32_t> cp_of(n1, 0xFFFFFFFFu);
+  for (uint32_t cp = 1; cp < 65536; ++cp) {
+    unsigned char u[3];
+    const size_t n = utf8_of(cp, u);
+    if (!n) continue;
+    const uint32_t w = hs.vocab_index(murmur64a(u, n, 0));
+    if (w == 0 || w >= n1) continue;
+    const uint8_t* ur = buf + hs.unigram_off + 16 * (uint64_t)w;
+    hs.cpt[cp] = HostScorer::CptEntry{w, rdf(ur), rdf(ur + 4), 1u | (rd64(ur + 8) == rd64(ur + 24) ? 2u : 0u)};
+    cp_of[w] = cp;
+  }
+  // every bigram (u | w1) whose u is a code point: {w1, cp, prob, backoff, indep, slot}
+  struct Tup { uint32_t w1, cp; float prob, backoff; uint32_t slot; bool indep; };
+  std::vector<Tup> tups;
+  tups.reserve(n2);
+  const HostBitPacked& bp = hs.order == 2 ? hs.lon : hs.mid[0];
+  const uint64_t word_mask = (1ULL << bp.word_bits) - 1;
+  for (uint64_t u = 1; u < n1; ++u) {
+    if (cp_of[u] == 0xFFFFFFFFu) continue;
+    const uint64_t cb = rd64(buf + hs.unigram_off + 16 * u + 8), ce = rd64(buf + hs.unigram_off + 16 * (u + 1) + 8);
+    if (cb > ce || ce > n2) return false;
+    const uint64_t hu = rd64(buf + hs.vocab_off + 8 * (u - 1));
+    for (uint64_t c = cb; c < ce; ++c) {
+      const uint32_t w1 = (uint32_t)rd57(buf + bp.base_off, c * bp.total_bits, word_mask);
+      LmiEntry e;
+      const uint64_t key = lmi_step(hu, w1);
+      const uint32_t slot = lmi_probe(hs.lmi.data(), hs.lmi_buckets, lmi_bucket(key, hs.lmi_buckets), 2, w1, (uint32_t)u, e);
+      if (slot == LMI_NOT_FOUND) return false;   // (the index holds every record of order >= 2)
+      tups.push_back(Tup{w1, cp_of[u], e.prob, e.backoff, slot, (e.wl & LMI_INDEP_BIT) != 0});
+    }
+  }
+  std::sort(tups.begin(), tups.end(), [](const Tup& a, const Tup& b) { return a.w1 != b.w1 ? a.w1 < b.w1 : a.cp < b.cp; });
+  size_t n_ent = 0;
+  for (size_t i = 0; i < tups.size(); ++i) if (i == 0 || tups[i].w1 != tups[i - 1].w1 || (tups[i].cp >> 6) != (tups[i - 1].cp >> 6)) ++n_ent;
+  uint32_t cap = 16;
+  while ((uint64_t)cap < 2 * (uint64_t)n_ent + 2) cap <<= 1;
+  if (tups.size() >= 0xFFFFFFF0ull) return false;
+  hs.cpb_tab.assign(cap, HostScorer::CpbEntry{0xFFFFFFFFu, 0u, 0u, 0u, 0ull, 0ull});
+  hs.cpb_mask = cap - 1;
+  hs.cpb_rec.resize(tups.size());
+  for (size_t i = 0; i < tups.size();) {
+    size_t j = i;
+    HostScorer::CpbEntry en{tups[i].w1, tups[i].cp >> 6, (uint32_t)i, 0u, 0ull, 0ull};
+    while (j < tups.size() && tups[j].w1 == en.w1 && (tups[j].cp >> 6) == en.block) {
+      const uint64_t bit = 1ull << (tups[j].cp & 63u);
+      if (en.present & bit) return false;   // (one record per (w1, u))
+      en.present |= bit;
+      if (tups[j].indep) en.indep |= bit;
+      hs.cpb_rec[j] = HostScorer::CpbRec{tups[j].prob, tups[j].backoff, tups[j].slot};
+      ++j;
+    }
+    en.count = (uint32_t)(j - i);
+    uint32_t h = cpb_hash(en.w1, en.block) & hs.cpb_mask;
+    while (hs.cpb_tab[h].w1 != 0xFFFFFFFFu) h = (h + 1) & hs.cpb_mask;
+    hs.cpb_tab[h] = en;
+    i = j;
+  }
+  hs.cpb_ok = true;
+  return true;
+}
+
+float HostScorer::full_score_blocks(const KState& in, uint32_t cp, KState& out, int& ngram_length, uint32_t& word_index) const {
+  unsigned char ub[3];
+  const size_t un = cp < 65536 ? utf8_of(cp, ub) : 0;
+  const CptEntry ct = (un && cp < cpt.size()) ? cpt[cp] : CptEntry{0u, 0.0f, 0.0f, 0u};
+  if (!(ct.flags & 1u)) {   // not a word of the model: <unk> -- through the index alone, as every unit without a block
+    return full_score_indexed(in, reinterpret_cast<const char*>(ub), un, out, ngram_length, word_index);
+  }
+  const uint32_t wi = ct.wi;
+  word_index = wi;
+  const bool uindep = (ct.flags & 2u) != 0;
+  LmiLevel lv[LMI_MAX_HIST] = {};
+  if (!uindep && in.length > 0 && order >= 2) {
+    // order 2: ONE entry for (w1, the block of 64 code points u lies in) -- the same entry for all 64 siblings -- and a slice
+    const uint32_t w1 = in.words[0], block = cp >> 6;
+    uint32_t h = cpb_hash(w1, block) & cpb_mask;
+    const CpbEntry* en = nullptr;
+    for (;;) {
+      const CpbEntry& t = cpb_tab[h];
+      if (t.w1 == 0xFFFFFFFFu) break;
+      if (t.w1 == w1 && t.block == block) { en = &t; break; }
+      h = (h + 1) & cpb_mask;
+    }
+    const uint64_t bit = 1ull << (cp & 63u);
+    if (en && (en->present & bit)) {
+      const CpbRec& r = cpb_rec[en->offset + (uint32_t)__builtin_popcountll(en->present & (bit - 1))];
+      lv[0].found = 1; lv[0].prob = r.prob; lv[0].backoff = r.backoff; lv[0].indep = (en->indep & bit) ? 1 : 0;
+      // orders >= 3: the hashed index, from the bigram's slot on (full_score_indexed's loop, entered at its second trip)
+      uint64_t key = lmi_step(murmur64a(ub, un, 0), w1);
+      uint32_t parent = r.slot;
+      for (int hi = 1; hi < order - 1 && hi < in.length && hi < LMI_MAX_HIST && !lv[hi - 1].indep; ++hi) {
+        key = lmi_step(key, in.words[hi]);
+        LmiEntry e;
+        const uint32_t slot = lmi_probe(lmi.data(), lmi_buckets, lmi_bucket(key, lmi_buckets), hi + 2, in.words[hi], parent, e);
+        if (slot == LMI_NOT_FOUND) break;
+        lv[hi].found = 1; lv[hi].prob = e.prob; lv[hi].backoff = e.backoff; lv[hi].indep = (e.wl & LMI_INDEP_BIT) ? 1 : 0;
+        parent = slot;
+      }
+    }
+  }
+  return lmi_combine(order, in, wi, ct.prob, ct.backoff, uindep, lv, out, ngram_length);
+}
+
 // SortedVocabulary::Index (lm/vocab.hh:72-83): binary search over the sorted hashes (host side)
 uint32_t HostScorer::vocab_index(uint64_t h) const {
   uint64_t lo = 0, hi = vocab_n;
@@ -519,6 +642,7 @@ int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, 
   catch (const std::bad_alloc&) { hs.lmi_ok = false; }  // no memory for the table: the scorer still loads (trie walk), as it does in the reference
   if (!hs.lmi_ok) { hs.lmi.clear(); hs.lmi.shrink_to_fit(); hs.lmi_buckets = 0; }
   if (hs.utf8 && !lm_only && tune().unit_bounds != 0) build_unit_bounds(hs);
+  if ((hs.utf8 || lm_only) && tune().cp_blocks != 0) (void)build_cp_blocks(hs);
   return STT_ERR_OK;
 }
 

@@ -52,6 +52,22 @@ struct HostScorer {
   std::vector<float> cp_ub;
   float cp_ub_max = 0.0f;
 
+  // code-point scorers (tunable cp_blocks; host side and its tests in round 4, the search step's use comes next -- DESIGN.md 7.1):
+  // the bigrams (u | w1) regrouped by CONTEXT and by blocks of 64 consecutive code points u, so that the 64 children of a prefix that
+  // complete a code point -- one context, 64 consecutive u -- find their records through ONE table entry and one contiguous slice
+  // instead of 64 scattered probes.  cpt: unigram record by code point; cpb_tab: open addressing over (w1, u >> 6);
+  // cpb_rec[offset + popcount(present below u & 63)] = {prob, backoff, slot of the bigram in the hashed index (its orders >= 3 continue there)}
+  struct CptEntry { uint32_t wi; float prob, backoff; uint32_t flags; };                        // flags: 1 = in the vocabulary, 2 = no longer n-gram ends with it
+  struct CpbEntry { uint32_t w1, block, offset, count; uint64_t present, indep; };              // w1 == 0xFFFFFFFF: free
+  struct CpbRec { float prob, backoff; uint32_t slot; };
+  std::vector<CptEntry> cpt;
+  std::vector<CpbEntry> cpb_tab;
+  std::vector<CpbRec> cpb_rec;
+  uint32_t cpb_mask = 0;
+  bool cpb_ok = false;
+  // FullScore of code point `cp` (U+0001 .. U+FFFF) from state `in` through cpt / cpb_tab (order 2) and the hashed index (orders >= 3)
+  float full_score_blocks(const KState& in, uint32_t cp, KState& out, int& ngram_length, uint32_t& word_index) const;
+
   float middle_prob(int om2, uint64_t at) const;
   float middle_backoff(int om2, uint64_t at) const;
   float longest_prob(uint64_t at) const;
