@@ -212,9 +212,23 @@ STTX_EXPORT int STTX_TestDense(int aM, int aN, int aK, const float* aX, const fl
  * models: tflitemodelstate.cc:200, tensorflow/lite/kernels/fully_connected.cc EvalHybrid) on the int8 matrix cores -- every row of aX
  * (f32 [aM][aK]) quantised with its own scale max|x| / 127, int8 x int8 -> int32, aY = aBias + float(sum) * (row scale x weight scale);
  * aWq int8 [aN][aK], aWScale [aNScales = 1 or aN].  aQ / aRowScale (optional): the quantised rows and their scales.  aReps > 0: that many
- * timed repetitions, *aElapsedMs per repetition.  aK a multiple of 128, aN of 256.  Not yet a model path. */
+ * timed repetitions, *aElapsedMs per repetition.  aK a multiple of 128, aN of 256 (of 64 for aM <= 16: the skinny form).  aEpi: 0 = bias only,
+ * 1 = + the graph's clipped ReLU (aClip), as layers 1-3 and 5 run it.  The model path built from these kernels: STTX_GetAcousticMode. */
 STTX_EXPORT int STTX_TestDenseHybrid(const float* aX, unsigned int aM, unsigned int aK, const signed char* aWq, const float* aWScale, unsigned int aNScales,
-                                      const float* aBias, unsigned int aN, float* aY, signed char* aQ, float* aRowScale, unsigned int aReps, float* aElapsedMs);
+                                      const float* aBias, unsigned int aN, float* aY, signed char* aQ, float* aRowScale, unsigned int aReps, float* aElapsedMs,
+                                      int aEpi, float aClip);
+/* Which arithmetic the acoustic model of aCtx runs in: 0 = f16 MFMA operands / f32 accumulate (north_star's; int8 weights of a quantised
+ * file are de-quantised), 1 = the released models' own (TensorFlow Lite's hybrid int8 FULLY_CONNECTED end to end: int8 activations per row,
+ * int32 sums; taken for a dynamic-range quantised `.tflite`, or with the tunable am_i8 = 1).  Replaces nothing in coqui-stt.h: the
+ * reference's CPU path has only the second one (native_client/tflitemodelstate.cc:200,369-405). */
+STTX_EXPORT int STTX_GetAcousticMode(const ModelState* aCtx);
+/* Test hook for the int8 path (aCtx must be in mode 1): aWindows f32 [aT * aB][19 x 26] context windows, row = t * aB + b, through layers
+ * 1-3, the cell (state aC / aH [aB][n_hidden] f32, NULL = zeros), layers 5-6 and the softmax as ONE call of the engine's one-stream path.
+ * Outputs (each may be NULL): aL3 [aT*aB][n_hidden] layer 3's f32 rows; aAccX [aT*aB][4 n_hidden] the x half of the cell's int32 sums;
+ * aHAll [aT*aB][n_hidden] h_t; aLogits [aT*aB][n_classes]; aProbs [aB][aT][n_classes]; aNewC / aNewH [aB][n_hidden];
+ * *aSlowRows = rows the recurrent steps computed again at the joint scale during this call (max |h| > max |x_t|). */
+STTX_EXPORT int STTX_TestHybridChain(ModelState* aCtx, const float* aWindows, unsigned int aB, unsigned int aT, const float* aC, const float* aH,
+                                      float* aL3, int* aAccX, float* aHAll, float* aLogits, float* aProbs, float* aNewC, float* aNewH, unsigned int* aSlowRows);
 /* The recurrent step kernel alone (deepspeech_model.py:144-168, one LSTMCell step per launch) on the model's packed recurrent
  * matrix: aSteps steps from a zero state, step t adding x-projection block t % aPeriod (aXproj [aPeriod * aBatch][4 * n_hidden] f32,
  * row = block * aBatch + b).  aC, aH [aBatch][n_hidden]: the final state; aHAll (may be NULL) [aPeriod * aBatch][n_hidden] f16 bits:

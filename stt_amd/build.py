@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libstt.so")
-SOURCES = ["kernels_am.hip", "ctc.hip", "hostutil.cpp", "scorer_dev.cpp", "model.cpp", "tflite_reader.cpp", "engine.cpp", "api.cpp", "fleet.cpp"]
+SOURCES = ["kernels_am.hip", "kernels_i8.hip", "ctc.hip", "hostutil.cpp", "scorer_dev.cpp", "model.cpp", "tflite_reader.cpp", "engine.cpp", "api.cpp", "fleet.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "hip", "-Wno-unused-result"]
 # ctc.hip: the search kernels run 1024 threads per workgroup (128 registers per lane) through one very long timestep loop.  Machine-level
 # loop-invariant code motion hoists every `thread index * 4 + LDS constant` address and every f64 polynomial coefficient of the bit-exact

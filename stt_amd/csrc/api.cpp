@@ -1082,15 +1082,21 @@ int STTX_InferChunk(ModelState* m, const float* aMfcc, unsigned int aNumFrames, 
   return guarded([&]() {
     HIP_CHECK(hipSetDevice(m->device));
     const Geometry& g = m->g;
-    const int T = (int)aNumFrames, kw = g.n_in1(), kp = g.k1_pad(), H = g.n_hidden, C = g.n_classes;
-    std::vector<_Float16> x1((size_t)T * kp, (_Float16)0.0f);
-    for (int t = 0; t < T; ++t)
-      for (int k = 0; k < kw; ++k) x1[(size_t)t * kp + k] = (_Float16)aMfcc[(size_t)t * kw + k];
-    m->ws_x1.upload(x1.data(), x1.size() * 2, m->stream);
+    const int T = (int)aNumFrames, kw = g.n_in1(), kp = m->x1_cols(), H = g.n_hidden, C = g.n_classes;
+    if (m->i8) {
+      std::vector<float> x1((size_t)T * kp, 0.0f);
+      for (int t = 0; t < T; ++t) memcpy(&x1[(size_t)t * kp], aMfcc + (size_t)t * kw, (size_t)kw * 4);
+      m->ws_x1.upload(x1.data(), x1.size() * 4, m->stream);
+    } else {
+      std::vector<_Float16> x1((size_t)T * kp, (_Float16)0.0f);
+      for (int t = 0; t < T; ++t)
+        for (int k = 0; k < kw; ++k) x1[(size_t)t * kp + k] = (_Float16)aMfcc[(size_t)t * kw + k];
+      m->ws_x1.upload(x1.data(), x1.size() * 2, m->stream);
+    }
     DevBuf c, h;
     c.upload(aStateC, (size_t)H * 4, m->stream); h.upload(aStateH, (size_t)H * 4, m->stream);
     m->ws_probs.reserve((size_t)T * C * 4);
-    m->run_acoustic_rows(m->ws_x1.as<_Float16>(), 1, T, c.as<float>(), h.as<float>(), true, m->ws_probs.as<float>(), T);
+    m->run_acoustic_rows(m->ws_x1.p, 1, T, c.as<float>(), h.as<float>(), true, m->ws_probs.as<float>(), T);
     HIP_CHECK(hipMemcpyAsync(aProbs, m->ws_probs.p, (size_t)T * C * 4, hipMemcpyDeviceToHost, m->stream));
     HIP_CHECK(hipMemcpyAsync(aNewStateC, c.p, (size_t)H * 4, hipMemcpyDeviceToHost, m->stream));
     HIP_CHECK(hipMemcpyAsync(aNewStateH, h.p, (size_t)H * 4, hipMemcpyDeviceToHost, m->stream));
@@ -1264,18 +1270,52 @@ int STTX_TestDense(int M, int N, int K, const float* aX, const float* aW, const 
 // TFLite's hybrid FULLY_CONNECTED on the int8 MFMA path (kernels.h: launch_quantize_rows + launch_dense_hybrid_i8), as a test hook:
 // x f32 [M][K], wq int8 [N][K], wscale [n_scales = 1 or N], bias [N] -> y f32 [M][N] (and, if asked for, the quantised rows and their
 // scales); aReps timed repetitions of quantisation + product (HIP events) -> *aElapsedMs per repetition.
+int STTX_GetAcousticMode(const ModelState* m) { return m && m->i8 ? 1 : 0; }
+
+int STTX_TestHybridChain(ModelState* m, const float* aWindows, unsigned int aB, unsigned int aT, const float* aC, const float* aH, float* aL3, int* aAccX, float* aHAll,
+                         float* aLogits, float* aProbs, float* aNewC, float* aNewH, unsigned int* aSlowRows) {
+  return guarded([&]() {
+    if (!m->i8 || !aB || !aT || (int)aB > 128) return (int)STT_ERR_INVALID_SHAPE;
+    HIP_CHECK(hipSetDevice(m->device));
+    const Geometry& g = m->g;
+    const int B = (int)aB, T = (int)aT, M = B * T, kw = g.n_in1(), kp = m->x1_cols(), H = g.n_hidden, C = g.n_classes, CP = g.c_pad8();
+    std::vector<float> x1((size_t)M * kp, 0.0f);
+    for (int r = 0; r < M; ++r) memcpy(&x1[(size_t)r * kp], aWindows + (size_t)r * kw, (size_t)kw * 4);
+    m->ws_x1.upload(x1.data(), x1.size() * 4, m->stream);
+    DevBuf c, h;
+    std::vector<float> zeros((size_t)B * H, 0.0f);
+    c.upload(aC ? aC : zeros.data(), (size_t)B * H * 4, m->stream); h.upload(aH ? aH : zeros.data(), (size_t)B * H * 4, m->stream);
+    m->ws_probs.reserve((size_t)M * C * 4);
+    unsigned slow0 = 0, slow1 = 0;
+    if (m->ws_slow.p) HIP_CHECK(hipMemcpy(&slow0, m->ws_slow.p, 4, hipMemcpyDeviceToHost));
+    m->run_acoustic_rows(m->ws_x1.p, B, T, c.as<float>(), h.as<float>(), true, m->ws_probs.as<float>(), T);
+    HIP_CHECK(hipStreamSynchronize(m->stream));
+    HIP_CHECK(hipMemcpy(&slow1, m->ws_slow.p, 4, hipMemcpyDeviceToHost));
+    if (aSlowRows) *aSlowRows = slow1 - slow0;
+    if (aL3) HIP_CHECK(hipMemcpy(aL3, m->ws_a.p, (size_t)M * H * 4, hipMemcpyDeviceToHost));
+    if (aAccX) HIP_CHECK(hipMemcpy(aAccX, m->ws_xproj.p, (size_t)M * 4 * H * 4, hipMemcpyDeviceToHost));
+    if (aHAll) HIP_CHECK(hipMemcpy(aHAll, m->ws_hall.p, (size_t)M * H * 4, hipMemcpyDeviceToHost));
+    if (aLogits) HIP_CHECK(hipMemcpy2D(aLogits, (size_t)C * 4, m->ws_logits.p, (size_t)CP * 4, (size_t)C * 4, (size_t)M, hipMemcpyDeviceToHost));
+    if (aProbs) HIP_CHECK(hipMemcpy(aProbs, m->ws_probs.p, (size_t)M * C * 4, hipMemcpyDeviceToHost));
+    if (aNewC) HIP_CHECK(hipMemcpy(aNewC, c.p, (size_t)B * H * 4, hipMemcpyDeviceToHost));
+    if (aNewH) HIP_CHECK(hipMemcpy(aNewH, h.p, (size_t)B * H * 4, hipMemcpyDeviceToHost));
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
+
 int STTX_TestDenseHybrid(const float* aX, unsigned int aM, unsigned int aK, const signed char* aWq, const float* aWScale, unsigned int aNScales, const float* aBias,
-                           unsigned int aN, float* aY, signed char* aQ, float* aRowScale, unsigned int aReps, float* aElapsedMs) {
+                           unsigned int aN, float* aY, signed char* aQ, float* aRowScale, unsigned int aReps, float* aElapsedMs, int aEpi, float aClip) {
   return guarded([&]() {
     const size_t M = aM, K = aK, N = aN;
-    if (!M || K % 128 != 0 || N % 256 != 0 || (aNScales != 1 && aNScales != aN)) return (int)STT_ERR_INVALID_SHAPE;
+    if (!M || K % 128 != 0 || (N % 256 != 0 && !(M <= 16 && N % 64 == 0)) || (aNScales != 1 && aNScales != aN)) return (int)STT_ERR_INVALID_SHAPE;
     hipStream_t st = nullptr;
     DevBuf x, q, rs, wq, ws, b, y;
     x.upload(aX, M * K * 4, st); wq.upload(aWq, N * K, st); ws.upload(aWScale, (size_t)aNScales * 4, st); b.upload(aBias, N * 4, st);
     q.reserve(M * K); rs.reserve(M * 4); y.reserve(M * N * 4);
     auto once = [&]() {
       launch_quantize_rows(x.as<float>(), q.as<signed char>(), rs.as<float>(), (int)M, (int)K, st);
-      launch_dense_hybrid_i8(q.as<signed char>(), rs.as<float>(), wq.as<signed char>(), ws.as<float>(), (int)aNScales, b.as<float>(), y.as<float>(), (int)M, (int)N, (int)K, st);
+      launch_dense_hybrid_i8(q.as<signed char>(), rs.as<float>(), wq.as<signed char>(), ws.as<float>(), (int)aNScales, b.as<float>(), y.as<float>(), (int)M, (int)N, (int)K, st,
+                             aEpi == 1 ? DENSE_EPI_I8_RELU_F32 : DENSE_EPI_I8_F32, aClip);
     };
     once();
     HIP_CHECK(hipStreamSynchronize(st));

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <initializer_list>
 
 #include "../../include/coqui-stt.h"
@@ -34,8 +35,77 @@ void ModelState::run_mfcc(const int16_t* d_audio, const int* h_nsamples, int B, 
 // rows: x1 [T*B][k1_pad] f16, row = t*B + b.  B <= 64.
 // carry: 0 = zero state, 1 = state from the f32 vectors d_c/d_h (streaming), 2 = continue from the engine's own
 // buffers (next time-chunk of the same batch; `t_par` = number of steps already run, for the h ping-pong parity).
-static void acoustic_rows(ModelState& m, const _Float16* d_x1, int B, int T, float* d_c, float* d_h, int carry, int t_par,
+// The same chain in the released models' own arithmetic (ModelState::i8; oracle/am_hybrid.py: HybridModel.forward_batch): every
+// FULLY_CONNECTED as TFLite's hybrid kernel -- the f32 input rows quantised to int8 one by one (launch_quantize_rows), int32 sums on
+// v_mfma_i32_16x16x64_i8, rescale + bias (+ clipped ReLU) in f32 -- and the cell with the joint [x_t, h_(t-1)] row scale (kernels_i8.hip).
+// x1: f32 [T*B][k1_pad8], row = t*B + b.  carry as acoustic_rows(); the carried h lives in f32 (d_h, or ws_hlast between the chunks of a batch).
+static void acoustic_rows_i8(ModelState& m, const float* d_x1, int B, int T, float* d_c, float* d_h, int carry, float* d_probs_out, int probs_t_max) {
+  const Geometry& g = m.g;
+  hipStream_t st = m.stream;
+  const int H = g.n_hidden, M = T * B, C = g.n_classes, K1 = g.k1_pad8(), CP = g.c_pad8();
+  const int NT = lstm_nt_for_batch(B);
+  if (NT < 0) throw std::runtime_error("run_acoustic_rows: more batch rows than one recurrent launch covers");
+  const int NTR = NT * 16, NWG = H / 16;
+  m.ws_a.reserve((size_t)M * H * 4); m.ws_b.reserve((size_t)M * H * 4);
+  m.ws_xproj.reserve((size_t)M * 4 * H * 4); m.ws_hall.reserve((size_t)M * H * 4);
+  m.ws_logits.reserve((size_t)M * CP * 4);
+  m.q_x.reserve((size_t)M * std::max(K1, H)); m.q_s.reserve((size_t)M * 4); m.q_rng.reserve((size_t)M * 8);
+  const size_t hq_bytes = lstm_i8_hq_bytes(H, NT);
+  m.ws_hq0.reserve(hq_bytes); m.ws_hq1.reserve(hq_bytes);
+  m.ws_hprev0.reserve((size_t)B * H * 4); m.ws_hlast.reserve((size_t)B * H * 4);
+  m.ws_pmax.reserve((size_t)2 * NTR * NWG * 4); m.ws_flag.reserve((size_t)2 * NTR * 4); m.ws_zslow.reserve((size_t)NWG * NTR * 64 * 4);
+  m.ws_c.reserve((size_t)B * H * 4);
+  if (!m.ws_slow.p) { m.ws_slow.reserve(4); HIP_CHECK(hipMemsetAsync(m.ws_slow.p, 0, 4, st)); }
+  signed char* qx = m.q_x.as<signed char>();
+  float* qs = m.q_s.as<float>();
+  float *xs3 = m.q_rng.as<float>(), *xr3 = xs3 + M;       // layer 3's rows: scaling factor and range (max |x_t|)
+  float *act_a = m.ws_a.as<float>(), *act_b = m.ws_b.as<float>();
+  stt_prof_mark(&m, 1);
+  // layers 1-3 (deepspeech_model.py:204-224)
+  launch_quantize_rows(d_x1, qx, qs, M, K1, st);
+  launch_dense_hybrid_i8(qx, qs, m.w1q.as<signed char>(), m.s1.as<float>(), m.sn[0], m.b1.as<float>(), act_a, M, H, K1, st, DENSE_EPI_I8_RELU_F32, g.relu_clip);
+  launch_quantize_rows(act_a, qx, qs, M, H, st);
+  launch_dense_hybrid_i8(qx, qs, m.w2q.as<signed char>(), m.s2.as<float>(), m.sn[1], m.b2.as<float>(), act_b, M, H, H, st, DENSE_EPI_I8_RELU_F32, g.relu_clip);
+  launch_quantize_rows(act_b, qx, qs, M, H, st);
+  launch_dense_hybrid_i8(qx, qs, m.w3q.as<signed char>(), m.s3.as<float>(), m.sn[2], m.b3.as<float>(), act_a, M, H, H, st, DENSE_EPI_I8_RELU_F32, g.relu_clip);
+  // x half of the cell's int32 sums for all timesteps at once, from layer 3's rows quantised at their own scale
+  launch_quantize_rows(act_a, qx, xs3, M, H, st, xr3);
+  launch_dense_hybrid_i8(qx, xs3, m.wxq.as<signed char>(), m.sk.as<float>(), m.sn[3], m.bl.as<float>(), m.ws_xproj.p, M, 4 * H, H, st, DENSE_EPI_I8_RAW);
+  stt_prof_mark(&m, 2);
+  // recurrence
+  float* cbuf = (carry != 2 && d_c) ? d_c : m.ws_c.as<float>();
+  if (carry == 0 || (carry == 1 && !d_c)) HIP_CHECK(hipMemsetAsync(cbuf, 0, (size_t)B * H * 4, st));
+  const float* h_src = carry == 1 ? d_h : (carry == 2 ? m.ws_hlast.as<float>() : nullptr);
+  LstmI8Args l{};
+  l.whp = m.whpq.as<signed char>(); l.accx = m.ws_xproj.as<int>(); l.bias = m.bl.as<float>(); l.wscale = m.sk.as<float>(); l.wscale_n = m.sn[3];
+  l.xscale = xs3; l.xrange = xr3; l.c = cbuf; l.h_all = m.ws_hall.as<float>();
+  l.h_last = (carry == 1 && d_h) ? d_h : m.ws_hlast.as<float>();
+  l.pmax = m.ws_pmax.as<float>(); l.flag = m.ws_flag.as<int>(); l.y3 = act_a; l.h_prev0 = m.ws_hprev0.as<float>();
+  l.wxq = m.wxq.as<signed char>(); l.whq = m.whq.as<signed char>(); l.zslow = m.ws_zslow.as<float>();
+  l.n_hidden = H; l.batch = B; l.T = T; l.slow_count = m.ws_slow.as<unsigned>();
+  l.hq_in = m.ws_hq0.as<signed char>(); l.hq_out = m.ws_hq1.as<signed char>();
+  launch_lstm_i8_prep(l, h_src, NT, st);
+  for (int t = 0; t < T; ++t) {
+    l.t = t;
+    l.hq_in = (t & 1) ? m.ws_hq1.as<signed char>() : m.ws_hq0.as<signed char>();
+    l.hq_out = (t & 1) ? m.ws_hq0.as<signed char>() : m.ws_hq1.as<signed char>();
+    launch_lstm_i8_step(l, NT, st);
+  }
+  stt_prof_mark(&m, 3);
+  // layer 5, layer 6, softmax (deepspeech_model.py:241-252, 357)
+  launch_quantize_rows(m.ws_hall.as<float>(), qx, qs, M, H, st);
+  launch_dense_hybrid_i8(qx, qs, m.w5q.as<signed char>(), m.s5.as<float>(), m.sn[4], m.b5.as<float>(), act_b, M, H, H, st, DENSE_EPI_I8_RELU_F32, g.relu_clip);
+  launch_quantize_rows(act_b, qx, qs, M, H, st);
+  launch_dense_hybrid_i8(qx, qs, m.w6q.as<signed char>(), m.s6.as<float>(), m.sn[5], m.b6q.as<float>(), m.ws_logits.p, M, CP, H, st, DENSE_EPI_I8_F32);
+  SoftmaxArgs s{};
+  s.logits = m.ws_logits.as<float>(); s.probs = d_probs_out; s.M = M; s.C = C; s.ldl = CP; s.batch = B; s.t_max = probs_t_max;
+  launch_softmax(s, st);
+}
+
+static void acoustic_rows(ModelState& m, const void* d_x1v, int B, int T, float* d_c, float* d_h, int carry, int t_par,
                           float* d_probs_out, int probs_t_max) {
+  if (m.i8) { acoustic_rows_i8(m, static_cast<const float*>(d_x1v), B, T, d_c, d_h, carry, d_probs_out, probs_t_max); return; }
+  const _Float16* d_x1 = static_cast<const _Float16*>(d_x1v);
   const Geometry& g = m.g;
   hipStream_t stream = m.stream;
   const int H = g.n_hidden, M = T * B, C = g.n_classes;
@@ -91,30 +161,30 @@ static void acoustic_rows(ModelState& m, const _Float16* d_x1, int B, int T, flo
   }
 }
 
-void ModelState::run_acoustic_rows(const _Float16* d_x1, int B, int T, float* d_c, float* d_h, bool carry_in, float* d_probs_out, int probs_t_max) {
+void ModelState::run_acoustic_rows(const void* d_x1, int B, int T, float* d_c, float* d_h, bool carry_in, float* d_probs_out, int probs_t_max) {
   acoustic_rows(*this, d_x1, B, T, d_c, d_h, carry_in ? 1 : 0, 0, d_probs_out, probs_t_max);
 }
 
 void ModelState::run_acoustic(const float* d_feats, const int* d_nframes, int B, int t_max, float* d_c, float* d_h, bool carry_in) {
   const int M = t_max * B;
-  ws_x1.reserve((size_t)M * g.k1_pad() * 2);
+  ws_x1.reserve(x1_bytes(M));
   ws_probs.reserve((size_t)B * t_max * g.n_classes * 4);
   ContextArgs c{};
-  c.feats = d_feats; c.n_frames = d_nframes; c.x1 = ws_x1.as<_Float16>();
-  c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = g.k1_pad(); c.t0 = 0;
+  c.feats = d_feats; c.n_frames = d_nframes; c.x1 = ws_x1.as<_Float16>(); c.x1_f32 = i8 ? ws_x1.as<float>() : nullptr;
+  c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = x1_cols(); c.t0 = 0;
   launch_context(c, M, stream);
-  run_acoustic_rows(ws_x1.as<_Float16>(), B, t_max, d_c, d_h, carry_in, ws_probs.as<float>(), t_max);
+  run_acoustic_rows(ws_x1.p, B, t_max, d_c, d_h, carry_in, ws_probs.as<float>(), t_max);
 }
 
 void ModelState::run_acoustic_chunk(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs) {
   const int M = T * B;
-  ws_x1.reserve((size_t)M * g.k1_pad() * 2);
+  ws_x1.reserve(x1_bytes(M));
   ContextArgs c{};
-  c.feats = d_feats; c.n_frames = d_nframes; c.x1 = ws_x1.as<_Float16>();
-  c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = g.k1_pad(); c.t0 = t0;
+  c.feats = d_feats; c.n_frames = d_nframes; c.x1 = ws_x1.as<_Float16>(); c.x1_f32 = i8 ? ws_x1.as<float>() : nullptr;
+  c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = x1_cols(); c.t0 = t0;
   launch_context(c, M, stream);
   // probs[b][t0 + t][:]: the softmax writes row (t, b) at probs + ((b*t_max + t)*C), so offsetting the base by t0*C lands it
-  acoustic_rows(*this, ws_x1.as<_Float16>(), B, T, nullptr, nullptr, t0 == 0 ? 0 : 2, t0, d_probs + (size_t)t0 * g.n_classes, t_max);
+  acoustic_rows(*this, ws_x1.p, B, T, nullptr, nullptr, t0 == 0 ? 0 : 2, t0, d_probs + (size_t)t0 * g.n_classes, t_max);
 }
 
 // ------------------------------------------------------------------------------------------- acoustic model, three engines
@@ -138,7 +208,139 @@ static int dense_lds_floor() {  // bytes; > 80 KiB = one GEMM workgroup per CU w
   return kb <= 0 ? 0 : kb * 1024;
 }
 
+// The three engines in the released models' own arithmetic (ModelState::i8): the same hand-over (rings of kAmRing chunk buffers, one event
+// pair per slot), the kernels of acoustic_rows_i8().  Engine 1 leaves per ring slot: the x half of the cell's int32 sums (am_xproj), layer
+// 3's f32 rows (am_y3: the recurrent step's slow path) and their scaling factors / ranges (am_xs); engine 2 (prep + T steps, one hipGraph)
+// leaves h_t in f32 (am_hall); engine 3 quantises those rows for layer 5.
+void ModelState::run_acoustic_chunk_piped_i8(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs, hipEvent_t done) {
+  const int H = g.n_hidden, M = T * B, C = g.n_classes, K1 = g.k1_pad8(), CP = g.c_pad8();
+  const int NT = lstm_nt_for_batch(B);
+  if (NT < 0) throw std::runtime_error("run_acoustic_chunk: more batch rows than one recurrent launch covers");
+  const int NTR = NT * 16, NWG = H / 16;
+  const int slot = (int)(am_seq % kAmRing);
+  const bool wrapped = am_seq >= (unsigned long long)kAmRing;
+  ++am_seq;
+  ws_x1.reserve(x1_bytes(M));
+  ws_a.reserve((size_t)M * H * 4); ws_b.reserve((size_t)M * H * 4); ws_o.reserve((size_t)M * H * 4);
+  am_xproj[slot].reserve((size_t)M * 4 * H * 4); am_hall[slot].reserve((size_t)M * H * 4); am_y3[slot].reserve((size_t)M * H * 4); am_xs[slot].reserve((size_t)M * 8);
+  am_logits.reserve((size_t)M * CP * 4);
+  am_qx.reserve((size_t)M * std::max(K1, H)); am_qs.reserve((size_t)M * 4); am_qo.reserve((size_t)M * H); am_qos.reserve((size_t)M * 4);
+  const size_t hq_bytes = lstm_i8_hq_bytes(H, NT);
+  am_hq0.reserve(hq_bytes); am_hq1.reserve(hq_bytes);
+  am_c.reserve((size_t)B * H * 4); am_hprev0.reserve((size_t)B * H * 4); am_hlast.reserve((size_t)B * H * 4);
+  am_pmax.reserve((size_t)2 * NTR * NWG * 4); am_flag.reserve((size_t)2 * NTR * 4); am_zslow.reserve((size_t)NWG * NTR * 64 * 4);
+  if (!ws_slow.p) { ws_slow.reserve(4); HIP_CHECK(hipMemsetAsync(ws_slow.p, 0, 4, stream)); HIP_CHECK(hipStreamSynchronize(stream)); }
+
+  // ---- engine 1 (`stream`)
+  if (wrapped) HIP_CHECK(hipStreamWaitEvent(stream, ev_x_free[slot], 0));
+  ContextArgs c{};
+  c.feats = d_feats; c.n_frames = d_nframes; c.x1 = nullptr; c.x1_f32 = ws_x1.as<float>();
+  c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = K1; c.t0 = t0;
+  launch_context(c, M, stream);
+  stt_prof_mark_on(this, 1, 0, stream);
+  signed char* qx = am_qx.as<signed char>();
+  float* qs = am_qs.as<float>();
+  float *xs3 = am_xs[slot].as<float>(), *xr3 = xs3 + M;
+  float *act_a = ws_a.as<float>(), *act_b = ws_b.as<float>(), *y3 = am_y3[slot].as<float>();
+  launch_quantize_rows(ws_x1.as<float>(), qx, qs, M, K1, stream);
+  launch_dense_hybrid_i8(qx, qs, w1q.as<signed char>(), s1.as<float>(), sn[0], b1.as<float>(), act_a, M, H, K1, stream, DENSE_EPI_I8_RELU_F32, g.relu_clip);
+  launch_quantize_rows(act_a, qx, qs, M, H, stream);
+  launch_dense_hybrid_i8(qx, qs, w2q.as<signed char>(), s2.as<float>(), sn[1], b2.as<float>(), act_b, M, H, H, stream, DENSE_EPI_I8_RELU_F32, g.relu_clip);
+  launch_quantize_rows(act_b, qx, qs, M, H, stream);
+  launch_dense_hybrid_i8(qx, qs, w3q.as<signed char>(), s3.as<float>(), sn[2], b3.as<float>(), y3, M, H, H, stream, DENSE_EPI_I8_RELU_F32, g.relu_clip);
+  launch_quantize_rows(y3, qx, xs3, M, H, stream, xr3);
+  launch_dense_hybrid_i8(qx, xs3, wxq.as<signed char>(), sk.as<float>(), sn[3], bl.as<float>(), am_xproj[slot].p, M, 4 * H, H, stream, DENSE_EPI_I8_RAW);
+  stt_prof_mark_on(this, -1, 0, stream);
+  HIP_CHECK(hipEventRecord(ev_x_ready[slot], stream));
+
+  // ---- engine 2 (`stream_l`): prep + T steps; c in am_c, the carried h in am_hlast (f32)
+  HIP_CHECK(hipStreamWaitEvent(stream_l, ev_x_ready[slot], 0));
+  if (wrapped) HIP_CHECK(hipStreamWaitEvent(stream_l, ev_h_free[slot], 0));
+  stt_prof_mark_on(this, 2, 5, stream_l);
+  if (t0 == 0) HIP_CHECK(hipMemsetAsync(am_c.p, 0, (size_t)B * H * 4, stream_l));
+  LstmI8Args l{};
+  l.whp = whpq.as<signed char>(); l.accx = am_xproj[slot].as<int>(); l.bias = bl.as<float>(); l.wscale = sk.as<float>(); l.wscale_n = sn[3];
+  l.xscale = xs3; l.xrange = xr3; l.c = am_c.as<float>(); l.h_all = am_hall[slot].as<float>(); l.h_last = am_hlast.as<float>();
+  l.pmax = am_pmax.as<float>(); l.flag = am_flag.as<int>(); l.y3 = y3; l.h_prev0 = am_hprev0.as<float>();
+  l.wxq = wxq.as<signed char>(); l.whq = whq.as<signed char>(); l.zslow = am_zslow.as<float>();
+  l.n_hidden = H; l.batch = B; l.T = T; l.prio = tune().lstm_prio; l.slow_count = ws_slow.as<unsigned>();
+  const float* h_src = t0 == 0 ? nullptr : am_hlast.as<float>();
+  auto steps = [&]() {
+    l.t = 0; l.hq_in = am_hq0.as<signed char>(); l.hq_out = am_hq1.as<signed char>();
+    launch_lstm_i8_prep(l, h_src, NT, stream_l);
+    for (int t = 0; t < T; ++t) {
+      l.t = t;
+      l.hq_in = (t & 1) ? am_hq1.as<signed char>() : am_hq0.as<signed char>();
+      l.hq_out = (t & 1) ? am_hq0.as<signed char>() : am_hq1.as<signed char>();
+      launch_lstm_i8_step(l, NT, stream_l);
+    }
+  };
+  if (tune().lstm_graph) {
+    LstmGraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.xproj = am_xproj[slot].p; key.hall = am_hall[slot].p; key.c = am_c.p; key.hp0 = am_hq0.p; key.hp1 = am_hq1.p; key.whp = am_y3[slot].p;
+    key.T = T; key.par = t0 == 0 ? 0 : 1; key.B = B; key.NT = NT; key.passes = 100; key.prio = l.prio; key.H = H; key.first = 0;
+    run_lstm_graph(key, steps);
+  } else steps();
+  stt_prof_mark_on(this, -1, 5, stream_l);
+  HIP_CHECK(hipEventRecord(ev_x_free[slot], stream_l));
+  HIP_CHECK(hipEventRecord(ev_h_ready[slot], stream_l));
+
+  // ---- engine 3 (`stream_o`): layer 5, layer 6, softmax -> probs[b][t0 + t][:]
+  HIP_CHECK(hipStreamWaitEvent(stream_o, ev_h_ready[slot], 0));
+  stt_prof_mark_on(this, 3, 6, stream_o);
+  float* probs_out = d_probs + (size_t)t0 * C;
+  signed char* qo = am_qo.as<signed char>();
+  float* qos = am_qos.as<float>();
+  launch_quantize_rows(am_hall[slot].as<float>(), qo, qos, M, H, stream_o);
+  HIP_CHECK(hipEventRecord(ev_h_free[slot], stream_o));
+  launch_dense_hybrid_i8(qo, qos, w5q.as<signed char>(), s5.as<float>(), sn[4], b5.as<float>(), ws_o.p, M, H, H, stream_o, DENSE_EPI_I8_RELU_F32, g.relu_clip);
+  launch_quantize_rows(ws_o.as<float>(), qo, qos, M, H, stream_o);
+  launch_dense_hybrid_i8(qo, qos, w6q.as<signed char>(), s6.as<float>(), sn[5], b6q.as<float>(), am_logits.p, M, CP, H, stream_o, DENSE_EPI_I8_F32);
+  SoftmaxArgs sm{};
+  sm.logits = am_logits.as<float>(); sm.probs = probs_out; sm.M = M; sm.C = C; sm.ldl = CP; sm.batch = B; sm.t_max = t_max;
+  launch_softmax(sm, stream_o);
+  stt_prof_mark_on(this, -1, 6, stream_o);
+  HIP_CHECK(hipEventRecord(done, stream_o));
+}
+
+// The recurrence of a chunk as one hipGraph (engine.h: LstmGraphKey): `steps` enqueues the launches on stream_l.
+void ModelState::run_lstm_graph(const LstmGraphKey& key, const std::function<void()>& steps) {
+  // A combination is captured the SECOND time it comes up (the first ran eagerly: module load, function attributes).  First
+  // sightings live in their own small set, so a ragged job's many one-off shapes never push the graphs out of the cache; when
+  // the cache is full (or holds graphs of buffers that have since been reallocated) it is emptied and refills with what recurs.
+  auto found = lstm_graphs_.find(key);
+  if (found != lstm_graphs_.end()) {
+    if (found->second.exec) HIP_CHECK(hipGraphLaunch(found->second.exec, stream_l));
+    else steps();                                       // instantiation failed once: this combination stays on plain launches
+  } else if (!lstm_seen_.count(key)) {
+    if (lstm_seen_.size() >= 1024) lstm_seen_.clear();
+    lstm_seen_.insert(key);
+    steps();
+  } else {
+    if (lstm_graphs_.size() >= 256) {
+      HIP_CHECK(hipStreamSynchronize(stream_l));        // (rare) nothing may still be replaying what is destroyed
+      for (auto& kv : lstm_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+      lstm_graphs_.clear();
+    }
+    LstmGraph gr;
+    hipGraph_t graph = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(stream_l, hipStreamCaptureModeRelaxed));
+    try { steps(); }
+    catch (...) { (void)hipStreamEndCapture(stream_l, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }  // never leave the stream capturing
+    HIP_CHECK(hipStreamEndCapture(stream_l, &graph));
+    const hipError_t ie = hipGraphInstantiate(&gr.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) { gr.exec = nullptr; (void)hipGetLastError(); }
+    lstm_graphs_[key] = gr;
+    lstm_seen_.erase(key);
+    if (gr.exec) HIP_CHECK(hipGraphLaunch(gr.exec, stream_l));
+    else steps();
+  }
+}
+
 void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs, hipEvent_t done) {
+  if (i8) { run_acoustic_chunk_piped_i8(d_feats, d_nframes, B, t_max, t0, T, d_probs, done); return; }
   const int H = g.n_hidden, M = T * B, C = g.n_classes;
   const int NT = lstm_nt_for_batch(B);
   if (NT < 0 || B > lstm_max_rows(H)) throw std::runtime_error("run_acoustic_chunk: more batch rows than one recurrent launch covers");
@@ -207,39 +409,8 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
     memset(&key, 0, sizeof(key));  // (padding bytes take part in the comparison)
     key.xproj = am_xproj[slot].p; key.hall = am_hall[slot].p; key.c = am_c.p; key.hp0 = am_hp0.p; key.hp1 = am_hp1.p; key.whp = whp.p;
     key.T = T; key.par = t0 & 1; key.B = B; key.NT = NT; key.passes = l.passes; key.prio = l.prio; key.H = H; key.first = tune().lstm_form * 16 + tune().lstm_prefetch;  // (what else selects the kernel instance)
-    // A combination is captured the SECOND time it comes up (the first ran eagerly: module load, function attributes).  First
-    // sightings live in their own small set, so a ragged job's many one-off shapes never push the graphs out of the cache; when
-    // the cache is full (or holds graphs of buffers that have since been reallocated) it is emptied and refills with what recurs.
-    auto found = lstm_graphs_.find(key);
-    if (found != lstm_graphs_.end()) {
-      if (found->second.exec) HIP_CHECK(hipGraphLaunch(found->second.exec, stream_l));
-      else steps();                                       // instantiation failed once: this combination stays on plain launches
-    } else if (!lstm_seen_.count(key)) {
-      if (lstm_seen_.size() >= 1024) lstm_seen_.clear();
-      lstm_seen_.insert(key);
-      steps();
-    } else {
-      if (lstm_graphs_.size() >= 256) {
-        HIP_CHECK(hipStreamSynchronize(stream_l));        // (rare) nothing may still be replaying what is destroyed
-        for (auto& kv : lstm_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-        lstm_graphs_.clear();
-      }
-      LstmGraph gr;
-      hipGraph_t graph = nullptr;
-      HIP_CHECK(hipStreamBeginCapture(stream_l, hipStreamCaptureModeRelaxed));
-      try { steps(); }
-      catch (...) { (void)hipStreamEndCapture(stream_l, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }  // never leave the stream capturing
-      HIP_CHECK(hipStreamEndCapture(stream_l, &graph));
-      const hipError_t ie = hipGraphInstantiate(&gr.exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      if (ie != hipSuccess) { gr.exec = nullptr; (void)hipGetLastError(); }
-      lstm_graphs_[key] = gr;
-      lstm_seen_.erase(key);
-      if (gr.exec) HIP_CHECK(hipGraphLaunch(gr.exec, stream_l));
-      else steps();
-    }
+    run_lstm_graph(key, steps);
   } else steps();
-recurrence_enqueued:
   stt_prof_mark_on(this, -1, 5, stream_l);
   HIP_CHECK(hipEventRecord(ev_x_free[slot], stream_l));
   HIP_CHECK(hipEventRecord(ev_h_ready[slot], stream_l));
@@ -561,7 +732,7 @@ void StreamingState::flushBuffers(bool addZeroMfccVectors) {
 void StreamingState::processReady(bool flush_partial, bool final_flush) {
   ModelState& m = *model_;
   const Geometry& g = m.g;
-  const int H = g.n_hidden, C = g.n_classes, kp = g.k1_pad(), kw = g.n_in1();
+  const int H = g.n_hidden, C = g.n_classes, kp = m.x1_cols(), kw = g.n_in1();
   for (;;) {
     const int ready = std::max(0, frames_ - 2 * g.n_context) - windows_done_;
     int take = 0;
@@ -570,12 +741,12 @@ void StreamingState::processReady(bool flush_partial, bool final_flush) {
     if (take == 0) break;
     const int T = (take < g.n_steps && !final_flush) ? g.n_steps : take;  // padded steps perturb the carried state (coqui-stt.h:393-399 of the reference)
     // windows are contiguous slices of the frame list: window w = frames[w .. w+19) flattened (stt.cc:292-309)
-    m.ws_x1.reserve((size_t)T * kp * 2);
+    m.ws_x1.reserve(m.x1_bytes(T));
     // raw gather: x1[t][k] = frames_flat[(windows_done_ + t) * n_input + k], k < 494; rows >= take are written as zeros
-    launch_window_rows(d_frames.as<float>() + (size_t)windows_done_ * g.n_input, m.ws_x1.as<_Float16>(), take, T, g.n_input, kw, kp, m.stream);
+    launch_window_rows(d_frames.as<float>() + (size_t)windows_done_ * g.n_input, m.ws_x1.p, take, T, g.n_input, kw, kp, m.stream, m.i8);
     d_c.reserve((size_t)H * 4); d_h.reserve((size_t)H * 4);
     m.ws_probs.reserve((size_t)T * C * 4);
-    m.run_acoustic_rows(m.ws_x1.as<_Float16>(), 1, T, d_c.as<float>(), d_h.as<float>(), state_nonzero, m.ws_probs.as<float>(), T);
+    m.run_acoustic_rows(m.ws_x1.p, 1, T, d_c.as<float>(), d_h.as<float>(), state_nonzero, m.ws_probs.as<float>(), T);
     state_nonzero = true;
     if (keep_emissions_) {  // stt.cc:326-329: probs_ is *replaced* by the last batch
       std::vector<float> pr((size_t)take * C);
@@ -658,7 +829,7 @@ bool streams_process(const std::vector<StreamingState*>& ss, bool flush_partial,
   bool synced = false;
   ModelState& m = *ss[0]->model_;
   const Geometry& g = m.g;
-  const int H = g.n_hidden, C = g.n_classes, kp = g.k1_pad(), kw = g.n_in1(), T = g.n_steps;
+  const int H = g.n_hidden, C = g.n_classes, kp = m.x1_cols(), kw = g.n_in1(), T = g.n_steps;
   DevScorer ds = m.current_scorer(ss[0]->scorer_, ss[0]->hot_words_, ss[0]->hot_tables_);
   for (int pass = 0;; ++pass) {
     std::vector<StreamingState*> R;
@@ -704,13 +875,13 @@ bool streams_process(const std::vector<StreamingState*>& ss, bool flush_partial,
       DecStream* const* d_tp = reinterpret_cast<DecStream* const*>(db + (size_t)3 * B * 8);
       const int* d_int = reinterpret_cast<const int*>(db + n_ptr * 8);
       const unsigned char* d_valid = db + n_ptr * 8 + (size_t)3 * B * 4;
-      m.ws_x1.reserve((size_t)T * B * kp * 2);
-      launch_window_rows_batch(d_frames, d_int, d_int + B, m.ws_x1.as<_Float16>(), B, T, g.n_input, kw, kp, m.stream);
+      m.ws_x1.reserve(m.x1_bytes(T * B));
+      launch_window_rows_batch(d_frames, d_int, d_int + B, m.ws_x1.p, B, T, g.n_input, kw, kp, m.stream, m.i8);
       m.sb_c.reserve((size_t)B * H * 4); m.sb_h.reserve((size_t)B * H * 4);
       launch_gather_rows(d_cp, d_valid, m.sb_c.as<float>(), B, H, m.stream);
       launch_gather_rows(d_hp, d_valid, m.sb_h.as<float>(), B, H, m.stream);
       m.ws_probs.reserve((size_t)B * T * C * 4);
-      m.run_acoustic_rows(m.ws_x1.as<_Float16>(), B, T, m.sb_c.as<float>(), m.sb_h.as<float>(), true, m.ws_probs.as<float>(), T);
+      m.run_acoustic_rows(m.ws_x1.p, B, T, m.sb_c.as<float>(), m.sb_h.as<float>(), true, m.ws_probs.as<float>(), T);
       launch_scatter_rows(d_cp, m.sb_c.as<float>(), B, H, m.stream);
       launch_scatter_rows(d_hp, m.sb_h.as<float>(), B, H, m.stream);
       m.sb_table.reserve(sizeof(DecStream) * B);

@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <functional>
 #include <map>
 #include <set>
 #include <memory>
@@ -108,6 +109,8 @@ struct Geometry {
   int n_in1() const { return n_input * (2 * n_context + 1); }
   int k1_pad() const { return (n_in1() + 63) / 64 * 64; }
   int c_pad() const { return (n_classes + 127) / 128 * 128; }
+  int k1_pad8() const { return (n_in1() + 127) / 128 * 128; }   // int8 path: K-tiles of 128 int8
+  int c_pad8() const { return (n_classes + 255) / 256 * 256; }  // int8 path: the 128 x 256 tile
   int fft_len() const { int n = 1; while (n < win_len) n <<= 1; return n; }  // TF AudioSpectrogram: NextPowerOfTwo(window_size)
 };
 
@@ -117,6 +120,12 @@ struct ModelTensors {
   Geometry g;
   std::string alphabet;
   std::vector<float> l1w, l1b, l2w, l2b, l3w, l3b, lk, lb, l5w, l5b, l6w, l6b;
+  // A dynamic-range quantised `.tflite` (export.py:145-146) also keeps what the file stores for the six matrices (layers 1-3, the cell's
+  // kernel, layers 5, 6): int8 [outputs][inputs] as FULLY_CONNECTED holds them, zero point 0, one scale per tensor or per output row.
+  // All six present = the reference's CPU path runs them through TFLite's hybrid kernel, and so does the engine (ModelState::i8).
+  std::vector<int8_t> wq[6];
+  std::vector<float> wq_scale[6];
+  bool all_int8() const { for (int l = 0; l < 6; ++l) if (wq[l].empty()) return false; return true; }
 };
 bool looks_like_tflite(const char* buf, size_t len);
 int read_tflite_model(const char* buf, size_t len, ModelTensors& out, std::string& err);  // STT_ERR_* code
@@ -127,6 +136,7 @@ struct ModelView {
   size_t alphabet_bytes = 0;
   const float* t[12] = {};  // l1w l1b l2w l2b l3w l3b lk lb l5w l5b l6w l6b
   size_t count[12] = {};
+  const ModelTensors* quant = nullptr;   // the int8 matrices of a quantised `.tflite` (storage->all_int8()), else null
 };
 int parse_model_file(const char* buf, size_t len, ModelTensors& storage, ModelView& view, std::string& err);
 
@@ -188,6 +198,16 @@ struct ModelState {
   // weights in HBM (f16, transposed / packed; see kernels_am.hip header)
   DevBuf w1t, w2t, w3t, wxt, whp, w5t, w6t;
   DevBuf b1, b2, b3, bl, b5, b6;
+  // The released models' own arithmetic (dynamic-range quantised `.tflite`, or tunable am_i8 = 1): TFLite's hybrid FULLY_CONNECTED end to
+  // end (engine.cpp: acoustic_rows_i8; kernels.h: launch_dense_hybrid_i8, LstmI8Args).  int8 matrices [N][K] (K zero padded to a multiple of
+  // 128, the output layer's N to 256), the cell's kernel split into its x half (a GEMM operand), its h half packed for the recurrent step
+  // and the same h half in rows (the step's slow path); scales [1] or [N].
+  bool i8 = false;
+  DevBuf w1q, w2q, w3q, wxq, whq, whpq, w5q, w6q;
+  DevBuf s1, s2, s3, sk, s5, s6, b6q;     // b6q: the output layer's bias padded to c_pad8()
+  int sn[6] = {1, 1, 1, 1, 1, 1};         // scales per matrix (1 or N)
+  // workspaces of the int8 path (one-stream paths; the three-engine batch path has its own below)
+  DevBuf q_x, q_s, q_rng, ws_hq0, ws_hq1, ws_hprev0, ws_pmax, ws_flag, ws_zslow, ws_hlast, ws_slow;
   // feature tables
   DevBuf t_window, t_twiddle, t_melw, t_mel_idx, t_dct;
   // alphabet on device
@@ -272,6 +292,7 @@ struct ModelState {
   static constexpr int kAmRing = 3;
   hipStream_t stream_l = nullptr, stream_o = nullptr;
   DevBuf am_xproj[kAmRing], am_hall[kAmRing], ws_o;
+  DevBuf am_y3[kAmRing], am_xs[kAmRing], am_qx, am_qs, am_qo, am_qos, am_hq0, am_hq1, am_hprev0, am_pmax, am_flag, am_zslow, am_hlast;   // int8 path
   DevBuf am_c, am_hp0, am_hp1, am_logits;  // the recurrence's own state / the output engine's own logits: stream_l and stream_o never touch
                                            // what the one-stream paths (streaming API, blocking calls) use on `stream`
   hipEvent_t ev_x_ready[kAmRing] = {}, ev_x_free[kAmRing] = {}, ev_h_ready[kAmRing] = {}, ev_h_free[kAmRing] = {};
@@ -291,6 +312,8 @@ struct ModelState {
   bool am_pipe_init();            // creates the streams / events on first use; false when switched off
   // chunk [t0, t0+T) of a batch through the three engines; `done` is recorded on stream_o behind the softmax
   void run_acoustic_chunk_piped(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs, hipEvent_t done);
+  void run_acoustic_chunk_piped_i8(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs, hipEvent_t done);
+  void run_lstm_graph(const LstmGraphKey& key, const std::function<void()>& steps);
 
   ModelState() { tuning_model_count(+1); }   // (tuning.h: load-time knobs are frozen while a model is alive)
   ~ModelState();
@@ -303,7 +326,10 @@ struct ModelState {
   // feats (device, [B][t_max][n_input]) -> probs (ws_probs [B][t_max][C]); c/h are [B][H] f32 device (in/out, may be null = zero)
   void run_acoustic(const float* d_feats, const int* d_nframes, int B, int t_max, float* d_c, float* d_h, bool carry_in);
   // windows (device f16 [rows][k1_pad], row = t*B+b) -> probs; used by the chunked streaming path and STTX_InferChunk
-  void run_acoustic_rows(const _Float16* d_x1, int B, int T, float* d_c, float* d_h, bool carry_in, float* d_probs_out, int probs_t_max);
+  // (x1: f16 [rows][k1_pad], or f32 [rows][k1_pad8] for an int8-path model: x1_cols() / x1_bytes())
+  void run_acoustic_rows(const void* d_x1, int B, int T, float* d_c, float* d_h, bool carry_in, float* d_probs_out, int probs_t_max);
+  int x1_cols() const { return i8 ? g.k1_pad8() : g.k1_pad(); }
+  size_t x1_bytes(int rows) const { return (size_t)rows * x1_cols() * (i8 ? 4 : 2); }
   // one time-chunk [t0, t0+T) of a batch: context rows from feats, then the layers; the LSTM state continues from the
   // previous chunk (internal buffers) unless t0 == 0
   void run_acoustic_chunk(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs);
@@ -366,3 +392,6 @@ extern int g_debug_arena_frames;
 void stt_prof_mark(ModelState* m, int i);  // HIP-event marks for STTX_GetStageTimes (api.cpp)
 void stt_prof_mark_on(ModelState* m, int id, int which, hipStream_t st);
 void pack_lstm_recurrent_host(const float* kernel /*[2H][4H]*/, int H, _Float16* out);
+void pack_lstm_recurrent_i8_host(const int8_t* kernel_q /*[4H][2H]*/, int H, int8_t* out);
+// what the converter's dynamic-range quantisation stores for a [in][out] float matrix (oracle/am_hybrid.py: quantize_weights): int8 [out][in], one scale
+void quantize_weights_host(const float* w_in_out, int n_in, int n_out, std::vector<int8_t>& q, std::vector<float>& scale);

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void context_kernel(ContextArgs a) {
       const int ft = t - a.n_context + j;
       if (ft >= 0 && ft < nf) v = a.feats[((size_t)b * a.t_max + ft) * a.n_coef + c];
     }
-    a.x1[(size_t)row * a.k_pad + k] = (_Float16)v;
+    if (a.x1_f32) a.x1_f32[(size_t)row * a.k_pad + k] = v;
+    else a.x1[(size_t)row * a.k_pad + k] = (_Float16)v;
   }
 }
 
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void dense_wide_kernel(DenseArgs a) {
   }
   const int n0 = tile_n * BN, m0 = tile_m * BM;
   const int K = a.K;
-  constexpr bool I8 = EPI == DENSE_EPI_I8_F32;   // int8 operands: a row of a K-tile is the same 128 bytes (128 k-values instead of 64), K counts 2-byte units
+  constexpr bool I8 = EPI >= DENSE_EPI_I8_F32;   // int8 operands: a row of a K-tile is the same 128 bytes (128 k-values instead of 64), K counts 2-byte units
   typedef int i32x4_ __attribute__((ext_vector_type(4)));
   typedef typename std::conditional<I8, i32x4_, f32x4>::type acc_t;
   acc_t acc[4][MJ];
@@ -420,27 +421,39 @@ __global__ __launch_bounds__(512, 2) void dense_wide_kernel(DenseArgs a) {
 #undef STAGE_W
   if constexpr (I8) {
     // y = bias + float(acc) * (row scale * weight scale): portable_tensor_utils.cc MatrixBatchVectorMultiplyAccumulate (int8), in its order,
-    // every operation rounded on its own as the portable x86-64 build does (no fused multiply-add)
+    // every operation rounded on its own as the portable x86-64 build does (no fused multiply-add).  DENSE_EPI_I8_RELU_F32 adds the graph's
+    // RELU + MINIMUM (deepspeech_model.py:82-86) on the f32 result; DENSE_EPI_I8_RAW hands out the int32 sums themselves (the x half of the
+    // cell's product, rescaled inside the recurrent step together with the h half: lstm_i8_step_kernel).
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
-      const float4 bias = *reinterpret_cast<const float4*>(a.bias + n);
-      float cs[4];
+      if constexpr (EPI == DENSE_EPI_I8_RAW) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cs[r] = a.col_scale[a.col_scale_n > 1 ? n + r : 0];
-#pragma unroll
-      for (int j = 0; j < MJ; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + (lane & 15);
-        if (m >= a.M) continue;
-        const float rs = a.row_scale[m];
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float prod;   // (an instruction of its own: the compiler contracts a * b + c into v_fma_f32 whatever the pragma says for inlined operators)
-          asm volatile("v_mul_f32 %0, %1, %2" : "=v"(prod) : "v"((float)acc[i][j][r]), "v"(__fmul_rn(rs, cs[r])));
-          v[r] = (&bias.x)[r] + prod;
+        for (int j = 0; j < MJ; ++j) {
+          const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+          if (m >= a.M) continue;
+          *reinterpret_cast<i32x4_*>(reinterpret_cast<int*>(a.y) + (size_t)m * a.ldy + n) = acc[i][j];
         }
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        const float4 bias = *reinterpret_cast<const float4*>(a.bias + n);
+        float cs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[r] = a.col_scale[a.col_scale_n > 1 ? n + r : 0];
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+          const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+          if (m >= a.M) continue;
+          const float rs = a.row_scale[m];
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float prod;   // (an instruction of its own: the compiler contracts a * b + c into v_fma_f32 whatever the pragma says for inlined operators)
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(prod) : "v"((float)acc[i][j][r]), "v"(__fmul_rn(rs, cs[r])));
+            v[r] = (&bias.x)[r] + prod;
+            if constexpr (EPI == DENSE_EPI_I8_RELU_F32) v[r] = fminf(fmaxf(v[r], 0.f), a.relu_clip);
+          }
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
       }
     }
     return;
@@ -469,28 +482,53 @@ __global__ __launch_bounds__(512, 2) void dense_wide_kernel(DenseArgs a) {
 // PortableSymmetricQuantizeFloats per row (tensorflow/lite/kernels/internal/reference/portable_tensor_utils.cc): range = max |x|;
 // range == 0 -> zeros, scale 1; else q = clamp(round(x * (127 / range)), -127, 127) (std::round: half away from zero), scale = range / 127.
 // One wave per row.
-__global__ __launch_bounds__(256) void quantize_rows_kernel(const float* __restrict__ x, signed char* __restrict__ q, float* __restrict__ scale, int M, int K) {
+// The row is held in registers between the two passes when it fits (K <= 2048: eight float4 per lane), so the activations are read once.
+__device__ __forceinline__ signed char quantize_one_(float v, float inv) { return (signed char)fminf(fmaxf(roundf(__fmul_rn(v, inv)), -127.0f), 127.0f); }
+__global__ __launch_bounds__(256) void quantize_rows_kernel(const float* __restrict__ x, signed char* __restrict__ q, float* __restrict__ scale, float* __restrict__ range, int M, int K, int ldx) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
-  const float* xr = x + (size_t)row * K;
-  float mx = 0.0f;
-  for (int k = lane * 4; k < K; k += 256) { const float4 v = *reinterpret_cast<const float4*>(xr + k); mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-  const float inv = mx > 0.0f ? __fdiv_rn(127.0f, mx) : 0.0f;
-  if (lane == 0) scale[row] = mx > 0.0f ? __fdiv_rn(mx, 127.0f) : 1.0f;
+  const float* xr = x + (size_t)row * ldx;
   signed char* qr = q + (size_t)row * K;
-  for (int k = lane * 4; k < K; k += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(xr + k);
-    char4 o;
-    o.x = (signed char)fminf(fmaxf(roundf(__fmul_rn(v.x, inv)), -127.0f), 127.0f); o.y = (signed char)fminf(fmaxf(roundf(__fmul_rn(v.y, inv)), -127.0f), 127.0f);
-    o.z = (signed char)fminf(fmaxf(roundf(__fmul_rn(v.z, inv)), -127.0f), 127.0f); o.w = (signed char)fminf(fmaxf(roundf(__fmul_rn(v.w, inv)), -127.0f), 127.0f);
-    *reinterpret_cast<char4*>(qr + k) = o;
+  float mx = 0.0f;
+  if (K <= 2048) {
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = lane * 4 + i * 256;
+      v[i] = k < K ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    const float inv = mx > 0.0f ? __fdiv_rn(127.0f, mx) : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = lane * 4 + i * 256;
+      if (k >= K) break;
+      char4 o;
+      o.x = quantize_one_(v[i].x, inv); o.y = quantize_one_(v[i].y, inv); o.z = quantize_one_(v[i].z, inv); o.w = quantize_one_(v[i].w, inv);
+      *reinterpret_cast<char4*>(qr + k) = o;
+    }
+  } else {
+    for (int k = lane * 4; k < K; k += 256) { const float4 v = *reinterpret_cast<const float4*>(xr + k); mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    const float inv = mx > 0.0f ? __fdiv_rn(127.0f, mx) : 0.0f;
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + k);
+      char4 o;
+      o.x = quantize_one_(v.x, inv); o.y = quantize_one_(v.y, inv); o.z = quantize_one_(v.z, inv); o.w = quantize_one_(v.w, inv);
+      *reinterpret_cast<char4*>(qr + k) = o;
+    }
+  }
+  if (lane == 0) {
+    scale[row] = mx > 0.0f ? __fdiv_rn(mx, 127.0f) : 1.0f;
+    if (range) range[row] = mx;
   }
 }
-void launch_quantize_rows(const float* x, signed char* q, float* scale, int M, int K, hipStream_t st) {
+void launch_quantize_rows(const float* x, signed char* q, float* scale, int M, int K, hipStream_t st, float* range, int ldx) {
   if (K % 4 != 0) throw std::runtime_error("launch_quantize_rows: K must be a multiple of 4");
-  hipLaunchKernelGGL(quantize_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, q, scale, M, K);
+  hipLaunchKernelGGL(quantize_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, q, scale, range, M, K, ldx > 0 ? ldx : K);
 }
 
 // Skinny form for M <= 16 rows (one stream's 16-frame chunk: STT_FeedAudioContent / STT_SpeechToText): the tiled kernel
@@ -541,6 +579,56 @@ __global__ __launch_bounds__(256) void dense_skinny_kernel(DenseArgs a) {
 }
 template __global__ void dense_skinny_kernel<DENSE_EPI_RELU_F16>(DenseArgs);
 template __global__ void dense_skinny_kernel<DENSE_EPI_BIAS_F32>(DenseArgs);
+
+// The skinny form on int8 operands (a stream's 16-frame chunk through the hybrid path): v_mfma_i32_16x16x64_i8, one k-step = 64 int8 =
+// the same 16 bytes per lane, so the addressing is the f16 form's (K and ldx count 2-byte units, as in dense_wide_kernel).  Integer
+// sums are exact: whatever form computes them, the rescale sees the same int32.
+template <int EPI>
+__global__ __launch_bounds__(256) void dense_skinny_i8_kernel(DenseArgs a) {
+  typedef int i32x4_ __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = (blockIdx.x * 4 + wave) * 16;
+  if (nb >= a.N) return;
+  const int K = a.K;
+  int row = lane & 15;
+  row = row < a.M ? row : a.M - 1;
+  const uint4* wp = reinterpret_cast<const uint4*>(a.wt + (size_t)(nb + (lane & 15)) * K + (lane >> 4) * 8);
+  const uint4* xp = reinterpret_cast<const uint4*>(a.x + (size_t)row * a.ldx + (lane >> 4) * 8);
+  i32x4_ acc = (i32x4_){0, 0, 0, 0};
+  constexpr int D = 8;
+  const int nks = K / 32;   // k-steps of 64 int8 (= 32 two-byte units)
+  uint4 wa[D], xa[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nks) { wa[d] = wp[d * 4]; xa[d] = xp[d * 4]; }
+  for (int s0 = 0; s0 < nks; s0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (s0 + d < nks) {
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_, wa[d]), __builtin_bit_cast(i32x4_, xa[d]), acc, 0, 0, 0);
+        if (s0 + D + d < nks) { wa[d] = wp[(size_t)(s0 + D + d) * 4]; xa[d] = xp[(size_t)(s0 + D + d) * 4]; }
+      }
+    }
+  }
+  const int m = lane & 15;
+  if (m >= a.M) return;
+  const int n = nb + (lane >> 4) * 4;
+  if constexpr (EPI == DENSE_EPI_I8_RAW) {
+    *reinterpret_cast<i32x4_*>(reinterpret_cast<int*>(a.y) + (size_t)m * a.ldy + n) = acc;
+  } else {
+    const float4 bias = *reinterpret_cast<const float4*>(a.bias + n);
+    const float rs = a.row_scale[m];
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float prod;
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(prod) : "v"((float)acc[r]), "v"(__fmul_rn(rs, a.col_scale[a.col_scale_n > 1 ? n + r : 0])));
+      v[r] = (&bias.x)[r] + prod;
+      if constexpr (EPI == DENSE_EPI_I8_RELU_F32) v[r] = fminf(fmaxf(v[r], 0.f), a.relu_clip);
+    }
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
 
 
 // =============================================================================================
@@ -888,26 +976,29 @@ __global__ void pack_h_kernel(const float* h, _Float16* hp, int B, int H, int NT
 
 // streaming path: the frame list already contains the explicit zero context frames, so window t is the
 // contiguous slice frames[t*n_input .. t*n_input + kw) (stt.cc:292-309)
-__global__ void window_rows_kernel(const float* frames, _Float16* x1, int rows_valid, int rows_total, int n_input, int kw, int kp) {
+template <typename OutT>
+__global__ void window_rows_kernel(const float* frames, OutT* x1, int rows_valid, int rows_total, int n_input, int kw, int kp) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows_total * kp) return;
   const int t = idx / kp, k = idx - t * kp;
-  x1[idx] = (_Float16)((k < kw && t < rows_valid) ? frames[(size_t)t * n_input + k] : 0.0f);
+  x1[idx] = (OutT)((k < kw && t < rows_valid) ? frames[(size_t)t * n_input + k] : 0.0f);
 }
-__global__ void window_rows_batch_kernel(const float* const* frames_ptrs, const int* win_off, const int* take, _Float16* x1, int B, int T, int n_input, int kw, int kp) {
+template <typename OutT>
+__global__ void window_rows_batch_kernel(const float* const* frames_ptrs, const int* win_off, const int* take, OutT* x1, int B, int T, int n_input, int kw, int kp) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * B * kp) return;
   const int row = idx / kp, k = idx - row * kp;
   const int t = row / B, b = row - t * B;
   float v = 0.0f;
   if (k < kw && t < take[b]) v = frames_ptrs[b][(size_t)(win_off[b] + t) * n_input + k];
-  x1[idx] = (_Float16)v;
+  x1[idx] = (OutT)v;
 }
-void launch_window_rows_batch(const float* const* frames_ptrs, const int* win_off, const int* take, _Float16* x1, int B, int T, int n_input, int kw, int kp,
-                              hipStream_t st) {
+void launch_window_rows_batch(const float* const* frames_ptrs, const int* win_off, const int* take, void* x1, int B, int T, int n_input, int kw, int kp,
+                              hipStream_t st, bool f32) {
   const int n = T * B * kp;
   if (n <= 0) return;
-  hipLaunchKernelGGL(window_rows_batch_kernel, dim3((n + 255) / 256), dim3(256), 0, st, frames_ptrs, win_off, take, x1, B, T, n_input, kw, kp);
+  if (f32) hipLaunchKernelGGL(window_rows_batch_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, frames_ptrs, win_off, take, (float*)x1, B, T, n_input, kw, kp);
+  else hipLaunchKernelGGL(window_rows_batch_kernel<_Float16>, dim3((n + 255) / 256), dim3(256), 0, st, frames_ptrs, win_off, take, (_Float16*)x1, B, T, n_input, kw, kp);
 }
 __global__ void gather_rows_kernel(const float* const* src, const unsigned char* valid, float* dst, int B, int H) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -927,10 +1018,11 @@ void launch_gather_rows(const float* const* src, const unsigned char* valid, flo
 void launch_scatter_rows(float* const* dst, const float* src, int B, int H, hipStream_t st) {
   hipLaunchKernelGGL(scatter_rows_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, dst, src, B, H);
 }
-void launch_window_rows(const float* frames, _Float16* x1, int rows_valid, int rows_total, int n_input, int kw, int kp, hipStream_t st) {
+void launch_window_rows(const float* frames, void* x1, int rows_valid, int rows_total, int n_input, int kw, int kp, hipStream_t st, bool f32) {
   const int n = rows_total * kp;
   if (n <= 0) return;
-  hipLaunchKernelGGL(window_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, frames, x1, rows_valid, rows_total, n_input, kw, kp);
+  if (f32) hipLaunchKernelGGL(window_rows_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, frames, (float*)x1, rows_valid, rows_total, n_input, kw, kp);
+  else hipLaunchKernelGGL(window_rows_kernel<_Float16>, dim3((n + 255) / 256), dim3(256), 0, st, frames, (_Float16*)x1, rows_valid, rows_total, n_input, kw, kp);
 }
 
 // softmax over the first C of ldl logits per row (deepspeech_model.py:357); row m = t*B+b -> probs[b][t][:].
@@ -1048,13 +1140,23 @@ void launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t st)
   const int blocks = (int)std::min<size_t>(64, (items + 255) / 256);
   hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, st, (unsigned char*)dst, (const unsigned char*)src, bytes, wide);
 }
-void launch_dense_hybrid_i8(const signed char* q, const float* row_scale, const signed char* wq, const float* col_scale, int col_scale_n, const float* bias, float* y,
-                            int M, int N, int K, hipStream_t st) {
-  if (K % 128 != 0 || N % 256 != 0 || M < 1) throw std::runtime_error("launch_dense_hybrid_i8: K must be a multiple of 128, N of 256");
+void launch_dense_hybrid_i8(const signed char* q, const float* row_scale, const signed char* wq, const float* col_scale, int col_scale_n, const float* bias, void* y,
+                            int M, int N, int K, hipStream_t st, int epi, float relu_clip, int ldy) {
+  if (K % 128 != 0 || M < 1) throw std::runtime_error("launch_dense_hybrid_i8: K must be a multiple of 128");
   DenseArgs b{};
   b.wt = reinterpret_cast<const _Float16*>(wq); b.x = reinterpret_cast<const _Float16*>(q); b.bias = bias; b.y = y;
-  b.M = M; b.N = N; b.K = K / 2; b.ldx = K / 2; b.ldy = N;   // (K and ldx in 2-byte units: the tile loops of the f16 form, unchanged)
-  b.row_scale = row_scale; b.col_scale = col_scale; b.col_scale_n = col_scale_n;
+  b.M = M; b.N = N; b.K = K / 2; b.ldx = K / 2; b.ldy = ldy > 0 ? ldy : N;   // (K and ldx in 2-byte units: the tile loops of the f16 form, unchanged)
+  b.row_scale = row_scale; b.col_scale = col_scale; b.col_scale_n = col_scale_n; b.relu_clip = relu_clip;
+  if (M <= 16 && N % 64 == 0) {   // one stream's chunk: a wave per 16 output features, no LDS
+    const dim3 grid(N / 64), block(256);
+    switch (epi) {
+      case DENSE_EPI_I8_RELU_F32: hipLaunchKernelGGL(dense_skinny_i8_kernel<DENSE_EPI_I8_RELU_F32>, grid, block, 0, st, b); break;
+      case DENSE_EPI_I8_RAW: hipLaunchKernelGGL(dense_skinny_i8_kernel<DENSE_EPI_I8_RAW>, grid, block, 0, st, b); break;
+      default: hipLaunchKernelGGL(dense_skinny_i8_kernel<DENSE_EPI_I8_F32>, grid, block, 0, st, b); break;
+    }
+    return;
+  }
+  if (N % 256 != 0) throw std::runtime_error("launch_dense_hybrid_i8: N must be a multiple of 256 (64 for M <= 16)");
   const int ntn = N / 256, ntm = (M + 127) / 128;
   int best = 1 << 30;
   b.xa = 1; b.xb = 8;
@@ -1069,8 +1171,16 @@ void launch_dense_hybrid_i8(const signed char* q, const float* row_scale, const 
   static std::once_flag once[16];
   int dev = 0;
   (void)hipGetDevice(&dev);
-  std::call_once(once[dev & 15], [&]() { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_I8_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
-  hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_I8_F32>), dim3(8 * per_xcd), dim3(512), smem, st, b);
+  std::call_once(once[dev & 15], [&]() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_I8_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_I8_RELU_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_I8_RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  });
+  switch (epi) {
+    case DENSE_EPI_I8_RELU_F32: hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_I8_RELU_F32>), dim3(8 * per_xcd), dim3(512), smem, st, b); break;
+    case DENSE_EPI_I8_RAW: hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_I8_RAW>), dim3(8 * per_xcd), dim3(512), smem, st, b); break;
+    default: hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_I8_F32>), dim3(8 * per_xcd), dim3(512), smem, st, b); break;
+  }
 }
 void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st) {
   switch (a.fft_len) {

@@ -1,0 +1,322 @@
+// stt_amd/csrc/kernels_i8.hip -- the recurrent cell in the released models' own arithmetic (gfx950).
+//
+// Released models are dynamic-range quantised (training/coqui_stt_training/export.py:145-146) and the reference's CPU path runs every
+// FULLY_CONNECTED -- the unrolled LSTM cell's concat([x_t, h_(t-1)]) . kernel included -- through TensorFlow Lite's hybrid kernel
+// (native_client/tflitemodelstate.cc:200,369-405; restated in oracle/am_hybrid.py): the float input row is quantised to int8 with ONE
+// scale, max |row| / 127, int8 x int8 products are summed in int32, the sum is rescaled by (row scale x weight scale) and added to the
+// float bias; LOGISTIC / TANH / MUL / ADD stay float32, each operation rounded on its own.
+//
+// How that maps onto the recurrence (kernels.h: LstmI8Args):
+//   * integer sums are exact and associative, so the x half of a row's dot products (a GEMM over all timesteps of a chunk,
+//     dense_wide_kernel<DENSE_EPI_I8_RAW>) and the h half (this file, one launch per timestep) may be computed apart and added as int32 --
+//     PROVIDED both halves were quantised with the row's joint scale.  The x half is quantised with max |x_t| / 127; that is the joint
+//     scale whenever max |x_t| >= max |h_(t-1)|.  |h| < 1 always, layer 3's clipped ReLU over 2048 units is nearly always >= 1.
+//   * the step that produces h_(t-1) quantises it for its consumer with 127 / max |x_t| (known before the recurrence starts) and CHECKS
+//     the assumption: a workgroup whose units hold a larger |h| flags the row; the consuming step then computes that row again from the
+//     f32 x_t and h_(t-1) at the true joint scale (the slow path below: plain int8 dot products over K = 2H for the row).
+//   * the cross-wave reduction of the int32 partial sums uses LDS atomics (order does not matter for integers).
+// Layouts: recurrent weights int8 packed per (workgroup, k-step of 64, gate tile, lane) -- 16 bytes per lane and MFMA, the same
+// fragment rule as the f16 form with twice the k per instruction; h_(t-1) int8 in B-fragment order [H/64][NT][64 lanes][16].
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <stdexcept>
+
+#include "kernels.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// TFLite's LOGISTIC / TANH are float kernels; oracle/am_hybrid.py evaluates 1 / (1 + exp(-x)) and tanh(x) in float32.  Accurate expf /
+// tanhf and an IEEE division here (not the f16 path's v_exp / v_rcp forms): what is left against the restatement is the last bit of the
+// transcendental functions.
+__device__ __forceinline__ float sigmoid_i8_(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+__device__ __forceinline__ signed char quant_i8_(float v, float inv) { return (signed char)fminf(fmaxf(roundf(__fmul_rn(v, inv)), -127.0f), 127.0f); }
+
+template <bool PIN>
+__device__ __forceinline__ void mfma_i8_(i32x4& acc, const i32x4& a, const i32x4& b) {
+  if constexpr (PIN) asm("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
+}
+
+template <int NT>
+__device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
+  constexpr bool PIN = NT == 8;                  // 128 accumulator registers pinned in the accumulator file (see kernels_am.hip: lstm_mfma)
+  constexpr int NTR = NT * 16;                   // rows a launch covers
+  constexpr int SLOTS = NT * 64, ITS = (SLOTS + 255) / 256;
+  __shared__ int red[4][NT][4][64];              // [gate tile][batch tile][component][lane]: component-major -> conflict-free 4-byte atomics
+  __shared__ __attribute__((aligned(16))) signed char sq[2 * 4096];   // slow path: one row's [x_t | h_(t-1)] at the joint scale
+  __shared__ float sred[256];
+  __shared__ int s_nflag;
+  __shared__ unsigned char s_flist[NTR];
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, wg = blockIdx.x;
+  const int H = a.n_hidden, B = a.batch, KS = H / 64, NWG = H / 16;
+  const int par = a.t & 1, epoch = a.t + 1;
+  // issued now, consumed behind the k-loop: is any row of this step flagged?
+  const int myflag = (tid < NTR && tid < B) ? (a.flag[par * NTR + tid] == epoch ? 1 : 0) : 0;
+
+  const i32x4* wp = reinterpret_cast<const i32x4*>(a.whp) + (size_t)wg * KS * 4 * 64 + lane;
+  const i32x4* hp = reinterpret_cast<const i32x4*>(a.hq_in) + lane;
+  i32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (i32x4){0, 0, 0, 0};
+
+  // wave q takes the k-steps q, q + 4, ...
+#define I8_LOAD(W, Hh, s_)                                                                  \
+  do {                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) W[i] = wp[(size_t)((s_) * 4 + i) * 64];   \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) Hh[j] = hp[(size_t)((s_) * NT + j) * 64]; \
+  } while (0)
+#define I8_MMA(W, Hh)                                                                       \
+  do {                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) mfma_i8_<PIN>(acc[i][j], W[i], Hh[j]);  \
+    }                                                                                       \
+  } while (0)
+#define I8_FENCE() __builtin_amdgcn_sched_barrier(0)
+  if (KS % 8 == 0) {
+    // every wave has an even number (>= 2) of k-steps: two operand groups in flight, the last pair peeled (kernels_am.hip: the same
+    // structure and the same reasons -- the asm MFMAs carry no scheduling model, a prefetch condition inside the loop costs a vmcnt(0))
+    const int n_my = KS / 4;
+    i32x4 wa[4], ha[NT], wb[4], hb[NT];
+    I8_LOAD(wa, ha, q);
+    int i = 0;
+    for (; i + 2 < n_my; i += 2) {
+      I8_LOAD(wb, hb, q + 4 * (i + 1));
+      I8_FENCE();
+      I8_MMA(wa, ha);
+      I8_FENCE();
+      I8_LOAD(wa, ha, q + 4 * (i + 2));
+      I8_FENCE();
+      I8_MMA(wb, hb);
+      I8_FENCE();
+    }
+    I8_LOAD(wb, hb, q + 4 * (i + 1));
+    I8_FENCE();
+    I8_MMA(wa, ha);
+    I8_FENCE();
+    I8_MMA(wb, hb);
+  } else {
+    for (int s = q; s < KS; s += 4) {
+      i32x4 w[4], hv[NT];
+      I8_LOAD(w, hv, s);
+      I8_MMA(w, hv);
+    }
+  }
+#undef I8_LOAD
+#undef I8_MMA
+#undef I8_FENCE
+  if constexpr (PIN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the hazard recogniser does not look inside inline asm
+
+  // ---- operands of the cell update: in flight while the partial sums meet in LDS
+  // slot s = tid + 256 * it: batch tile j = s >> 6, lane-slot ls = s & 63 = (unit group, row of the tile) in the MFMA output layout:
+  // this thread ends up with all four gates of units wg*16 + 4*ug .. +3 of batch row j*16 + (ls & 15)
+  const int ls = lane, ug = ls >> 4;
+  const int unit0 = wg * 16 + ug * 4;
+  i32x4 ax[ITS][4];
+  float4 cv[ITS];
+  float xs_[ITS];
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) {
+    const int s = tid + 256 * it, j = s >> 6, row = j * 16 + (ls & 15);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ax[it][g] = (i32x4){0, 0, 0, 0};
+    cv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    xs_[it] = 1.0f;
+    if (s < SLOTS && row < B) {
+      const size_t rowi = (size_t)a.t * B + row;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) ax[it][g] = *reinterpret_cast<const i32x4*>(a.accx + rowi * (size_t)(4 * H) + (size_t)g * H + unit0);
+      cv[it] = *reinterpret_cast<const float4*>(a.c + (size_t)row * H + unit0);
+      xs_[it] = a.xscale[rowi];
+    }
+  }
+  float4 bias4[4], ws4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bias4[g] = *reinterpret_cast<const float4*>(a.bias + (size_t)g * H + unit0);
+    if (a.wscale_n > 1) ws4[g] = *reinterpret_cast<const float4*>(a.wscale + (size_t)g * H + unit0);
+    else { const float w0 = a.wscale[0]; ws4[g] = make_float4(w0, w0, w0, w0); }
+  }
+
+  // ---- cross-wave reduction of the int32 partial sums: wave 0 stores, the others add (integers: any order)
+  if (q == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[i][j][r][lane] = acc[i][j][r];
+  }
+  const int any = __syncthreads_or(myflag);
+  if (q != 0 && q < KS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&red[i][j][r][lane], acc[i][j][r]);
+  }
+
+  // ---- slow path (rare): rows whose max |h_(t-1)| exceeded max |x_t| -- both halves again, at the true joint scale
+  if (any) {
+    if (tid == 0) s_nflag = 0;
+    __syncthreads();
+    if (myflag) { const int i = atomicAdd(&s_nflag, 1); s_flist[i] = (unsigned char)tid; }
+    __syncthreads();
+    const int nf = s_nflag;
+    for (int fi = 0; fi < nf; ++fi) {
+      const int r = s_flist[fi];
+      float m = 0.0f;
+      for (int w = tid; w < NWG; w += 256) m = fmaxf(m, a.pmax[((size_t)par * NTR + r) * NWG + w]);
+      sred[tid] = m;
+      __syncthreads();
+      for (int d = 128; d > 0; d >>= 1) {
+        if (tid < d) sred[tid] = fmaxf(sred[tid], sred[tid + d]);
+        __syncthreads();
+      }
+      const float mh = sred[0];
+      const size_t rowi = (size_t)a.t * B + r;
+      const float range = fmaxf(a.xrange[rowi], mh);                    // PortableSymmetricQuantizeFloats over concat([x_t, h])
+      const float inv = range > 0.0f ? __fdiv_rn(127.0f, range) : 0.0f;
+      const float sf = range > 0.0f ? __fdiv_rn(range, 127.0f) : 1.0f;
+      const float* xsrc = a.y3 + rowi * H;
+      const float* hsrc = a.t == 0 ? a.h_prev0 + (size_t)r * H : a.h_all + ((size_t)(a.t - 1) * B + r) * H;
+      for (int k = tid; k < H; k += 256) { sq[k] = quant_i8_(xsrc[k], inv); sq[H + k] = quant_i8_(hsrc[k], inv); }
+      __syncthreads();
+      const int col = tid >> 2, part = tid & 3;                         // 64 gate columns x four lanes each
+      const int n = (col >> 4) * H + wg * 16 + (col & 15);
+      const int kq = H / 4;
+      const signed char* wxr = a.wxq + (size_t)n * H + part * kq;
+      const signed char* whr = a.whq + (size_t)n * H + part * kq;
+      const signed char* sx = sq + part * kq;
+      const signed char* sh = sq + H + part * kq;
+      int dot = 0;
+      for (int k = 0; k < kq; ++k) dot += (int)wxr[k] * (int)sx[k] + (int)whr[k] * (int)sh[k];
+      dot += __shfl_xor(dot, 1);
+      dot += __shfl_xor(dot, 2);
+      if (part == 0) {
+        float prod;
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(prod) : "v"((float)dot), "v"(__fmul_rn(sf, a.wscale[a.wscale_n > 1 ? n : 0])));
+        a.zslow[((size_t)wg * NTR + r) * 64 + col] = a.bias[n] + prod;
+      }
+      __syncthreads();
+    }
+    if (wg == 0 && tid == 0 && a.slow_count) atomicAdd(a.slow_count, (unsigned)nf);
+  }
+  __syncthreads();
+
+  // ---- cell update, publish
+  const bool last = a.t + 1 >= a.T;
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) {
+    const int s = tid + 256 * it, j = s >> 6, row = j * 16 + (ls & 15);
+    if (s >= SLOTS) break;
+    const bool live = row < B;
+    const size_t rowi = (size_t)a.t * B + row;
+    const bool slow = any && live && a.flag[par * NTR + row] == epoch;
+    float hv[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 cn4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float z[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int sum = ax[it][g][r] + red[g][j][r][ls];
+          float prod;   // bias + float(sum) * (row scale * weight scale), each operation rounded on its own (oracle/am_hybrid.py: fully_connected_hybrid)
+          asm volatile("v_mul_f32 %0, %1, %2" : "=v"(prod) : "v"((float)sum), "v"(__fmul_rn(xs_[it], (&ws4[g].x)[r])));
+          z[g] = (&bias4[g].x)[r] + prod;
+          if (slow) z[g] = a.zslow[((size_t)wg * NTR + row) * 64 + g * 16 + ug * 4 + r];
+        }
+        // gate order i, j, f, o (deepspeech_model.py:144-168); MUL, MUL, ADD as separate float ops
+        const float cn = __fadd_rn(__fmul_rn(sigmoid_i8_(z[2]), (&cv[it].x)[r]), __fmul_rn(sigmoid_i8_(z[0]), tanhf(z[1])));
+        (&cn4.x)[r] = cn;
+        hv[r] = __fmul_rn(sigmoid_i8_(z[3]), tanhf(cn));
+      }
+      *reinterpret_cast<float4*>(a.c + (size_t)row * H + unit0) = cn4;
+      const float4 h4 = make_float4(hv[0], hv[1], hv[2], hv[3]);
+      *reinterpret_cast<float4*>(a.h_all + rowi * H + unit0) = h4;
+      if (last) *reinterpret_cast<float4*>(a.h_last + (size_t)row * H + unit0) = h4;
+    }
+    if (!last) {
+      // h_t for step t+1, quantised with 127 / max |x_(t+1)| -- valid when that is the joint range; checked here, per workgroup
+      const float rn = live ? a.xrange[rowi + B] : 0.0f;
+      const float inv = rn > 0.0f ? __fdiv_rn(127.0f, rn) : 0.0f;
+      const unsigned pk = (unsigned)(unsigned char)quant_i8_(hv[0], inv) | ((unsigned)(unsigned char)quant_i8_(hv[1], inv) << 8) |
+                          ((unsigned)(unsigned char)quant_i8_(hv[2], inv) << 16) | ((unsigned)(unsigned char)quant_i8_(hv[3], inv) << 24);
+      const int ks = wg >> 2, grp = wg & 3;
+      reinterpret_cast<unsigned*>(a.hq_out)[(((size_t)ks * NT + j) * 64 + grp * 16 + (ls & 15)) * 4 + ug] = pk;
+      float m = fmaxf(fmaxf(fabsf(hv[0]), fabsf(hv[1])), fmaxf(fabsf(hv[2]), fabsf(hv[3])));
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (ug == 0) {
+        a.pmax[((size_t)(par ^ 1) * NTR + row) * NWG + wg] = m;
+        if (live && m > rn) a.flag[(par ^ 1) * NTR + row] = epoch + 1;
+      }
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void lstm_i8_step_kernel(LstmI8Args a) { lstm_i8_step_body<NT>(a); }
+// 128 rows: 128 accumulator registers + the operand double buffer (kernels_am.hip: lstm_step8_kernel)
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(160))) void lstm_i8_step8_kernel(LstmI8Args a) { lstm_i8_step_body<8>(a); }
+
+// Before step 0 of a launch sequence: the carried h ([B][H] f32; null = zeros) quantised for step 0 at 127 / max |x_0| -- with the
+// TRUE max |h| known here (one workgroup reads the whole row), so the flag of step 0 is exact --, a copy of it for the slow path, and
+// the per-step tables cleared.
+__global__ __launch_bounds__(256) void lstm_i8_prep_kernel(LstmI8Args a, const float* __restrict__ h_src, int NT) {
+  __shared__ float sred[256];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const int H = a.n_hidden, B = a.batch, NTR = NT * 16, NWG = H / 16;
+  const bool live = row < B && h_src != nullptr;
+  float m = 0.0f;
+  if (live)
+    for (int k = tid; k < H; k += 256) m = fmaxf(m, fabsf(h_src[(size_t)row * H + k]));
+  sred[tid] = m;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (tid < d) sred[tid] = fmaxf(sred[tid], sred[tid + d]);
+    __syncthreads();
+  }
+  const float mh = sred[0];
+  const float mx = row < B ? a.xrange[row] : 0.0f;                    // row (t = 0, b = row)
+  const float inv = mx > 0.0f ? __fdiv_rn(127.0f, mx) : 0.0f;
+  for (int k = tid; k < H; k += 256) {
+    const float v = live ? h_src[(size_t)row * H + k] : 0.0f;
+    if (row < B) const_cast<float*>(a.h_prev0)[(size_t)row * H + k] = v;
+    // byte of (row, k) in the fragment-ordered buffer: [k / 64][row / 16][(k % 64) / 16 * 16 + row % 16][k % 16]
+    const_cast<signed char*>(a.hq_in)[((((size_t)(k >> 6) * NT + (row >> 4)) * 64 + ((k & 63) >> 4) * 16 + (row & 15)) << 4) + (k & 15)] = quant_i8_(v, inv);
+  }
+  for (int w = tid; w < NWG; w += 256) a.pmax[(size_t)row * NWG + w] = w == 0 ? mh : 0.0f;   // pmax[0][row][:]
+  if (tid == 0) {
+    a.flag[row] = (row < B && mh > mx) ? 1 : 0;     // flag[0][row]: epoch of step 0 is 1
+    a.flag[NTR + row] = 0;
+  }
+}
+
+}  // namespace
+
+size_t lstm_i8_hq_bytes(int H, int NT) { return (size_t)(H / 64) * NT * 64 * 16; }
+
+void launch_lstm_i8_prep(const LstmI8Args& a, const float* h_src, int NT, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_i8_prep_kernel, dim3(NT * 16), dim3(256), 0, st, a, h_src, NT);
+}
+
+void launch_lstm_i8_step(const LstmI8Args& a, int NT, hipStream_t st) {
+  if (a.n_hidden % 64 != 0 || a.n_hidden > 4096) throw std::runtime_error("lstm int8 step: n_hidden must be a multiple of 64, at most 4096");
+  const dim3 grid(a.n_hidden / 16), block(256);
+  switch (NT) {
+    case 1: hipLaunchKernelGGL(lstm_i8_step_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(lstm_i8_step_kernel<2>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(lstm_i8_step_kernel<4>, grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL(lstm_i8_step8_kernel, grid, block, 0, st, a); break;
+    default: throw std::runtime_error("lstm int8 step: batch tiles must be 1, 2, 4 or 8");
+  }
+}

@@ -15,6 +15,7 @@
 //     layer_5/weights [H][H], layer_5/bias, layer_6/weights [H][C], layer_6/bias [C]
 // `.tflite` exports of the reference (float or hybrid int8) are recognised by their file identifier and read by
 // tflite_reader.cpp into the same twelve tensors.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -69,6 +70,34 @@ void pack_lstm_recurrent_host(const float* kernel, int H, _Float16* out) {
           }
 }
 
+// Recurrent half of the int8 kernel ([4H][2H] as the file holds it: rows = gate columns i|j|f|o, columns = [x(H); h(H)]), packed for
+// lstm_i8_step_kernel (kernels_i8.hip): 16 hidden units x 4 gates per workgroup, k-steps of 64,
+//   out[(((wg*KS + s)*4 + mt)*64 + lane)*16 + e] = kernel_q[mt*H + wg*16 + (lane & 15)][H + s*64 + (lane >> 4)*16 + e],  KS = H / 64
+void pack_lstm_recurrent_i8_host(const int8_t* kq, int H, int8_t* out) {
+  const int KS = H / 64;
+  for (int wg = 0; wg < H / 16; ++wg)
+    for (int s = 0; s < KS; ++s)
+      for (int mt = 0; mt < 4; ++mt)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int n = mt * H + wg * 16 + (lane & 15);
+          const int k0 = s * 64 + (lane >> 4) * 16;
+          memcpy(out + ((((size_t)wg * KS + s) * 4 + mt) * 64 + lane) * 16, kq + (size_t)n * 2 * H + H + k0, 16);
+        }
+}
+
+void quantize_weights_host(const float* w, int n_in, int n_out, std::vector<int8_t>& q, std::vector<float>& scale) {
+  float amax = 0.0f;
+  for (size_t i = 0; i < (size_t)n_in * n_out; ++i) amax = std::max(amax, std::fabs(w[i]));
+  const float sc = std::max(amax, 1e-30f) / 127.0f;
+  scale.assign(1, sc);
+  q.resize((size_t)n_in * n_out);
+  for (int k = 0; k < n_in; ++k)
+    for (int n = 0; n < n_out; ++n) {
+      const float r = std::nearbyintf(w[(size_t)k * n_out + n] / sc);           // np.rint: half to even
+      q[(size_t)n * n_in + k] = (int8_t)std::min(127.0f, std::max(-127.0f, r));
+    }
+}
+
 ModelState::~ModelState() {
   tuning_model_count(-1);
   for (StreamingState* s : stream_pool_) delete s;
@@ -94,6 +123,7 @@ int parse_model_file(const char* buf, size_t len, ModelTensors& tfl, ModelView& 
     v.alphabet = tfl.alphabet.data(); v.alphabet_bytes = tfl.alphabet.size();
     const std::vector<float>* src[12] = {&tfl.l1w, &tfl.l1b, &tfl.l2w, &tfl.l2b, &tfl.l3w, &tfl.l3b, &tfl.lk, &tfl.lb, &tfl.l5w, &tfl.l5b, &tfl.l6w, &tfl.l6b};
     for (int i = 0; i < 12; ++i) { v.t[i] = src[i]->data(); v.count[i] = src[i]->size(); }
+    v.quant = tfl.all_int8() ? &tfl : nullptr;
   } else {
     if (len < sizeof(SttwHeader)) { err = "model file too short"; return STT_ERR_FAIL_READ_PROTOBUF; }
     SttwHeader h;
@@ -167,6 +197,50 @@ int ModelState::InitFromBuffer(const char* buf, size_t len) {
     std::vector<float> b6p(g.c_pad(), 0.0f);
     memcpy(b6p.data(), l6b, C * 4);
     b6.upload(b6p.data(), b6p.size() * 4, stream);
+  }
+  // ---- the released models' own arithmetic: the int8 matrices as the file holds them (or quantised here as the converter would)
+  {
+    const int want = tune().am_i8;
+    i8 = (want > 0 || (want < 0 && v.quant != nullptr)) && H % 256 == 0 && H <= 4096;
+    if ((want > 0 || (want < 0 && v.quant)) && !i8)
+      fprintf(stderr, "Note: n_hidden = %d is outside the int8 path's shapes (multiples of 256 up to 4096): int8 weights are de-quantised to f16.\n", H);
+  }
+  if (i8) {
+    std::vector<int8_t> q[6];
+    std::vector<float> qs[6];
+    const float* wf[6] = {l1w, l2w, l3w, lk, l5w, l6w};
+    const int kin[6] = {K1, H, H, 2 * H, H, H}, nout[6] = {H, H, H, 4 * H, H, C};
+    for (int l = 0; l < 6; ++l) {
+      if (v.quant) { q[l] = v.quant->wq[l]; qs[l] = v.quant->wq_scale[l]; }
+      else quantize_weights_host(wf[l], kin[l], nout[l], q[l], qs[l]);
+      sn[l] = (int)qs[l].size();
+    }
+    auto up_rows = [&](DevBuf& dst, const int8_t* src, int N, int K, int ld, int Np, int Kp) {   // [N][K] (row stride ld) -> [Np][Kp], zero padded
+      std::vector<int8_t> t((size_t)Np * Kp, 0);
+      for (int n = 0; n < N; ++n) memcpy(t.data() + (size_t)n * Kp, src + (size_t)n * ld, (size_t)K);
+      dst.upload(t.data(), t.size(), stream);
+    };
+    up_rows(w1q, q[0].data(), H, K1, K1, H, g.k1_pad8());
+    up_rows(w2q, q[1].data(), H, H, H, H, H);
+    up_rows(w3q, q[2].data(), H, H, H, H, H);
+    up_rows(wxq, q[3].data(), 4 * H, H, 2 * H, 4 * H, H);
+    up_rows(whq, q[3].data() + H, 4 * H, H, 2 * H, 4 * H, H);
+    up_rows(w5q, q[4].data(), H, H, H, H, H);
+    up_rows(w6q, q[5].data(), C, H, H, g.c_pad8(), H);
+    {
+      std::vector<int8_t> packed((size_t)4 * H * H);
+      pack_lstm_recurrent_i8_host(q[3].data(), H, packed.data());
+      whpq.upload(packed.data(), packed.size(), stream);
+    }
+    DevBuf* sd[6] = {&s1, &s2, &s3, &sk, &s5, &s6};
+    for (int l = 0; l < 6; ++l) {
+      std::vector<float> sc = qs[l];
+      if (l == 5 && sc.size() > 1) sc.resize(g.c_pad8(), 1.0f);     // (padded output rows: zero weights, any scale)
+      sd[l]->upload(sc.data(), sc.size() * 4, stream);
+    }
+    std::vector<float> b6p(g.c_pad8(), 0.0f);
+    memcpy(b6p.data(), l6b, C * 4);
+    b6q.upload(b6p.data(), b6p.size() * 4, stream);
   }
   // ---- feature tables (oracle/am_ref.py MfccSpec; upstream tensorflow spectrogram.cc / mfcc_mel_filterbank.cc / mfcc_dct.cc)
   {

@@ -325,6 +325,13 @@ int read_tflite_model(const char* buf, size_t len, ModelTensors& m, std::string&
     std::vector<float> w;
     if (!gr.to_float(fcs[l].w, w, err)) return STT_ERR_MODEL_INCOMPATIBLE;
     transpose_oi(w, want[l][0], want[l][1], *wdst[l]);
+    // dynamic-range quantised weights as the file holds them (symmetric int8, per tensor or per output row): the hybrid path's operands
+    bool zp0 = true;
+    for (int64_t z : wt.zero_point) zp0 = zp0 && z == 0;
+    if (wt.type == T_INT8 && zp0 && (wt.scale.size() == 1 || (wt.scale.size() == (size_t)want[l][0] && wt.qdim == 0))) {
+      m.wq[l].assign(reinterpret_cast<const int8_t*>(wt.data), reinterpret_cast<const int8_t*>(wt.data) + (size_t)want[l][0] * want[l][1]);
+      m.wq_scale[l] = wt.scale;
+    }
     if (fcs[l].b >= 0) {
       if (!gr.to_float(fcs[l].b, *bdst[l], err)) return STT_ERR_MODEL_INCOMPATIBLE;
       if ((int)bdst[l]->size() != want[l][0]) { err = "bias " + std::to_string(l + 1) + " has an unexpected size"; return STT_ERR_INVALID_SHAPE; }

@@ -302,6 +302,29 @@ class Model(object):
             raise RuntimeError("STTX_InferChunk failed 0x%X" % status)
         return probs, nc, nh
 
+    def acousticMode(self):
+        """0 = f16 MFMA operands / f32 accumulate, 1 = TFLite's hybrid int8 arithmetic end to end (include/stt_amd.h: STTX_GetAcousticMode)."""
+        return int(native.lib().STTX_GetAcousticMode(self._impl))
+
+    def hybridChain(self, windows, state_c=None, state_h=None):
+        """Test hook (int8-path models): windows f32 [T][B][n_in1] -> dict of the chain's intermediate results (STTX_TestHybridChain)."""
+        g = self.geometry()
+        w = np.ascontiguousarray(windows, dtype=np.float32)
+        T, B, _ = w.shape
+        H, Cn = g["n_hidden"], g["n_classes"]
+        c = None if state_c is None else np.ascontiguousarray(state_c, dtype=np.float32)
+        h = None if state_h is None else np.ascontiguousarray(state_h, dtype=np.float32)
+        out = {"l3": np.zeros((T, B, H), np.float32), "accx": np.zeros((T, B, 4 * H), np.int32), "h_all": np.zeros((T, B, H), np.float32),
+               "logits": np.zeros((T, B, Cn), np.float32), "probs": np.zeros((B, T, Cn), np.float32), "c": np.zeros((B, H), np.float32), "h": np.zeros((B, H), np.float32)}
+        slow = C.c_uint(0)
+        status = native.lib().STTX_TestHybridChain(self._impl, w.ctypes.data, B, T, None if c is None else c.ctypes.data, None if h is None else h.ctypes.data,
+                                                   out["l3"].ctypes.data, out["accx"].ctypes.data, out["h_all"].ctypes.data, out["logits"].ctypes.data,
+                                                   out["probs"].ctypes.data, out["c"].ctypes.data, out["h"].ctypes.data, C.byref(slow))
+        if status != 0:
+            raise RuntimeError("STTX_TestHybridChain failed 0x%X" % status)
+        out["slow_rows"] = int(slow.value)
+        return out
+
     def createDecoder(self, n_streams=1, beam_width=None, cutoff_prob=1.0, cutoff_top_n=40):
         return Decoder(self, n_streams, beam_width or self.beamWidth(), cutoff_prob, cutoff_top_n)
 

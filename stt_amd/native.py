@@ -47,7 +47,7 @@ COQUI_STT_H = [
 ]
 STT_AMD_H = [
     "STTX_SetDevice", "STTX_GetDeviceCount", "STTX_SpeechToTextBatch", "STTX_SpeechToTextBatchWithMetadata",
-    "STTX_SpeechToTextBatchDevice", "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmitDevice", "STTX_BatchCollect", "STTX_BatchCollectWithMetadata", "STTX_BatchCollectScored", "STTX_DebugBatchProbs", "STTX_SetTuning", "STTX_GetTuning", "STTX_ConfigureRuntime", "STTX_TestLstmSteps", "STTX_TestDenseHybrid", "STTX_FeedAudioContentBatch", "STTX_FeedAudioContentBatchEx", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_DecodeStreamsBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
+    "STTX_SpeechToTextBatchDevice", "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmitDevice", "STTX_BatchCollect", "STTX_BatchCollectWithMetadata", "STTX_BatchCollectScored", "STTX_DebugBatchProbs", "STTX_SetTuning", "STTX_GetTuning", "STTX_ConfigureRuntime", "STTX_TestLstmSteps", "STTX_TestDenseHybrid", "STTX_GetAcousticMode", "STTX_TestHybridChain", "STTX_FeedAudioContentBatch", "STTX_FeedAudioContentBatchEx", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_DecodeStreamsBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
     "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_GetDecoderStamps", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
     "STTX_DecoderStats", "STTX_DecoderSetProfiling", "STTX_DecoderGetProfile", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
@@ -116,7 +116,9 @@ def lib():
         "STTX_GetTuning": (ci, [cs, pp(ci)]),
         "STTX_ConfigureRuntime": (None, []),
         "STTX_TestLstmSteps": (ci, [vp, cu, cu, cu, ci, vp, vp, vp, vp, pp(cf)]),
-        "STTX_TestDenseHybrid": (ci, [vp, cu, cu, vp, vp, cu, vp, cu, vp, vp, vp, cu, pp(cf)]),
+        "STTX_TestDenseHybrid": (ci, [vp, cu, cu, vp, vp, cu, vp, cu, vp, vp, vp, cu, pp(cf), ci, cf]),
+        "STTX_GetAcousticMode": (ci, [vp]),
+        "STTX_TestHybridChain": (ci, [vp, vp, cu, cu, vp, vp, vp, vp, vp, vp, vp, vp, vp, pp(cu)]),
         "STTX_FeedAudioContentBatch": (None, [pp(vp), pp(vp), pp(cu), cu]),
         "STTX_FeedAudioContentBatchEx": (None, [pp(vp), pp(vp), pp(cu), vp, cu]),
         "STTX_IntermediateDecodeBatch": (pp(vp), [pp(vp), cu]),

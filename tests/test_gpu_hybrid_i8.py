@@ -15,7 +15,7 @@ from oracle import am_hybrid
 pytestmark = pytest.mark.gpu
 
 
-def _run(x, wq, wscale, bias, reps=0):
+def _run(x, wq, wscale, bias, reps=0, epi=0, clip=0.0):
     from stt_amd import native
     L = native.lib()
     M, K = x.shape
@@ -25,7 +25,7 @@ def _run(x, wq, wscale, bias, reps=0):
     y = np.zeros((M, N), dtype=np.float32); q = np.zeros((M, K), dtype=np.int8); rs = np.zeros(M, dtype=np.float32)
     ms = C.c_float(0)
     rc = L.STTX_TestDenseHybrid(x.ctypes.data, M, K, wq.ctypes.data, wscale.ctypes.data, len(wscale), bias.ctypes.data, N, y.ctypes.data, q.ctypes.data, rs.ctypes.data,
-                                  reps, C.byref(ms))
+                                  reps, C.byref(ms), epi, C.c_float(clip))
     assert rc == 0, hex(rc)
     return y, q, rs, float(ms.value)
 
@@ -72,3 +72,19 @@ def test_hybrid_gemm_at_the_bench_shape():
            "note": "row quantisation + 128 x 256 tile on v_mfma_i32_16x16x64_i8, alone on the chip; the f16 form of the same product: benchmarks / DESIGN.md 8.3 (0.94 PF/s alone)"}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "hybrid_i8_gemm.json"), "w"))
+
+
+@pytest.mark.parametrize("M", [16, 5, 40])
+def test_hybrid_layer_forms_with_the_clipped_relu(M):
+    """What layers 1-3 and 5 of the int8 model path launch: the skinny form (M <= 16: one stream's chunk) and the 128 x 256 tile with
+    rows clamped (a few streams), clipped-ReLU epilogue; bit-equal to the restatement's _dense."""
+    rng = np.random.default_rng(23 + M)
+    K, N = 512, 256
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.1, 9.0, size=(M, 1))).astype(np.float32)
+    w = (rng.standard_normal((K, N)) * 0.2).astype(np.float32)
+    wq, wscale = am_hybrid.quantize_weights(w, False)
+    bias = rng.standard_normal(N).astype(np.float32)
+    y, q, rs, _ = _run(x, wq, wscale, bias, epi=1, clip=20.0)
+    want = np.minimum(np.maximum(am_hybrid.fully_connected_hybrid(x, wq, wscale, bias), np.float32(0)), np.float32(20))
+    assert (want == 20).any() and (want == 0).any()
+    assert np.array_equal(y, want), float(np.abs(y - want).max())

@@ -19,7 +19,14 @@ def test_tflite_model_equals_container_with_the_same_tensors(tmp_path, fix, kw):
     p_tfl, p_raw = str(tmp_path / "m.tflite"), str(tmp_path / "m.sttw")
     eff = tflitefile.write_tflite(p_tfl, w, synth.ENGLISH_LABELS, beam_width=64, **kw)
     modelfile.write_model(p_raw, {n: eff[n] for n in modelfile.TENSOR_ORDER}, synth.ENGLISH_LABELS, beam_width=64)
-    a, b = Model(p_tfl), Model(p_raw)
+    # (am_i8 = 0: the reader's de-quantised tensors on the f16 path; by default a quantised file takes TFLite's hybrid int8 arithmetic instead --
+    # tests/test_gpu_i8_path.py)
+    native.set_tuning("am_i8", 0)
+    try:
+        a, b = Model(p_tfl), Model(p_raw)
+    finally:
+        native.set_tuning("am_i8", -1)
+    assert a.acousticMode() == 0 and b.acousticMode() == 0
     assert a.sampleRate() == 16000 and a.beamWidth() == 64
     for m in (a, b):
         m.enableExternalScorer(os.path.join(fix, "pruned_lm.scorer"))
