@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's metric on BASELINE.json's config, one process per GPU.
 
-    python bench.py --gpus 1 --steps K --warmup W [--workload batch|stream|ragged|bytes|peaky|peaky_bytes]
+    python bench.py --gpus 1 --steps K --warmup W [--workload batch|batch_i8|stream|ragged|bytes|peaky|peaky_bytes]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 metric   audio-seconds per wall-second (RTF x), whole job, audio already resident in HBM when the clock starts
@@ -22,9 +22,11 @@ workload batch  (default, the driver's line) configs[1]: 64 synthetic 5 s 16 kHz
          peaky  configs[1]'s decoder stage alone on peaky synthetic emissions (SURVEY.md 8d Config 2: blank ~0.9, labels held two
                 frames) of sentences drawn from vocab.pruned.txt, 64 streams x 250 frames: DecoderState::next + decode, state
                 slabs allocated before the clock starts
+         batch_i8  configs[1] on the int8 PATH: the same synthetic weights quantised as the converter's dynamic-range quantisation does
+                (export.py:145-146), every FULLY_CONNECTED as TFLite's hybrid kernel (the reference CPU path's own arithmetic), same scorer
          peaky_bytes  configs[4]'s decoder stage alone on peaky byte emissions of code-point sentences (what a trained byte-output
                 model emits; `bytes` runs a random-init one: near-uniform over 256 classes), 64 streams x 250 frames, beam 1024
-         The default run (batch, one GPU) appends the other five as `workloads` sub-lines, measured in the same process on the
+         The default run (batch, one GPU) appends the other six as `workloads` sub-lines, measured in the same process on the
          same build (--no-extras skips them).
 weights  seeded random init of the reference architecture (no checkpoint exists offline); scorer = a synthetic
          huge-vocabulary package written at start-up by stt_amd/tools (500 k pseudo-words, order 5, 30 M n-grams, KenLM
@@ -33,7 +35,9 @@ weights  seeded random init of the reference architecture (no checkpoint exists 
 scaling  weak: every rank decodes its own utterances; one RCCL gather of the transcripts per step
 verified after the clock stops, EVERY distinct timed batch is decoded again by the REAL reference decoder (oracle/_ref:
          ctc_beam_search_decoder_batch on the GPU's emissions of that batch, same scorer, same beam) and the timed transcripts and
-         confidences must equal its output (`verified_against: "reference"`); without oracle/_ref: against a blocking call
+         confidences must equal its output (`verified_against: "reference"`); every side workload is checked the same way (streams: final
+         transcripts against the reference, every hop's intermediate result against the oracle's restatement); without oracle/_ref:
+         against a blocking call.  A check that fails makes the run EXIT 3 after the line is printed (exit_code())
 --gpus N with WORLD_SIZE unset, N > 1 re-launches itself as N ranks through torch.distributed.run (gloo + shared devices when the
          box has fewer than N GPUs: a plumbing check, flagged in the line); under a launcher WORLD_SIZE must equal N
 
@@ -129,10 +133,11 @@ def cpu_baseline(model, weights, audio, scorer_path):
                                "kind": "port", "sample": "one 5 s utterance, one worker, 4 threads, nothing else on the host"}}
 
 
-def cpu_baseline_reference_decoder(cx, wl):
+def cpu_baseline_reference_decoder(cx, wl, scorer_path=None):
     """-> {"decode": f(list of [T][C] float32 emissions) = (transcripts, confidences) through the REAL reference decoder (oracle/_ref),
     "port": g(list of emissions) = [(steps with a (score, character) tie across the beam boundary, transcript, confidence)] through the
-    oracle's C restatement}, or None.
+    oracle's C restatement, "port_prefixes": h(emissions, list of frame counts) = the restatement's transcript after each of those many
+    frames (what STT_IntermediateDecode must print)}, or None.
     Part of the cpu_baseline leg (the only place bench.py may touch oracle/): the same reference build that is timed as the CPU
     baseline is the CHECKER of the timed batches -- called after the clock has stopped, never inside a timed region, never measured
     as the product."""
@@ -141,18 +146,20 @@ def cpu_baseline_reference_decoder(cx, wl):
         if not ref.available():
             return None
         cores = os.cpu_count() or 1
-        if wl == "bytes":
+        if wl in ("bytes", "peaky_bytes"):
+            sp = scorer_path or cx.bytes_scorer_path
             A = ref.Alphabet(None)
-            S = ref.Scorer(cx.bytes_scorer_path, A)
+            S = ref.Scorer(sp, A)
             beam = 1024
             labels, space = port.utf8_alphabet()
-            PS = port.Scorer(cx.bytes_scorer_path) if port.available() else None
+            PS = port.Scorer(sp) if port.available() else None
         else:
+            sp = scorer_path or cx.scorer_path
             A = ref.Alphabet(os.path.join(FIX, "alphabet.txt"))
-            S = ref.Scorer(cx.scorer_path, A)
+            S = ref.Scorer(sp, A)
             beam = BEAM
             labels, space = port.parse_alphabet_file(os.path.join(FIX, "alphabet.txt"))
-            PS = port.Scorer(cx.scorer_path) if port.available() else None
+            PS = port.Scorer(sp) if port.available() else None
 
         def run(plist):
             tmax = max(p.shape[0] for p in plist)
@@ -174,10 +181,82 @@ def cpu_baseline_reference_decoder(cx, wl):
                 return [None] * len(plist)
             with ThreadPoolExecutor(max_workers=max(1, min(len(plist), cores))) as ex:
                 return list(ex.map(one, plist))
-        return {"decode": run, "port": run_port}
+
+        def run_port_prefixes(jobs):
+            """jobs: [(emissions [T][C], [frames done after hop 0, 1, ...])] -> per job the restatement's best transcript after each count
+            (the decoder state is carried from count to count, as a stream's is)."""
+            from concurrent.futures import ThreadPoolExecutor
+
+            def one(job):
+                p, counts = job
+                d = port.Decoder(labels, space, beam, PS)
+                out, done = [], 0
+                for c in counts:
+                    if c > done:
+                        d.next(p[done:c])
+                        done = c
+                    r = d.decode(1)
+                    out.append(A.decode(r[0][1]).decode("utf-8", "replace") if r else "")
+                return out
+            if PS is None:
+                return None
+            with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), cores))) as ex:
+                return list(ex.map(one, jobs))
+        return {"decode": run, "port": run_port, "port_prefixes": run_port_prefixes}
     except Exception as ex:      # a broken checker must be visible in the line (verified_against: blocking), not take the measurement down
         sys.stderr.write("bench.py: reference decoder unavailable: %r\n" % (ex,))
         return None
+
+
+def judge_against_reference(items, tie_of):
+    """The rule every workload's check goes through (pure: tests/test_host_logic.py feeds it forged mismatches).
+    items: [{"id", "got_text", "got_conf" (or None), "want_text", "want_conf" (or None), "against"}], one per timed utterance that was checked;
+    tie_of: {id: (boundary-tie steps, restatement text, restatement confidence)} for the ids that differ (None where unknown).
+    An utterance that differs from the reference is acceptable in exactly one case: at some step of ITS search a tie of (score, character)
+    straddled the beam boundary -- two equally scored prefixes, one place.  The reference keeps whichever libstdc++'s nth_element leaves in
+    front (unspecified by the standard); the kernels and the oracle's C restatement keep (live before new, beam index), the deviation
+    DESIGN.md section 2 documents.  The restatement counts those steps: a differing utterance must show at least one AND the timed output
+    must equal the restatement's.  Anything else is a real mismatch.
+    -> (ok, counts, first mismatches)"""
+    n_diff = n_tie = 0
+    mismatches = []
+    for it in items:
+        bad_t = it["got_text"] != it["want_text"]
+        bad_c = it.get("want_conf") is not None and it.get("got_conf") is not None and it["got_conf"] != it["want_conf"]      # (doubles, compared exactly)
+        if not (bad_t or bad_c):
+            continue
+        n_diff += 1
+        tr = tie_of.get(it["id"]) if (tie_of and it.get("against") == "reference") else None
+        equals_port = bool(tr and tr[1] == it["got_text"] and (it.get("got_conf") is None or tr[2] == it["got_conf"]))
+        explained = bool(tr and tr[0] > 0 and equals_port)
+        n_tie += 1 if explained else 0
+        if len(mismatches) < 6:
+            mismatches.append({"id": it["id"], "against": it.get("against"), "got": it["got_text"], "want": it["want_text"], "got_confidence": it.get("got_conf"),
+                               "want_confidence": it.get("want_conf"), "boundary_tie_steps": tr[0] if tr else None, "equals_the_restatement": equals_port,
+                               "explained_by_a_boundary_tie": explained})
+    counts = {"timed_utterances_checked": len(items), "equal": len(items) - n_diff,
+              "differ_with_a_boundary_tie_and_equal_to_the_restatement": n_tie, "unexplained": n_diff - n_tie}
+    return n_diff == n_tie, counts, mismatches
+
+
+def exit_code(res):
+    """0 when every check of the line held, 3 otherwise: a `verified` that is not true, an unexplained difference, a side workload that
+    raised, or a workload that could only be checked against the engine itself although the reference was available."""
+    def bad(r):
+        if r is None:
+            return False
+        if "error" in r:
+            return True
+        if r.get("verified") is not True:
+            return True
+        vc = r.get("verify_counts") or {}
+        return bool(vc.get("unexplained", 0))
+    if bad(res):
+        return 3
+    for r in (res.get("workloads") or {}).values():
+        if bad(r):
+            return 3
+    return 0
 
 
 class Ctx:
@@ -262,6 +341,17 @@ def measure(wl, args, cx, steps, warmup):
     from stt_amd import model as M
     from stt_amd import native, synth
     rank, world, dev, cdev, dist = cx.rank, cx.world, cx.dev, cx.cdev, cx.dist
+    i8 = wl == "batch_i8"      # configs[1] on the int8 path: the same weights quantised at load as the converter does (tunable am_i8 = 1)
+    if i8:
+        wl = "batch"
+        if cx.i8_model is None:
+            native.set_tuning("am_i8", 1)
+            try:
+                cx.i8_model, _ = make_model(29, BEAM, synth.ENGLISH_LABELS)
+            finally:
+                native.set_tuning("am_i8", -1)
+            assert cx.i8_model.acousticMode() == 1
+            cx.i8_model.enableExternalScorer(cx.scorer_path)
     byte_mode = wl in ("bytes", "peaky_bytes")
     C = 256 if byte_mode else 29
     beam = 1024 if byte_mode else BEAM
@@ -271,7 +361,7 @@ def measure(wl, args, cx, steps, warmup):
             cx.bytes_model.enableExternalScorer(cx.bytes_scorer_path)
         model, scorer_desc = cx.bytes_model, cx.bytes_scorer_desc
     else:
-        model, scorer_desc = cx.model, cx.scorer_desc
+        model, scorer_desc = (cx.i8_model if i8 else cx.model), cx.scorer_desc
     hop_lat, extra = [], {}
     n = int(SECONDS * 16000)
     if wl in ("batch", "bytes"):
@@ -282,13 +372,15 @@ def measure(wl, args, cx, steps, warmup):
         variants = [synth.synth_audio_batch(BATCH, n, seed=100003 * (rank + 1) + v) for v in range(n_distinct)]
         d_audios = [torch.from_numpy(v).to(dev) for v in variants]     # int16 [B][stride]
         audio_s_step = BATCH * SECONDS
-        desc = ("configs[1]: 64 x 5 s synthetic utterances/GPU (a different batch every step), English geometry, beam_width=500, scorer = "
+        desc = ("configs[1]%s: 64 x 5 s synthetic utterances/GPU (a different batch every step), English geometry, beam_width=500, scorer = "
+                % (" in the released models' own arithmetic (weights quantised to int8 as the converter does, TFLite's hybrid FULLY_CONNECTED end to end: int8 activations per row, "
+                   "int32 sums on v_mfma_i32_16x16x64_i8, the cell with the joint [x_t, h] row scale)" if i8 else "")
                 if wl == "batch" else "configs[4]: 64 x 5 s synthetic utterances/GPU (a different batch every step), byte-output model (256 classes, alphabet-free), beam_width=1024, scorer = ") + scorer_desc
         gbatch = world * BATCH
     elif wl == "ragged":
         # configs[3]: ONE list for the whole job, dealt over the ranks longest-processing-time-first (the reference's transcribe.py:136-148
         # hands one list to its workers); weak scaling: --utterances per rank x ranks (1250 x 8 = the 10 k of configs[3])
-        per_rank = args.utterances or 1250
+        per_rank = args.utterances or (10000 if world == 1 else 1250)      # one GPU takes the whole list of configs[3]
         nu_all = per_rank * world
         lens_all = (np.random.RandomState(2).uniform(1.0, 15.0, size=nu_all) * 16000).astype(np.int64)
         shards = sdist.shard_utterances(lens_all, world)
@@ -355,6 +447,7 @@ def measure(wl, args, cx, steps, warmup):
         gbatch = world * BATCH
         decoders = [model.createDecoder(BATCH, BEAM) for _ in range(steps + warmup)]    # state slabs: allocated before the clock starts
     step_no = [0]
+    step_conf = []      # peaky workloads: the best transcript's confidence per stream, per step
 
     def step():
         k = step_no[0]
@@ -376,6 +469,7 @@ def measure(wl, args, cx, steps, warmup):
                 texts = [bytes(int(t) + 1 for t in r[0][1]).decode("utf-8", "replace") if r else "" for r in res]
             else:
                 texts = ["".join(" " if t == 0 else ("'" if t == 27 else chr(ord("a") + int(t) - 1)) for t in r[0][1]) if r else "" for r in res]
+            step_conf.append([float(r[0][0]) if r else 0.0 for r in res])
         return sdist.gather_transcripts(texts, device=cdev) if world > 1 else [texts]
 
     pipelined = wl in ("batch", "bytes") and not args.no_pipeline
@@ -428,9 +522,12 @@ def measure(wl, args, cx, steps, warmup):
         for _ in range(steps):
             ts = time.perf_counter()
             kk = step_no[0] % max(1, len(d_audios)) if wl in ("batch", "bytes", "ragged") else 0
+            step_conf.clear()
             out = step()
             step_s.append(time.perf_counter() - ts)
             timed_texts.append((kk, out[rank] if world > 1 else out[0]))
+            if step_conf:
+                timed_conf.append(step_conf[-1])
             timed_all.append(out)
             if profiled:
                 for k, v in model.stageTimes().items():
@@ -440,63 +537,54 @@ def measure(wl, args, cx, steps, warmup):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     model.setProfiling(False)
-    # ---- after the clock: every DISTINCT timed batch is decoded again by the real reference decoder (oracle/_ref) on the GPU's own
-    # emissions of that batch; the timed transcripts (and, where the timed path reports them, confidences) must equal its output.
-    # The oracle is the checker here, never the thing measured.  Without oracle/_ref (or for the shapes it would take minutes on):
-    # against a blocking call of the engine on the same audio.
-    verified, verified_what, verified_against, vcounts = None, None, None, None
+    # ---- after the clock: every number of the line is checked against the REAL reference decoder (oracle/_ref) run on the GPU's own emissions
+    # -- transcripts and, where the timed path reports them, confidences (doubles, exactly).  The oracle is the checker here, never the thing
+    # measured.  judge_against_reference() holds the one rule for accepting a difference (a boundary tie, equal to the restatement).  Without
+    # oracle/_ref: against a blocking call of the engine (`verified_against` says so, and the run then exits non-zero only on a mismatch).
+    verified, verified_what, verified_against, vcounts, mismatches = None, None, None, None, []
+    refd = None
+    if rank == 0 and not args.no_reference_check:
+        refd = cpu_baseline_reference_decoder(cx, wl, scorer_path=(FIXTURE_SCORER if wl == "peaky" else None))
     if wl in ("batch", "bytes", "ragged"):
-        refd = cpu_baseline_reference_decoder(cx, wl) if (rank == 0 and not args.no_reference_check) else None
         want, ref_s = {}, 0.0
         ok, n_ref_utts = True, 0
-        mismatches, differs = [], {}
-        # bytes: the reference needs about a minute per utterance at beam 1024 on a code-point scorer -- the first 8 utterances of the
-        # first distinct batch; ragged: the first 64 utterances of this rank's shard (its longest); batch: all 64 of every distinct batch
-        ref_rows = list(range(BATCH)) if wl == "batch" else list(range(min(8 if wl == "bytes" else 64, len(sizes))))
+        items, diff_em = [], {}
+        # batch, bytes: all 64 utterances of every distinct timed batch (bytes: of the first one -- the reference needs about a minute per
+        # utterance at beam 1024 on a code-point scorer, one utterance per host core); ragged: the 64 longest utterances of this rank's shard
+        # by the reference, every other one against a blocking call
+        ref_rows = list(range(BATCH)) if wl in ("batch", "bytes") else list(range(min(64, len(sizes))))
         ref_batches = (len(d_audios) if world == 1 else 2) if wl == "batch" else 1
         for ti, (kk, texts) in enumerate(timed_texts):
             if kk not in want:
                 if refd is not None and len(want) < ref_batches:
                     rows = [variants[kk][b_, :sizes[b_]] for b_ in ref_rows]
                     tr0 = time.perf_counter()
-                    em_ = model.acousticProbs(rows)
+                    em_ = model.acousticProbs(rows) if len(rows) <= 128 and wl != "ragged" else [model.acousticProbs([r_])[0] for r_ in rows]
                     rt, rc = refd["decode"](em_)
                     ref_s += time.perf_counter() - tr0
-                    want[kk] = ("reference", ref_rows, rt, rc, em_)
+                    rest = None
+                    if wl == "ragged" and len(ref_rows) < len(sizes):      # the rest of the list: the engine's blocking path on the same audio
+                        rest = model.sttBatchDevice(d_audios[kk].data_ptr(), stride, sizes)
+                    want[kk] = ("reference", ref_rows, rt, rc, em_, rest)
                     n_ref_utts += len(rows)
                 else:
-                    want[kk] = ("blocking", list(range(len(sizes))), model.sttBatchDevice(d_audios[kk].data_ptr(), stride, sizes), None, None)
-            how, rows, wt, wc, _ = want[kk]
+                    want[kk] = ("blocking", list(range(len(sizes))), model.sttBatchDevice(d_audios[kk].data_ptr(), stride, sizes), None, None, None)
+            how, rows, wt, wc, em_, rest = want[kk]
             for j, b_ in enumerate(rows):
-                bad_t = texts[b_] != wt[j]
-                bad_c = wc is not None and ti < len(timed_conf) and timed_conf[ti][b_] != wc[j]        # (doubles, compared exactly)
-                if bad_t or bad_c:
-                    differs.setdefault((kk, j), []).append((ti, b_))
-        # An utterance that differs from the reference is acceptable in exactly one case: at some step of ITS search a tie of (score,
-        # character) straddled the beam boundary -- two equally scored prefixes, one place.  The reference keeps whichever libstdc++'s
-        # nth_element leaves in front (unspecified by the standard); the kernels and the oracle's C restatement keep (live before new,
-        # beam index), the deviation DESIGN.md section 2 documents.  The restatement counts those steps: a differing utterance must show
-        # at least one AND the timed output must equal the restatement's.  Anything else is a real mismatch.
-        n_tie = 0
-        if differs:
-            keys = sorted(differs)
-            ref_keys = [k_ for k_ in keys if want[k_[0]][0] == "reference"]
-            tie_res = refd["port"]([want[k_[0]][4][k_[1]] for k_ in ref_keys]) if (refd is not None and ref_keys) else []
-            tie_of = dict(zip(ref_keys, tie_res))
-            for k_ in keys:
-                how, rows, wt, wc, _ = want[k_[0]]
-                for ti, b_ in differs[k_]:
-                    got_t, got_c = timed_texts[ti][1][b_], (timed_conf[ti][b_] if ti < len(timed_conf) else None)
-                    tr_ = tie_of.get(k_)
-                    explained = tr_ is not None and tr_[0] > 0 and tr_[1] == got_t and (got_c is None or tr_[2] == got_c)
-                    n_tie += 1 if explained else 0
-                    if not explained:
-                        ok = False
-                    if len(mismatches) < 6:
-                        mismatches.append({"timed_batch": ti, "distinct_batch": k_[0], "utterance": b_, "against": how, "got": got_t, "want": wt[k_[1]],
-                                           "got_confidence": got_c, "want_confidence": wc[k_[1]] if wc is not None else None,
-                                           "boundary_tie_steps": tr_[0] if tr_ else None, "equals_the_restatement": bool(tr_ and tr_[1] == got_t and (got_c is None or tr_[2] == got_c)),
-                                           "explained_by_a_boundary_tie": explained})
+                iid = (ti, kk, b_)
+                items.append({"id": iid, "got_text": texts[b_], "got_conf": (timed_conf[ti][b_] if ti < len(timed_conf) else None), "want_text": wt[j],
+                              "want_conf": (wc[j] if wc is not None else None), "against": how})
+                if em_ is not None and (texts[b_] != wt[j] or (wc is not None and ti < len(timed_conf) and timed_conf[ti][b_] != wc[j])):
+                    diff_em[iid] = em_[j]
+            if rest is not None:
+                for b_ in range(len(sizes)):
+                    if b_ not in rows:
+                        items.append({"id": (ti, kk, b_), "got_text": texts[b_], "got_conf": None, "want_text": rest[b_], "want_conf": None, "against": "blocking"})
+        tie_of = {}
+        if diff_em and refd is not None:
+            keys = sorted(diff_em)
+            tie_of = dict(zip(keys, refd["port"]([diff_em[k_] for k_ in keys])))
+        ok, vcounts, mismatches = judge_against_reference(items, tie_of)
         if wl == "ragged" and world > 1 and rank == 0:      # the gathered transcripts, put back into list order: every utterance exactly once
             for out in timed_all:
                 full = [None] * nu_all
@@ -507,26 +595,98 @@ def measure(wl, args, cx, steps, warmup):
                 ok = ok and all(t is not None for t in full)
         verified = bool(ok)
         n_refb = sum(1 for v in want.values() if v[0] == "reference")
-        n_checked = sum(len(want[kk][1]) for kk, _ in timed_texts)
-        n_diff = sum(len(v) for v in differs.values())
-        vcounts = {"timed_utterances_checked": n_checked, "equal": n_checked - n_diff, "differ_with_a_boundary_tie_and_equal_to_the_restatement": n_tie,
-                   "unexplained": n_diff - n_tie, "distinct_batches": len(want), "distinct_batches_against_reference": n_refb}
-        verified_against = "reference" if n_refb == len(want) and refd is not None else ("reference+blocking" if n_refb else "blocking")
+        vcounts.update({"distinct_batches": len(want), "distinct_batches_against_reference": n_refb,
+                        "checked_against_reference": sum(1 for it in items if it["against"] == "reference"),
+                        "checked_against_blocking_call": sum(1 for it in items if it["against"] == "blocking")})
+        verified_against = "reference" if (n_refb == len(want) and refd is not None and wl != "ragged") else ("reference+blocking" if n_refb else "blocking")
         verified_what = ("%d timed batches, %d distinct, %d of them (%d utterances) decoded again by the REAL reference decoder (oracle/_ref, ctc_beam_search_decoder_batch on the GPU's "
-                         "emissions of that batch, same scorer and beam), the other %d by a blocking call of the engine: transcripts%s of %d of %d timed utterances are equal; %d differ in "
+                         "emissions of that batch, same scorer and beam), %d timed utterances against a blocking call of the engine: transcripts%s of %d of %d timed utterances are equal; %d differ in "
                          "utterances where a (score, character) tie straddled the beam boundary (the reference's choice there is libstdc++'s nth_element order; DESIGN.md 2) and equal "
                          "the oracle's C restatement instead; %d unexplained; %d of %d transcripts non-empty; reference time %.1f s"
-                         % (len(timed_texts), len(want), n_refb, n_ref_utts, len(want) - n_refb, " and confidences (exactly)" if timed_conf else "", n_checked - n_diff, n_checked, n_tie,
-                            n_diff - n_tie, sum(1 for _, t in timed_texts for s_ in t if s_), sum(len(t) for _, t in timed_texts), ref_s))
+                         % (len(timed_texts), len(want), n_refb, n_ref_utts, vcounts["checked_against_blocking_call"], " and confidences (exactly)" if timed_conf else "",
+                            vcounts["equal"], vcounts["timed_utterances_checked"], vcounts["differ_with_a_boundary_tie_and_equal_to_the_restatement"],
+                            vcounts["unexplained"], sum(1 for _, t in timed_texts for s_ in t if s_), sum(len(t) for _, t in timed_texts), ref_s))
     elif wl == "stream":
-        want_s = model.sttBatch(utts)          # STT_SpeechToText's arithmetic on the whole utterance (the blocking batch path)
-        verified = all(t == want_s for _, t in timed_texts)
-        verified_against = "blocking"
-        verified_what = ("final transcripts of the %d streamed utterances of every timed pass == the one-shot batch path on the whole utterances "
-                         "(stt.cc:641-688: one-shot = create stream, feed everything, finish); %d non-empty" % (len(utts), sum(1 for t in want_s if t)))
+        # (1) final transcripts: every timed pass must agree with itself across passes, and the first 64 utterances with the REAL reference
+        #     decoder on the engine's emissions of the whole utterance (stt.cc:641-688: one-shot = create stream, feed everything, finish);
+        # (2) intermediate results: 8 streams fed in 320 ms hops once more, untimed, every hop's STT_IntermediateDecode against the oracle's
+        #     C restatement carried over the same emissions (stt.cc:311-334: 16 windows per model call)
+        ok = all(t == timed_texts[0][1] for _, t in timed_texts)
+        got = timed_texts[0][1]
+        items, tie_of, n_inter, n_inter_ok = [], {}, 0, 0
+        if refd is not None:
+            n_chk = min(64, len(utts))
+            em_ = [cx.stream_models[0].acousticProbs([utts[u]])[0] for u in range(n_chk)]
+            rt, _ = refd["decode"](em_)
+            for ti, (_, texts) in enumerate(timed_texts):
+                for u in range(n_chk):
+                    items.append({"id": (ti, u), "got_text": texts[u], "got_conf": None, "want_text": rt[u], "want_conf": None, "against": "reference"})
+            dk = sorted({it["id"] for it in items if it["got_text"] != it["want_text"]})
+            if dk:
+                tie_of = dict(zip(dk, refd["port"]([em_[u] for _, u in dk])))
+            # (2)
+            short = sorted(range(n_chk), key=lambda u: len(utts[u]))[:8]
+            sm = cx.stream_models[0]
+            streams = {u: sm.createStream() for u in short}
+            inter = {u: [] for u in short}
+            counts = {u: [] for u in short}
+            fed = {u: 0 for u in short}
+            live = list(short)
+            while live:
+                M.feedAudioContentBatch([streams[u] for u in live], [utts[u][fed[u]:fed[u] + 5120] for u in live])
+                res_ = M.intermediateDecodeBatch([streams[u] for u in live])
+                for u, t_ in zip(live, res_):
+                    fed[u] = min(len(utts[u]), fed[u] + 5120)
+                    frames = (fed[u] - 512) // 320 + 1 if fed[u] >= 512 else 0
+                    inter[u].append(t_); counts[u].append(max(0, frames - 9) // 16 * 16)
+                live = [u for u in live if fed[u] < len(utts[u])]
+            finals = M.finishStreamBatch([streams[u] for u in short])
+            wantp = refd["port_prefixes"]([(em_[u], counts[u] + [em_[u].shape[0]]) for u in short])
+            if wantp is not None:
+                for u, f_, wp_ in zip(short, finals, wantp):
+                    for a_, b_ in zip(inter[u] + [f_], wp_):
+                        n_inter += 1
+                        n_inter_ok += 1 if a_ == b_ else 0
+                    ok = ok and f_ == got[u]
+                ok = ok and n_inter == n_inter_ok
+            verified_against = "reference"
+        else:
+            want_s = model.sttBatch(utts)          # STT_SpeechToText's arithmetic on the whole utterance (the blocking batch path)
+            items = [{"id": (ti, u), "got_text": t[u], "got_conf": None, "want_text": want_s[u], "want_conf": None, "against": "blocking"} for ti, (_, t) in enumerate(timed_texts) for u in range(len(utts))]
+            verified_against = "blocking"
+        ok2, vcounts, mismatches = judge_against_reference(items, tie_of)
+        vcounts.update({"intermediate_results_checked_against_the_restatement": n_inter, "intermediate_results_equal": n_inter_ok})
+        verified = bool(ok and ok2)
+        verified_what = ("final transcripts of the first %d streamed utterances of every timed pass == the REAL reference decoder (oracle/_ref) on the engine's emissions of the whole "
+                         "utterance (%d equal, %d tie-explained, %d unexplained); every timed pass gives the same %d transcripts (%d non-empty); %d intermediate results of 8 streams "
+                         "(every 320 ms hop) == the oracle's C restatement carried over the same emissions: %d equal"
+                         % (min(64, len(utts)), vcounts["equal"], vcounts["differ_with_a_boundary_tie_and_equal_to_the_restatement"], vcounts["unexplained"], len(got),
+                            sum(1 for t in got if t), n_inter, n_inter_ok))
     elif wl in ("peaky", "peaky_bytes"):
-        verified = all(t for _, t in timed_texts) and len({tuple(t) for _, t in timed_texts}) == 1
-        verified_what = "all timed steps give the same non-empty transcripts"
+        # every timed step decoded the same 64 emission matrices: each step's transcripts AND confidences against the REAL reference decoder on them
+        ok = all(t for _, t in timed_texts)
+        items, tie_of = [], {}
+        if refd is not None:
+            rt, rc = refd["decode"]([em[b_] for b_ in range(BATCH)])
+            for ti, (_, texts) in enumerate(timed_texts):
+                for b_ in range(BATCH):
+                    items.append({"id": (ti, b_), "got_text": texts[b_], "got_conf": timed_conf[ti][b_], "want_text": rt[b_], "want_conf": rc[b_], "against": "reference"})
+            dk = sorted({it["id"] for it in items if it["got_text"] != it["want_text"] or it["got_conf"] != it["want_conf"]})
+            if dk:
+                tie_of = dict(zip(dk, refd["port"]([em[b_] for _, b_ in dk])))
+            verified_against = "reference"
+        else:
+            items = [{"id": (ti, b_), "got_text": t[b_], "got_conf": None, "want_text": timed_texts[0][1][b_], "want_conf": None, "against": "blocking"} for ti, (_, t) in enumerate(timed_texts) for b_ in range(BATCH)]
+            verified_against = "blocking"
+        ok2, vcounts, mismatches = judge_against_reference(items, tie_of)
+        # how often the reference's own choice is implementation-defined on TRAINED-LIKE emissions: utterances with a boundary tie at any step
+        if refd is not None:
+            ties_ = refd["port"]([em[b_] for b_ in range(BATCH)])
+            vcounts["boundary_tie_utterances"] = sum(1 for t_ in ties_ if t_ is not None and t_[0] > 0)
+            vcounts["boundary_tie_utterances_of"] = BATCH
+        verified = bool(ok and ok2)
+        verified_what = ("transcripts and confidences (doubles, exactly) of all %d timed steps x 64 streams == the REAL reference decoder (oracle/_ref) on the same emissions: %d equal, "
+                         "%d tie-explained, %d unexplained; all non-empty" % (len(timed_texts), vcounts["equal"], vcounts["differ_with_a_boundary_tie_and_equal_to_the_restatement"], vcounts["unexplained"]))
         if wl == "peaky_bytes":   # ... and they are the sentences the emissions were drawn from (3 bytes per code point, nothing lost or split)
             n_cp = [len(t) for t in timed_texts[0][1]]
             verified = verified and all(15 <= n <= 21 for n in n_cp)   # (noise can add a code point the LM likes; none may vanish wholesale)
@@ -557,14 +717,16 @@ def measure(wl, args, cx, steps, warmup):
     res = {
         "metric": "audio-seconds/sec (RTF)", "value": world * audio_s_step * K / elapsed, "unit": "audio-seconds/sec", "n_gpus": world,
         "steps": K, "warmup": warmup, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16 (MFMA operands, f32 accumulate/state; decoder f32+f64)", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": ("int8 (MFMA operands: int8 weights x per-row int8 activations, int32 sums, f32 rescale/state -- TFLite's hybrid kernels; decoder f32+f64)" if i8
+                  else "f16 (MFMA operands, f32 accumulate/state; decoder f32+f64)"), "data": "synthetic",
         "config": {"workload": desc, "global_batch": gbatch, "parallelism": "dp%d (utterance shards, RCCL transcript gather)" % world,
                    "rccl_ranks": world if cx.backend.startswith("nccl") else 0, "backend": cx.backend,
                    "batches_in_flight": depth,
                    # two 64-utterance batches share one recurrence where the step is acoustic-bound (tunable `pair`; not the search-bound bytes setup)
                    "rows_per_recurrent_step": (128 if (native.get_tuning("pair") and wl != "bytes" and (pipelined or wl == "ragged")) else 64)},
         "verified": verified, "verified_against": verified_against, "verified_what": verified_what,
-        "verify_counts": vcounts, "verify_mismatches": (mismatches if wl in ("batch", "bytes", "ragged") else []),
+        "verify_counts": vcounts, "verify_mismatches": mismatches,
         # nothing reference-held pins the acoustic half (TensorFlow Lite is an un-vendored submodule, no model offline) nor
         # the .tflite container: those rows are checked against restatements only.  The decoder half is pinned to the reference itself.
         "parity_unpinned": ["a3 (MFCC)", "a5 (dense/LSTM/softmax)", "f1 (.tflite container)"],
@@ -605,6 +767,9 @@ def measure(wl, args, cx, steps, warmup):
         # recurrent matrix H x 4H f16 once per launch + per row: x-projection (f32 4H) in, h (f16 H) in/out, c (f32 H) in/out
         lstm_bytes = H * 4 * H * 2 + rows * (4 * H * 4 + 2 * H * 2 + 2 * H * 4)
         lstm_name = "lstm_step8_kernel<1>" if rows == 128 else "lstm_step_kernel<4, 2, 4, 3>"      # as rocprofv3 names them
+        if i8:   # recurrent matrix int8 once per launch + per row: x half of the sums (int32 4H) in, h int8 in/out, h f32 out, c (f32 H) in/out
+            lstm_bytes = H * 4 * H + rows * (4 * H * 4 + 2 * H + H * 4 + 2 * H * 4)
+            lstm_name = "lstm_i8_step8_kernel" if rows == 128 else "lstm_i8_step_kernel<4>"
         dec_ms = stage["decoder_next_ms"] / K
         steps_total = max(1, dstats["steps"])
         tsteps = stage["timesteps"]                  # utterance-timesteps through the acoustic model in the timed region
@@ -623,8 +788,8 @@ def measure(wl, args, cx, steps, warmup):
         # HBM traffic from the committed rocprofv3 --pmc passes of this round's build (FETCH_SIZE and WRITE_SIZE cannot share a pass, and
         # counters are never collected inside a timed run).  Only valid for the batch workload's shapes.
         pmc, pmc_file = {}, None
-        if wl == "batch":
-            for prof in ("r04_n_pmc_traffic.json", "r03_l_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        if wl == "batch" and not i8:
+            for prof in ("r05_pmc_traffic.json", "r04_n_pmc_traffic.json", "r03_l_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
                     pmc_file = prof
@@ -650,6 +815,8 @@ def measure(wl, args, cx, steps, warmup):
         allk = {k: {"bound": "hbm", "GB/s": v["bytes"] / (v["avg_ms"] * 1e-3) / 1e9, "frac": v["bytes"] / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "avg_ms": v["avg_ms"], "ms_per_step": v["share_ms"]} for k, v in kernels.items()}
         din, dout = stage["dense_in_ms"], stage["dense_out_ms"]
+        if i8:      # int8 operands: ops, against the int8 MFMA peak (twice the f16 one)
+            allk["note_int8"] = "GEMM engines below: int8 multiply-adds counted as flops; peak for int8 MFMA is 2 x %.0f TOP/s, `frac` is quoted against the f16 figure" % MFMA_PEAK_TFLOPS
         allk["dense_kernel (layers 1-3 + LSTM x-projection; GEMM engine stream)"] = {
             "bound": "mfma", "TFLOP/s": fl_in / (din * 1e-3) / 1e12, "frac": fl_in / (din * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "ms_per_step": din / K,
             "note": "flops of the timed region / busy time of the GEMM engine's stream (HIP events); the kernels run one workgroup per CU beside the recurrent step"}
@@ -710,7 +877,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", default="batch", choices=["batch", "stream", "ragged", "bytes", "peaky", "peaky_bytes"])
+    ap.add_argument("--workload", default="batch", choices=["batch", "batch_i8", "stream", "ragged", "bytes", "peaky", "peaky_bytes"])
     ap.add_argument("--utterances", type=int, default=0, help="stream: utterances per step (default 1000); ragged: per rank (default 1250; the list holds this x ranks)")
     ap.add_argument("--streams", type=int, default=128, help="stream: live streams per cohort, advanced together (one recurrent launch covers 128 rows)")
     ap.add_argument("--cohorts", type=int, default=2, help="stream: independent live sets, each on its own model replica and host thread")
@@ -773,6 +940,7 @@ def main():
     native.lib().STTX_SetDevice(local_rank)
     wl = args.workload
     cx.bytes_model = None
+    cx.i8_model = None
     cx.stream_models = []
     cx.bytes_scorer_path, cx.bytes_scorer_desc = os.path.join(FIX, "pruned_lm.bytes.scorer"), "pruned_lm.bytes.scorer fixture (code-point level, order 2)"
     cx.tmpdirs = []
@@ -794,12 +962,12 @@ def main():
     if rank == 0 and wl == "batch" and world == 1 and not args.no_extras and not args.no_profile:
         # the other configs, same process, same build: short runs (a few seconds each), each with its own roofline
         sub = {}
-        for w, k, wu, kw in (("ragged", 2, 1, {}), ("stream", 3, 1, {"utterances": 1000}), ("bytes", 8, 5, {}), ("peaky", 10, 2, {}), ("peaky_bytes", 6, 2, {})):   # (bytes: four batches in flight -- the warm-up covers every slot's first use)
+        for w, k, wu, kw in (("batch_i8", 12, 5, {}), ("ragged", 2, 1, {}), ("stream", 3, 1, {"utterances": 1000}), ("bytes", 8, 5, {}), ("peaky", 10, 2, {}), ("peaky_bytes", 6, 2, {})):   # (bytes: four batches in flight -- the warm-up covers every slot's first use)
             a2 = argparse.Namespace(**vars(args))
             a2.utterances = kw.get("utterances", 0)
             try:
                 r = measure(w, a2, cx, k, wu)
-                sub[w] = {key: r[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "verified", "verified_against", "verified_what", "p50_utterance_latency_ms", "hop_latency_ms",
+                sub[w] = {key: r[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "verified", "verified_against", "verified_what", "verify_counts", "verify_mismatches", "p50_utterance_latency_ms", "hop_latency_ms",
                                                   "stage_ms_per_step", "roofline", "config") if key in r}
                 if "roofline" in sub[w] and "all" in sub[w]["roofline"]:
                     sub[w]["roofline"] = {kk: vv for kk, vv in sub[w]["roofline"].items() if kk != "all"}
@@ -811,8 +979,14 @@ def main():
             audio = list(synth.synth_audio_batch(BATCH, int(SECONDS * 16000), seed=100003 * (rank + 1) + (args.warmup % max(1, min(args.steps + args.warmup, 32)))))   # = the first timed batch
             res["cpu_baseline"] = cpu_baseline(cx.model, weights, audio, cx.scorer_path)
         print(json.dumps(res))
+        sys.stdout.flush()
     if cx.dist is not None:
         cx.dist.destroy_process_group()
+    if rank == 0 and res is not None and not args.no_profile:
+        rc = exit_code(res)
+        if rc:      # the line above says which check failed (`verified`, `verify_counts.unexplained`, `workloads.*.error`)
+            sys.stderr.write("bench.py: a check of the line failed (verified / unexplained / error): exit %d\n" % rc)
+            sys.exit(rc)
 
 
 if __name__ == "__main__":

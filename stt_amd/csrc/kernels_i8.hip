@@ -69,13 +69,14 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
   // wave q takes the k-steps q, q + 4, ...
 #define I8_LOAD(W, Hh, s_)                                                                  \
   do {                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) W[i] = wp[(size_t)((s_) * 4 + i) * 64];   \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j) Hh[j] = hp[(size_t)((s_) * NT + j) * 64]; \
+    const int ks_ = (s_);                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) W[i_] = wp[(size_t)(ks_ * 4 + i_) * 64];   \
+    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) Hh[j_] = hp[(size_t)(ks_ * NT + j_) * 64]; \
   } while (0)
 #define I8_MMA(W, Hh)                                                                       \
   do {                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                        \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) mfma_i8_<PIN>(acc[i][j], W[i], Hh[j]);  \
+    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) {                                     \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) mfma_i8_<PIN>(acc[i_][j_], W[i_], Hh[j_]);  \
     }                                                                                       \
   } while (0)
 #define I8_FENCE() __builtin_amdgcn_sched_barrier(0)

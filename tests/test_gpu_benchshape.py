@@ -135,6 +135,6 @@ def test_bench_shape_and_scorer_against_the_real_reference_decoder_all_64(big, r
                 assert got[k][0][b] == port.decode_text(labels, r[1]).decode() and got[k][1][b] == float(r[0]), (k, b)
                 n_tie += 1
         print("bench shape vs the real reference: %d of 128 equal, %d tie-affected and equal to the restatement" % (n_equal, n_tie))
-        assert n_equal >= 100
+        assert n_equal >= 118          # (measured 121-124 of 128: the tie rate of 3-5 % plus margin; a regression that broke more would show here)
     finally:
         model.disableExternalScorer()

@@ -156,5 +156,41 @@ def test_product_never_touches_the_oracle():
             inside += chunk.count("from oracle import")
     assert bench.count("from oracle import") == inside
     # the checker runs after the clock: its only call site sits below the line that stops the timed region
-    call = bench.index("cpu_baseline_reference_decoder(cx, wl)", bench.index("def measure"))
-    assert call > bench.index("elapsed = time.perf_counter() - t0")
+    measure = bench[bench.index("def measure"):]
+    assert measure.count("cpu_baseline_reference_decoder(") == 1
+    assert measure.index("cpu_baseline_reference_decoder(") > measure.index("elapsed = time.perf_counter() - t0")
+
+
+def test_bench_checks_fail_the_run_on_a_forged_mismatch():
+    """bench.py's verdict logic, without a GPU: an utterance that differs from the reference is accepted only when the restatement shows a
+    boundary tie AND gives the timed output; anything else is `unexplained`, `verified` false, exit code 3 -- also for a side workload."""
+    import bench
+    good = [{"id": i, "got_text": "a b", "got_conf": -1.5, "want_text": "a b", "want_conf": -1.5, "against": "reference"} for i in range(4)]
+    ok, counts, mm = bench.judge_against_reference(good, {})
+    assert ok and counts["equal"] == 4 and counts["unexplained"] == 0 and not mm
+    # a forged transcript mismatch, no tie information: unexplained
+    forged = [dict(good[0], got_text="a c")] + good[1:]
+    ok, counts, mm = bench.judge_against_reference(forged, {})
+    assert not ok and counts["unexplained"] == 1 and mm[0]["explained_by_a_boundary_tie"] is False
+    # the same difference WITH a boundary tie and the restatement agreeing with the timed output: explained
+    ok, counts, mm = bench.judge_against_reference(forged, {0: (2, "a c", -1.5)})
+    assert ok and counts["differ_with_a_boundary_tie_and_equal_to_the_restatement"] == 1 and counts["unexplained"] == 0
+    # ... a tie, but the restatement does not give the timed output either: a real mismatch
+    ok, counts, _ = bench.judge_against_reference(forged, {0: (2, "a d", -1.5)})
+    assert not ok and counts["unexplained"] == 1
+    # ... the restatement agrees but saw no tie: a real mismatch (the restatement itself is off the reference without its one excuse)
+    ok, counts, _ = bench.judge_against_reference(forged, {0: (0, "a c", -1.5)})
+    assert not ok
+    # a confidence that differs in the last bit is a mismatch as well
+    ok, counts, _ = bench.judge_against_reference([dict(good[0], got_conf=-1.5000000000000002)], {})
+    assert not ok
+    # differences against a blocking call can never be excused by a tie
+    ok, _, _ = bench.judge_against_reference([dict(good[0], got_text="x", against="blocking")], {0: (1, "x", -1.5)})
+    assert not ok
+    line = {"verified": True, "verify_counts": {"unexplained": 0}, "workloads": {"peaky": {"verified": True, "verify_counts": {"unexplained": 0}}}}
+    assert bench.exit_code(line) == 0
+    assert bench.exit_code(dict(line, verified=False)) == 3
+    assert bench.exit_code(dict(line, verified=None)) == 3
+    assert bench.exit_code(dict(line, verify_counts={"unexplained": 1})) == 3
+    assert bench.exit_code(dict(line, workloads={"stream": {"verified": False}})) == 3
+    assert bench.exit_code(dict(line, workloads={"bytes": {"error": "RuntimeError('x')"}})) == 3
