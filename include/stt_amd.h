@@ -58,6 +58,11 @@ STTX_EXPORT int STTX_BatchPipelineDepth(void);
 /* ... for THIS model as configured now: a search-bound setup (code-point scorer, beam width beyond 512) takes four slots and
  * runs their searches side by side, everything else two. */
 STTX_EXPORT int STTX_BatchPipelineDepthFor(ModelState* aCtx);
+/* The same pipeline fed with HOST buffers, as every call of coqui-stt.h is (const short* aBuffer, unsigned int aBufferSize:
+ * native_client/coqui-stt.h:294-297, stt.cc:641-688): the aBatch utterances (1..64) are gathered into page-locked memory, copied to HBM on a
+ * queue of their own and enqueued behind that copy; returns the ticket (STTX_BatchCollect*), negative on error.  The buffers may be
+ * reused as soon as the call returns.  This is the entry bench.py times; STTX_BatchSubmitDevice is for callers whose audio is already in HBM. */
+STTX_EXPORT int STTX_BatchSubmit(ModelState* aCtx, const short* const* aBuffers, const unsigned int* aBufferSizes, unsigned int aBatch);
 STTX_EXPORT int STTX_BatchSubmitDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride,
                                        const unsigned int* aBufferSizes, unsigned int aBatch);
 STTX_EXPORT char** STTX_BatchCollect(ModelState* aCtx, int aTicket, unsigned int* aCount);
@@ -78,7 +83,7 @@ STTX_EXPORT int STTX_DebugBatchProbs(ModelState* aCtx, int aTicket, float* aProb
  * Returns STT_ERR_INVALID_SHAPE for an unknown name. */
 STTX_EXPORT int STTX_SetTuning(const char* aName, int aValue);
 STTX_EXPORT int STTX_GetTuning(const char* aName, int* aValue);
-/* Call once BEFORE the process makes its first HIP call (before STT_CreateModel): asks the HIP runtime for 8 hardware queues
+/* Call once BEFORE the process makes its first HIP call (before STT_CreateModel): asks the HIP runtime for 16 hardware queues
  * (GPU_MAX_HW_QUEUES, unless the caller set it), so that the streams of the batch path and of streaming replicas do not share queues.  Without it everything
  * still works; streams that share a queue run one after the other. */
 STTX_EXPORT void STTX_ConfigureRuntime(void);
@@ -125,7 +130,9 @@ STTX_EXPORT void STTX_FeedAudioContentBatch(StreamingState* const* aStreams, con
  * few of them in every hop; their flushes cost a whole pass each otherwise.)  aLast[i] == 2: the same, but whatever the flush leaves
  * after the call's first pass (at most n_steps - 1 windows: the flush adds n_context + 1 frames to a full hop) is not given a pass of
  * its own: it rides in the stream's NEXT STTX_FeedAudioContentBatch(Ex) call (pass the stream with an empty buffer, beside the live
- * streams' hop) or is processed by its finish.  aLast may be NULL (= STTX_FeedAudioContentBatch). */
+ * streams' hop) or is processed by its finish.  aLast may be NULL (= STTX_FeedAudioContentBatch).
+ * After a stream's final audio only decodes and the finish mean anything: audio fed to it later (here or through STT_FeedAudioContent) is
+ * IGNORED -- the call only drains a deferred tail -- and the ...FlushBuffers decodes add no further partial-window frame. */
 STTX_EXPORT void STTX_FeedAudioContentBatchEx(StreamingState* const* aStreams, const short* const* aBuffers, const unsigned int* aBufferSizes,
                                               const unsigned char* aLast, unsigned int aCount);
 /* aCount malloc'd strings (free with STTX_FreeStrings), or NULL on error. */

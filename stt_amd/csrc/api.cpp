@@ -166,6 +166,7 @@ struct BatchPart {
   unsigned stride;
   const unsigned* sizes;
   std::vector<unsigned> idx;
+  hipEvent_t ready = nullptr;   // the audio is there once this event has been reached (STTX_BatchSubmit's copy); null: it is there now
 };
 // Enqueue everything one group needs, on both streams, without waiting for anything: features + acoustic chunks on
 // `stream`, the beam search of every chunk + the final ranking + the copy of the results to page-locked memory on
@@ -178,7 +179,7 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::ve
   {  // remember the group (the callers' size arrays do not outlive their call); `parts` may itself be built on a moved-out copy of this
     std::vector<ModelState::GroupSlot::SavedPart> keep;
     for (const BatchPart& pt : parts) {
-      ModelState::GroupSlot::SavedPart sp{pt.d_audio, pt.stride, {}, pt.idx};
+      ModelState::GroupSlot::SavedPart sp{pt.d_audio, pt.stride, {}, pt.idx};   // (not `ready`: see the retry)
       unsigned mx = 0;
       for (unsigned i : pt.idx) mx = std::max(mx, i);
       sp.sizes.assign(pt.sizes, pt.sizes + (pt.idx.empty() ? 0 : mx + 1));
@@ -230,6 +231,7 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::ve
     int off = 0;
     for (const BatchPart& pt : parts) {
       const int Bp = (int)pt.idx.size();
+      if (pt.ready) HIP_CHECK(hipStreamWaitEvent(m->stream, pt.ready, 0));   // (a retry passes none: the first attempt's copy has long landed)
       MfccArgs fa = m->mfcc_args();
       fa.audio = pt.d_audio; fa.rows = d_row + off; fa.n_samples = d_ns + off; fa.n_frames = d_nf + off;
       fa.feats = m->ws_feats.as<float>() + (size_t)off * t_max * m->g.n_input; fa.n_max = (int)pt.stride; fa.t_max = t_max;
@@ -468,8 +470,8 @@ void submit_enqueue(ModelState* m, const std::vector<BatchPart>& parts, const in
   sl.results_ready = false; sl.results.clear();
   ++m->async_groups_;
 }
-int batch_submit(ModelState* m, const int16_t* d_audio, unsigned stride, const unsigned* sizes, unsigned B) {
-  if (B == 0 || B > 64) throw std::runtime_error("STTX_BatchSubmitDevice takes 1..64 utterances (one batch) per call");
+int batch_submit(ModelState* m, const int16_t* d_audio, unsigned stride, const unsigned* sizes, unsigned B, hipEvent_t ready = nullptr) {
+  if (B == 0 || B > 64) throw std::runtime_error("STTX_BatchSubmit / STTX_BatchSubmitDevice take 1..64 utterances (one batch) per call");
   HIP_CHECK(hipSetDevice(m->device));
   batch_init_slots(m);
   Prof& pr = prof_of(m);
@@ -488,7 +490,7 @@ int batch_submit(ModelState* m, const int16_t* d_audio, unsigned stride, const u
   }
   if (m->async_pair_ && !m->pending_.valid) {  // first half of a pair: noted, not enqueued (its slot need only be free when its partner arrives)
     m->pending_.valid = true; m->pending_.d_audio = d_audio; m->pending_.stride = stride;
-    m->pending_.sizes.assign(sizes, sizes + B); m->pending_.ticket = m->async_next_;
+    m->pending_.sizes.assign(sizes, sizes + B); m->pending_.ticket = m->async_next_; m->pending_.ready = ready;
     return m->async_next_++;
   }
   std::vector<BatchPart> parts;
@@ -496,10 +498,10 @@ int batch_submit(ModelState* m, const int16_t* d_audio, unsigned stride, const u
   if (m->pending_.valid) {
     std::vector<unsigned> pidx(m->pending_.sizes.size());
     for (size_t i = 0; i < pidx.size(); ++i) pidx[i] = (unsigned)i;
-    parts.push_back(BatchPart{m->pending_.d_audio, m->pending_.stride, m->pending_.sizes.data(), pidx});
+    parts.push_back(BatchPart{m->pending_.d_audio, m->pending_.stride, m->pending_.sizes.data(), pidx, m->pending_.ready});
     tickets[0] = m->pending_.ticket;
   }
-  parts.push_back(BatchPart{d_audio, stride, sizes, idx});
+  parts.push_back(BatchPart{d_audio, stride, sizes, idx, ready});
   tickets[parts.size() - 1] = m->async_next_;
   submit_enqueue(m, parts, tickets);
   m->pending_.valid = false;
@@ -510,7 +512,7 @@ ModelState::GroupSlot& slot_of_ticket(ModelState* m, int ticket, int& part) {
   if (ticket >= 0 && m->pending_.valid && m->pending_.ticket == ticket) {
     std::vector<unsigned> pidx(m->pending_.sizes.size());
     for (size_t i = 0; i < pidx.size(); ++i) pidx[i] = (unsigned)i;
-    std::vector<BatchPart> parts{BatchPart{m->pending_.d_audio, m->pending_.stride, m->pending_.sizes.data(), pidx}};
+    std::vector<BatchPart> parts{BatchPart{m->pending_.d_audio, m->pending_.stride, m->pending_.sizes.data(), pidx, m->pending_.ready}};
     const int tickets[2] = {ticket, -1};
     submit_enqueue(m, parts, tickets);
     m->pending_.valid = false;
@@ -549,6 +551,32 @@ std::vector<std::vector<Output>> batch_collect(ModelState* m, int ticket) {
   }
   return out;
 }
+// STTX_BatchSubmit: host buffers -> one page-locked block [B][stride] -> HBM on the copy queue -> batch_submit() gated by the copy's event.
+// The host pays one pass over the samples (the gather into page-locked memory: the ABI hands over ordinary pageable buffers, which no
+// DMA engine may read in place); the transfer itself overlaps whatever the GPU is doing for the batches before this one.
+int batch_submit_host(ModelState* m, const short* const* bufs, const unsigned* sizes, unsigned B) {
+  if (B == 0 || B > 64) throw std::runtime_error("STTX_BatchSubmit takes 1..64 utterances (one batch) per call");
+  HIP_CHECK(hipSetDevice(m->device));
+  if (!m->stream_h2d) HIP_CHECK(hipStreamCreateWithFlags(&m->stream_h2d, hipStreamNonBlocking));
+  ModelState::HostStage& hs = m->stage_[m->stage_seq_ % ModelState::kStage];
+  unsigned stride = 8;
+  for (unsigned i = 0; i < B; ++i) stride = std::max(stride, sizes[i]);
+  stride = (stride + 7) & ~7u;
+  const size_t bytes = (size_t)B * stride * 2;
+  if (!hs.copied) HIP_CHECK(hipEventCreateWithFlags(&hs.copied, hipEventDisableTiming));
+  else HIP_CHECK(hipEventSynchronize(hs.copied));          // (kStage submits ago: reached long since)
+  hs.pin.reserve(bytes); hs.dev.reserve(bytes);
+  int16_t* hp = hs.pin.as<int16_t>();
+  for (unsigned i = 0; i < B; ++i) {
+    if (sizes[i]) memcpy(hp + (size_t)i * stride, bufs[i], (size_t)sizes[i] * 2);
+    if (sizes[i] < stride) memset(hp + (size_t)i * stride + sizes[i], 0, (size_t)(stride - sizes[i]) * 2);
+  }
+  HIP_CHECK(hipMemcpyAsync(hs.dev.p, hs.pin.p, bytes, hipMemcpyHostToDevice, m->stream_h2d));
+  HIP_CHECK(hipEventRecord(hs.copied, m->stream_h2d));
+  const int ticket = batch_submit(m, hs.dev.as<int16_t>(), stride, sizes, B, hs.copied);
+  ++m->stage_seq_;     // (only a submit that went through takes the entry)
+  return ticket;
+}
 // Debug: the acoustic probabilities of a submitted batch exactly as the pipelined path computed them (three engines, graph-replayed
 // recurrence, ring slots, 64 or 128 rows per step) -- the block the group's beam search reads.  Before the batch is collected.
 void batch_probs(ModelState* m, int ticket, float* out, unsigned max_frames, unsigned* n_frames) {
@@ -574,6 +602,22 @@ uint64_t stt_murmur64a(const void* key, size_t len);
 // hooks used by engine.cpp for the profiling marks inside run_acoustic_rows
 void stt_prof_mark(ModelState* m, int i) { mark(m, i); }
 void stt_prof_mark_on(ModelState* m, int id, int which, hipStream_t st) { mark_on(m, id, which, st); }
+
+// The one-by-one fallback of the batched string calls (streams that do not share model / beam / scorer): all of the strings or none --
+// a decode that throws partway frees what was built and the caller sees NULL, never an array with holes ("aCount strings or NULL").
+template <class F>
+char** strings_each(const std::vector<StreamingState*>& ss, F&& one) {
+  std::vector<char*> tmp;
+  try {
+    for (StreamingState* s : ss) tmp.push_back(one(s));
+  } catch (...) {
+    for (char* c : tmp) free(c);
+    throw;
+  }
+  char** r = (char**)malloc(sizeof(char*) * std::max<size_t>(1, tmp.size()));
+  for (size_t i = 0; i < tmp.size(); ++i) r[i] = tmp[i];
+  return r;
+}
 
 extern "C" {
 
@@ -753,7 +797,7 @@ char** STTX_IntermediateDecodeBatch(StreamingState* const* aStreams, unsigned in
     std::vector<StreamingState*> ss(aStreams, aStreams + aCount);
     HIP_CHECK(hipSetDevice(ss[0]->model_->device));
     if (streams_batchable(ss)) r = strings_of(ss[0]->model_, streams_decode_batch(ss, 1));
-    else { r = (char**)malloc(sizeof(char*) * aCount); for (unsigned i = 0; i < aCount; ++i) r[i] = decode_string(ss[i]); }
+    else r = strings_each(ss, [](StreamingState* s) { return decode_string(s); });
     return 0;
   }, 0);
   return r;
@@ -769,8 +813,8 @@ char** STTX_DecodeStreamsBatch(StreamingState* const* aStreams, const unsigned c
       if (!fin.empty()) streams_flush_batch(fin, true);        // (nothing left to do for streams whose last audio carried the flush)
       r = strings_of(ss[0]->model_, streams_decode_batch(ss, 1));   // ONE ranking + back-tracking launch: the hop's intermediate results and the finishes'
     } else {
-      r = (char**)malloc(sizeof(char*) * aCount);
-      for (unsigned i = 0; i < aCount; ++i) { if (aFinish && aFinish[i]) ss[i]->flushBuffers(true); r[i] = decode_string(ss[i]); }
+      unsigned i = 0;
+      r = strings_each(ss, [&](StreamingState* s) { if (aFinish && aFinish[i++]) s->flushBuffers(true); return decode_string(s); });
     }
     return 0;
   }, 0);
@@ -784,7 +828,7 @@ char** STTX_FinishStreamBatch(StreamingState* const* aStreams, unsigned int aCou
     std::vector<StreamingState*> ss(aStreams, aStreams + aCount);
     HIP_CHECK(hipSetDevice(ss[0]->model_->device));
     if (streams_batchable(ss)) { streams_flush_batch(ss, true); r = strings_of(ss[0]->model_, streams_decode_batch(ss, 1)); }
-    else { r = (char**)malloc(sizeof(char*) * aCount); for (unsigned i = 0; i < aCount; ++i) { ss[i]->flushBuffers(true); r[i] = decode_string(ss[i]); } }
+    else r = strings_each(ss, [](StreamingState* s) { s->flushBuffers(true); return decode_string(s); });
     return 0;
   }, 0);
   for (unsigned i = 0; i < aCount; ++i) STT_FreeStream(aStreams[i]);
@@ -895,6 +939,12 @@ int STTX_BatchPipelineDepthFor(ModelState* aCtx) { return aCtx ? pipeline_depth(
 int STTX_BatchSubmitDevice(ModelState* aCtx, const short* aDeviceAudio, unsigned int aStride, const unsigned int* aBufferSizes, unsigned int aBatch) {
   int ticket = -STT_ERR_FAIL_RUN_SESS;
   guarded([&]() { ticket = batch_submit(aCtx, aDeviceAudio, aStride, aBufferSizes, aBatch); return 0; }, 0);
+  return ticket;
+}
+
+int STTX_BatchSubmit(ModelState* aCtx, const short* const* aBuffers, const unsigned int* aBufferSizes, unsigned int aBatch) {
+  int ticket = -STT_ERR_FAIL_RUN_SESS;
+  guarded([&]() { ticket = batch_submit_host(aCtx, aBuffers, aBufferSizes, aBatch); return 0; }, 0);
   return ticket;
 }
 

@@ -109,10 +109,18 @@ __device__ __forceinline__ float absent() { return __uint_as_float(ABSENT_BITS);
 
 // Path key of "parent + label": one multiply-xorshift round per label (a 64-bit FNV-1a style rolling hash with a final
 // fold; the search kernel is instruction-issue bound and every expand item computes one of these).
-__device__ __forceinline__ uint64_t child_key(uint64_t parent_key, uint32_t c) {
+// COLLISIONS.  The key is a 63-bit hash of the label sequence, not the sequence: two different prefixes with one key would be taken for
+// the same prefix by the LDS hash (a child of one merged into the other).  Chance: a lookup meets a foreign equal key with probability
+// <= live prefixes / 2^63; a step makes <= beam x classes lookups -- 500 x 500 x 28 / 2^63 = 7.6e-13 per step, 2e-10 per 5 s utterance.
+// Guard (collision_guard below): on every hit the found entry's LAST LABEL is compared with the label that was looked up -- equal for a
+// true child by construction; a foreign prefix with the same key has a different last label in C - 1 of C cases -- and a mismatch raises
+// error bit 0x20: the stream's results are refused (check_decoder_errors), never silently wrong.  What is left undetected is a
+// collision between prefixes that also end in the same label: 1 / C of the figure above.  `kmask` (DecParams::key_mask, tunable
+// debug_key_bits) truncates the keys so that a test can watch the guard fire (tests/test_gpu_errors.py).
+__device__ __forceinline__ uint64_t child_key(uint64_t parent_key, uint32_t c, uint64_t kmask) {
   uint64_t x = (parent_key ^ (uint64_t)(c + 1)) * 0x9E3779B97F4A7C15ULL;
   x ^= x >> 29;
-  return x | 1ULL;  // 0 is the empty marker of the LDS hash
+  return (x & kmask) | 1ULL;  // 0 is the empty marker of the LDS hash
 }
 
 // selection key: ascending key order == (score desc, character asc, live before new, beam index asc)
@@ -1398,9 +1406,10 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
           float log_p = __fadd_rn(lpc, rep ? pbi : sci);
           if (rep && !(pbi > NEG)) log_p = NEG;
           const uint32_t needs_lm = c == space_u ? 1u : 0u;
-          const uint64_t ck = child_key(L.key[cur][i], c);
+          const uint64_t ck = child_key(L.key[cur][i], c, p.key_mask);
           const int jj = ht_find(L, ck);
           if (jj >= 0) {  // the child is a live prefix: one extension event per live prefix per step
+            if (L.ch[cur][jj] != c) lds_or(&sc[SC_ERR], 0x20);   // collision guard (child_key)
             L.ev_ext[jj] = log_p;
             L.ev_exti[jj] = (uint32_t)i | (needs_lm << 31);
             // (no queue of scored extensions in this form: bit 31 marks them, the key phase adds the score -- score_ext below)
@@ -1514,7 +1523,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
             else needs_lm = is_scoring_boundary(s, al, S.pa_generic(), L.node[cur][i], c, c, probes) ? 1u : 0u;
           } else needs_lm = (int)c == al.space_id ? 1u : 0u;
         }
-        const uint64_t ck = child_key(L.key[cur][i], c);
+        const uint64_t ck = child_key(L.key[cur][i], c, p.key_mask);
         if (p.stamps && wave == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) { L.stm[51] += t_ - xt0_; L.stm[54] += 1; } xt0_ = t_; }
         // (code-point scorer, see `thr`: a new prefix that cannot reach the beam even with the best language-model score any code point
         // has is not made; one without a score to come is compared as it is.  Extensions into LIVE prefixes are events of prefixes
@@ -1527,6 +1536,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
         }
         if (p.stamps && wave == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) L.stm[52] += t_ - xt0_; xt0_ = t_; }
         if (jj >= 0) {  // the child is a live prefix: one extension event per live prefix per step
+          if (L.ch[cur][jj] != c) lds_or(&sc[SC_ERR], 0x20);     // collision guard (child_key)
           L.ev_ext[jj] = log_p;
           L.ev_exti[jj] = (uint32_t)i | (needs_lm << 31);
           if (needs_lm && lm_queue) { const int qi = lds_add(&sc[SC_NQ], 1); L.ssrc[qi] = 0x80000000u | (uint32_t)jj; }
@@ -1944,7 +1954,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
           const uint32_t sp = MODE == 1 ? (uint32_t)s.fst_has_space[cf] : 0u;
           L.a0[nxt][r] = f0; L.an[nxt][r] = (uint16_t)((f1 - f0) | (sp << 15));
         }
-        nkey = child_key(L.key[cur][i], c);
+        nkey = child_key(L.key[cur][i], c, p.key_mask);
         uint32_t b = L.bnd[cur][i];
         if (MODE == 1 && (int)c == al.space_id) b = L.pqe.p0 ? L.pqe[cur][i] : S.pq()[pnode];  // the boundary entry scored in P3 (or earlier)
         L.bnd[nxt][r] = b;
@@ -2336,6 +2346,7 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
   }
   p.n_lm_waves = tune().lm_waves; p.item_cap = tune().item_table_cap;
   p.wait_spins = tune().wait_spins > 0 ? tune().wait_spins : (1 << 22);
+  p.key_mask = (tune().debug_key_bits >= 4 && tune().debug_key_bits < 63) ? ((1ULL << tune().debug_key_bits) - 1ULL) : ~0ULL;
   p.lm_prio = tune().lm_prio;
   const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : ((!wide && ctc_masked_ok(p, s, al)) ? 4 : 1));
   const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : (mode == 4 ? 32 : p.C), s.enabled && s.utf8);   // (mode 4: the kernel carves its layout for 32 classes)

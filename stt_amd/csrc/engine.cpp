@@ -610,7 +610,7 @@ void check_decoder_errors(const int* errors, int n) {
   if (err) {
     char hex[16];
     snprintf(hex, sizeof(hex), "0x%x", (unsigned)err);
-    throw std::runtime_error(std::string("decoder state error bits ") + hex + " (0x1 path arena, 0x2 time arena, 0x4 candidates, 0x8 scorer cache, 0x10 intra-workgroup counter wait timed out)");
+    throw std::runtime_error(std::string("decoder state error bits ") + hex + " (0x1 path arena, 0x2 time arena, 0x4 candidates, 0x8 scorer cache, 0x10 intra-workgroup counter wait timed out, 0x20 two prefixes with one path key)");
   }
 }
 
@@ -700,6 +700,10 @@ void StreamingState::pushFrames(const int16_t* span, int n_span, int n_new_frame
 
 void StreamingState::feedAudioContent(const short* buffer, unsigned int buffer_size) {
   const Geometry& g = model_->g;
+  if (flushed_) {   // the stream's last audio went in with aLast (include/stt_amd.h): only decode and finish are meaningful now.  Audio fed anyway
+    processReady(true, true);   // is ignored -- appending frames behind the trailing zero-context frames would silently change the transcript --
+    return;                     // and what a deferred tail left is drained
+  }
   // identical to filling audio_buffer_ sample by sample and firing a window whenever it holds win_len samples (stt.cc:105-128)
   std::vector<int16_t> all(audio_buffer_);
   all.insert(all.end(), buffer, buffer + buffer_size);
@@ -715,9 +719,9 @@ void StreamingState::feedAudioContent(const short* buffer, unsigned int buffer_s
 }
 
 void StreamingState::flushBuffers(bool addZeroMfccVectors) {
-  if (addZeroMfccVectors && flushed_) {   // its last audio came through STTX_FeedAudioContentBatchEx with the last flag: already flushed ...
-    processReady(true, true);              // ... except for a tail that was deferred and has not ridden along yet
-    return;
+  if (flushed_) {                          // its last audio came through STTX_FeedAudioContentBatchEx with the last flag: already flushed ...
+    processReady(true, true);              // ... except for a tail that was deferred and has not ridden along yet.  Also for the
+    return;                                // ...FlushBuffers decodes (addZeroMfccVectors false): no further partial-window frame behind the final flush
   }
   if (addZeroMfccVectors) flushed_ = true;
   // stt.cc:236-254: the partial audio window goes through the feature graph as is (zero padded), audio_buffer_ is kept
@@ -951,12 +955,12 @@ void streams_feed_batch(const std::vector<StreamingState*>& ss, const short* con
   bool any_last = false;
   for (int i = 0; i < n; ++i) {  // the window arithmetic of StreamingState::feedAudioContent, per stream
     StreamingState* s = ss[i];
+    if (s->flushed_) { fl[i] = 2; any_last = true; continue; }   // flushed by an earlier call that deferred its tail (last = 2): the tail rides in this pass; audio passed with it is ignored
     std::vector<int16_t> all(s->audio_buffer_);
     all.insert(all.end(), buffers[i], buffers[i] + sizes[i]);
     const int len = (int)all.size();
     const int W = len >= g.win_len ? (len - g.win_len) / g.win_step + 1 : 0;
     const bool is_last = last && last[i] && !s->flushed_;
-    if (s->flushed_) { fl[i] = 2; any_last = true; }   // flushed by an earlier call that deferred its tail (last = 2): the tail rides in this pass
     if (is_last) {   // W full windows and the partial one behind them (zero padded by the feature kernel), from one span
       fl[i] = last[i] == 2 ? 2 : 1; any_last = true;
       spans[i] = all;

@@ -271,7 +271,16 @@ struct ModelState {
   GroupSlot slots_[kSlots];
   // STTX_BatchSubmitDevice / STTX_BatchCollect: the next ticket, the next slot, and the first half of a pair that waits for its
   // partner (the caller's next submit) -- or for its own collect, which sends it through alone
-  struct PendingHalf { bool valid = false; const int16_t* d_audio = nullptr; unsigned stride = 0; std::vector<unsigned> sizes; int ticket = -1; };
+  struct PendingHalf { bool valid = false; const int16_t* d_audio = nullptr; unsigned stride = 0; std::vector<unsigned> sizes; int ticket = -1; hipEvent_t ready = nullptr; };
+  // STTX_BatchSubmit (host audio, the ABI's own contract: const short* buffers, coqui-stt.h:294-297): the rows are gathered into a page-locked
+  // staging buffer and copied on a queue of their own; the group's feature kernel waits for the copy's event, nothing else does.  A ring of
+  // kStage entries: more than the tickets a caller may hold (kSlots x 2) + the noted first half of a pair, so the entry a submit takes has
+  // always been collected.
+  static constexpr int kStage = 10;
+  struct HostStage { PinnedBuf pin; DevBuf dev; hipEvent_t copied = nullptr; };
+  HostStage stage_[kStage];
+  hipStream_t stream_h2d = nullptr;
+  unsigned long long stage_seq_ = 0;
   PendingHalf pending_;
   int async_next_ = 0;    // next ticket
   int async_groups_ = 0;  // groups enqueued by submits so far (slot = async_groups_ % depth)

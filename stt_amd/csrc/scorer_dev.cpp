@@ -239,7 +239,11 @@ static void build_unit_bounds(HostScorer& hs) {
     bplus += mb;
     root_prev.swap(root_cur); next_prev.swap(next_cur);
   }
-  auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; };
+  // KenLM adds the probability and the backoffs in FLOAT, one rounding per term; with positive backoffs a real score could end up an ulp or
+  // two above a bound that was summed in higher precision and rounded up once.  One more float step up per backoff term covers every such
+  // rounding (with all backoffs <= 0 -- the common case -- bplus is 0 and float rounding can only lower the real sum: nothing is added).
+  const int slack = bplus > 0.0f ? ord : 0;
+  auto up = [slack](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); for (int k = 0; k < slack; ++k) f = std::nextafterf(f, INFINITY); return f; };
   hs.cp_ub.assign(65536, -1000.0f);   // OOV_SCORE (scorer.h:16)
   float mx = -1000.0f;                // (over EVERY unit of the vocabulary, also those beyond U+FFFF that have no table entry)
   for (uint64_t w = 0; w < n1; ++w) mx = std::max(mx, up(((double)ub[w] + (double)bplus) / (double)0.4342944819f));
@@ -726,11 +730,19 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label, bool lm_on
   }
   const bool memo_on = tune().lm_memo != 0;  // (0: measure without)
   if (hs.utf8 && ord <= 5 && !lm_only && memo_on) {  // FullScore cache of the code-point search (ctc.h: DevScorer::memo)
-    const int lg = tune().lm_memo >= 10 && tune().lm_memo <= 26 ? tune().lm_memo : 24;   // (lm_memo 1 = the default 2^24 entries = 512 MB of the 288 GB, 10..26 = log2 of the entry count)
-    const size_t n = (size_t)1 << lg;
-    memo_.reserve(n * 32);
-    HIP_CHECK(hipMemset(memo_.p, 0, n * 32));
-    ds.memo = memo_.as<uint32_t>(); ds.memo_mask = (uint32_t)n - 1;
+    int lg = tune().lm_memo >= 10 && tune().lm_memo <= 26 ? tune().lm_memo : 24;   // (lm_memo 1 = the default 2^24 entries = 512 MB of the 288 GB, 10..26 = log2 of the entry count)
+    // The memo is an accelerator, not a requirement (a miss goes through the index or the trie walk): a device that cannot spare the
+    // default -- many replicas, a shared GPU -- gets a smaller one, or none, instead of a scorer that fails to load.
+    for (; lg >= 14; lg -= 2) {
+      const size_t n = (size_t)1 << lg;
+      void* p = nullptr;
+      if (hipMalloc(&p, n * 32) != hipSuccess) { (void)hipGetLastError(); continue; }
+      (void)hipFree(p);
+      memo_.reserve(n * 32);
+      HIP_CHECK(hipMemset(memo_.p, 0, n * 32));
+      ds.memo = memo_.as<uint32_t>(); ds.memo_mask = (uint32_t)n - 1;
+      break;
+    }
   }
   dev = ds;
   is_utf8 = hs.utf8; order = ord; blob_bytes = hs.lm_end; lmi_bytes = hs.lmi.size() * sizeof(LmiEntry);

@@ -38,6 +38,7 @@
   X(lm_waves, 0, "language-model waves of the search step (0 = by beam width)")                                                    \
   X(exp_waves, 0, "expand waves of the search step (0 = all the others)")                                                          \
   X(wait_spins, 0, "test hook: polls (of 256 cycles) an intra-workgroup counter wait of the search step may take before it gives up with error bit 0x10 (0 = 4 M, about half a second)") \
+  X(debug_key_bits, 0, "test hook: path keys of the search truncated to this many bits (4..62; 0 = all 63): forces key collisions, which the guard must flag (error bit 0x20)") \
   X(item_table_cap, 0, "test hook: items per pass of the bitmap step's expand table (0 = what fits; small values force the several-pass path)") \
   X(stream_frames, 256, "frames (20 ms each) a new stream's search arenas are laid out for; longer utterances grow them (an allocation and a copy in the middle of a hop): a server sets its longest expected utterance") \
   X(decode_cache, 1, "streams: a decode with one result walks the best path back only to where it meets the previously decoded one (0: the whole path every time); read when a stream is created") \

@@ -177,6 +177,23 @@ class Model(object):
             raise RuntimeError("STTX_BatchSubmitDevice failed (%d)" % t)
         return t
 
+    def submitBatch(self, audio_buffers):
+        """STTX_BatchSubmit: 1..64 host int16 buffers -> ticket (collectBatch*).  `audio_buffers`: a list of int16 arrays, or a prepared
+        (pointer array, size array, count, keep-alive) tuple from prepareBatch() -- a caller that submits the same buffers again and again
+        (a benchmark) builds the two small ctypes arrays once."""
+        ptrs, sizes, n, _ = audio_buffers if isinstance(audio_buffers, tuple) else self.prepareBatch(audio_buffers)
+        t = native.lib().STTX_BatchSubmit(self._impl, ptrs, sizes, n)
+        if t < 0:
+            raise RuntimeError("STTX_BatchSubmit failed 0x%X" % -t)
+        return t
+
+    @staticmethod
+    def prepareBatch(audio_buffers):
+        arrs = [np.ascontiguousarray(a, dtype=np.int16) for a in audio_buffers]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        sizes = (C.c_uint * len(arrs))(*[a.shape[0] for a in arrs])
+        return ptrs, sizes, len(arrs), arrs
+
     def pipelineDepth(self):
         """Batches STTX_BatchSubmitDevice accepts for this model before the oldest must be collected (STTX_BatchPipelineDepthFor)."""
         return int(native.lib().STTX_BatchPipelineDepthFor(self._impl))
@@ -362,12 +379,14 @@ class StreamBatchCall(object):
         self.sizes = (C.c_uint * capacity)()
         self.last = (C.c_ubyte * capacity)()
         self.finish = (C.c_ubyte * capacity)()
+        self._objs = [None] * capacity      # the Stream objects of the rows: kept alive between set() and feed() / decode()
 
     def set(self, i, stream, audio_address, n_samples, last=0, finish=0):
         """row i: `stream` (a Stream) gets n_samples int16 samples at audio_address (0 / None with n_samples 0: nothing) in feed();
         last as STTX_FeedAudioContentBatchEx's aLast; finish != 0: decode() finishes (destroys) the stream"""
         stream._check()
         self.streams[i] = stream._impl
+        self._objs[i] = stream
         self.audio[i] = audio_address if n_samples else None
         self.sizes[i] = n_samples
         self.last[i] = last
@@ -377,12 +396,16 @@ class StreamBatchCall(object):
         native.lib().STTX_FeedAudioContentBatchEx(self.streams, self.audio, self.sizes, self.last, n)
 
     def decode(self, n, finished_streams=()):
-        """STTX_DecodeStreamsBatch over rows [0, n): -> n strings; pass the Stream objects of the rows flagged finish so that they are marked destroyed"""
+        """STTX_DecodeStreamsBatch over rows [0, n): -> n strings.  Every row flagged finish is destroyed by the call, whether it succeeds or
+        not (include/stt_amd.h): its Stream object is marked so here -- a later freeStream() / __del__ must not hand the native stream back
+        a second time.  (`finished_streams` is accepted for callers of round 4 and ignored: the rows themselves say which streams went.)"""
         if n == 0:
             return []
         r = native.lib().STTX_DecodeStreamsBatch(self.streams, self.finish, n)
-        for st in finished_streams:
-            st._impl = None
+        for i in range(n):
+            if self.finish[i] and self._objs[i] is not None:
+                self._objs[i]._impl = None
+                self._objs[i] = None
         if not r:
             raise RuntimeError("STTX_DecodeStreamsBatch failed")
         out = [C.string_at(r[i]).decode("utf-8", "replace") for i in range(n)]

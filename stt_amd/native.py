@@ -47,7 +47,7 @@ COQUI_STT_H = [
 ]
 STT_AMD_H = [
     "STTX_SetDevice", "STTX_GetDeviceCount", "STTX_SpeechToTextBatch", "STTX_SpeechToTextBatchWithMetadata",
-    "STTX_SpeechToTextBatchDevice", "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmitDevice", "STTX_BatchCollect", "STTX_BatchCollectWithMetadata", "STTX_BatchCollectScored", "STTX_DebugBatchProbs", "STTX_SetTuning", "STTX_GetTuning", "STTX_ConfigureRuntime", "STTX_TestLstmSteps", "STTX_TestDenseHybrid", "STTX_GetAcousticMode", "STTX_TestHybridChain", "STTX_FeedAudioContentBatch", "STTX_FeedAudioContentBatchEx", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_DecodeStreamsBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
+    "STTX_SpeechToTextBatchDevice", "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmit", "STTX_BatchSubmitDevice", "STTX_BatchCollect", "STTX_BatchCollectWithMetadata", "STTX_BatchCollectScored", "STTX_DebugBatchProbs", "STTX_SetTuning", "STTX_GetTuning", "STTX_ConfigureRuntime", "STTX_TestLstmSteps", "STTX_TestDenseHybrid", "STTX_GetAcousticMode", "STTX_TestHybridChain", "STTX_FeedAudioContentBatch", "STTX_FeedAudioContentBatchEx", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_DecodeStreamsBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
     "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_GetDecoderStamps", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
     "STTX_DecoderStats", "STTX_DecoderSetProfiling", "STTX_DecoderGetProfile", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
@@ -107,6 +107,7 @@ def lib():
         "STTX_SpeechToTextBatchDevice": (pp(vp), [vp, vp, cu, pp(cu), cu]),
         "STTX_BatchPipelineDepth": (ci, []),
         "STTX_BatchPipelineDepthFor": (ci, [vp]),
+        "STTX_BatchSubmit": (ci, [vp, pp(vp), pp(cu), cu]),
         "STTX_BatchSubmitDevice": (ci, [vp, vp, cu, pp(cu), cu]),
         "STTX_BatchCollect": (pp(vp), [vp, ci, pp(cu)]),
         "STTX_BatchCollectWithMetadata": (pp(pp(Metadata)), [vp, ci, pp(cu)]),

@@ -154,3 +154,44 @@ def test_collect_with_confidence_and_with_metadata(model):
             assert [g["text"] for g in got] == [w["text"] for w in want[k]]
             assert [g["confidence"] for g in got] == [w["confidence"] for w in want[k]]
             assert [[tk[1] for tk in g["tokens"]] for g in got] == [[tk[1] for tk in w["tokens"]] for w in want[k]]
+
+
+@pytest.mark.parametrize("pair", [1, 0])
+def test_host_audio_submit_equals_the_device_path(model, pair):
+    """STTX_BatchSubmit (the ABI's own contract: host buffers, coqui-stt.h:294-297): staged through page-locked memory, copied on its own
+    queue, the group gated by the copy's event -- 25 batches (the staging ring wraps twice), ragged lengths incl. an empty utterance,
+    the caller's buffers overwritten right after the call; transcripts and confidences of the device-resident path."""
+    native.set_tuning("pair", pair)
+    try:
+        rng = np.random.RandomState(5)
+        n_batches, B = 25, 9
+        host = []
+        for k in range(n_batches):
+            lens = [0 if (i == 4 and k % 3 == 0) else 6000 + int(rng.randint(0, 20000)) for i in range(B)]
+            host.append([synth.synth_audio(n, seed=700 + 50 * k + i) for i, n in enumerate(lens)])
+        want = [model.sttBatch(h) for h in host]
+        depth = model.pipelineDepth()
+        got, inflight = [], []
+        for h in host:
+            if len(inflight) == depth:
+                got.append(model.collectBatchScored(inflight.pop(0)))
+            mine = [a.copy() for a in h]
+            inflight.append(model.submitBatch(mine))
+            for a in mine:
+                a[:] = 12345                                  # the buffers belong to the caller again
+        while inflight:
+            got.append(model.collectBatchScored(inflight.pop(0)))
+        assert [g[0] for g in got] == want
+        assert any(any(s for s in b) for b in want)
+        # the same batches through the device entry: equal confidences, bit for bit
+        for k in (0, 11, 24):
+            stride = max(8, max(len(a) for a in host[k]))
+            arr = np.zeros((B, stride), dtype=np.int16)
+            for i, a in enumerate(host[k]):
+                arr[i, :len(a)] = a
+            d = _DeviceArray(arr)
+            t = model.submitBatchDevice(d.data_ptr(), stride, [len(a) for a in host[k]])
+            texts, conf = model.collectBatchScored(t)
+            assert texts == got[k][0] and list(conf) == list(got[k][1])
+    finally:
+        native.set_tuning("pair", 1)

@@ -80,3 +80,38 @@ def test_batch_group_with_an_overflowing_optimistic_arena_is_decoded_again(tmp_p
     assert r1 > r0 and r2 > r1, "the shrunken arenas were expected to overflow"
     assert got == want and got2 == [want, want]
     assert any(want)
+
+
+def test_two_prefixes_with_one_path_key_are_flagged_not_merged(tmp_path, fix):
+    """A prefix's identity in the search is a 63-bit hash of its labels (ctc.hip: child_key): a collision would merge two prefixes.  At 63
+    bits it does not happen (2e-10 per utterance); with the keys truncated to 9 bits (tunable debug_key_bits) it happens at once, and the
+    guard -- the found entry's last label against the label looked up -- must raise error bit 0x20 on every step variant: a refused
+    result, not a wrong one."""
+    from stt_amd import Model, native
+    w = synth.synth_weights(5, n_hidden=256)
+    path = str(tmp_path / "m.sttw")
+    modelfile.write_model(path, w, synth.ENGLISH_LABELS, beam_width=200)
+    m = Model(path)
+    rng = np.random.RandomState(3)
+    x = rng.rand(120, 29).astype(np.float32) + 0.05
+    x /= x.sum(1, keepdims=True)
+    for scorer in (None, os.path.join(fix, "pruned_lm.scorer")):          # the generic step (no scorer) and the bitmap step (word scorer)
+        if scorer:
+            m.enableExternalScorer(scorer)
+        d = m.createDecoder(1, 200)
+        d.next(x)
+        good = d.decode(1)
+        assert d.stats()["error"] == 0 and good[0]
+        native.set_tuning("debug_key_bits", 9)
+        try:
+            d2 = m.createDecoder(1, 200)
+            d2.next(x)
+            assert d2.stats()["error"] & 0x20, hex(d2.stats()["error"])
+            with pytest.raises(RuntimeError):
+                d2.decode(1)
+        finally:
+            native.set_tuning("debug_key_bits", 0)
+        d3 = m.createDecoder(1, 200)                                       # full-width keys again: the same beam as before
+        d3.next(x)
+        r3 = d3.decode(1)
+        assert d3.stats()["error"] == 0 and r3[0][0][0] == good[0][0][0] and np.array_equal(r3[0][0][1], good[0][0][1])
