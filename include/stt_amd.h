@@ -233,9 +233,11 @@ STTX_EXPORT int STTX_GetAcousticMode(const ModelState* aCtx);
  * 1-3, the cell (state aC / aH [aB][n_hidden] f32, NULL = zeros), layers 5-6 and the softmax as ONE call of the engine's one-stream path.
  * Outputs (each may be NULL): aL3 [aT*aB][n_hidden] layer 3's f32 rows; aAccX [aT*aB][4 n_hidden] the x half of the cell's int32 sums;
  * aHAll [aT*aB][n_hidden] h_t; aLogits [aT*aB][n_classes]; aProbs [aB][aT][n_classes]; aNewC / aNewH [aB][n_hidden];
- * *aSlowRows = rows the recurrent steps computed again at the joint scale during this call (max |h| > max |x_t|). */
+ * *aSlowRows = rows the recurrent steps computed again at the joint scale during this call (max |h| > max |x_t|); *aLstmMs (may be NULL) =
+ * HIP-event time of the recurrence alone (the prep launch + aT step launches). */
 STTX_EXPORT int STTX_TestHybridChain(ModelState* aCtx, const float* aWindows, unsigned int aB, unsigned int aT, const float* aC, const float* aH,
-                                      float* aL3, int* aAccX, float* aHAll, float* aLogits, float* aProbs, float* aNewC, float* aNewH, unsigned int* aSlowRows);
+                                      float* aL3, int* aAccX, float* aHAll, float* aLogits, float* aProbs, float* aNewC, float* aNewH, unsigned int* aSlowRows,
+                                      float* aLstmMs);
 /* The recurrent step kernel alone (deepspeech_model.py:144-168, one LSTMCell step per launch) on the model's packed recurrent
  * matrix: aSteps steps from a zero state, step t adding x-projection block t % aPeriod (aXproj [aPeriod * aBatch][4 * n_hidden] f32,
  * row = block * aBatch + b).  aC, aH [aBatch][n_hidden]: the final state; aHAll (may be NULL) [aPeriod * aBatch][n_hidden] f16 bits:

@@ -1323,7 +1323,7 @@ int STTX_TestDense(int M, int N, int K, const float* aX, const float* aW, const 
 int STTX_GetAcousticMode(const ModelState* m) { return m && m->i8 ? 1 : 0; }
 
 int STTX_TestHybridChain(ModelState* m, const float* aWindows, unsigned int aB, unsigned int aT, const float* aC, const float* aH, float* aL3, int* aAccX, float* aHAll,
-                         float* aLogits, float* aProbs, float* aNewC, float* aNewH, unsigned int* aSlowRows) {
+                         float* aLogits, float* aProbs, float* aNewC, float* aNewH, unsigned int* aSlowRows, float* aLstmMs) {
   return guarded([&]() {
     if (!m->i8 || !aB || !aT || (int)aB > 128) return (int)STT_ERR_INVALID_SHAPE;
     HIP_CHECK(hipSetDevice(m->device));
@@ -1338,8 +1338,14 @@ int STTX_TestHybridChain(ModelState* m, const float* aWindows, unsigned int aB, 
     m->ws_probs.reserve((size_t)M * C * 4);
     unsigned slow0 = 0, slow1 = 0;
     if (m->ws_slow.p) HIP_CHECK(hipMemcpy(&slow0, m->ws_slow.p, 4, hipMemcpyDeviceToHost));
-    m->run_acoustic_rows(m->ws_x1.p, B, T, c.as<float>(), h.as<float>(), true, m->ws_probs.as<float>(), T);
+    if (aLstmMs) { HIP_CHECK(hipEventCreate(&m->dbg_ev_[0])); HIP_CHECK(hipEventCreate(&m->dbg_ev_[1])); }
+    try { m->run_acoustic_rows(m->ws_x1.p, B, T, c.as<float>(), h.as<float>(), true, m->ws_probs.as<float>(), T); }
+    catch (...) { for (auto& e : m->dbg_ev_) if (e) { (void)hipEventDestroy(e); e = nullptr; } throw; }
     HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (aLstmMs) {   // prep + aT recurrent steps, HIP events on the stream they run on
+      HIP_CHECK(hipEventElapsedTime(aLstmMs, m->dbg_ev_[0], m->dbg_ev_[1]));
+      for (auto& e : m->dbg_ev_) { (void)hipEventDestroy(e); e = nullptr; }
+    }
     HIP_CHECK(hipMemcpy(&slow1, m->ws_slow.p, 4, hipMemcpyDeviceToHost));
     if (aSlowRows) *aSlowRows = slow1 - slow0;
     if (aL3) HIP_CHECK(hipMemcpy(aL3, m->ws_a.p, (size_t)M * H * 4, hipMemcpyDeviceToHost));

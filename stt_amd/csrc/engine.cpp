@@ -83,7 +83,9 @@ static void acoustic_rows_i8(ModelState& m, const float* d_x1, int B, int T, flo
   l.pmax = m.ws_pmax.as<float>(); l.flag = m.ws_flag.as<int>(); l.y3 = act_a; l.h_prev0 = m.ws_hprev0.as<float>();
   l.wxq = m.wxq.as<signed char>(); l.whq = m.whq.as<signed char>(); l.zslow = m.ws_zslow.as<float>();
   l.n_hidden = H; l.batch = B; l.T = T; l.slow_count = m.ws_slow.as<unsigned>();
+  l.probe = m.dbg_ev_[0] ? tune().lstm_probe : 0;     // (only a timed test-hook call may ask for a probe kernel)
   l.hq_in = m.ws_hq0.as<signed char>(); l.hq_out = m.ws_hq1.as<signed char>();
+  if (m.dbg_ev_[0]) HIP_CHECK(hipEventRecord(m.dbg_ev_[0], st));
   launch_lstm_i8_prep(l, h_src, NT, st);
   for (int t = 0; t < T; ++t) {
     l.t = t;
@@ -91,6 +93,7 @@ static void acoustic_rows_i8(ModelState& m, const float* d_x1, int B, int T, flo
     l.hq_out = (t & 1) ? m.ws_hq0.as<signed char>() : m.ws_hq1.as<signed char>();
     launch_lstm_i8_step(l, NT, st);
   }
+  if (m.dbg_ev_[1]) HIP_CHECK(hipEventRecord(m.dbg_ev_[1], st));
   stt_prof_mark(&m, 3);
   // layer 5, layer 6, softmax (deepspeech_model.py:241-252, 357)
   launch_quantize_rows(m.ws_hall.as<float>(), qx, qs, M, H, st);

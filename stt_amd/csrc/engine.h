@@ -203,6 +203,7 @@ struct ModelState {
   // 128, the output layer's N to 256), the cell's kernel split into its x half (a GEMM operand), its h half packed for the recurrent step
   // and the same h half in rows (the step's slow path); scales [1] or [N].
   bool i8 = false;
+  hipEvent_t dbg_ev_[2] = {nullptr, nullptr};   // STTX_TestHybridChain: HIP events around the recurrence of the next acoustic_rows_i8 call (null: none)
   DevBuf w1q, w2q, w3q, wxq, whq, whpq, w5q, w6q;
   DevBuf s1, s2, s3, sk, s5, s6, b6q;     // b6q: the output layer's bias padded to c_pad8()
   int sn[6] = {1, 1, 1, 1, 1, 1};         // scales per matrix (1 or N)

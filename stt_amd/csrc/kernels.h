@@ -114,6 +114,7 @@ struct LstmI8Args {
   int n_hidden, batch, t, T;
   int prio;
   unsigned int* slow_count;    // counts slow-path rows (diagnostics / tests; may be null)
+  int probe;                   // STTX_TestHybridChain only: the tunable lstm_probe (timing probes with wrong results; never set by the batch / streaming paths)
 };
 // before step 0 of a launch sequence: h_src ([B][H] f32, null = zeros) -> hq (buffer of step 0), h_prev0, pmax / flag of step 0
 void launch_lstm_i8_prep(const LstmI8Args& a, const float* h_src, int NT, hipStream_t st);

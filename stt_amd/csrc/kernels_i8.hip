@@ -41,7 +41,9 @@ __device__ __forceinline__ void mfma_i8_(i32x4& acc, const i32x4& a, const i32x4
   else acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
 }
 
-template <int NT>
+// DBG (timing probes only, wrong results; tunable lstm_probe through STTX_TestHybridChain): bit 0 = activations replaced by a multiply, bit 1 =
+// no cross-wave reduction, bit 2 = no cell-update operand loads, bit 3 = every operand load of the k-loop reads the wave's first fragment.
+template <int NT, int DBG = 0>
 __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
   constexpr bool PIN = NT == 8;                  // 128 accumulator registers pinned in the accumulator file (see kernels_am.hip: lstm_mfma)
   constexpr int NTR = NT * 16;                   // rows a launch covers
@@ -70,8 +72,8 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
 #define I8_LOAD(W, Hh, s_)                                                                  \
   do {                                                                                      \
     const int ks_ = (s_);                                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) W[i_] = wp[(size_t)(ks_ * 4 + i_) * 64];   \
-    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) Hh[j_] = hp[(size_t)(ks_ * NT + j_) * 64]; \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) W[i_] = wp[(DBG & 8) ? (size_t)0 : (size_t)(ks_ * 4 + i_) * 64];   \
+    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) Hh[j_] = hp[(DBG & 8) ? (size_t)0 : (size_t)(ks_ * NT + j_) * 64]; \
   } while (0)
 #define I8_MMA(W, Hh)                                                                       \
   do {                                                                                      \
@@ -129,7 +131,7 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
     for (int g = 0; g < 4; ++g) ax[it][g] = (i32x4){0, 0, 0, 0};
     cv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     xs_[it] = 1.0f;
-    if (s < SLOTS && row < B) {
+    if (s < SLOTS && row < B && !(DBG & 4)) {
       const size_t rowi = (size_t)a.t * B + row;
 #pragma unroll
       for (int g = 0; g < 4; ++g) ax[it][g] = *reinterpret_cast<const i32x4*>(a.accx + rowi * (size_t)(4 * H) + (size_t)g * H + unit0);
@@ -146,16 +148,16 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
   }
 
   // ---- cross-wave reduction of the int32 partial sums: wave 0 stores, the others add (integers: any order)
-  if (q == 0) {
+  if (q == 0 || (DBG & 2)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[i][j][r][lane] = acc[i][j][r];
+        for (int r = 0; r < 4; ++r) if (!(DBG & 2) || j == q || j == q + 4) red[i][j][r][lane] = acc[i][j][r];
   }
   const int any = __syncthreads_or(myflag);
-  if (q != 0 && q < KS) {
+  if (q != 0 && q < KS && !(DBG & 2)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -236,9 +238,13 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
           if (slow) z[g] = a.zslow[((size_t)wg * NTR + row) * 64 + g * 16 + ug * 4 + r];
         }
         // gate order i, j, f, o (deepspeech_model.py:144-168); MUL, MUL, ADD as separate float ops
-        const float cn = __fadd_rn(__fmul_rn(sigmoid_i8_(z[2]), (&cv[it].x)[r]), __fmul_rn(sigmoid_i8_(z[0]), tanhf(z[1])));
+        float cn;
+        if constexpr (DBG & 1) { cn = __fadd_rn(__fmul_rn(z[2], (&cv[it].x)[r]), __fmul_rn(z[0], z[1])); hv[r] = __fmul_rn(z[3], cn) * 1e-3f; }
+        else {
+          cn = __fadd_rn(__fmul_rn(sigmoid_i8_(z[2]), (&cv[it].x)[r]), __fmul_rn(sigmoid_i8_(z[0]), tanhf(z[1])));
+          hv[r] = __fmul_rn(sigmoid_i8_(z[3]), tanhf(cn));
+        }
         (&cn4.x)[r] = cn;
-        hv[r] = __fmul_rn(sigmoid_i8_(z[3]), tanhf(cn));
       }
       *reinterpret_cast<float4*>(a.c + (size_t)row * H + unit0) = cn4;
       const float4 h4 = make_float4(hv[0], hv[1], hv[2], hv[3]);
@@ -268,6 +274,8 @@ template <int NT>
 __global__ __launch_bounds__(256, 2) void lstm_i8_step_kernel(LstmI8Args a) { lstm_i8_step_body<NT>(a); }
 // 128 rows: 128 accumulator registers + the operand double buffer (kernels_am.hip: lstm_step8_kernel)
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(160))) void lstm_i8_step8_kernel(LstmI8Args a) { lstm_i8_step_body<8>(a); }
+template <int DBG>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(160))) void lstm_i8_probe8_kernel(LstmI8Args a) { lstm_i8_step_body<8, DBG>(a); }
 
 // Before step 0 of a launch sequence: the carried h ([B][H] f32; null = zeros) quantised for step 0 at 127 / max |x_0| -- with the
 // TRUE max |h| known here (one workgroup reads the whole row), so the flag of step 0 is exact --, a copy of it for the slow path, and
@@ -317,7 +325,16 @@ void launch_lstm_i8_step(const LstmI8Args& a, int NT, hipStream_t st) {
     case 1: hipLaunchKernelGGL(lstm_i8_step_kernel<1>, grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL(lstm_i8_step_kernel<2>, grid, block, 0, st, a); break;
     case 4: hipLaunchKernelGGL(lstm_i8_step_kernel<4>, grid, block, 0, st, a); break;
-    case 8: hipLaunchKernelGGL(lstm_i8_step8_kernel, grid, block, 0, st, a); break;
+    case 8:
+      switch (a.probe) {      // (STTX_TestHybridChain with the tunable lstm_probe: timing probes, wrong results)
+        case 1: hipLaunchKernelGGL(lstm_i8_probe8_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(lstm_i8_probe8_kernel<2>, grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(lstm_i8_probe8_kernel<4>, grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL(lstm_i8_probe8_kernel<8>, grid, block, 0, st, a); break;
+        case 15: hipLaunchKernelGGL(lstm_i8_probe8_kernel<15>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(lstm_i8_step8_kernel, grid, block, 0, st, a); break;
+      }
+      break;
     default: throw std::runtime_error("lstm int8 step: batch tiles must be 1, 2, 4 or 8");
   }
 }

@@ -334,12 +334,14 @@ class Model(object):
         out = {"l3": np.zeros((T, B, H), np.float32), "accx": np.zeros((T, B, 4 * H), np.int32), "h_all": np.zeros((T, B, H), np.float32),
                "logits": np.zeros((T, B, Cn), np.float32), "probs": np.zeros((B, T, Cn), np.float32), "c": np.zeros((B, H), np.float32), "h": np.zeros((B, H), np.float32)}
         slow = C.c_uint(0)
+        ms = C.c_float(0)
         status = native.lib().STTX_TestHybridChain(self._impl, w.ctypes.data, B, T, None if c is None else c.ctypes.data, None if h is None else h.ctypes.data,
                                                    out["l3"].ctypes.data, out["accx"].ctypes.data, out["h_all"].ctypes.data, out["logits"].ctypes.data,
-                                                   out["probs"].ctypes.data, out["c"].ctypes.data, out["h"].ctypes.data, C.byref(slow))
+                                                   out["probs"].ctypes.data, out["c"].ctypes.data, out["h"].ctypes.data, C.byref(slow), C.byref(ms))
         if status != 0:
             raise RuntimeError("STTX_TestHybridChain failed 0x%X" % status)
         out["slow_rows"] = int(slow.value)
+        out["lstm_ms"] = float(ms.value)
         return out
 
     def createDecoder(self, n_streams=1, beam_width=None, cutoff_prob=1.0, cutoff_top_n=40):

@@ -119,7 +119,7 @@ def lib():
         "STTX_TestLstmSteps": (ci, [vp, cu, cu, cu, ci, vp, vp, vp, vp, pp(cf)]),
         "STTX_TestDenseHybrid": (ci, [vp, cu, cu, vp, vp, cu, vp, cu, vp, vp, vp, cu, pp(cf), ci, cf]),
         "STTX_GetAcousticMode": (ci, [vp]),
-        "STTX_TestHybridChain": (ci, [vp, vp, cu, cu, vp, vp, vp, vp, vp, vp, vp, vp, vp, pp(cu)]),
+        "STTX_TestHybridChain": (ci, [vp, vp, cu, cu, vp, vp, vp, vp, vp, vp, vp, vp, vp, pp(cu), pp(cf)]),
         "STTX_FeedAudioContentBatch": (None, [pp(vp), pp(vp), pp(cu), cu]),
         "STTX_FeedAudioContentBatchEx": (None, [pp(vp), pp(vp), pp(cu), vp, cu]),
         "STTX_IntermediateDecodeBatch": (pp(vp), [pp(vp), cu]),
