@@ -63,8 +63,18 @@ def fully_connected_hybrid(x, wq, wscale, bias, wq_f64_t=None):
     return (out + (acc.astype(F32) * scale).astype(F32)).astype(F32)               # (int32 -> float conversion, then float multiply-add)
 
 
+# LOGISTIC and TANH are float kernels in TFLite, and their last bits depend on the build: the reference kernels call std::exp / std::tanh
+# (reference/logistic.h, reference/tanh.h), the optimised ones Eigen's rational approximations -- each within an ulp or two of the correctly
+# rounded float of the real function.  That value is what this restatement takes: float64 evaluation, one rounding to float32.  (numpy's own
+# float32 exp / tanh are SIMD approximations 1-3 ulp off: not a better stand-in for TFLite than the correctly rounded value, and the
+# quantised recurrence amplifies last-bit differences -- tests/test_gpu_hybrid.py.)  oracle/cr_activations_check.c pins the float64
+# algorithm the engine uses for them against this definition.
 def _sigmoid(x):
-    return (F32(1) / (F32(1) + np.exp(-x.astype(F32)))).astype(F32)
+    return (1.0 / (1.0 + np.exp(-np.asarray(x, dtype=np.float64)))).astype(F32)
+
+
+def _tanh(x):
+    return np.tanh(np.asarray(x, dtype=np.float64)).astype(F32)
 
 
 class HybridModel:
@@ -111,8 +121,8 @@ class HybridModel:
         for t in range(T):
             z = self._fc(np.concatenate([l3[:, t], h], axis=1), "lstm/kernel", self.b["lstm/bias"])     # concat([x_t, h]) . kernel + bias
             i, j, f, o = np.split(z, 4, axis=1)                                                          # gate order i, j, f, o (deepspeech_model.py:144-168)
-            c = (_sigmoid(f) * c + _sigmoid(i) * np.tanh(j.astype(F32))).astype(F32)
-            h = (_sigmoid(o) * np.tanh(c)).astype(F32)
+            c = (_sigmoid(f) * c + _sigmoid(i) * _tanh(j)).astype(F32)
+            h = (_sigmoid(o) * _tanh(c)).astype(F32)
             hs[:, t] = h
         l5 = self._dense(hs.reshape(B * T, self.H), "layer_5")
         logits = self._fc(l5, "layer_6/weights", self.b["layer_6/bias"])

@@ -79,7 +79,7 @@ static void acoustic_rows_i8(ModelState& m, const float* d_x1, int B, int T, flo
   LstmI8Args l{};
   l.whp = m.whpq.as<signed char>(); l.accx = m.ws_xproj.as<int>(); l.bias = m.bl.as<float>(); l.wscale = m.sk.as<float>(); l.wscale_n = m.sn[3];
   l.xscale = xs3; l.xrange = xr3; l.c = cbuf; l.h_all = m.ws_hall.as<float>();
-  l.h_last = (carry == 1 && d_h) ? d_h : m.ws_hlast.as<float>();
+  l.h_last = d_h ? d_h : m.ws_hlast.as<float>();     // (a stream's first chunk starts from zeros, carry 0, and still hands its state back)
   l.pmax = m.ws_pmax.as<float>(); l.flag = m.ws_flag.as<int>(); l.y3 = act_a; l.h_prev0 = m.ws_hprev0.as<float>();
   l.wxq = m.wxq.as<signed char>(); l.whq = m.whq.as<signed char>(); l.zslow = m.ws_zslow.as<float>();
   l.n_hidden = H; l.batch = B; l.T = T; l.slow_count = m.ws_slow.as<unsigned>();

@@ -29,10 +29,54 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-// TFLite's LOGISTIC / TANH are float kernels; oracle/am_hybrid.py evaluates 1 / (1 + exp(-x)) and tanh(x) in float32.  Accurate expf /
-// tanhf and an IEEE division here (not the f16 path's v_exp / v_rcp forms): what is left against the restatement is the last bit of the
-// transcendental functions.
-__device__ __forceinline__ float sigmoid_i8_(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+__device__ __constant__ const uint64_t kExp2TabI8[32] = {      // bits(2^(i/32)) - (i << 47), as glibc's expf keeps them
+    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,
+    0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,
+    0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,
+    0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,
+    0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
+    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
+    0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
+    0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
+
+// LOGISTIC and TANH.  TFLite evaluates them with float kernels whose last bits depend on the build (std::exp / std::tanh in the reference
+// kernels, Eigen's rational approximations in the optimised ones): each is within an ulp or two of the CORRECTLY ROUNDED float of the
+// real function, and that value is what oracle/am_hybrid.py takes (float64 evaluation, one rounding).  The recurrence is unforgiving about
+// the difference: a last-bit change of one activation can flip one int8 of the next step's quantised row, and the quantised network
+// amplifies that within a few steps (measured: activations 1-3 ulp off -> transcripts of 18 of 64 utterances move).  So the
+// device evaluates both functions in float64 as well -- exp(y) - 1 for y <= 0 from a 32-entry table of 2^(i/32) and a degree-7 polynomial
+// (absolute error ~3e-16), one IEEE division, one rounding to float -- and agrees with the oracle except where a float64 error of 1e-15
+// straddles a float rounding boundary (about one call in 1e7).  Cost: ~35 float64 instructions per activation, full rate on gfx950.
+template <bool WANT_EXP>
+__device__ __forceinline__ double em1_neg_(double y, const uint64_t* tab) {       // WANT_EXP ? exp(y) : exp(y) - 1, for -104 <= y <= 0
+  const double InvLn2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p+52;
+  const double Ln2N_hi = 6.93147180369123816490e-01 / 32.0, Ln2N_lo = 1.90821492927058770002e-10 / 32.0;   // fdlibm's ln2 split: k * hi is exact
+  double kd = __dadd_rn(__dmul_rn(y, InvLn2N), SHIFT);
+  const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+  kd = __dadd_rn(kd, -SHIFT);
+  double r = __fma_rn(-kd, Ln2N_hi, y);
+  r = __fma_rn(-kd, Ln2N_lo, r);                                                  // |r| <= ln2 / 64
+  double p = __fma_rn(r, 1.0 / 5040.0, 1.0 / 720.0);
+  p = __fma_rn(p, r, 1.0 / 120.0);
+  p = __fma_rn(p, r, 1.0 / 24.0);
+  p = __fma_rn(p, r, 1.0 / 6.0);
+  p = __fma_rn(p, r, 0.5);
+  p = __fma_rn(__dmul_rn(p, r), r, r);                                            // e^r - 1
+  const double T = __longlong_as_double((long long)(tab[ki & 31] + (ki << 47)));  // 2^(k/32): the table holds bits(2^(i/32)) - (i << 47)
+  return __fma_rn(T, p, WANT_EXP ? T : __dadd_rn(T, -1.0));    // (1 + exp(y) - 1 would cancel for y << 0, exp(y) - 1 computed from exp(y) for y ~ 0)
+}
+__device__ __forceinline__ float sigmoid_i8_(float x, const uint64_t* tab) {
+  const double a = fmin(fabs((double)x), 104.0);           // (exp(-104) is below the smallest float)
+  const double E = em1_neg_<true>(-a, tab);                // exp(-|x|)
+  const double q = 1.0 / __dadd_rn(1.0, E);                // 1 / (1 + exp(-|x|))
+  return (float)(x >= 0.0f ? q : __dmul_rn(E, q));
+}
+__device__ __forceinline__ float tanh_i8_(float x, const uint64_t* tab) {
+  const double a = fmin(fabs((double)x), 22.0);
+  const double e = em1_neg_<false>(__dmul_rn(-2.0, a), tab);   // exp(-2|x|) - 1
+  const double t = -e / __dadd_rn(2.0, e);                 // (1 - exp(-2|x|)) / (1 + exp(-2|x|))
+  return (float)(x < 0.0f ? -t : t);
+}
 __device__ __forceinline__ signed char quant_i8_(float v, float inv) { return (signed char)fminf(fmaxf(roundf(__fmul_rn(v, inv)), -127.0f), 127.0f); }
 
 template <bool PIN>
@@ -53,8 +97,10 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
   __shared__ float sred[256];
   __shared__ int s_nflag;
   __shared__ unsigned char s_flist[NTR];
+  __shared__ uint64_t s_exp2[32];                // 2^(i/32) for the activations (a data-dependent read of __constant__ memory is a vector load through the caches)
   if (a.prio) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, wg = blockIdx.x;
+  if (tid < 32) s_exp2[tid] = kExp2TabI8[tid];   // (visible behind the reduction's barriers, long before the cell update reads it)
   const int H = a.n_hidden, B = a.batch, KS = H / 64, NWG = H / 16;
   const int par = a.t & 1, epoch = a.t + 1;
   // issued now, consumed behind the k-loop: is any row of this step flagged?
@@ -241,8 +287,8 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
         float cn;
         if constexpr (DBG & 1) { cn = __fadd_rn(__fmul_rn(z[2], (&cv[it].x)[r]), __fmul_rn(z[0], z[1])); hv[r] = __fmul_rn(z[3], cn) * 1e-3f; }
         else {
-          cn = __fadd_rn(__fmul_rn(sigmoid_i8_(z[2]), (&cv[it].x)[r]), __fmul_rn(sigmoid_i8_(z[0]), tanhf(z[1])));
-          hv[r] = __fmul_rn(sigmoid_i8_(z[3]), tanhf(cn));
+          cn = __fadd_rn(__fmul_rn(sigmoid_i8_(z[2], s_exp2), (&cv[it].x)[r]), __fmul_rn(sigmoid_i8_(z[0], s_exp2), tanh_i8_(z[1], s_exp2)));
+          hv[r] = __fmul_rn(sigmoid_i8_(z[3], s_exp2), tanh_i8_(cn, s_exp2));
         }
         (&cn4.x)[r] = cn;
       }

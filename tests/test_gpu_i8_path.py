@@ -45,8 +45,8 @@ def _oracle_cell(hm, x, c, h):
     from oracle import am_hybrid
     z = hm._fc(np.concatenate([x, h], axis=1), "lstm/kernel", hm.b["lstm/bias"])
     i, j, f, o = np.split(z, 4, axis=1)
-    c = (am_hybrid._sigmoid(f) * c + am_hybrid._sigmoid(i) * np.tanh(j.astype(np.float32))).astype(np.float32)
-    h = (am_hybrid._sigmoid(o) * np.tanh(c)).astype(np.float32)
+    c = (am_hybrid._sigmoid(f) * c + am_hybrid._sigmoid(i) * am_hybrid._tanh(j)).astype(np.float32)
+    h = (am_hybrid._sigmoid(o) * am_hybrid._tanh(c)).astype(np.float32)
     return c, h
 
 

@@ -2,6 +2,8 @@
 Lite is an un-vendored submodule, SURVEY.md 8c: "parity unpinned"), so these are independent re-derivations, not pins
 against the reference: the layer stack written a second time with torch's own Linear / LSTMCell kernels (gate order
 re-mapped: TensorFlow i, j, f, o -> torch i, f, g, o), and the spectrogram against a direct FFT (scipy)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -91,3 +93,15 @@ def test_torch_f32_restatement_agrees_with_the_f64_one():
     want = am_ref.utterance_probs(a, w)
     got = am_torch.utterance_probs(a, am_torch.to_torch(w))
     assert got.shape == want.shape and np.abs(got - want).max() < 1e-5
+
+
+def test_the_float64_activation_algorithm_gives_the_restatements_values(tmp_path):
+    """oracle/cr_activations_check.c: the table + polynomial evaluation of LOGISTIC / TANH that the int8 recurrent step runs on the GPU,
+    restated in C, against float64 numpy-style evaluation rounded once (oracle/am_hybrid.py's definition) and against long double: equal
+    on every one of 20 M float inputs but a handful of half-way cases."""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "chk")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "oracle", "cr_activations_check.c"), "-lm"], check=True)
+    n, s64, sl, t64, tl = (int(v) for v in subprocess.run([exe, "40000000"], check=True, capture_output=True, text=True).stdout.split())
+    assert n > 15_000_000 and s64 <= 3 and sl <= 3 and t64 <= 3 and tl <= 3, (n, s64, sl, t64, tl)
