@@ -21,12 +21,14 @@ pytestmark = pytest.mark.gpu
 # in the output layer's input and therefore grows with that layer's weights -- `head` times the weights, `head` times the bound
 # (measured at x 8: 8.8e-3 / 5.8e-2).  It consists of the activation quantisation noise of the reference's OWN CPU path: against
 # the float graph of the same de-quantised weights the engine stays within 1e-4 / 2e-3 (tests/test_gpu_benchshape.py).
-ABS_TOL = {"f16": 1e-3, "int8": 2e-4}
-LOG_TOL = {"f16": 1.25e-2, "int8": 2.5e-3}
+# int8 path: what is left is float rounding in the softmax (the engine multiplies by 1 / sum, the restatement divides) -- measured
+# |d p| 1.5e-8 ... 3e-7, |d ln p| 4.8e-7 ... 9.5e-7 at every head scale (profiles/r05_hybrid_tolerance.json): the bound does not grow with the head.
+ABS_TOL = {"f16": 1e-3, "int8": 1e-6}
+LOG_TOL = {"f16": 1.25e-2, "int8": 4e-6}
 # transcripts equal to the reference decoder's on the hybrid path's probabilities, of 64: a random-init head is a coin toss per frame
 # (mean top probability 0.04) and any perturbation re-routes the beam; the more a model commits, the fewer transcripts move
 MIN_EQUAL = {"f16": {1.0: 0, 8.0: 48, 32.0: 62},       # measured: 4, 57, 64 (profiles/r04_hybrid_tolerance.json)
-             "int8": {1.0: 56, 8.0: 62, 32.0: 64}}
+             "int8": {1.0: 60, 8.0: 63, 32.0: 64}}     # measured: 63, 64, 64 -- and every transcript that differs must be a boundary tie of the SEARCH (below)
 
 
 _WANT = {}
@@ -47,7 +49,7 @@ def _model(tmp, w, name, mode, beam=500):
 
 @pytest.mark.parametrize("mode", ["int8", "f16"])
 @pytest.mark.parametrize("head", [1.0, 8.0, 32.0], ids=["random-init head", "head x 8", "head x 32 (peaky outputs)"])
-def test_engine_against_the_hybrid_int8_path(tmp_path, ref, fix, head, mode):
+def test_engine_against_the_hybrid_int8_path(tmp_path, ref, port, english, fix, head, mode):
     from oracle import am_hybrid
     B = 64
     w = synth.synth_weights(0, n_hidden=2048)
@@ -71,14 +73,27 @@ def test_engine_against_the_hybrid_int8_path(tmp_path, ref, fix, head, mode):
     res = ref.decode_batch(want.astype(np.float64), [250] * B, A, 500, os.cpu_count() or 1, S)
     ref_texts = [A.decode(tok).decode("utf-8", "replace") for _, tok in res]
     same = sum(1 for x, y in zip(texts, ref_texts) if x == y)
+    n_tie = 0
+    if mode == "int8":
+        # the acoustic halves agree to the last bits, so a transcript may only differ where the reference DECODER's own choice is
+        # implementation-defined: a (score, character) tie across the beam boundary -- the restatement must show one and agree with the engine
+        labels, space = english
+        P = port.Scorer(os.path.join(fix, "pruned_lm.scorer"))
+        for b in range(B):
+            if texts[b] != ref_texts[b]:
+                d = port.Decoder(labels, space, 500, P)
+                d.next(got[b])
+                r = d.decode(1)[0]
+                assert d.boundary_ties() > 0 and texts[b] == port.decode_text(labels, r[1]).decode(), (b, texts[b], ref_texts[b])
+                n_tie += 1
     # ... and how sure the model is: mean probability of the best class (a random-init head is near-uniform: 1 / 29 = 0.034)
     top = float(got.max(axis=2).mean())
-    line = {"engine_path": mode, "head_scale": head, "max_abs_dp": a_err, "max_abs_dlnp": l_err, "rms_dlnp": rms, "transcripts_equal": same, "of": B, "mean_top_probability": top}
+    line = {"engine_path": mode, "head_scale": head, "max_abs_dp": a_err, "max_abs_dlnp": l_err, "rms_dlnp": rms, "transcripts_equal": same, "differ_at_a_boundary_tie_of_the_search": n_tie, "of": B, "mean_top_probability": top}
     print("hybrid-int8 tolerance:", json.dumps(line))
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, "hybrid_tolerance_%s_head%d.json" % (mode, int(head))), "w") as f:
         json.dump(line, f)
-    assert l_err <= LOG_TOL[mode] * head, line                    # the bound is one on logits: it scales with the output layer
+    assert l_err <= LOG_TOL[mode] * (head if mode == "f16" else 1.0), line      # (f16: a bound on logits, it scales with the output layer)
     if head == 1.0:
         assert a_err <= ABS_TOL[mode], line
     assert same >= MIN_EQUAL[mode][head], line
