@@ -188,6 +188,10 @@ STTX_EXPORT int STTX_DecoderBeam(const STTX_Decoder* aDec, unsigned int aStream,
 STTX_EXPORT int STTX_DecoderStats(const STTX_Decoder* aDec, unsigned long long* aOut4);
 /* Profiling of a standalone decoder (benchmarks/search_micro.py): level 1 = HIP-event time of the search launches, 2 = also the
  * kernel's own phase cycle counters (8, summed over streams) and fine-grained stamps (64).  No equivalent in the reference. */
+/* The OR of the streams' search-state error bits (0 = every stream's state is intact): 0x1 path arena, 0x2 time arena, 0x4 candidates, 0x8 scorer
+ * cache, 0x10 an intra-workgroup wait timed out, 0x20 two prefixes with one path key (stt_amd/csrc/ctc.hip: child_key).  A stream with a
+ * bit set yields no results (STTX_DecoderDecode fails): the reference has no such states (heap trie), a refused result stands in for them. */
+STTX_EXPORT int STTX_DecoderErrorBits(const STTX_Decoder* aDec, int* aBits);
 STTX_EXPORT int STTX_DecoderSetProfiling(STTX_Decoder* aDec, int aLevel);
 STTX_EXPORT int STTX_DecoderGetProfile(const STTX_Decoder* aDec, unsigned long long* aPhase8, unsigned long long* aStamps64, float* aSearchMs);
 STTX_EXPORT void STTX_DecoderFree(STTX_Decoder* aDec);

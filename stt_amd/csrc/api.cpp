@@ -1287,6 +1287,17 @@ int STTX_DecoderStats(const STTX_Decoder* d, unsigned long long* aOut4) {
     return err ? (int)STT_ERR_FAIL_RUN_SESS : (int)STT_ERR_OK;
   }, STT_ERR_FAIL_RUN_SESS);
 }
+int STTX_DecoderErrorBits(const STTX_Decoder* d, int* aBits) {
+  return guarded([&]() {
+    HIP_CHECK(hipSetDevice(d->m->device));
+    std::vector<DecStream> tb(d->db.n_streams);
+    HIP_CHECK(hipMemcpy(tb.data(), d->db.table.p, sizeof(DecStream) * tb.size(), hipMemcpyDeviceToHost));
+    int err = 0;
+    for (auto& S : tb) err |= S.error;
+    *aBits = err;
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
 void STTX_DecoderFree(STTX_Decoder* d) { delete d; }
 
 // ---- kernel-level hooks

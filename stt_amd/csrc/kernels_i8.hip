@@ -65,24 +65,16 @@ __device__ __forceinline__ double em1_neg_(double y, const uint64_t* tab) {     
   const double T = __longlong_as_double((long long)(tab[ki & 31] + (ki << 47)));  // 2^(k/32): the table holds bits(2^(i/32)) - (i << 47)
   return __fma_rn(T, p, WANT_EXP ? T : __dadd_rn(T, -1.0));    // (1 + exp(y) - 1 would cancel for y << 0, exp(y) - 1 computed from exp(y) for y ~ 0)
 }
-// 1 / d for d in [1, 2]: v_rcp_f64 and two Newton steps (relative error ~2e-16; the IEEE division sequence -- v_div_scale x 2, v_div_fmas,
-// v_div_fixup around the same iteration -- buys nothing here: no scaling cases, and the result is rounded to float anyway)
-__device__ __forceinline__ double rcp12_(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  r = __fma_rn(__fma_rn(-d, r, 1.0), r, r);
-  r = __fma_rn(__fma_rn(-d, r, 1.0), r, r);
-  return r;
-}
 __device__ __forceinline__ float sigmoid_i8_(float x, const uint64_t* tab) {
   const double a = fmin(fabs((double)x), 104.0);           // (exp(-104) is below the smallest float)
   const double E = em1_neg_<true>(-a, tab);                // exp(-|x|)
-  const double q = rcp12_(__dadd_rn(1.0, E));              // 1 / (1 + exp(-|x|))
+  const double q = 1.0 / __dadd_rn(1.0, E);                // 1 / (1 + exp(-|x|))
   return (float)(x >= 0.0f ? q : __dmul_rn(E, q));
 }
 __device__ __forceinline__ float tanh_i8_(float x, const uint64_t* tab) {
   const double a = fmin(fabs((double)x), 22.0);
   const double e = em1_neg_<false>(__dmul_rn(-2.0, a), tab);   // exp(-2|x|) - 1
-  const double t = __dmul_rn(-e, rcp12_(__dadd_rn(2.0, e)));   // (1 - exp(-2|x|)) / (1 + exp(-2|x|))
+  const double t = -e / __dadd_rn(2.0, e);                 // (1 - exp(-2|x|)) / (1 + exp(-2|x|))
   return (float)(x < 0.0f ? -t : t);
 }
 __device__ __forceinline__ signed char quant_i8_(float v, float inv) { return (signed char)fminf(fmaxf(roundf(__fmul_rn(v, inv)), -127.0f), 127.0f); }
@@ -114,19 +106,6 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
   // issued now, consumed behind the k-loop: is any row of this step flagged?
   const int myflag = (tid < NTR && tid < B) ? (a.flag[par * NTR + tid] == epoch ? 1 : 0) : 0;
 
-  // The cell update's operands -- the x half of the sums, freshly written by the GEMM, and the cell state -- come from HBM / the Infinity
-  // Cache; read behind the k-loop they cost ~2 us in the open.  Holding them in registers through the loop does not fit (the accumulators
-  // and the operand double buffer have the file), so every line is TOUCHED here, one dword per (row, gate) and lane, and the real loads
-  // behind the loop find them in L2.  (The values are kept live to the end of the loop so that the loads are counted and not sunk.)
-  int pf_x[ITS];
-  float pf_c[ITS];
-#pragma unroll
-  for (int it = 0; it < ITS; ++it) {
-    const int row = min(((tid + 256 * it) >> 6) * 16 + (lane & 15), B - 1), g = lane >> 4;
-    pf_x[it] = (DBG & 4) ? 0 : a.accx[((size_t)a.t * B + row) * (size_t)(4 * H) + (size_t)g * H + wg * 16];
-    pf_c[it] = (DBG & 4) ? 0.f : a.c[(size_t)row * H + wg * 16];
-  }
-  __builtin_amdgcn_sched_barrier(0);
   const i32x4* wp = reinterpret_cast<const i32x4*>(a.whp) + (size_t)wg * KS * 4 * 64 + lane;
   const i32x4* hp = reinterpret_cast<const i32x4*>(a.hq_in) + lane;
   i32x4 acc[4][NT];
@@ -182,9 +161,19 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
 #undef I8_MMA
 #undef I8_FENCE
   if constexpr (PIN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the hazard recogniser does not look inside inline asm
-#pragma unroll
-  for (int it = 0; it < ITS; ++it) asm volatile("" ::"v"(pf_x[it]), "v"(pf_c[it]));
 
+  // The x half of the NEXT step's sums (4 MB per step for 128 rows, written by the GEMM: HBM / Infinity Cache) is touched now, one dword per
+  // (row, gate) and lane: workgroup i of every launch runs on XCD i % 8, so the lines wait in the L2 that step t+1's workgroup i reads them
+  // from, and their latency passes behind this step's reduction and cell update instead of in front of the next one's.
+  int touch[ITS];
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) {
+    touch[it] = 0;
+    if (a.t + 1 < a.T && !(DBG & 4)) {
+      const int row = min(((tid + 256 * it) >> 6) * 16 + (lane & 15), B - 1);
+      touch[it] = a.accx[((size_t)(a.t + 1) * B + row) * (size_t)(4 * H) + (size_t)(lane >> 4) * H + wg * 16];
+    }
+  }
   // ---- operands of the cell update: in flight while the partial sums meet in LDS
   // slot s = tid + 256 * it: batch tile j = s >> 6, lane-slot ls = s & 63 = (unit group, row of the tile) in the MFMA output layout:
   // this thread ends up with all four gates of units wg*16 + 4*ug .. +3 of batch row j*16 + (ls & 15)
@@ -337,6 +326,8 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
       }
     }
   }
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) asm volatile("" ::"v"(touch[it]));   // (the touches are loads whose values nobody needs: keep them from being dropped)
 }
 
 template <int NT>

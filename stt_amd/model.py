@@ -568,6 +568,13 @@ class Decoder(object):
         status = native.lib().STTX_DecoderStats(self._impl, st)
         return dict(steps=st[0], candidates=st[1], lm_queries=st[2], lm_probes=st[3], error=status)
 
+    def error_bits(self):
+        """OR of the streams' search-state error bits (include/stt_amd.h: STTX_DecoderErrorBits); 0 = intact."""
+        b = C.c_int(0)
+        if native.lib().STTX_DecoderErrorBits(self._impl, C.byref(b)) != 0:
+            raise RuntimeError("STTX_DecoderErrorBits failed")
+        return int(b.value)
+
     def close(self):
         if self._impl:
             native.lib().STTX_DecoderFree(self._impl)

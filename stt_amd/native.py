@@ -50,7 +50,7 @@ STT_AMD_H = [
     "STTX_SpeechToTextBatchDevice", "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmit", "STTX_BatchSubmitDevice", "STTX_BatchCollect", "STTX_BatchCollectWithMetadata", "STTX_BatchCollectScored", "STTX_DebugBatchProbs", "STTX_SetTuning", "STTX_GetTuning", "STTX_ConfigureRuntime", "STTX_TestLstmSteps", "STTX_TestDenseHybrid", "STTX_GetAcousticMode", "STTX_TestHybridChain", "STTX_FeedAudioContentBatch", "STTX_FeedAudioContentBatchEx", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_DecodeStreamsBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
     "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_GetDecoderStamps", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
-    "STTX_DecoderStats", "STTX_DecoderSetProfiling", "STTX_DecoderGetProfile", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
+    "STTX_DecoderStats", "STTX_DecoderErrorBits", "STTX_DecoderSetProfiling", "STTX_DecoderGetProfile", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
     "STTX_InspectModel", "STTX_ReadModelTensor", "STTX_TestLm", "STTX_TestDictionaryWalk", "STTX_DebugLimitArena", "STTX_FleetCreate", "STTX_FleetSize",
     "STTX_FleetEnableExternalScorer", "STTX_FleetSetBeamWidth", "STTX_FleetSpeechToTextBatch", "STTX_FleetFree", "STTX_ShardUtterances", "STTX_TestFleetRecords", "STTX_DebugFleetFailShard",
 ]
@@ -141,6 +141,7 @@ def lib():
         "STTX_DecoderDecode": (ci, [vp, cu, cu, vp, vp, vp, vp, vp]),
         "STTX_DecoderBeam": (ci, [vp, cu, vp, vp, vp, vp, cu]),
         "STTX_DecoderStats": (ci, [vp, pp(C.c_ulonglong)]),
+        "STTX_DecoderErrorBits": (ci, [vp, pp(ci)]),
         "STTX_TestDictionaryWalk": (ci, [vp, cu, ci, vp, cu, cu, vp]),
         "STTX_DecoderSetProfiling": (ci, [vp, ci]),
         "STTX_DecoderGetProfile": (ci, [vp, pp(C.c_ulonglong), pp(C.c_ulonglong), pp(cf)]),

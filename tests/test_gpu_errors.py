@@ -106,7 +106,7 @@ def test_two_prefixes_with_one_path_key_are_flagged_not_merged(tmp_path, fix):
         try:
             d2 = m.createDecoder(1, 200)
             d2.next(x)
-            assert d2.stats()["error"] & 0x20, hex(d2.stats()["error"])
+            assert d2.error_bits() & 0x20, hex(d2.error_bits())
             with pytest.raises(RuntimeError):
                 d2.decode(1)
         finally:
