@@ -177,7 +177,13 @@ def cpu_baseline_reference_decoder(cx, wl, scorer_path=None):
                 d = port.Decoder(labels, space, beam, PS)
                 d.next(p)
                 r = d.decode(1)
-                return (d.boundary_ties(), A.decode(r[0][1]).decode("utf-8", "replace") if r else "", float(r[0][0]) if r else 0.0)
+                # ... and the restatement in the REFERENCE'S OWN order (pointer trie, libstdc++'s nth_element / partial_sort restated: stt_port.c
+                # Part D): it must reproduce what the reference printed for this utterance -- the difference is then exactly the order effect
+                o = port.Decoder(labels, space, beam, PS, reference_order=True)
+                o.next(p)
+                ro = o.decode(1)
+                return (d.boundary_ties(), A.decode(r[0][1]).decode("utf-8", "replace") if r else "", float(r[0][0]) if r else 0.0,
+                        A.decode(ro[0][1]).decode("utf-8", "replace") if ro else "", float(ro[0][0]) if ro else 0.0)
             if PS is None:
                 return [None] * len(plist)
             with ThreadPoolExecutor(max_workers=max(1, min(len(plist), cores))) as ex:
@@ -212,14 +218,16 @@ def cpu_baseline_reference_decoder(cx, wl, scorer_path=None):
 def judge_against_reference(items, tie_of):
     """The rule every workload's check goes through (pure: tests/test_host_logic.py feeds it forged mismatches).
     items: [{"id", "got_text", "got_conf" (or None), "want_text", "want_conf" (or None), "against"}], one per timed utterance that was checked;
-    tie_of: {id: (boundary-tie steps, restatement text, restatement confidence)} for the ids that differ (None where unknown).
+    tie_of: {id: (boundary-tie steps, restatement text, restatement confidence[, reference-order restatement text, confidence])} for the ids
+    that differ (None where unknown).
     An utterance that differs from the reference is acceptable in exactly one case: at some step of ITS search a tie of (score, character)
     straddled the beam boundary -- two equally scored prefixes, one place.  The reference keeps whichever libstdc++'s nth_element leaves in
     front (unspecified by the standard); the kernels and the oracle's C restatement keep (live before new, beam index), the deviation
     DESIGN.md section 2 documents.  The restatement counts those steps: a differing utterance must show at least one AND the timed output
-    must equal the restatement's.  Anything else is a real mismatch.
+    must equal the restatement's -- and, where the reference-order restatement ran (stt_port.c Part D: the reference's trie order and
+    libstdc++'s selection restated), THAT one must print exactly what the reference printed.  Anything else is a real mismatch.
     -> (ok, counts, first mismatches)"""
-    n_diff = n_tie = 0
+    n_diff = n_tie = n_repro = 0
     mismatches = []
     for it in items:
         bad_t = it["got_text"] != it["want_text"]
@@ -229,14 +237,17 @@ def judge_against_reference(items, tie_of):
         n_diff += 1
         tr = tie_of.get(it["id"]) if (tie_of and it.get("against") == "reference") else None
         equals_port = bool(tr and tr[1] == it["got_text"] and (it.get("got_conf") is None or tr[2] == it["got_conf"]))
-        explained = bool(tr and tr[0] > 0 and equals_port)
+        reproduced = None if (not tr or len(tr) < 5) else bool(tr[3] == it["want_text"] and (it.get("want_conf") is None or tr[4] == it["want_conf"]))
+        explained = bool(tr and tr[0] > 0 and equals_port and reproduced is not False)
         n_tie += 1 if explained else 0
+        n_repro += 1 if (explained and reproduced) else 0
         if len(mismatches) < 6:
             mismatches.append({"id": it["id"], "against": it.get("against"), "got": it["got_text"], "want": it["want_text"], "got_confidence": it.get("got_conf"),
                                "want_confidence": it.get("want_conf"), "boundary_tie_steps": tr[0] if tr else None, "equals_the_restatement": equals_port,
-                               "explained_by_a_boundary_tie": explained})
+                               "reference_reproduced_by_the_reference_order_restatement": reproduced, "explained_by_a_boundary_tie": explained})
     counts = {"timed_utterances_checked": len(items), "equal": len(items) - n_diff,
-              "differ_with_a_boundary_tie_and_equal_to_the_restatement": n_tie, "unexplained": n_diff - n_tie}
+              "differ_with_a_boundary_tie_and_equal_to_the_restatement": n_tie, "of_those_the_reference_reproduced_in_reference_order": n_repro,
+              "unexplained": n_diff - n_tie}
     return n_diff == n_tie, counts, mismatches
 
 

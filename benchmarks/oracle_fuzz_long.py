@@ -37,6 +37,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=20)
     ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--reference-order", action="store_true", help="the pointer-trie restatement with libstdc++'s nth_element / partial_sort restated (stt_port.c, Part D): every case must EQUAL the reference, tie cases included")
     ap.add_argument("--one-seed", type=int, default=-1, help="(child) run this seed only")
     ap.add_argument("--show-case", type=int, default=-1, help="(child) with --one-seed: print both decoders' results of this case")
     ap.add_argument("--only-case", type=int, default=-1, help="(child) with --one-seed: decode this case with the restatement only (does IT survive?)")
@@ -68,6 +69,8 @@ def main():
     rigs["cp"] = (labels, space, A, port.Scorer(pkg), ref.Scorer(pkg, A))
     t0 = time.time()
     tot = dict(cases=0, equal=0, differ_with_boundary_tie=0, differ_in_the_order_of_equal_scores=0, unexplained=0)
+    if a.reference_order:
+        tot = dict(cases=0, equal=0, equal_and_the_flat_restatement_differs=0, equal_with_a_boundary_tie=0, unexplained=0)
     bad = []
     for seed in [a.one_seed]:
         rng = np.random.RandomState(9000 + seed)
@@ -96,7 +99,8 @@ def main():
             if a.only_case >= 0 and case != a.only_case:
                 continue
             print("case %d" % case, file=sys.stderr, flush=True)
-            o = port.Decoder(labels, space, beam, P if lm else None, cp, ctn, hot or None)
+            o = port.Decoder(labels, space, beam, P if lm else None, cp, ctn, hot or None, reference_order=a.reference_order)
+            flat = port.Decoder(labels, space, beam, P if lm else None, cp, ctn, hot or None) if a.reference_order else None
             if a.only_case >= 0:
                 for k in range(0, T, chunk):
                     o.next(p[k:k + chunk])
@@ -105,17 +109,27 @@ def main():
             r = ref.Decoder(A, beam, S if lm else None, cp, ctn, hot or None)
             for k in range(0, T, chunk):
                 o.next(p[k:k + chunk]); r.next(p[k:k + chunk])
+                if flat is not None:
+                    flat.next(p[k:k + chunk])
             tot["cases"] += 1
             if a.show_case == case:
                 ra, rb = o.decode(n), r.decode(n)
-                print(mode, "lm", lm, "beam", beam, "T", T, "cutoff", cp, ctn, "chunk", chunk, "n", n, "boundary ties", o.boundary_ties())
+                print(mode, "lm", lm, "beam", beam, "T", T, "cutoff", cp, ctn, "chunk", chunk, "n", n, "boundary ties", (flat or o).boundary_ties())
                 for i in range(max(len(ra), len(rb))):
                     for nm, rr in (("port", ra), ("ref ", rb)):
                         print(i, nm, (rr[i][0], [int(x) for x in rr[i][1]], [int(x) for x in rr[i][2]]) if i < len(rr) else None)
                 np.save("/tmp/fuzz_case_emissions.npy", p)
                 return 0
             ca, cb = canon(o.decode(n)), canon(r.decode(n))
-            if ca == cb:
+            if a.reference_order:
+                if ca == cb:
+                    tot["equal"] += 1
+                    tot["equal_and_the_flat_restatement_differs"] += 1 if canon(flat.decode(n)) != cb else 0
+                    tot["equal_with_a_boundary_tie"] += 1 if flat.boundary_ties() > 0 else 0
+                else:
+                    tot["unexplained"] += 1
+                    bad.append((seed, case, mode, lm, beam, T, cp, ctn, hot, chunk, n))
+            elif ca == cb:
                 tot["equal"] += 1
             elif o.boundary_ties() > 0:
                 tot["differ_with_boundary_tie"] += 1
@@ -135,11 +149,12 @@ def parent(a):
     t0 = time.time()
     tot, bad, ref_crashes = {}, [], []
     for seed in range(a.seeds):
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-seed", str(seed), "--cases", str(a.cases)], capture_output=True, text=True)
+        extra = ["--reference-order"] if a.reference_order else []
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-seed", str(seed), "--cases", str(a.cases)] + extra, capture_output=True, text=True)
         last = [l for l in r.stderr.splitlines() if l.startswith("case ")]
         if r.returncode != 0:
             case = int(last[-1].split()[1]) if last else -1
-            alone = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-seed", str(seed), "--cases", str(a.cases), "--only-case", str(case)], capture_output=True, text=True)
+            alone = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-seed", str(seed), "--cases", str(a.cases), "--only-case", str(case)] + extra, capture_output=True, text=True)
             ref_crashes.append({"seed": 9000 + seed, "case": case, "child_rc": r.returncode, "restatement_alone_rc": alone.returncode})
             print(json.dumps({"seed": 9000 + seed, "died_in_case": case, "restatement_alone_rc": alone.returncode, "elapsed_s": round(time.time() - t0, 1)}), flush=True)
             continue

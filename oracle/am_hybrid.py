@@ -67,7 +67,7 @@ def fully_connected_hybrid(x, wq, wscale, bias, wq_f64_t=None):
 # (reference/logistic.h, reference/tanh.h), the optimised ones Eigen's rational approximations -- each within an ulp or two of the correctly
 # rounded float of the real function.  That value is what this restatement takes: float64 evaluation, one rounding to float32.  (numpy's own
 # float32 exp / tanh are SIMD approximations 1-3 ulp off: not a better stand-in for TFLite than the correctly rounded value, and the
-# quantised recurrence amplifies last-bit differences -- tests/test_gpu_hybrid.py.)  oracle/cr_activations_check.c pins the float64
+# quantised recurrence amplifies last-bit differences -- tests/test_gpu_hybrid.py.)  oracle/checks/cr_activations_check.c pins the float64
 # algorithm the engine uses for them against this definition.
 def _sigmoid(x):
     return (1.0 / (1.0 + np.exp(-np.asarray(x, dtype=np.float64)))).astype(F32)

@@ -1,4 +1,4 @@
-/* oracle/cr_activations_check.c -- TEST INFRASTRUCTURE ONLY.
+/* oracle/checks/cr_activations_check.c -- TEST INFRASTRUCTURE ONLY.
  *
  * The float64 algorithm the int8 recurrent step uses for LOGISTIC and TANH (stt_amd/csrc/kernels_i8.hip: em1_neg_, sigmoid_i8_, tanh_i8_),
  * restated in plain C, against the DEFINITION oracle/am_hybrid.py uses for them: the float64 evaluation of 1 / (1 + exp(-x)) and tanh(x),

@@ -141,31 +141,44 @@ class Scorer:
 
 
 class Decoder:
-    def __init__(self, labels, space, beam, scorer=None, cutoff_prob=1.0, cutoff_top_n=40, hot_words=None):
+    """reference_order=False: the flat restatement the kernels share their tie rule with (ties of (score, character) broken by live before new,
+    beam index).  reference_order=True: the pointer-trie restatement with libstdc++'s nth_element / partial_sort restated (stt_port.c, Part D):
+    the compiled reference's output including the tie cases."""
+
+    def __init__(self, labels, space, beam, scorer=None, cutoff_prob=1.0, cutoff_top_n=40, hot_words=None, reference_order=False):
         self.labels = labels
+        self._t = bool(reference_order)
         self.C = len(labels) + 1
         self._bytes = np.frombuffer(b"".join(labels) + b"\0", dtype=np.uint8).copy()
         self._off = np.cumsum([len(l) for l in labels]).astype(np.int32)
         hot_words = hot_words or {}
         words = list(hot_words.keys())
         boosts = (C.c_float * max(1, len(words)))(*[hot_words[w] for w in words])
-        self.h = lib().port_decoder_new(self.C, space, beam, cutoff_prob, cutoff_top_n, scorer.h if scorer else None,
-                                        self._bytes.ctypes.data, self._off.ctypes.data, _cstrs(words), boosts, len(words))
+        L = lib()
+        if self._t:
+            L.port_tdecoder_new.restype = C.c_void_p
+            L.port_tdecoder_new.argtypes = L.port_decoder_new.argtypes
+            L.port_tdecoder_next.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+            L.port_tdecoder_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            L.port_tdecoder_free.argtypes = [C.c_void_p]
+        new = L.port_tdecoder_new if self._t else L.port_decoder_new
+        self.h = new(self.C, space, beam, cutoff_prob, cutoff_top_n, scorer.h if scorer else None,
+                     self._bytes.ctypes.data, self._off.ctypes.data, _cstrs(words), boosts, len(words))
         self.beam = beam
         self._keep = scorer
 
     def next(self, probs):
         p = np.ascontiguousarray(probs, dtype=np.float64)
         assert p.ndim == 2 and p.shape[1] == self.C
-        lib().port_decoder_next(self.h, p.ctypes.data, p.shape[0], p.shape[1])
+        (lib().port_tdecoder_next if self._t else lib().port_decoder_next)(self.h, p.ctypes.data, p.shape[0], p.shape[1])
 
     def decode(self, num_results=1, max_len=4096):
         tok = np.zeros((num_results, max_len), dtype=np.uint32)
         ts = np.zeros((num_results, max_len), dtype=np.uint32)
         lens = np.zeros(num_results, dtype=np.int32)
         conf = np.zeros(num_results, dtype=np.float64)
-        n = lib().port_decoder_decode(self.h, num_results, tok.ctypes.data, ts.ctypes.data, lens.ctypes.data,
-                                      conf.ctypes.data, max_len)
+        n = (lib().port_tdecoder_decode if self._t else lib().port_decoder_decode)(self.h, num_results, tok.ctypes.data, ts.ctypes.data, lens.ctypes.data,
+                                                                                   conf.ctypes.data, max_len)
         if n < 0:
             raise RuntimeError("result longer than max_len")
         return [(conf[i], tok[i, :lens[i]].copy(), ts[i, :lens[i]].copy()) for i in range(n)]
@@ -174,8 +187,9 @@ class Decoder:
         cap = self.beam + 8
         sc = np.zeros(cap, np.float32); pb = np.zeros(cap, np.float32); pnb = np.zeros(cap, np.float32)
         ch = np.zeros(cap, np.int32); ln = np.zeros(cap, np.int32)
-        n = lib().port_decoder_beam(self.h, sc.ctypes.data, pb.ctypes.data, pnb.ctypes.data, ch.ctypes.data,
-                                    ln.ctypes.data, cap)
+        f = lib().port_tdecoder_beam if self._t else lib().port_decoder_beam
+        f.argtypes = [C.c_void_p] * 6 + [C.c_int]
+        n = f(self.h, sc.ctypes.data, pb.ctypes.data, pnb.ctypes.data, ch.ctypes.data, ln.ctypes.data, cap)
         return sc[:n], pb[:n], pnb[:n], ch[:n], ln[:n]
 
     def boundary_ties(self):
@@ -192,7 +206,7 @@ class Decoder:
 
     def close(self):
         if self.h:
-            lib().port_decoder_free(self.h)
+            (lib().port_tdecoder_free if self._t else lib().port_decoder_free)(self.h)
             self.h = None
 
     def __del__(self):

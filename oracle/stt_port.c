@@ -887,3 +887,413 @@ float port_expf(float x) { return gf_expf(x); }
 float port_logf(float x) { return gf_logf(x); }
 void port_expf_array(const float* in, float* out, long n) { for (long i = 0; i < n; ++i) out[i] = gf_expf(in[i]); }
 void port_logf_array(const float* in, float* out, long n) { for (long i = 0; i < n; ++i) out[i] = gf_logf(in[i]); }
+
+/* ============================================================================================
+ * Part D. The same decoder in the REFERENCE'S OWN ORDER (round 5).
+ *
+ * Where two prefixes compare equal under prefix_compare (same float score, same last character) the reference's result depends on
+ * orders the C++ standard leaves open: the order in which PathTrie::iterate_to_vec (path_trie.cpp:159-190) emits the trie -- children
+ * before their parent, children in the order get_path_trie (path_trie.cpp:37-100) appended them, positions kept across remove()'s
+ * erase (path_trie.cpp:192-209) --, what libstdc++'s std::nth_element (introselect) does to that sequence
+ * (ctc_beam_search_decoder.cpp:264), and what std::partial_sort (heap select + sort_heap) does to the survivors at the start of the
+ * next step (:138) and in decode() (:305).  The flat decoder above replaces all of that by one documented total order; this one keeps
+ * the pointer trie and restates the three libstdc++ algorithms (GCC 11's bits/stl_algo.h / stl_heap.h, from their published
+ * description: median-of-three to the front, unguarded Hoare partition, depth limit 2 * lg(n) with heap-select fallback, insertion
+ * sort at <= 3 elements; make_heap / adjust_heap / push_heap with the hole technique), so that its output can be compared with the
+ * compiled reference INCLUDING the tie cases: tests/test_oracle_port.py, benchmarks/oracle_fuzz_long.py --reference-order.
+ * Everything else (scoring, dictionary, timesteps, arithmetic) is shared with the flat decoder.
+ * ==========================================================================================*/
+typedef struct TNode {
+  struct TNode* parent;
+  uint32_t ch;                 /* 0xFFFFFFFF = root */
+  int exists;
+  float b_prev, nb_prev, b_cur, nb_cur, score;
+  int fst;
+  uint32_t pa;                 /* path-arena node (tokens, n-gram reconstruction: shared helpers) */
+  uint32_t ts;                 /* time-arena entry = `timesteps`; 0xFFFFFFFF = nullptr */
+  int pend; uint32_t pend_from, new_t;   /* previous_timesteps / new_timestep (pend = previous_timesteps != nullptr) */
+  struct TNode** kids; int nk, capk;
+  float ext;                   /* decode(): scores[prefix] */
+} TNode;
+
+typedef struct {
+  PortDecoder* d;              /* scorer, alphabet, arenas, parameters (its own beam stays at the root and is not used) */
+  TNode* root;
+  TNode** pre; int np, capp;   /* prefixes_ */
+} PortTrieDecoder;
+
+static TNode* tnode_new(TNode* parent, uint32_t ch) {
+  TNode* t = (TNode*)calloc(1, sizeof(TNode));
+  t->parent = parent; t->ch = ch; t->exists = 1;
+  t->b_prev = t->nb_prev = t->b_cur = t->nb_cur = t->score = NEG_INF;
+  t->ts = 0xFFFFFFFFu;
+  return t;
+}
+static void tnode_free_rec(TNode* t) { for (int i = 0; i < t->nk; ++i) tnode_free_rec(t->kids[i]); free(t->kids); free(t); }
+
+/* prefix_compare, decoder_utils.cpp:66-76 */
+static inline int tcmp(const TNode* x, const TNode* y) {
+  if (x->score == y->score) { if (x->ch == y->ch) return 0; return x->ch < y->ch; }   /* `character` is unsigned (path_trie.h:93): the root, ROOT_ = -1, sorts last */
+  return x->score > y->score;
+}
+/* prefix_compare_external, decoder_utils.cpp:78-88 */
+static inline int tcmp_ext(const TNode* x, const TNode* y) {
+  if (x->ext == y->ext) { if (x->ch == y->ch) return 0; return x->ch < y->ch; }
+  return x->ext > y->ext;
+}
+typedef int (*tcmp_fn)(const TNode*, const TNode*);
+
+/* ---- libstdc++ heap primitives on TNode* sequences (stl_heap.h) */
+static void ls_push_heap(TNode** first, long hole, long top, TNode* value, tcmp_fn comp) {
+  long parent = (hole - 1) / 2;
+  while (hole > top && comp(first[parent], value)) { first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2; }
+  first[hole] = value;
+}
+static void ls_adjust_heap(TNode** first, long hole, long len, TNode* value, tcmp_fn comp) {
+  const long top = hole;
+  long second = hole;
+  while (second < (len - 1) / 2) {
+    second = 2 * (second + 1);
+    if (comp(first[second], first[second - 1])) second--;
+    first[hole] = first[second];
+    hole = second;
+  }
+  if ((len & 1) == 0 && second == (len - 2) / 2) {
+    second = 2 * (second + 1);
+    first[hole] = first[second - 1];
+    hole = second - 1;
+  }
+  ls_push_heap(first, hole, top, value, comp);
+}
+static void ls_make_heap(TNode** first, long len, tcmp_fn comp) {
+  if (len < 2) return;
+  long parent = (len - 2) / 2;
+  for (;;) {
+    TNode* v = first[parent];
+    ls_adjust_heap(first, parent, len, v, comp);
+    if (parent == 0) return;
+    parent--;
+  }
+}
+/* __pop_heap(first, last, result): the value at `result` goes through the heap [first, last), the old top lands at `result` */
+static void ls_pop_heap(TNode** first, long last, TNode** result, tcmp_fn comp) {
+  TNode* v = *result;
+  *result = first[0];
+  ls_adjust_heap(first, 0, last, v, comp);
+}
+static void ls_heap_select(TNode** first, long middle, long last, tcmp_fn comp) {
+  ls_make_heap(first, middle, comp);
+  for (long i = middle; i < last; ++i)
+    if (comp(first[i], first[0])) ls_pop_heap(first, middle, &first[i], comp);
+}
+static void ls_sort_heap(TNode** first, long last, tcmp_fn comp) {
+  while (last > 1) { --last; ls_pop_heap(first, last, &first[last], comp); }
+}
+static void ls_partial_sort(TNode** first, long middle, long last, tcmp_fn comp) {
+  if (middle == 0) return;                       /* (std::partial_sort with first == middle does nothing) */
+  ls_heap_select(first, middle, last, comp);
+  ls_sort_heap(first, middle, comp);
+}
+/* ---- std::nth_element (stl_algo.h: __introselect) */
+static inline void ls_swap(TNode** a, TNode** b) { TNode* t = *a; *a = *b; *b = t; }
+static void ls_move_median_to_first(TNode** result, TNode** a, TNode** b, TNode** c, tcmp_fn comp) {
+  if (comp(*a, *b)) {
+    if (comp(*b, *c)) ls_swap(result, b);
+    else if (comp(*a, *c)) ls_swap(result, c);
+    else ls_swap(result, a);
+  } else if (comp(*a, *c)) ls_swap(result, a);
+  else if (comp(*b, *c)) ls_swap(result, c);
+  else ls_swap(result, b);
+}
+static TNode** ls_unguarded_partition(TNode** first, TNode** last, TNode** pivot, tcmp_fn comp) {
+  for (;;) {
+    while (comp(*first, *pivot)) ++first;
+    --last;
+    while (comp(*pivot, *last)) --last;
+    if (!(first < last)) return first;
+    ls_swap(first, last);
+    ++first;
+  }
+}
+static void ls_insertion_sort(TNode** first, TNode** last, tcmp_fn comp) {
+  if (first == last) return;
+  for (TNode** i = first + 1; i != last; ++i) {
+    if (comp(*i, *first)) {
+      TNode* v = *i;
+      memmove(first + 1, first, (size_t)(i - first) * sizeof(TNode*));
+      *first = v;
+    } else {
+      TNode* v = *i; TNode** lastp = i; TNode** next = i - 1;
+      while (comp(v, *next)) { *lastp = *next; lastp = next; --next; }
+      *lastp = v;
+    }
+  }
+}
+static int ls_lg(long n) { int k = 0; while (n > 1) { n >>= 1; ++k; } return k; }
+static void ls_nth_element(TNode** base, long nth, long n, tcmp_fn comp) {
+  TNode** first = base; TNode** last = base + n; TNode** nthp = base + nth;
+  if (first == last || nthp == last) return;
+  long depth = 2L * ls_lg(n);
+  while (last - first > 3) {
+    if (depth == 0) {
+      ls_heap_select(first, (nthp + 1) - first, last - first, comp);
+      ls_swap(first, nthp);
+      return;
+    }
+    --depth;
+    TNode** mid = first + (last - first) / 2;
+    ls_move_median_to_first(first, first + 1, mid, last - 1, comp);
+    TNode** cut = ls_unguarded_partition(first + 1, last, first, comp);
+    if (cut <= nthp) first = cut; else last = cut;
+  }
+  ls_insertion_sort(first, last, comp);
+}
+/* ---- std::sort on (class, probability) pairs by probability descending (get_pruned_emissions, :338-339): introsort + final insertion sort */
+typedef struct { int cls; float p; } ClsP;
+static inline int cp_before(const ClsP* a, const ClsP* b) { return a->p > b->p; }
+static void cp_swap(ClsP* a, ClsP* b) { ClsP t = *a; *a = *b; *b = t; }
+static void cp_adjust_heap(ClsP* first, long hole, long len, ClsP value) {
+  const long top = hole; long second = hole;
+  while (second < (len - 1) / 2) { second = 2 * (second + 1); if (cp_before(&first[second], &first[second - 1])) second--; first[hole] = first[second]; hole = second; }
+  if ((len & 1) == 0 && second == (len - 2) / 2) { second = 2 * (second + 1); first[hole] = first[second - 1]; hole = second - 1; }
+  long parent = (hole - 1) / 2;
+  while (hole > top && cp_before(&first[parent], &value)) { first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2; }
+  first[hole] = value;
+}
+static void cp_heap_sort_all(ClsP* first, long len) {      /* __partial_sort(first, last, last) = make_heap + sort_heap over the whole range */
+  if (len >= 2) for (long parent = (len - 2) / 2;; --parent) { cp_adjust_heap(first, parent, len, first[parent]); if (parent == 0) break; }
+  for (long last = len; last > 1;) { --last; ClsP v = first[last]; first[last] = first[0]; cp_adjust_heap(first, 0, last, v); }
+}
+static void cp_introsort_loop(ClsP* first, ClsP* last, long depth) {
+  while (last - first > 16) {
+    if (depth == 0) { cp_heap_sort_all(first, last - first); return; }
+    --depth;
+    ClsP* mid = first + (last - first) / 2;
+    ClsP *a = first + 1, *b = mid, *c = last - 1;
+    if (cp_before(a, b)) { if (cp_before(b, c)) cp_swap(first, b); else if (cp_before(a, c)) cp_swap(first, c); else cp_swap(first, a); }
+    else if (cp_before(a, c)) cp_swap(first, a); else if (cp_before(b, c)) cp_swap(first, c); else cp_swap(first, b);
+    ClsP *lo = first + 1, *hi = last;
+    for (;;) { while (cp_before(lo, first)) ++lo; --hi; while (cp_before(first, hi)) --hi; if (!(lo < hi)) break; cp_swap(lo, hi); ++lo; }
+    cp_introsort_loop(lo, last, depth);
+    last = lo;
+  }
+}
+static void cp_insertion(ClsP* first, ClsP* last, int guarded) {
+  for (ClsP* i = first + (guarded ? 1 : 0); i < last; ++i) {
+    if (guarded && cp_before(i, first)) { ClsP v = *i; memmove(first + 1, first, (size_t)(i - first) * sizeof(ClsP)); *first = v; }
+    else { ClsP v = *i; ClsP* lastp = i; ClsP* next = i - 1; while (cp_before(&v, next)) { *lastp = *next; lastp = next; --next; } *lastp = v; }
+  }
+}
+static void cp_std_sort(ClsP* first, long n) {
+  if (n < 2) return;
+  cp_introsort_loop(first, first + n, 2L * ls_lg(n));
+  if (n > 16) { cp_insertion(first, first + 16, 1); cp_insertion(first + 16, first + n, 0); }     /* __final_insertion_sort: guarded head, unguarded tail */
+  else cp_insertion(first, first + n, 1);
+}
+
+PortTrieDecoder* port_tdecoder_new(int C, int space_id, int beam, double cutoff_prob, int cutoff_top_n, PortScorer* sc,
+                                   const uint8_t* label_bytes, const int* label_off, const char** hot_words, const float* boosts, int n_hot) {
+  PortTrieDecoder* t = (PortTrieDecoder*)calloc(1, sizeof(PortTrieDecoder));
+  t->d = port_decoder_new(C, space_id, beam, cutoff_prob, cutoff_top_n, sc, label_bytes, label_off, hot_words, boosts, n_hot);
+  t->root = tnode_new(NULL, 0xFFFFFFFFu);
+  t->root->score = 0.0f; t->root->b_prev = 0.0f;            /* ctc_beam_search_decoder.cpp:43-46 */
+  t->root->pa = 0; t->root->ts = 0;                         /* arena node 0 = root, time entry 0 = timestep_tree_root_ */
+  t->root->fst = sc ? (int)sc->fst_start : 0;
+  t->capp = 4 * beam + 64; t->pre = (TNode**)malloc(sizeof(TNode*) * t->capp);
+  t->pre[0] = t->root; t->np = 1;
+  return t;
+}
+void port_tdecoder_free(PortTrieDecoder* t) {
+  if (!t) return;
+  tnode_free_rec(t->root); free(t->pre); port_decoder_free(t->d); free(t);
+}
+
+/* PathTrie::remove, path_trie.cpp:192-209 */
+static void tnode_remove(TNode* x) {
+  x->exists = 0;
+  if (x->nk == 0) {
+    TNode* p = x->parent;
+    for (int i = 0; i < p->nk; ++i)
+      if (p->kids[i]->ch == x->ch) { memmove(&p->kids[i], &p->kids[i + 1], (size_t)(p->nk - i - 1) * sizeof(TNode*)); p->nk--; break; }
+    if (p->nk == 0 && !p->exists) tnode_remove(p);
+    free(x->kids); free(x);
+  }
+}
+/* PathTrie::iterate_to_vec, path_trie.cpp:159-190 */
+static void tnode_iterate(PortTrieDecoder* t, TNode* x) {
+  for (int i = 0; i < x->nk; ++i) tnode_iterate(t, x->kids[i]);
+  if (x->exists) {
+    x->b_prev = x->b_cur; x->nb_prev = x->nb_cur;
+    x->b_cur = NEG_INF; x->nb_cur = NEG_INF;
+    x->score = gf_log_sum_exp(x->b_prev, x->nb_prev);
+    if (x->pend) x->ts = ta_push(t->d, x->pend_from, x->new_t);     /* (the reference reuses an equal child of the time tree: same history either way) */
+    x->pend = 0;
+    if (t->np == t->capp) { t->capp *= 2; t->pre = (TNode**)realloc(t->pre, sizeof(TNode*) * t->capp); }
+    t->pre[t->np++] = x;
+  }
+}
+
+static int utf8_boundary_new(const PortDecoder* d, const TNode* prefix, uint32_t c) {   /* is_scoring_boundary(prefix_new, c), utf8 mode (as in step()) */
+  uint8_t fb = label_first_byte(d, c);
+  if ((fb & 0xC0) != 0x80) {
+    uint8_t first_byte = (uint8_t)((uint8_t)c + 1);
+    int needed = ((first_byte >> 3) == 0x1E) ? 4 : ((first_byte >> 4) == 0x0E) ? 3 : ((first_byte >> 5) == 0x06) ? 2 : ((first_byte >> 7) == 0) ? 1 : -1;
+    return needed == 1;
+  }
+  if (prefix->ch == 0xFFFFFFFFu) return 0;
+  int dist = 1; uint8_t first_byte = 0; int found = 0; uint32_t cur = prefix->pa;
+  for (;;) {
+    uint32_t cc = d->pa_ch[cur];
+    if ((label_first_byte(d, cc) & 0xC0) != 0x80) { first_byte = (uint8_t)((uint8_t)cc + 1); dist += 1; found = 1; break; }
+    uint32_t par = d->pa_parent[cur];
+    if (par != 0xFFFFFFFFu && d->pa_ch[par] != 0xFFFFFFFFu) { dist += 1; cur = par; continue; }
+    break;
+  }
+  if (!found) return 0;
+  int needed = ((first_byte >> 3) == 0x1E) ? 4 : ((first_byte >> 4) == 0x0E) ? 3 : ((first_byte >> 5) == 0x06) ? 2 : ((first_byte >> 7) == 0) ? 1 : -1;
+  return dist == needed;
+}
+
+/* One timestep of DecoderState::next, ctc_beam_search_decoder.cpp:118-275, on the trie */
+static void tstep(PortTrieDecoder* t, const double* prob) {
+  PortDecoder* d = t->d;
+  const int C = d->C; const long beam = d->beam;
+  if (prob[d->blank] < 0.999) d->start_expanding = 1;
+  if (!d->start_expanding) { d->abs_t++; return; }
+  float min_cutoff = NEG_INF; int full_beam = 0;
+  if (d->sc) {
+    long num = t->np < beam ? t->np : beam;
+    ls_partial_sort(t->pre, num, t->np, tcmp);
+    min_cutoff = (float)((double)t->pre[num - 1]->score + log(prob[d->blank]) - fmax(0.0, d->sc->beta));
+    full_beam = (num == beam);
+  }
+  ClsP* pc = (ClsP*)malloc(sizeof(ClsP) * C);
+  for (int i = 0; i < C; ++i) { pc[i].cls = i; pc[i].p = (float)prob[i]; }
+  int cutoff_len = C;
+  if (d->cutoff_prob < 1.0 || d->cutoff_top_n < cutoff_len) {
+    cp_std_sort(pc, C);
+    if (d->cutoff_prob < 1.0) {
+      double cum = 0.0; cutoff_len = 0;
+      for (int i = 0; i < C; ++i) { cum += pc[i].p; cutoff_len += 1; if (cum >= d->cutoff_prob || cutoff_len >= d->cutoff_top_n) break; }
+    }
+  }
+  for (int k = 0; k < cutoff_len; ++k) {
+    const uint32_t c = (uint32_t)pc[k].cls;
+    const float log_prob_c = gf_logf(pc[k].p + FLT_MIN);
+    for (long i = 0; i < t->np && i < beam; ++i) {
+      TNode* prefix = t->pre[i];
+      if (full_beam && log_prob_c + prefix->score < min_cutoff) break;
+      if (prefix->score == NEG_INF) continue;
+      if ((int)c == d->blank) {
+        float log_p = log_prob_c + prefix->score;
+        if (prefix->nb_cur < log_p) prefix->pend = 0;
+        prefix->b_cur = gf_log_sum_exp(prefix->b_cur, log_p);
+        continue;
+      }
+      if (c == prefix->ch) {
+        float log_p = log_prob_c + prefix->nb_prev;
+        if (prefix->nb_cur < log_p) prefix->pend = 0;
+        prefix->nb_cur = gf_log_sum_exp(prefix->nb_cur, log_p);
+      }
+      /* get_path_trie, path_trie.cpp:37-100 */
+      TNode* pn = NULL;
+      for (int q = 0; q < prefix->nk; ++q) if (prefix->kids[q]->ch == c) { pn = prefix->kids[q]; break; }
+      if (pn) {
+        if (!pn->exists) { pn->exists = 1; pn->b_prev = pn->nb_prev = pn->b_cur = pn->nb_cur = NEG_INF; }
+      } else {
+        int child_fst = 0;
+        if (d->sc) {
+          int next;
+          if (!fst_find(d->sc, prefix->fst, (int)c + 1, &next)) continue;
+          child_fst = fst_is_final(d->sc, next) ? (int)d->sc->fst_start : next;
+        }
+        pn = tnode_new(prefix, c);
+        pn->fst = child_fst;
+        pn->pa = pa_push(d, prefix->pa, c);
+        if (prefix->nk == prefix->capk) { prefix->capk = prefix->capk ? 2 * prefix->capk : 4; prefix->kids = (TNode**)realloc(prefix->kids, sizeof(TNode*) * prefix->capk); }
+        prefix->kids[prefix->nk++] = pn;
+        d->stat_candidates++;
+      }
+      float log_p = NEG_INF;
+      if (c == prefix->ch && prefix->b_prev > NEG_INF) log_p = log_prob_c + prefix->b_prev;
+      else if (c != prefix->ch) log_p = log_prob_c + prefix->score;
+      if (d->sc) {
+        const int boundary = d->sc->utf8 ? utf8_boundary_new(d, prefix, c) : ((int)c == d->space);
+        if (boundary) {
+          const float score = lm_score(d, d->sc->utf8 ? pn->pa : prefix->pa, 1);
+          log_p += score;
+          log_p = (float)((double)log_p + d->sc->beta);
+        }
+      }
+      if (pn->nb_cur < log_p) { pn->pend = 1; pn->pend_from = prefix->ts; pn->new_t = (uint32_t)d->abs_t; }
+      pn->nb_cur = gf_log_sum_exp(pn->nb_cur, log_p);
+    }
+  }
+  free(pc);
+  t->np = 0;
+  tnode_iterate(t, t->root);
+  if (t->np > beam) {
+    ls_nth_element(t->pre, beam, t->np, tcmp);
+    for (long i = beam; i < t->np; ++i) tnode_remove(t->pre[i]);
+    t->np = (int)beam;
+  }
+  d->stat_steps++;
+  d->abs_t++;
+}
+void port_tdecoder_next(PortTrieDecoder* t, const double* probs, int T, int C) {
+  for (int s = 0; s < T; ++s) tstep(t, probs + (size_t)s * C);
+}
+/* DecoderState::decode, ctc_beam_search_decoder.cpp:278-326 */
+int port_tdecoder_decode(PortTrieDecoder* t, int num_results, uint32_t* tokens, uint32_t* timesteps, int* lens, double* confidences, int max_len) {
+  PortDecoder* d = t->d;
+  const int n = t->np;
+  TNode** cp = (TNode**)malloc(sizeof(TNode*) * (n ? n : 1));
+  memcpy(cp, t->pre, sizeof(TNode*) * n);
+  for (int i = 0; i < n; ++i) cp[i]->ext = cp[i]->score;
+  if (d->sc) {
+    for (int i = 0; i < d->beam && i < n; ++i) {
+      TNode* p = cp[i];
+      uint32_t bnode, bch;
+      if (d->sc->utf8) { bnode = p->pa; bch = p->ch; }
+      else { if (!p->parent) continue; bnode = p->parent->pa; bch = p->parent->ch; }
+      if (!is_scoring_boundary(d, bnode, bch, p->ch)) {
+        float score = lm_score(d, p->pa, 0);
+        score = (float)((double)score + d->sc->beta);
+        p->ext += score;
+      }
+    }
+  }
+  int nret = n < num_results ? n : num_results;
+  ls_partial_sort(cp, nret, n, tcmp_ext);
+  for (int r = 0; r < nret; ++r) {
+    TNode* p = cp[r];
+    int len = 0;
+    for (uint32_t x = p->pa; x != 0xFFFFFFFFu && d->pa_ch[x] != 0xFFFFFFFFu; x = d->pa_parent[x]) len++;
+    if (len > max_len) { free(cp); return -1; }
+    lens[r] = len;
+    int j = len;
+    for (uint32_t x = p->pa; x != 0xFFFFFFFFu && d->pa_ch[x] != 0xFFFFFFFFu; x = d->pa_parent[x]) tokens[(size_t)r * max_len + --j] = d->pa_ch[x];
+    if (timesteps) {
+      int tl = 0;
+      for (uint32_t x = p->ts; x != 0xFFFFFFFFu && x != 0; x = d->ta_parent[x]) tl++;
+      j = tl < len ? tl : len;
+      int skip = tl - j;
+      for (uint32_t x = p->ts; x != 0xFFFFFFFFu && x != 0; x = d->ta_parent[x]) { if (skip > 0) { --skip; continue; } timesteps[(size_t)r * max_len + --j] = d->ta_t[x]; }
+    }
+    confidences[r] = (double)p->ext;
+  }
+  free(cp);
+  return nret;
+}
+/* prefixes_ in the order the vector holds them (test hook: step-by-step comparison with the reference's vector) */
+int port_tdecoder_beam(PortTrieDecoder* t, float* score, float* pb, float* pnb, int* last_char, int* path_len, int cap) {
+  int n = t->np < cap ? t->np : cap;
+  for (int i = 0; i < n; ++i) {
+    const TNode* x = t->pre[i];
+    score[i] = x->score; pb[i] = x->b_prev; pnb[i] = x->nb_prev; last_char[i] = (int)x->ch;
+    int len = 0;
+    for (const TNode* y = x; y->parent; y = y->parent) len++;
+    path_len[i] = len;
+  }
+  return n;
+}

@@ -133,6 +133,12 @@ def test_bench_shape_and_scorer_against_the_real_reference_decoder_all_64(big, r
                 r = d.decode(1)[0]
                 assert d.boundary_ties() > 0, (k, b, got[k][0][b], want_t)                       # a difference without a tie is a bug
                 assert got[k][0][b] == port.decode_text(labels, r[1]).decode() and got[k][1][b] == float(r[0]), (k, b)
+                # ... and the restatement in the reference's own order (trie order + libstdc++'s selection restated: stt_port.c Part D) prints
+                # what the reference printed: the difference is the order effect and nothing else
+                o = port.Decoder(labels, space, 500, P, reference_order=True)
+                o.next(probs[b])
+                ro = o.decode(1)[0]
+                assert port.decode_text(labels, ro[1]).decode() == want_t and float(ro[0]) == want_c, (k, b)
                 n_tie += 1
         print("bench shape vs the real reference: %d of 128 equal, %d tie-affected and equal to the restatement" % (n_equal, n_tie))
         assert n_equal >= 118          # (measured 121-124 of 128: the tie rate of 3-5 % plus margin; a regression that broke more would show here)

@@ -175,6 +175,11 @@ def test_bench_checks_fail_the_run_on_a_forged_mismatch():
     # the same difference WITH a boundary tie and the restatement agreeing with the timed output: explained
     ok, counts, mm = bench.judge_against_reference(forged, {0: (2, "a c", -1.5)})
     assert ok and counts["differ_with_a_boundary_tie_and_equal_to_the_restatement"] == 1 and counts["unexplained"] == 0
+    # ... with the reference-order restatement's verdict: it must reproduce the REFERENCE's output for the difference to count as the order effect
+    ok, counts, _ = bench.judge_against_reference(forged, {0: (2, "a c", -1.5, "a b", -1.5)})
+    assert ok and counts["of_those_the_reference_reproduced_in_reference_order"] == 1
+    ok, counts, _ = bench.judge_against_reference(forged, {0: (2, "a c", -1.5, "a x", -1.5)})
+    assert not ok and counts["unexplained"] == 1
     # ... a tie, but the restatement does not give the timed output either: a real mismatch
     ok, counts, _ = bench.judge_against_reference(forged, {0: (2, "a d", -1.5)})
     assert not ok and counts["unexplained"] == 1

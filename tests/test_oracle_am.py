@@ -96,12 +96,12 @@ def test_torch_f32_restatement_agrees_with_the_f64_one():
 
 
 def test_the_float64_activation_algorithm_gives_the_restatements_values(tmp_path):
-    """oracle/cr_activations_check.c: the table + polynomial evaluation of LOGISTIC / TANH that the int8 recurrent step runs on the GPU,
+    """oracle/checks/cr_activations_check.c: the table + polynomial evaluation of LOGISTIC / TANH that the int8 recurrent step runs on the GPU,
     restated in C, against float64 numpy-style evaluation rounded once (oracle/am_hybrid.py's definition) and against long double: equal
     on every one of 20 M float inputs but a handful of half-way cases."""
     import subprocess
     from conftest import ROOT
     exe = str(tmp_path / "chk")
-    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "oracle", "cr_activations_check.c"), "-lm"], check=True)
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "oracle", "checks", "cr_activations_check.c"), "-lm"], check=True)
     n, s64, sl, t64, tl = (int(v) for v in subprocess.run([exe, "40000000"], check=True, capture_output=True, text=True).stdout.split())
     assert n > 15_000_000 and s64 <= 3 and sl <= 3 and t64 <= 3 and tl <= 3, (n, s64, sl, t64, tl)

@@ -52,3 +52,35 @@ def test_port_equals_reference_decoder_on_random_cases(port, ref, fix):
             o.next(p[k:k + 16]); r.next(p[k:k + 16])
         n = 2
         assert canon(o.decode(n)) == canon(r.decode(n)), (case, mode, lm, beam, T, cp, ctn, hot)
+
+
+def test_reference_order_restatement_equals_the_reference_on_tie_cases(port, ref, fix):
+    """stt_port.c Part D: the pointer trie + libstdc++'s nth_element / partial_sort restated.  Emissions built to PRODUCE ties -- rows drawn from
+    a handful of values, so that different prefixes collect exactly equal float scores -- where the flat restatement (and the kernels,
+    which share its rule) may keep another member of a tied group than the reference: here every case must equal the compiled reference,
+    the whole vector of prefixes after every step (score, blank / non-blank probability, last label, length, IN ORDER) and the results."""
+    labels, space = port.parse_alphabet_file(os.path.join(fix, "alphabet.txt"))
+    A = ref.Alphabet(os.path.join(fix, "alphabet.txt"))
+    sp = os.path.join(fix, "pruned_lm.scorer")
+    P, S = port.Scorer(sp), ref.Scorer(sp, A)
+    rng = np.random.RandomState(4242)
+    C = len(labels) + 1
+    n_tie_cases = n_flat_differs = 0
+    for case in range(60):
+        lm = bool(case % 2)
+        beam = int(rng.choice([3, 8, 20, 64]))
+        T = int(rng.randint(8, 40))
+        levels = rng.choice([0.02, 0.05, 0.05, 0.2, 0.6], size=(T, C)).astype(np.float32)       # few distinct values: exact ties
+        p = (levels / levels.sum(1, keepdims=True)).astype(np.float32)
+        o = port.Decoder(labels, space, beam, P if lm else None, reference_order=True)
+        f = port.Decoder(labels, space, beam, P if lm else None)
+        r = ref.Decoder(A, beam, S if lm else None)
+        for t in range(T):
+            o.next(p[t:t + 1]); r.next(p[t:t + 1]); f.next(p[t:t + 1])
+            a, b = o.raw_beam(), r.raw_beam()
+            assert len(a[0]) == len(b[0]) and all(np.array_equal(x, y) for x, y in zip(a, b)), (case, t)
+        assert canon(o.decode(2)) == canon(r.decode(2)), case
+        n_tie_cases += 1 if f.boundary_ties() else 0
+        n_flat_differs += 1 if canon(f.decode(2)) != canon(r.decode(2)) else 0
+    assert n_tie_cases >= 10, n_tie_cases          # (the point of the construction)
+    print("tie cases %d of 60, flat restatement differs from the reference in %d" % (n_tie_cases, n_flat_differs))
