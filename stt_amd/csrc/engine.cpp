@@ -874,7 +874,6 @@ bool streams_process(const std::vector<StreamingState*>& ss, bool flush_partial,
         hi[b] = s->windows_done_; hi[B + b] = takes[g0 + b]; hi[2 * B + b] = 0;
         hv[b] = s->state_nonzero ? 1 : 0;
       }
-      HIP_CHECK(hipMemcpyAsync(m.sb_tab.p, hb, bytes, hipMemcpyHostToDevice, m.stream));
       uint8_t* db = m.sb_tab.as<uint8_t>();
       const float* const* d_frames = reinterpret_cast<const float* const*>(db);
       float* const* d_cp = reinterpret_cast<float* const*>(db + (size_t)B * 8);
@@ -882,22 +881,64 @@ bool streams_process(const std::vector<StreamingState*>& ss, bool flush_partial,
       DecStream* const* d_tp = reinterpret_cast<DecStream* const*>(db + (size_t)3 * B * 8);
       const int* d_int = reinterpret_cast<const int*>(db + n_ptr * 8);
       const unsigned char* d_valid = db + n_ptr * 8 + (size_t)3 * B * 4;
-      m.ws_x1.reserve(m.x1_bytes(T * B));
-      launch_window_rows_batch(d_frames, d_int, d_int + B, m.ws_x1.p, B, T, g.n_input, kw, kp, m.stream, m.i8);
-      m.sb_c.reserve((size_t)B * H * 4); m.sb_h.reserve((size_t)B * H * 4);
-      launch_gather_rows(d_cp, d_valid, m.sb_c.as<float>(), B, H, m.stream);
-      launch_gather_rows(d_hp, d_valid, m.sb_h.as<float>(), B, H, m.stream);
-      m.ws_probs.reserve((size_t)B * T * C * 4);
-      m.run_acoustic_rows(m.ws_x1.p, B, T, m.sb_c.as<float>(), m.sb_h.as<float>(), true, m.ws_probs.as<float>(), T);
-      launch_scatter_rows(d_cp, m.sb_c.as<float>(), B, H, m.stream);
-      launch_scatter_rows(d_hp, m.sb_h.as<float>(), B, H, m.stream);
-      m.sb_table.reserve(sizeof(DecStream) * B);
-      launch_gather_streams(d_tp, m.sb_table.as<DecStream>(), B, m.stream);
       DecParams p{};
       p.C = C; p.blank = C - 1; p.beam = R[g0]->dec.beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = T;  // stt.cc:539-540
-      m.ws_wide.reserve(ctc_rows_ws_bytes(p, B, T));
-      launch_ctc_next(p, ds, m.dev_alphabet, m.sb_table.as<DecStream>(), B, m.ws_probs.as<float>(), d_int + 2 * B, d_int + B, m.stream, T, m.ws_wide.p);
-      launch_scatter_streams(d_tp, m.sb_table.as<DecStream>(), B, m.stream);
+      // everything the pass enqueues: the table upload (from the page-locked block filled above), windows, state gather, the acoustic
+      // model, state scatter, the search.  Nothing in it depends on this hop except through that table.
+      auto enqueue = [&]() {
+        HIP_CHECK(hipMemcpyAsync(m.sb_tab.p, hb, bytes, hipMemcpyHostToDevice, m.stream));
+        m.ws_x1.reserve(m.x1_bytes(T * B));
+        launch_window_rows_batch(d_frames, d_int, d_int + B, m.ws_x1.p, B, T, g.n_input, kw, kp, m.stream, m.i8);
+        m.sb_c.reserve((size_t)B * H * 4); m.sb_h.reserve((size_t)B * H * 4);
+        launch_gather_rows(d_cp, d_valid, m.sb_c.as<float>(), B, H, m.stream);
+        launch_gather_rows(d_hp, d_valid, m.sb_h.as<float>(), B, H, m.stream);
+        m.ws_probs.reserve((size_t)B * T * C * 4);
+        m.run_acoustic_rows(m.ws_x1.p, B, T, m.sb_c.as<float>(), m.sb_h.as<float>(), true, m.ws_probs.as<float>(), T);
+        launch_scatter_rows(d_cp, m.sb_c.as<float>(), B, H, m.stream);
+        launch_scatter_rows(d_hp, m.sb_h.as<float>(), B, H, m.stream);
+        m.sb_table.reserve(sizeof(DecStream) * B);
+        launch_gather_streams(d_tp, m.sb_table.as<DecStream>(), B, m.stream);
+        m.ws_wide.reserve(ctc_rows_ws_bytes(p, B, T));
+        launch_ctc_next(p, ds, m.dev_alphabet, m.sb_table.as<DecStream>(), B, m.ws_probs.as<float>(), d_int + 2 * B, d_int + B, m.stream, T, m.ws_wide.p);
+        launch_scatter_streams(d_tp, m.sb_table.as<DecStream>(), B, m.stream);
+      };
+      bool replayed = false;
+      if (tune().stream_graph && !m.prof_.on) {
+        // key: the shape of the live set and everything baked into the launches by VALUE (the scorer description, the search parameters);
+        // addresses are covered by layout_generation().  First sighting: launched one by one (allocations, function attributes, module
+        // loads happen there, never inside a capture); second: captured; from then on: one graph launch per hop.
+        if (m.hop_generation_ != layout_generation()) {
+          for (auto& kv : m.hop_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+          m.hop_graphs_.clear(); m.hop_seen_.clear();
+          m.hop_generation_ = layout_generation();
+        }
+        uint64_t key = 0xCBF29CE484222325ULL;
+        auto mix = [&](const void* q, size_t nb) { const uint8_t* b8 = static_cast<const uint8_t*>(q); for (size_t k = 0; k < nb; ++k) { key ^= b8[k]; key *= 0x100000001B3ULL; } };
+        const int shape[6] = {B, T, p.beam, C, m.i8 ? 1 : 0, (int)bytes};
+        mix(shape, sizeof(shape)); mix(&ds, sizeof(ds)); mix(&m.dev_alphabet, sizeof(m.dev_alphabet));
+        auto found = m.hop_graphs_.find(key);
+        if (found != m.hop_graphs_.end()) {
+          if (found->second.exec) { HIP_CHECK(hipGraphLaunch(found->second.exec, m.stream)); replayed = true; __atomic_fetch_add(&tune().hop_replays, 1, __ATOMIC_RELAXED); }
+        } else if (!m.hop_seen_.count(key)) {
+          if (m.hop_seen_.size() >= 512) m.hop_seen_.clear();
+          m.hop_seen_.insert(key);
+        } else {
+          const unsigned long long gen0 = layout_generation();
+          ModelState::HopGraph gr;
+          hipGraph_t graph = nullptr;
+          HIP_CHECK(hipStreamBeginCapture(m.stream, hipStreamCaptureModeRelaxed));
+          try { enqueue(); }
+          catch (...) { (void)hipStreamEndCapture(m.stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+          HIP_CHECK(hipStreamEndCapture(m.stream, &graph));
+          if (layout_generation() != gen0 || hipGraphInstantiate(&gr.exec, graph, nullptr, nullptr, 0) != hipSuccess) { gr.exec = nullptr; (void)hipGetLastError(); }   // (a buffer moved inside the capture: not a graph to keep)
+          (void)hipGraphDestroy(graph);
+          if (m.hop_graphs_.size() >= 128) { for (auto& kv : m.hop_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); m.hop_graphs_.clear(); }
+          m.hop_graphs_[key] = gr;
+          m.hop_seen_.erase(key);
+          if (gr.exec) { HIP_CHECK(hipGraphLaunch(gr.exec, m.stream)); replayed = true; }
+        }
+      }
+      if (!replayed) enqueue();
       HIP_CHECK(hipStreamSynchronize(m.stream));  // the page-locked table is reused by the next group
       synced = true;
       for (int b = 0; b < B; ++b) { R[g0 + b]->windows_done_ += takes[g0 + b]; R[g0 + b]->state_nonzero = true; }

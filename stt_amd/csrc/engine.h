@@ -60,6 +60,7 @@ struct PinnedBuf {
 // hipMemcpyAsync: a copy-engine transfer costs a queue hand-over each way (signals between the compute queue and the DMA
 // engine), measured at 0.2 ms on some hosts and 1-2 ms on others -- per batch, on the critical stream.  A kernel that moves
 // the same 4-130 KB over the link is a few microseconds everywhere.  (STT_AMD_COPY_KERNEL=0: the copy engine, for A/B.)
+unsigned long long layout_generation();   // bumped when any DevBuf / PinnedBuf moves or a tunable changes (hostutil.cpp): what a captured graph may have baked in
 void copy_h2d(void* dst_dev, const PinnedBuf& src, size_t bytes, hipStream_t st);
 void copy_d2h(PinnedBuf& dst, const void* src_dev, size_t bytes, hipStream_t st, size_t dst_offset = 0);
 
@@ -288,6 +289,13 @@ struct ModelState {
   int async_depth_ = 0;   // slots in use while batches are in flight (api.cpp: pipeline_depth)
   bool async_pair_ = false;  // ... and whether they were submitted as pairs
   bool async_any() const { if (pending_.valid) return true; for (const GroupSlot& s : slots_) if (s.busy()) return true; return false; }
+  // The acoustic + search pass of a streaming hop (engine.cpp: streams_process) as ONE hipGraph per live-set shape: ~35 launches of a
+  // few microseconds each are launch-bound when enqueued one by one.  Keyed by the number of rows, the search configuration and
+  // layout_generation(); captured the second time a key comes up, dropped wholesale when the generation moves.
+  struct HopGraph { hipGraphExec_t exec = nullptr; };
+  std::map<uint64_t, HopGraph> hop_graphs_;
+  std::set<uint64_t> hop_seen_;
+  unsigned long long hop_generation_ = 0;
   // scratch of the batched streaming calls (STTX_FeedAudioContentBatch & co.)
   DevBuf sb_audio, sb_tab, sb_tab2, sb_tab3, sb_c, sb_h, sb_table;
   PinnedBuf sb_haudio, sb_htab, sb_htab2, sb_htab3;   // (…2: the feature pass's table -- the acoustic pass behind it fills sb_htab while that one is in flight; …3: the arena check's)

@@ -18,6 +18,11 @@ const TuneEntry kTune[] = {
 #undef X
 };
 }  // namespace
+// Bumped whenever a device or page-locked buffer moves or a tunable changes: everything that baked addresses or launch shapes into a
+// captured graph (engine.cpp: the streaming hop) compares generations instead of tracking every pointer.
+std::atomic<unsigned long long> g_layout_generation{1};
+unsigned long long layout_generation() { return g_layout_generation.load(std::memory_order_relaxed); }
+
 static std::atomic<int> g_models_alive{0};
 void tuning_model_count(int delta) { g_models_alive += delta; }
 int tuning_set(const char* name, int value) {
@@ -26,7 +31,7 @@ int tuning_set(const char* name, int value) {
   // under a live model the kernel shape would no longer match the packed matrix (wrong probabilities, silently).  Refused.
   if (!strcmp(name, "lstm_upw") && g_models_alive.load() > 0 && value != tune().lstm_upw) return -1;
   for (const TuneEntry& e : kTune)
-    if (!strcmp(e.name, name)) { tune().*(e.field) = value; return 0; }
+    if (!strcmp(e.name, name)) { tune().*(e.field) = value; g_layout_generation.fetch_add(1, std::memory_order_relaxed); return 0; }
   return -1;
 }
 int tuning_get(const char* name, int* value) {
@@ -59,6 +64,7 @@ Tuning& tune() {
 
 void DevBuf::reserve(size_t bytes, bool keep, hipStream_t st) {
   if (bytes <= cap && p) return;
+  g_layout_generation.fetch_add(1, std::memory_order_relaxed);
   size_t ncap = bytes + bytes / 4 + 256;
   void* np = nullptr;
   HIP_CHECK(hipMalloc(&np, ncap));
@@ -77,6 +83,7 @@ void DevBuf::reserve(size_t bytes, bool keep, hipStream_t st) {
 }
 void PinnedBuf::reserve(size_t bytes) {
   if (bytes <= cap && p) return;
+  g_layout_generation.fetch_add(1, std::memory_order_relaxed);
   if (p) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipHostFree(p)); }  // (a copy kernel may still be moving the old block)
   p = nullptr;
   cap = bytes + bytes / 4 + 256;

@@ -105,6 +105,7 @@ ModelState::~ModelState() {
   if (stream_dec) (void)hipStreamDestroy(stream_dec);
   for (auto& e : ev_chunk) if (e) (void)hipEventDestroy(e);
   for (auto& kv : lstm_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  for (auto& kv : hop_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   if (stream_h2d) (void)hipStreamDestroy(stream_h2d);
   for (auto& st : stage_) if (st.copied) (void)hipEventDestroy(st.copied);
   if (stream_l) (void)hipStreamDestroy(stream_l);

@@ -40,6 +40,7 @@
   X(wait_spins, 0, "test hook: polls (of 256 cycles) an intra-workgroup counter wait of the search step may take before it gives up with error bit 0x10 (0 = 4 M, about half a second)") \
   X(debug_key_bits, 0, "test hook: path keys of the search truncated to this many bits (4..62; 0 = all 63): forces key collisions, which the guard must flag (error bit 0x20)") \
   X(item_table_cap, 0, "test hook: items per pass of the bitmap step's expand table (0 = what fits; small values force the several-pass path)") \
+  X(stream_graph, 1, "batched streaming: the acoustic + search pass of a hop replayed as one hipGraph per live-set shape (0: launch by launch)") \
   X(stream_frames, 256, "frames (20 ms each) a new stream's search arenas are laid out for; longer utterances grow them (an allocation and a copy in the middle of a hop): a server sets its longest expected utterance") \
   X(decode_cache, 1, "streams: a decode with one result walks the best path back only to where it meets the previously decoded one (0: the whole path every time); read when a stream is created") \
   X(lm_memo, 1, "code-point scorer: FullScore memo table (0 off, 1 = 2^24 entries of 32 B -- measured on the code-point bench scorer: 2^18 66.4 ms per batch, 2^22 54.1, 2^24 49.3 --, 10..26 = log2 of the entry count); read when a scorer is loaded")                                                                         \
@@ -49,6 +50,7 @@
   X(cp_index, 1, "code-point scorer: a FullScore that misses the memo goes through the hashed n-gram index (one bucket read per order) instead of the trie walk (an interpolation search per order); read when a scorer is loaded")   \
   X(lm_index_mb, 4096, "hashed n-gram index: byte cap in MiB (larger models take the trie walk)")                                  \
   X(arena_shrink, 1, "test hook: divides the optimistic arena sizes of a batch group (forces the overflow -> decode-again path)")        \
+  X(hop_replays, 0, "counter, not a knob: streaming hops whose acoustic + search pass was replayed from a captured graph")                 \
   X(arena_retries, 0, "counter, not a knob: batch groups decoded again with full-size arenas after an overflow flag")                 \
   X(dump_marks, 0, "profiling: raw HIP-event timeline of the batch path on stderr")
 

@@ -280,3 +280,30 @@ def test_config3_deferred_flush_tail(model):
         hop += 1
     assert got == want
 
+
+
+def test_config3_hop_replayed_as_one_graph_gives_the_same_results(model):
+    """The acoustic + search pass of a batched hop is captured into one hipGraph per live-set shape the second time the shape comes up and
+    replayed from then on (engine.cpp: streams_process; tunable stream_graph).  A fixed live set of 12 streams over 30 hops: every
+    intermediate result and every final transcript equals the launch-by-launch run, and the graph path really ran (counter hop_replays)."""
+    from stt_amd import model as M, native
+    audio = [synth.synth_audio(5120 * 30, seed=1900 + i) for i in range(12)]
+
+    def run(graph):
+        native.set_tuning("stream_graph", graph)
+        streams = [model.createStream() for _ in audio]
+        inter = []
+        for k in range(0, 5120 * 30, 5120):
+            M.feedAudioContentBatch(streams, [a[k:k + 5120] for a in audio])
+            inter.append(M.intermediateDecodeBatch(streams))
+        return inter, M.finishStreamBatch(streams)
+    try:
+        before = native.get_tuning("hop_replays")
+        with_graph = run(1)
+        replays = native.get_tuning("hop_replays") - before
+        without = run(0)
+    finally:
+        native.set_tuning("stream_graph", 1)
+    assert with_graph == without
+    assert replays >= 20, replays
+    assert with_graph[1] == [model.stt(a) for a in audio]
