@@ -850,8 +850,8 @@ def measure(wl, args, cx, steps, warmup):
         # HBM traffic from the committed rocprofv3 --pmc passes of this round's build (FETCH_SIZE and WRITE_SIZE cannot share a pass, and
         # counters are never collected inside a timed run).  Only valid for the batch workload's shapes.
         pmc, pmc_file = {}, None
-        if wl == "batch" and not i8:
-            for prof in ("r05_pmc_traffic.json", "r04_n_pmc_traffic.json", "r03_l_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        if wl == "batch":
+            for prof in (("r05_b_i8_pmc_traffic.json",) if i8 else ("r05_b_pmc_traffic.json", "r04_n_pmc_traffic.json", "r03_l_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
                     pmc_file = prof
@@ -860,7 +860,7 @@ def measure(wl, args, cx, steps, warmup):
                     pass
 
         def pmc_entry(prefix):
-            ks = [k for k in pmc if k.startswith(prefix)]
+            ks = [k for k in pmc if k.startswith(prefix) or ("::" + prefix) in k]
             return pmc[ks[0]] if ks else None
 
         # per LAUNCH, like `achieved`: a search launch covers one time-chunk of the group's streams (16 + 48 ... frames x 64 or 128 streams)

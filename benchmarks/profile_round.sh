@@ -2,13 +2,14 @@
 # Per-round profile of `python bench.py` on the GPU box (scratch output under gpurun_out/prof_<tag>/, summaries copied
 # to profiles/ by hand):  1. rocprofv3 --kernel-trace --stats  2. --pmc FETCH_SIZE  3. --pmc WRITE_SIZE (separate passes:
 # the two cannot share the TCC slots, and counters never ride on a trace/timed run).
-# usage: bash benchmarks/profile_round.sh <tag>
+# usage: bash benchmarks/profile_round.sh <tag> [workload]      (workload: batch (default) or batch_i8 -- the int8 path's sub-line)
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 TAG=${1:-r03_x}
+WL=${2:-batch}
 OUT=gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python bench.py --steps 6 --warmup 4 --no-cpu-baseline --no-extras --no-reference-check > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python bench.py --workload $WL --steps 6 --warmup 4 --no-cpu-baseline --no-extras --no-reference-check > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C -d $OUT/pmc_$C -o pmc --output-format csv -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras --no-reference-check > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C -d $OUT/pmc_$C -o pmc --output-format csv -- python bench.py --workload $WL --steps 4 --warmup 2 --no-cpu-baseline --no-extras --no-reference-check > $OUT/pmc_$C.log 2>&1
 done
 python - "$TAG" "$OUT" <<'PY'
 import csv, glob, json, collections, sys, shutil
