@@ -22,7 +22,7 @@ acc = collections.defaultdict(float); calls = collections.defaultdict(int)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(out + "/pmc_%s/**/*counter_collection.csv" % c, recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             acc[(k, r["Counter_Name"])] += float(r["Counter_Value"]); calls[(k, r["Counter_Name"])] += 1
 steps = 11.0   # --steps 4 --warmup 2 + the untimed phase-counter step + one blocking verification call per distinct timed batch (4): batches of 64
 kern = {}

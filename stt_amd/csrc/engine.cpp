@@ -39,7 +39,8 @@ void ModelState::run_mfcc(const int16_t* d_audio, const int* h_nsamples, int B, 
 // FULLY_CONNECTED as TFLite's hybrid kernel -- the f32 input rows quantised to int8 one by one (launch_quantize_rows), int32 sums on
 // v_mfma_i32_16x16x64_i8, rescale + bias (+ clipped ReLU) in f32 -- and the cell with the joint [x_t, h_(t-1)] row scale (kernels_i8.hip).
 // x1: f32 [T*B][k1_pad8], row = t*B + b.  carry as acoustic_rows(); the carried h lives in f32 (d_h, or ws_hlast between the chunks of a batch).
-static void acoustic_rows_i8(ModelState& m, const float* d_x1, int B, int T, float* d_c, float* d_h, int carry, float* d_probs_out, int probs_t_max) {
+static void acoustic_rows_i8(ModelState& m, const float* d_x1, int B, int T, float* d_c, float* d_h, int carry, float* d_probs_out, int probs_t_max,
+                             const int* d_nframes = nullptr, int t0 = 0) {
   const Geometry& g = m.g;
   hipStream_t st = m.stream;
   const int H = g.n_hidden, M = T * B, C = g.n_classes, K1 = g.k1_pad8(), CP = g.c_pad8();
@@ -84,6 +85,7 @@ static void acoustic_rows_i8(ModelState& m, const float* d_x1, int B, int T, flo
   l.wxq = m.wxq.as<signed char>(); l.whq = m.whq.as<signed char>(); l.zslow = m.ws_zslow.as<float>();
   l.n_hidden = H; l.batch = B; l.T = T; l.slow_count = m.ws_slow.as<unsigned>();
   l.probe = m.dbg_ev_[0] ? tune().lstm_probe : 0;     // (only a timed test-hook call may ask for a probe kernel)
+  l.row_frames = d_nframes; l.t0 = t0;                // (batch path: rows past their utterance's end are never worth the slow path)
   l.hq_in = m.ws_hq0.as<signed char>(); l.hq_out = m.ws_hq1.as<signed char>();
   if (m.dbg_ev_[0]) HIP_CHECK(hipEventRecord(m.dbg_ev_[0], st));
   launch_lstm_i8_prep(l, h_src, NT, st);
@@ -106,8 +108,8 @@ static void acoustic_rows_i8(ModelState& m, const float* d_x1, int B, int T, flo
 }
 
 static void acoustic_rows(ModelState& m, const void* d_x1v, int B, int T, float* d_c, float* d_h, int carry, int t_par,
-                          float* d_probs_out, int probs_t_max) {
-  if (m.i8) { acoustic_rows_i8(m, static_cast<const float*>(d_x1v), B, T, d_c, d_h, carry, d_probs_out, probs_t_max); return; }
+                          float* d_probs_out, int probs_t_max, const int* d_nframes = nullptr) {
+  if (m.i8) { acoustic_rows_i8(m, static_cast<const float*>(d_x1v), B, T, d_c, d_h, carry, d_probs_out, probs_t_max, d_nframes, t_par); return; }
   const _Float16* d_x1 = static_cast<const _Float16*>(d_x1v);
   const Geometry& g = m.g;
   hipStream_t stream = m.stream;
@@ -187,7 +189,7 @@ void ModelState::run_acoustic_chunk(const float* d_feats, const int* d_nframes, 
   c.batch = B; c.t_max = t_max; c.n_coef = g.n_input; c.n_context = g.n_context; c.k_pad = x1_cols(); c.t0 = t0;
   launch_context(c, M, stream);
   // probs[b][t0 + t][:]: the softmax writes row (t, b) at probs + ((b*t_max + t)*C), so offsetting the base by t0*C lands it
-  acoustic_rows(*this, ws_x1.p, B, T, nullptr, nullptr, t0 == 0 ? 0 : 2, t0, d_probs + (size_t)t0 * g.n_classes, t_max);
+  acoustic_rows(*this, ws_x1.p, B, T, nullptr, nullptr, t0 == 0 ? 0 : 2, t0, d_probs + (size_t)t0 * g.n_classes, t_max, d_nframes);
 }
 
 // ------------------------------------------------------------------------------------------- acoustic model, three engines
@@ -267,6 +269,7 @@ void ModelState::run_acoustic_chunk_piped_i8(const float* d_feats, const int* d_
   l.pmax = am_pmax.as<float>(); l.flag = am_flag.as<int>(); l.y3 = y3; l.h_prev0 = am_hprev0.as<float>();
   l.wxq = wxq.as<signed char>(); l.whq = whq.as<signed char>(); l.zslow = am_zslow.as<float>();
   l.n_hidden = H; l.batch = B; l.T = T; l.prio = tune().lstm_prio; l.slow_count = ws_slow.as<unsigned>();
+  l.row_frames = d_nframes; l.t0 = t0;
   const float* h_src = t0 == 0 ? nullptr : am_hlast.as<float>();
   auto steps = [&]() {
     l.t = 0; l.hq_in = am_hq0.as<signed char>(); l.hq_out = am_hq1.as<signed char>();
@@ -282,7 +285,8 @@ void ModelState::run_acoustic_chunk_piped_i8(const float* d_feats, const int* d_
     LstmGraphKey key;
     memset(&key, 0, sizeof(key));
     key.xproj = am_xproj[slot].p; key.hall = am_hall[slot].p; key.c = am_c.p; key.hp0 = am_hq0.p; key.hp1 = am_hq1.p; key.whp = am_y3[slot].p;
-    key.T = T; key.par = t0 == 0 ? 0 : 1; key.B = B; key.NT = NT; key.passes = 100; key.prio = l.prio; key.H = H; key.first = 0;
+    key.T = T; key.par = t0; key.B = B; key.NT = NT; key.passes = 100; key.prio = l.prio; key.H = H; key.first = 0;   // (t0 and the frame table's address are baked into the launches)
+    key.hp1 = (const void*)((uintptr_t)am_hq1.p ^ (uintptr_t)d_nframes);
     run_lstm_graph(key, steps);
   } else steps();
   stt_prof_mark_on(this, -1, 5, stream_l);

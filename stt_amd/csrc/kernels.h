@@ -113,6 +113,12 @@ struct LstmI8Args {
   float* zslow;                // [H/16][NT*16][64] f32 scratch of the slow path
   int n_hidden, batch, t, T;
   int prio;
+  // Batch path only (null otherwise): frames of every row's utterance and the absolute time of step 0 of this launch sequence.  A row
+  // beyond its utterance's end (t0 + t >= row_frames[row]) runs on zero windows whose results nobody reads: it is never flagged for the
+  // slow path (a short utterance in a group of longer ones would otherwise pay ~7 us per step for nothing).  A STREAM's zero-padded steps
+  // are NOT such rows: they perturb the carried state exactly as the reference's do (stt.cc:236-254) and are computed in full.
+  const int* row_frames;
+  int t0;
   unsigned int* slow_count;    // counts slow-path rows (diagnostics / tests; may be null)
   int probe;                   // STTX_TestHybridChain only: the tunable lstm_probe (timing probes with wrong results; never set by the batch / streaming paths)
 };

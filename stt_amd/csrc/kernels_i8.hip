@@ -104,7 +104,8 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
   const int H = a.n_hidden, B = a.batch, KS = H / 64, NWG = H / 16;
   const int par = a.t & 1, epoch = a.t + 1;
   // issued now, consumed behind the k-loop: is any row of this step flagged?
-  const int myflag = (tid < NTR && tid < B) ? (a.flag[par * NTR + tid] == epoch ? 1 : 0) : 0;
+  const bool past_end = a.row_frames != nullptr && tid < B && a.t0 + a.t >= a.row_frames[tid < B ? tid : 0];   // (batch path: a row beyond its utterance)
+  const int myflag = (tid < NTR && tid < B && !past_end) ? (a.flag[par * NTR + tid] == epoch ? 1 : 0) : 0;
 
   const i32x4* wp = reinterpret_cast<const i32x4*>(a.whp) + (size_t)wg * KS * 4 * 64 + lane;
   const i32x4* hp = reinterpret_cast<const i32x4*>(a.hq_in) + lane;
@@ -280,7 +281,7 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
     if (s >= SLOTS) break;
     const bool live = row < B;
     const size_t rowi = (size_t)a.t * B + row;
-    const bool slow = any && live && a.flag[par * NTR + row] == epoch;
+    const bool slow = any && live && a.flag[par * NTR + row] == epoch && !(a.row_frames != nullptr && a.t0 + a.t >= a.row_frames[row]);
     float hv[4] = {0.f, 0.f, 0.f, 0.f};
     float4 cn4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
@@ -322,7 +323,7 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
       m = fmaxf(m, __shfl_xor(m, 32));
       if (ug == 0) {
         a.pmax[((size_t)(par ^ 1) * NTR + row) * NWG + wg] = m;
-        if (live && m > rn) a.flag[(par ^ 1) * NTR + row] = epoch + 1;
+        if (live && m > rn && !(a.row_frames != nullptr && a.t0 + a.t + 1 >= a.row_frames[row])) a.flag[(par ^ 1) * NTR + row] = epoch + 1;
       }
     }
   }
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void lstm_i8_prep_kernel(LstmI8Args a, const f
   }
   for (int w = tid; w < NWG; w += 256) a.pmax[(size_t)row * NWG + w] = w == 0 ? mh : 0.0f;   // pmax[0][row][:]
   if (tid == 0) {
-    a.flag[row] = (row < B && mh > mx) ? 1 : 0;     // flag[0][row]: epoch of step 0 is 1
+    a.flag[row] = (row < B && mh > mx && !(a.row_frames != nullptr && a.t0 >= a.row_frames[row])) ? 1 : 0;     // flag[0][row]: epoch of step 0 is 1
     a.flag[NTR + row] = 0;
   }
 }
