@@ -88,13 +88,24 @@ static void acoustic_rows_i8(ModelState& m, const float* d_x1, int B, int T, flo
   l.row_frames = d_nframes; l.t0 = t0;                // (batch path: rows past their utterance's end are never worth the slow path)
   l.hq_in = m.ws_hq0.as<signed char>(); l.hq_out = m.ws_hq1.as<signed char>();
   if (m.dbg_ev_[0]) HIP_CHECK(hipEventRecord(m.dbg_ev_[0], st));
-  launch_lstm_i8_prep(l, h_src, NT, st);
-  for (int t = 0; t < T; ++t) {
-    l.t = t;
-    l.hq_in = (t & 1) ? m.ws_hq1.as<signed char>() : m.ws_hq0.as<signed char>();
-    l.hq_out = (t & 1) ? m.ws_hq0.as<signed char>() : m.ws_hq1.as<signed char>();
-    launch_lstm_i8_step(l, NT, st);
-  }
+  auto steps = [&]() {
+    launch_lstm_i8_prep(l, h_src, NT, st);
+    for (int t = 0; t < T; ++t) {
+      l.t = t;
+      l.hq_in = (t & 1) ? m.ws_hq1.as<signed char>() : m.ws_hq0.as<signed char>();
+      l.hq_out = (t & 1) ? m.ws_hq0.as<signed char>() : m.ws_hq1.as<signed char>();
+      launch_lstm_i8_step(l, NT, st);
+    }
+  };
+  // the batch path's chunks (d_nframes given; carry 0 / 2: every address is the engine's own) replay their recurrence as one hipGraph, like
+  // the three-engine form does; streams and test hooks (caller-owned state vectors, probes) launch step by step
+  if (d_nframes && carry != 1 && tune().lstm_graph && !m.dbg_ev_[0] && !l.probe) {
+    ModelState::LstmGraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.xproj = m.ws_xproj.p; key.hall = m.ws_hall.p; key.c = cbuf; key.hp0 = m.ws_hq0.p; key.hp1 = (const void*)((uintptr_t)m.ws_hq1.p ^ (uintptr_t)d_nframes); key.whp = m.ws_a.p;
+    key.T = T; key.par = t0; key.B = B; key.NT = NT; key.passes = 101 + carry; key.prio = 0; key.H = H; key.first = (int)((uintptr_t)m.q_rng.p >> 8);
+    m.run_lstm_graph(key, steps, st);
+  } else steps();
   if (m.dbg_ev_[1]) HIP_CHECK(hipEventRecord(m.dbg_ev_[1], st));
   stt_prof_mark(&m, 3);
   // layer 5, layer 6, softmax (deepspeech_model.py:241-252, 357)
@@ -270,6 +281,7 @@ void ModelState::run_acoustic_chunk_piped_i8(const float* d_feats, const int* d_
   l.wxq = wxq.as<signed char>(); l.whq = whq.as<signed char>(); l.zslow = am_zslow.as<float>();
   l.n_hidden = H; l.batch = B; l.T = T; l.prio = tune().lstm_prio; l.slow_count = ws_slow.as<unsigned>();
   l.row_frames = d_nframes; l.t0 = t0;
+  l.probe = tune().lstm_probe >= 100 ? tune().lstm_probe - 100 : 0;     // (experiments only, lstm_probe = 100 + probe: a timing-probe kernel in the timed path -- wrong results)
   const float* h_src = t0 == 0 ? nullptr : am_hlast.as<float>();
   auto steps = [&]() {
     l.t = 0; l.hq_in = am_hq0.as<signed char>(); l.hq_out = am_hq1.as<signed char>();
@@ -312,7 +324,8 @@ void ModelState::run_acoustic_chunk_piped_i8(const float* d_feats, const int* d_
 }
 
 // The recurrence of a chunk as one hipGraph (engine.h: LstmGraphKey): `steps` enqueues the launches on stream_l.
-void ModelState::run_lstm_graph(const LstmGraphKey& key, const std::function<void()>& steps) {
+void ModelState::run_lstm_graph(const LstmGraphKey& key, const std::function<void()>& steps, hipStream_t st) {
+  hipStream_t stream_l = st ? st : this->stream_l;   // (the stream the launches go to)
   // A combination is captured the SECOND time it comes up (the first ran eagerly: module load, function attributes).  First
   // sightings live in their own small set, so a ragged job's many one-off shapes never push the graphs out of the cache; when
   // the cache is full (or holds graphs of buffers that have since been reallocated) it is emptied and refills with what recurs.

@@ -331,7 +331,7 @@ struct ModelState {
   // chunk [t0, t0+T) of a batch through the three engines; `done` is recorded on stream_o behind the softmax
   void run_acoustic_chunk_piped(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs, hipEvent_t done);
   void run_acoustic_chunk_piped_i8(const float* d_feats, const int* d_nframes, int B, int t_max, int t0, int T, float* d_probs, hipEvent_t done);
-  void run_lstm_graph(const LstmGraphKey& key, const std::function<void()>& steps);
+  void run_lstm_graph(const LstmGraphKey& key, const std::function<void()>& steps, hipStream_t st = nullptr);   // st: the stream `steps` enqueues on (null: stream_l)
 
   ModelState() { tuning_model_count(+1); }   // (tuning.h: load-time knobs are frozen while a model is alive)
   ~ModelState();

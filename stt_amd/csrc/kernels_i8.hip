@@ -299,6 +299,11 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
         // gate order i, j, f, o (deepspeech_model.py:144-168); MUL, MUL, ADD as separate float ops
         float cn;
         if constexpr (DBG & 1) { cn = __fadd_rn(__fmul_rn(z[2], (&cv[it].x)[r]), __fmul_rn(z[0], z[1])); hv[r] = __fmul_rn(z[3], cn) * 1e-3f; }
+        else if constexpr (DBG & 16) {   // experiment (tunable lstm_probe = 16, also honoured by the batch path): the device library's float expf / tanhf -- NOT bit-level
+          auto sg = [](float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); };
+          cn = __fadd_rn(__fmul_rn(sg(z[2]), (&cv[it].x)[r]), __fmul_rn(sg(z[0]), tanhf(z[1])));
+          hv[r] = __fmul_rn(sg(z[3]), tanhf(cn));
+        }
         else {
           cn = __fadd_rn(__fmul_rn(sigmoid_i8_(z[2], s_exp2), (&cv[it].x)[r]), __fmul_rn(sigmoid_i8_(z[0], s_exp2), tanh_i8_(z[1], s_exp2)));
           hv[r] = __fmul_rn(sigmoid_i8_(z[3], s_exp2), tanh_i8_(cn, s_exp2));
@@ -393,6 +398,7 @@ void launch_lstm_i8_step(const LstmI8Args& a, int NT, hipStream_t st) {
         case 4: hipLaunchKernelGGL(lstm_i8_probe8_kernel<4>, grid, block, 0, st, a); break;
         case 8: hipLaunchKernelGGL(lstm_i8_probe8_kernel<8>, grid, block, 0, st, a); break;
         case 15: hipLaunchKernelGGL(lstm_i8_probe8_kernel<15>, grid, block, 0, st, a); break;
+        case 16: hipLaunchKernelGGL(lstm_i8_probe8_kernel<16>, grid, block, 0, st, a); break;
         default: hipLaunchKernelGGL(lstm_i8_step8_kernel, grid, block, 0, st, a); break;
       }
       break;

@@ -226,3 +226,23 @@ def test_a_float_container_quantised_at_load_equals_the_quantised_file(tmp_path)
     for m in (a, b):
         m.enableExternalScorer(os.path.join(FIX, "pruned_lm.scorer"))
     assert a.sttBatch(audio) == b.sttBatch(audio)
+
+
+def test_ragged_batches_on_the_int8_path(tmp_path):
+    """Utterances of different lengths in one group: the rows of a short one run on zero windows behind its end (never read, and never
+    worth the step's slow path: LstmI8Args::row_frames) -- every utterance's probabilities and transcript are those it gets alone."""
+    w = synth.synth_weights(12, n_hidden=256)
+    w["layer_6/weights"] = (w["layer_6/weights"] * 6.0).astype(np.float32)
+    m = _model(tmp_path, w, "ragged")
+    m.enableExternalScorer(os.path.join(FIX, "pruned_lm.scorer"))
+    rng = np.random.RandomState(21)
+    lens = (rng.uniform(0.2, 2.6, size=14) * 16000).astype(int)
+    lens[3] = 300; lens[9] = 0
+    audio = [synth.synth_audio(int(n), seed=2100 + i) for i, n in enumerate(lens)]
+    together = m.acousticProbs(audio)
+    texts = m.sttBatch(audio)
+    for i, a in enumerate(audio):
+        alone = m.acousticProbs([a])[0]
+        assert np.array_equal(together[i], alone), i
+        assert texts[i] == m.stt(a), i
+    assert any(texts)
