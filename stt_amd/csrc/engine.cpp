@@ -97,15 +97,7 @@ static void acoustic_rows_i8(ModelState& m, const float* d_x1, int B, int T, flo
       launch_lstm_i8_step(l, NT, st);
     }
   };
-  // the batch path's chunks (d_nframes given; carry 0 / 2: every address is the engine's own) replay their recurrence as one hipGraph, like
-  // the three-engine form does; streams and test hooks (caller-owned state vectors, probes) launch step by step
-  if (d_nframes && carry != 1 && tune().lstm_graph && !m.dbg_ev_[0] && !l.probe) {
-    ModelState::LstmGraphKey key;
-    memset(&key, 0, sizeof(key));
-    key.xproj = m.ws_xproj.p; key.hall = m.ws_hall.p; key.c = cbuf; key.hp0 = m.ws_hq0.p; key.hp1 = (const void*)((uintptr_t)m.ws_hq1.p ^ (uintptr_t)d_nframes); key.whp = m.ws_a.p;
-    key.T = T; key.par = t0; key.B = B; key.NT = NT; key.passes = 101 + carry; key.prio = 0; key.H = H; key.first = (int)((uintptr_t)m.q_rng.p >> 8);
-    m.run_lstm_graph(key, steps, st);
-  } else steps();
+  steps();   // (launch by launch: replaying these chunks as hipGraphs on the shared acoustic stream measured SLOWER -- 22.6 against 20.0 us per step)
   if (m.dbg_ev_[1]) HIP_CHECK(hipEventRecord(m.dbg_ev_[1], st));
   stt_prof_mark(&m, 3);
   // layer 5, layer 6, softmax (deepspeech_model.py:241-252, 357)
