@@ -48,6 +48,7 @@ rng = np.random.default_rng(1)
 T, B = 48, 128
 wb = (rng.standard_normal((T, B, 494)) * 4).astype(np.float32)
 times = {}
+native.set_tuning("lstm_i8_rows", 128)          # (the probe kernels are forms of the one-group 128-row step)
 for probe in (0, 1, 2, 4, 8, 15):
     native.set_tuning("lstm_probe", probe)
     best = 1e9
@@ -57,11 +58,24 @@ for probe in (0, 1, 2, 4, 8, 15):
 native.set_tuning("lstm_probe", 0)
 out["i8_step_us_at_128_rows"] = {"as_shipped": times["0"], "cheap_activations": times["1"], "no_reduction": times["2"], "no_cell_operand_loads": times["4"],
                                   "operands_from_L1": times["8"], "all_four": times["15"]}
+native.set_tuning("lstm_i8_rows", 128)
 for Bx in (64, 16):
     best = 1e9
     for _ in range(4):
         best = min(best, m.hybridChain(wb[:, :Bx])["lstm_ms"])
     out["i8_step_us_at_%d_rows" % Bx] = 1e3 * best / T
+# 4. row groups: the launch's batch tiles dealt to 2 / 4 / 8 workgroups per 16-unit slice (tunable lstm_i8_rows = rows per workgroup)
+out["i8_step_us_by_rows_per_workgroup"] = {}
+for Bx in (128, 64):
+    for rows in (128, 64, 32, 16):
+        if rows > Bx:
+            continue
+        native.set_tuning("lstm_i8_rows", rows)
+        best = 1e9
+        for _ in range(4):
+            best = min(best, m.hybridChain(wb[:, :Bx])["lstm_ms"])
+        out["i8_step_us_by_rows_per_workgroup"]["%d_rows_in_groups_of_%d" % (Bx, rows)] = 1e3 * best / T
+native.set_tuning("lstm_i8_rows", 64)
 print(json.dumps(out, indent=1))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "i8_diag.json"), "w"), indent=1)

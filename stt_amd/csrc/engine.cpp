@@ -94,7 +94,7 @@ static void acoustic_rows_i8(ModelState& m, const float* d_x1, int B, int T, flo
       l.t = t;
       l.hq_in = (t & 1) ? m.ws_hq1.as<signed char>() : m.ws_hq0.as<signed char>();
       l.hq_out = (t & 1) ? m.ws_hq0.as<signed char>() : m.ws_hq1.as<signed char>();
-      launch_lstm_i8_step(l, NT, st);
+      launch_lstm_i8_step(l, NT, st, tune().lstm_i8_rows);
     }
   };
   steps();   // (launch by launch: replaying these chunks as hipGraphs on the shared acoustic stream measured SLOWER -- 22.6 against 20.0 us per step)
@@ -282,7 +282,7 @@ void ModelState::run_acoustic_chunk_piped_i8(const float* d_feats, const int* d_
       l.t = t;
       l.hq_in = (t & 1) ? am_hq1.as<signed char>() : am_hq0.as<signed char>();
       l.hq_out = (t & 1) ? am_hq0.as<signed char>() : am_hq1.as<signed char>();
-      launch_lstm_i8_step(l, NT, stream_l);
+      launch_lstm_i8_step(l, NT, stream_l, tune().lstm_i8_rows);
     }
   };
   if (tune().lstm_graph) {

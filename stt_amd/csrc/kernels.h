@@ -124,7 +124,7 @@ struct LstmI8Args {
 };
 // before step 0 of a launch sequence: h_src ([B][H] f32, null = zeros) -> hq (buffer of step 0), h_prev0, pmax / flag of step 0
 void launch_lstm_i8_prep(const LstmI8Args& a, const float* h_src, int NT, hipStream_t st);
-void launch_lstm_i8_step(const LstmI8Args& a, int NT, hipStream_t st);
+void launch_lstm_i8_step(const LstmI8Args& a, int NT, hipStream_t st, int rows_per_wg = 0);   // rows_per_wg: 16 / 32 / 64 below NT * 16 = that many rows per workgroup, NT * 16 / rows_per_wg workgroups per 16-unit slice
 size_t lstm_i8_hq_bytes(int H, int NT);
 
 struct SoftmaxArgs {

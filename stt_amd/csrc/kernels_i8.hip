@@ -90,7 +90,7 @@ __device__ __forceinline__ void mfma_i8_(i32x4& acc, const i32x4& a, const i32x4
 template <int NT, int DBG = 0>
 __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
   constexpr bool PIN = NT == 8;                  // 128 accumulator registers pinned in the accumulator file (see kernels_am.hip: lstm_mfma)
-  constexpr int NTR = NT * 16;                   // rows a launch covers
+  constexpr int NTR = NT * 16;                   // rows a WORKGROUP covers; gridDim.y workgroups share a 16-unit slice, each with its own rows
   constexpr int SLOTS = NT * 64, ITS = (SLOTS + 255) / 256;
   __shared__ int red[4][NT][4][64];              // [gate tile][batch tile][component][lane]: component-major -> conflict-free 4-byte atomics
   __shared__ __attribute__((aligned(16))) signed char sq[2 * 4096];   // slow path: one row's [x_t | h_(t-1)] at the joint scale
@@ -102,10 +102,12 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, wg = blockIdx.x;
   if (tid < 32) s_exp2[tid] = kExp2TabI8[tid];   // (visible behind the reduction's barriers, long before the cell update reads it)
   const int H = a.n_hidden, B = a.batch, KS = H / 64, NWG = H / 16;
+  const int NTT = NT * (int)gridDim.y, NTRT = NTT * 16;      // batch tiles / rows of the launch (the layouts of hq, flag, pmax, zslow)
+  const int jt0 = NT * (int)blockIdx.y, r0 = jt0 * 16;       // this workgroup's first batch tile / row
   const int par = a.t & 1, epoch = a.t + 1;
   // issued now, consumed behind the k-loop: is any row of this step flagged?
-  const bool past_end = a.row_frames != nullptr && tid < B && a.t0 + a.t >= a.row_frames[tid < B ? tid : 0];   // (batch path: a row beyond its utterance)
-  const int myflag = (tid < NTR && tid < B && !past_end) ? (a.flag[par * NTR + tid] == epoch ? 1 : 0) : 0;
+  const bool past_end = a.row_frames != nullptr && r0 + tid < B && a.t0 + a.t >= a.row_frames[r0 + tid < B ? r0 + tid : 0];   // (batch path: a row beyond its utterance)
+  const int myflag = (tid < NTR && r0 + tid < B && !past_end) ? (a.flag[par * NTRT + r0 + tid] == epoch ? 1 : 0) : 0;
 
   const i32x4* wp = reinterpret_cast<const i32x4*>(a.whp) + (size_t)wg * KS * 4 * 64 + lane;
   const i32x4* hp = reinterpret_cast<const i32x4*>(a.hq_in) + lane;
@@ -120,7 +122,7 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
   do {                                                                                      \
     const int ks_ = (s_);                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) W[i_] = wp[(DBG & 8) ? (size_t)0 : (size_t)(ks_ * 4 + i_) * 64];   \
-    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) Hh[j_] = hp[(DBG & 8) ? (size_t)0 : (size_t)(ks_ * NT + j_) * 64]; \
+    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) Hh[j_] = hp[(DBG & 8) ? (size_t)0 : (size_t)(ks_ * NTT + jt0 + j_) * 64]; \
   } while (0)
 #define I8_MMA(W, Hh)                                                                       \
   do {                                                                                      \
@@ -171,7 +173,7 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
   for (int it = 0; it < ITS; ++it) {
     touch[it] = 0;
     if (a.t + 1 < a.T && !(DBG & 4)) {
-      const int row = min(((tid + 256 * it) >> 6) * 16 + (lane & 15), B - 1);
+      const int row = min(r0 + ((tid + 256 * it) >> 6) * 16 + (lane & 15), B - 1);
       touch[it] = a.accx[((size_t)(a.t + 1) * B + row) * (size_t)(4 * H) + (size_t)(lane >> 4) * H + wg * 16];
     }
   }
@@ -185,7 +187,7 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
   float xs_[ITS];
 #pragma unroll
   for (int it = 0; it < ITS; ++it) {
-    const int s = tid + 256 * it, j = s >> 6, row = j * 16 + (ls & 15);
+    const int s = tid + 256 * it, j = s >> 6, row = r0 + j * 16 + (ls & 15);
 #pragma unroll
     for (int g = 0; g < 4; ++g) ax[it][g] = (i32x4){0, 0, 0, 0};
     cv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -233,9 +235,9 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
     __syncthreads();
     const int nf = s_nflag;
     for (int fi = 0; fi < nf; ++fi) {
-      const int r = s_flist[fi];
+      const int r = r0 + s_flist[fi];
       float m = 0.0f;
-      for (int w = tid; w < NWG; w += 256) m = fmaxf(m, a.pmax[((size_t)par * NTR + r) * NWG + w]);
+      for (int w = tid; w < NWG; w += 256) m = fmaxf(m, a.pmax[((size_t)par * NTRT + r) * NWG + w]);
       sred[tid] = m;
       __syncthreads();
       for (int d = 128; d > 0; d >>= 1) {
@@ -265,11 +267,11 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
       if (part == 0) {
         float prod;
         asm volatile("v_mul_f32 %0, %1, %2" : "=v"(prod) : "v"((float)dot), "v"(__fmul_rn(sf, a.wscale[a.wscale_n > 1 ? n : 0])));
-        a.zslow[((size_t)wg * NTR + r) * 64 + col] = a.bias[n] + prod;
+        a.zslow[((size_t)wg * NTRT + r) * 64 + col] = a.bias[n] + prod;
       }
       __syncthreads();
     }
-    if (wg == 0 && tid == 0 && a.slow_count) atomicAdd(a.slow_count, (unsigned)nf);
+    if (wg == 0 && tid == 0 && a.slow_count) atomicAdd(a.slow_count, (unsigned)nf);   // (one add per row group)
   }
   __syncthreads();
 
@@ -277,11 +279,11 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
   const bool last = a.t + 1 >= a.T;
 #pragma unroll
   for (int it = 0; it < ITS; ++it) {
-    const int s = tid + 256 * it, j = s >> 6, row = j * 16 + (ls & 15);
+    const int s = tid + 256 * it, j = s >> 6, row = r0 + j * 16 + (ls & 15);
     if (s >= SLOTS) break;
     const bool live = row < B;
     const size_t rowi = (size_t)a.t * B + row;
-    const bool slow = any && live && a.flag[par * NTR + row] == epoch && !(a.row_frames != nullptr && a.t0 + a.t >= a.row_frames[row]);
+    const bool slow = any && live && a.flag[par * NTRT + row] == epoch && !(a.row_frames != nullptr && a.t0 + a.t >= a.row_frames[row]);
     float hv[4] = {0.f, 0.f, 0.f, 0.f};
     float4 cn4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
@@ -294,7 +296,7 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
           float prod;   // bias + float(sum) * (row scale * weight scale), each operation rounded on its own (oracle/am_hybrid.py: fully_connected_hybrid)
           asm volatile("v_mul_f32 %0, %1, %2" : "=v"(prod) : "v"((float)sum), "v"(__fmul_rn(xs_[it], (&ws4[g].x)[r])));
           z[g] = (&bias4[g].x)[r] + prod;
-          if (slow) z[g] = a.zslow[((size_t)wg * NTR + row) * 64 + g * 16 + ug * 4 + r];
+          if (slow) z[g] = a.zslow[((size_t)wg * NTRT + row) * 64 + g * 16 + ug * 4 + r];
         }
         // gate order i, j, f, o (deepspeech_model.py:144-168); MUL, MUL, ADD as separate float ops
         float cn;
@@ -322,13 +324,13 @@ __device__ __forceinline__ void lstm_i8_step_body(const LstmI8Args& a) {
       const unsigned pk = (unsigned)(unsigned char)quant_i8_(hv[0], inv) | ((unsigned)(unsigned char)quant_i8_(hv[1], inv) << 8) |
                           ((unsigned)(unsigned char)quant_i8_(hv[2], inv) << 16) | ((unsigned)(unsigned char)quant_i8_(hv[3], inv) << 24);
       const int ks = wg >> 2, grp = wg & 3;
-      reinterpret_cast<unsigned*>(a.hq_out)[(((size_t)ks * NT + j) * 64 + grp * 16 + (ls & 15)) * 4 + ug] = pk;
+      reinterpret_cast<unsigned*>(a.hq_out)[(((size_t)ks * NTT + jt0 + j) * 64 + grp * 16 + (ls & 15)) * 4 + ug] = pk;
       float m = fmaxf(fmaxf(fabsf(hv[0]), fabsf(hv[1])), fmaxf(fabsf(hv[2]), fabsf(hv[3])));
       m = fmaxf(m, __shfl_xor(m, 16));
       m = fmaxf(m, __shfl_xor(m, 32));
       if (ug == 0) {
-        a.pmax[((size_t)(par ^ 1) * NTR + row) * NWG + wg] = m;
-        if (live && m > rn && !(a.row_frames != nullptr && a.t0 + a.t + 1 >= a.row_frames[row])) a.flag[(par ^ 1) * NTR + row] = epoch + 1;
+        a.pmax[((size_t)(par ^ 1) * NTRT + row) * NWG + wg] = m;
+        if (live && m > rn && !(a.row_frames != nullptr && a.t0 + a.t + 1 >= a.row_frames[row])) a.flag[(par ^ 1) * NTRT + row] = epoch + 1;
       }
     }
   }
@@ -384,10 +386,16 @@ void launch_lstm_i8_prep(const LstmI8Args& a, const float* h_src, int NT, hipStr
   hipLaunchKernelGGL(lstm_i8_prep_kernel, dim3(NT * 16), dim3(256), 0, st, a, h_src, NT);
 }
 
-void launch_lstm_i8_step(const LstmI8Args& a, int NT, hipStream_t st) {
+void launch_lstm_i8_step(const LstmI8Args& a, int NT, hipStream_t st, int rows_per_wg) {
   if (a.n_hidden % 64 != 0 || a.n_hidden > 4096) throw std::runtime_error("lstm int8 step: n_hidden must be a multiple of 64, at most 4096");
-  const dim3 grid(a.n_hidden / 16), block(256);
-  switch (NT) {
+  // Row groups: the NT batch tiles of a launch may be dealt to NT / nt workgroups per 16-unit slice (gridDim.y), nt tiles each.  The
+  // weights are then read once per row group (from the L2s: 16 MB), but a workgroup's matrix-core work, float64 activations and x-half
+  // reads shrink with its rows -- and 128 slices x 2 groups is one workgroup on every compute unit instead of on half of them.
+  int nt = NT;
+  if (!a.probe && rows_per_wg >= 16 && rows_per_wg < NT * 16) nt = rows_per_wg / 16;
+  if (nt != 1 && nt != 2 && nt != 4 && nt != 8) nt = NT;
+  const dim3 grid(a.n_hidden / 16, NT / nt), block(256);
+  switch (nt) {
     case 1: hipLaunchKernelGGL(lstm_i8_step_kernel<1>, grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL(lstm_i8_step_kernel<2>, grid, block, 0, st, a); break;
     case 4: hipLaunchKernelGGL(lstm_i8_step_kernel<4>, grid, block, 0, st, a); break;

@@ -30,6 +30,7 @@
   X(lstm_cotenant, 0, "STTX_TestLstmSteps only: this many x-projection GEMMs (6144 x 8192 x 2048, form dense_solo) run beside the steps") \
   X(lstm_stamps, 0, "STTX_TestLstmSteps only: in-kernel REFCLK stamps, summary on stderr")                                         \
   X(am_i8, -1, "acoustic model in the released models' own arithmetic (TFLite's hybrid int8 FULLY_CONNECTED: int8 activations per row, int32 sums): -1 = when the file is a dynamic-range quantised .tflite, 0 = never (int8 weights are de-quantised to f16), 1 = always (float weights are quantised at load as the converter does); read when a model is loaded") \
+  X(lstm_i8_rows, 64, "int8 recurrent step: rows per workgroup (16 / 32 / 64 / 128); a step of more rows runs that many row groups per 16-unit slice") \
   X(am_i8_pipe, 0, "int8 path: batches in flight through three acoustic engines like the f16 path (1) instead of one acoustic stream (0, measured best: the int8 GEMMs as co-tenants stretch the int8 recurrent step from 18 to 50 us)") \
   X(lstm_upw, 16, "hidden units per recurrent workgroup (16 or 8); read when a model is loaded")                                   \
   X(copy_kernel, 1, "small tables / result blocks through a copy kernel and mapped page-locked memory (0: copy engine)")           \

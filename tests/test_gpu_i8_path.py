@@ -143,6 +143,35 @@ def test_a_chunk_of_steps_and_the_state_carried_between_calls(tmp_path):
     assert np.array_equal(one["probs"][0], whole["probs"][7])
 
 
+@pytest.mark.parametrize("B", [128, 100, 64, 40])
+def test_row_groups_of_the_step_give_the_same_bits(tmp_path, B):
+    """The recurrent step deals its batch tiles to 1 / 2 / 4 / 8 workgroups per 16-unit slice (tunable lstm_i8_rows: 128 / 64 / 32 / 16 rows per
+    workgroup): integer sums, per-row flags and maxima do not depend on which workgroup holds a row -- every form the bits of the one-group
+    form, slow-path rows (layer 3 scaled down: about half the rows) included."""
+    rng = np.random.default_rng(70 + B)
+    H, T = 256, 12
+    w = synth.synth_weights(6, n_hidden=H)
+    w["layer_3/weights"] = (w["layer_3/weights"] * 0.05).astype(np.float32)
+    w["layer_3/bias"] = (w["layer_3/bias"] * 0.05).astype(np.float32)
+    m = _model(tmp_path, w, "rg%d" % B)
+    win = _windows(rng, T, B)
+    win[:, ::3] *= 60.0                                # a third of the rows on the hoisted form throughout
+    c0 = (rng.standard_normal((B, H)) * 0.5).astype(np.float32)
+    h0 = (np.tanh(rng.standard_normal((B, H))) * 0.9).astype(np.float32)
+    try:
+        native.set_tuning("lstm_i8_rows", 128)
+        want = m.hybridChain(win, c0, h0)
+        assert 0 < want["slow_rows"] < T * B
+        for rows in (64, 32, 16):
+            native.set_tuning("lstm_i8_rows", rows)
+            got = m.hybridChain(win, c0, h0)
+            for k in ("h_all", "c", "h", "probs"):
+                assert np.array_equal(got[k], want[k]), (rows, k)
+            assert got["slow_rows"] == want["slow_rows"], rows
+    finally:
+        native.set_tuning("lstm_i8_rows", 64)
+
+
 @pytest.fixture(scope="module")
 def big(tmp_path_factory):
     w = synth.synth_weights(0, n_hidden=2048)
