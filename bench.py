@@ -831,7 +831,7 @@ def measure(wl, args, cx, steps, warmup):
         lstm_name = "lstm_step8_kernel<1>" if rows == 128 else "lstm_step_kernel<4, 2, 4, 3>"      # as rocprofv3 names them
         if i8:   # recurrent matrix int8 once per launch + per row: x half of the sums (int32 4H) in, h int8 in/out, h f32 out, c (f32 H) in/out
             lstm_bytes = H * 4 * H + rows * (4 * H * 4 + 2 * H + H * 4 + 2 * H * 4)
-            lstm_name = "lstm_i8_step8_kernel" if rows == 128 else "lstm_i8_step_kernel<4>"
+            lstm_name = "lstm_i8_step_kernel<4>"      # (128 rows: two row groups of 64 per 16-unit slice, tunable lstm_i8_rows; the matrix is then read twice, from the L2s -- the algorithmic bytes count it once)
         dec_ms = stage["decoder_next_ms"] / K
         steps_total = max(1, dstats["steps"])
         tsteps = stage["timesteps"]                  # utterance-timesteps through the acoustic model in the timed region
@@ -851,7 +851,7 @@ def measure(wl, args, cx, steps, warmup):
         # counters are never collected inside a timed run).  Only valid for the batch workload's shapes.
         pmc, pmc_file = {}, None
         if wl == "batch":
-            for prof in (("r05_b_i8_pmc_traffic.json",) if i8 else ("r05_b_pmc_traffic.json", "r04_n_pmc_traffic.json", "r03_l_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
+            for prof in (("r05_c_i8_pmc_traffic.json", "r05_b_i8_pmc_traffic.json") if i8 else ("r05_b_pmc_traffic.json", "r04_n_pmc_traffic.json", "r03_l_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
                     pmc_file = prof
