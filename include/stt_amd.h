@@ -233,6 +233,9 @@ STTX_EXPORT int STTX_TestDenseHybrid(const float* aX, unsigned int aM, unsigned 
  * int32 sums; taken for a dynamic-range quantised `.tflite`, or with the tunable am_i8 = 1).  Replaces nothing in coqui-stt.h: the
  * reference's CPU path has only the second one (native_client/tflitemodelstate.cc:200,369-405). */
 STTX_EXPORT int STTX_GetAcousticMode(const ModelState* aCtx);
+/* Test hook (int8 path): rows that took the recurrent step's slow path (max |h| above max |x_t|: both halves again at the joint scale) since the
+ * model was created, over every engine form; waits for everything in flight.  0 rows on a float model. */
+STTX_EXPORT int STTX_DebugSlowRows(ModelState* aCtx, unsigned int* aRows);
 /* Test hook for the int8 path (aCtx must be in mode 1): aWindows f32 [aT * aB][19 x 26] context windows, row = t * aB + b, through layers
  * 1-3, the cell (state aC / aH [aB][n_hidden] f32, NULL = zeros), layers 5-6 and the softmax as ONE call of the engine's one-stream path.
  * Outputs (each may be NULL): aL3 [aT*aB][n_hidden] layer 3's f32 rows; aAccX [aT*aB][4 n_hidden] the x half of the cell's int32 sums;

@@ -1346,6 +1346,16 @@ int STTX_TestDense(int M, int N, int K, const float* aX, const float* aW, const 
 // x f32 [M][K], wq int8 [N][K], wscale [n_scales = 1 or N], bias [N] -> y f32 [M][N] (and, if asked for, the quantised rows and their
 // scales); aReps timed repetitions of quantisation + product (HIP events) -> *aElapsedMs per repetition.
 int STTX_GetAcousticMode(const ModelState* m) { return m && m->i8 ? 1 : 0; }
+int STTX_DebugSlowRows(ModelState* m, unsigned int* aRows) {
+  return guarded([&]() {
+    if (!m || !aRows) return (int)STT_ERR_INVALID_SHAPE;
+    HIP_CHECK(hipSetDevice(m->device));
+    HIP_CHECK(hipDeviceSynchronize());
+    *aRows = 0;
+    if (m->ws_slow.p) HIP_CHECK(hipMemcpy(aRows, m->ws_slow.p, 4, hipMemcpyDeviceToHost));
+    return (int)STT_ERR_OK;
+  }, STT_ERR_FAIL_RUN_SESS);
+}
 
 int STTX_TestHybridChain(ModelState* m, const float* aWindows, unsigned int aB, unsigned int aT, const float* aC, const float* aH, float* aL3, int* aAccX, float* aHAll,
                          float* aLogits, float* aProbs, float* aNewC, float* aNewH, unsigned int* aSlowRows, float* aLstmMs) {

@@ -323,6 +323,15 @@ class Model(object):
         """0 = f16 MFMA operands / f32 accumulate, 1 = TFLite's hybrid int8 arithmetic end to end (include/stt_amd.h: STTX_GetAcousticMode)."""
         return int(native.lib().STTX_GetAcousticMode(self._impl))
 
+    def slowRows(self):
+        """int8 path, test hook: rows that took the recurrent step's slow path so far (include/stt_amd.h: STTX_DebugSlowRows)."""
+        import ctypes
+        n = ctypes.c_uint(0)
+        status = native.lib().STTX_DebugSlowRows(self._impl, ctypes.byref(n))
+        if status != 0:
+            raise RuntimeError("STTX_DebugSlowRows failed with '{}' (0x{:X})".format(native.error_message(status), status))
+        return int(n.value)
+
     def hybridChain(self, windows, state_c=None, state_h=None):
         """Test hook (int8-path models): windows f32 [T][B][n_in1] -> dict of the chain's intermediate results (STTX_TestHybridChain)."""
         g = self.geometry()

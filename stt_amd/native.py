@@ -47,7 +47,7 @@ COQUI_STT_H = [
 ]
 STT_AMD_H = [
     "STTX_SetDevice", "STTX_GetDeviceCount", "STTX_SpeechToTextBatch", "STTX_SpeechToTextBatchWithMetadata",
-    "STTX_SpeechToTextBatchDevice", "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmit", "STTX_BatchSubmitDevice", "STTX_BatchCollect", "STTX_BatchCollectWithMetadata", "STTX_BatchCollectScored", "STTX_DebugBatchProbs", "STTX_SetTuning", "STTX_GetTuning", "STTX_ConfigureRuntime", "STTX_TestLstmSteps", "STTX_TestDenseHybrid", "STTX_GetAcousticMode", "STTX_TestHybridChain", "STTX_FeedAudioContentBatch", "STTX_FeedAudioContentBatchEx", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_DecodeStreamsBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
+    "STTX_SpeechToTextBatchDevice", "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmit", "STTX_BatchSubmitDevice", "STTX_BatchCollect", "STTX_BatchCollectWithMetadata", "STTX_BatchCollectScored", "STTX_DebugBatchProbs", "STTX_SetTuning", "STTX_GetTuning", "STTX_ConfigureRuntime", "STTX_TestLstmSteps", "STTX_TestDenseHybrid", "STTX_GetAcousticMode", "STTX_DebugSlowRows", "STTX_TestHybridChain", "STTX_FeedAudioContentBatch", "STTX_FeedAudioContentBatchEx", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_DecodeStreamsBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
     "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_GetDecoderStamps", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
     "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
     "STTX_DecoderStats", "STTX_DecoderErrorBits", "STTX_DecoderSetProfiling", "STTX_DecoderGetProfile", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
@@ -119,6 +119,7 @@ def lib():
         "STTX_TestLstmSteps": (ci, [vp, cu, cu, cu, ci, vp, vp, vp, vp, pp(cf)]),
         "STTX_TestDenseHybrid": (ci, [vp, cu, cu, vp, vp, cu, vp, cu, vp, vp, vp, cu, pp(cf), ci, cf]),
         "STTX_GetAcousticMode": (ci, [vp]),
+        "STTX_DebugSlowRows": (ci, [vp, C.POINTER(C.c_uint)]),
         "STTX_TestHybridChain": (ci, [vp, vp, cu, cu, vp, vp, vp, vp, vp, vp, vp, vp, vp, pp(cu), pp(cf)]),
         "STTX_FeedAudioContentBatch": (None, [pp(vp), pp(vp), pp(cu), cu]),
         "STTX_FeedAudioContentBatchEx": (None, [pp(vp), pp(vp), pp(cu), vp, cu]),
