@@ -851,7 +851,7 @@ def measure(wl, args, cx, steps, warmup):
         # counters are never collected inside a timed run).  Only valid for the batch workload's shapes.
         pmc, pmc_file = {}, None
         if wl == "batch":
-            for prof in (("r05_c_i8_pmc_traffic.json", "r05_b_i8_pmc_traffic.json") if i8 else ("r05_b_pmc_traffic.json", "r04_n_pmc_traffic.json", "r03_l_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
+            for prof in (("r05_c_i8_pmc_traffic.json", "r05_b_i8_pmc_traffic.json") if i8 else ("r05_c_pmc_traffic.json", "r05_b_pmc_traffic.json", "r04_n_pmc_traffic.json", "r03_l_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
                     pmc_file = prof
@@ -920,7 +920,9 @@ def measure(wl, args, cx, steps, warmup):
             roofline["critical_path"] = {"kernel": lstm_name, "stream_busy_frac_of_step": kernels[lstm_name]["share_ms"] / (1e3 * elapsed / K), "bound": "hbm",
                                          "achieved": lg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lg / HBM_PEAK_GBS, "us_per_launch": 1e3 * lstm_avg_ms,
                                          "rows_per_launch": rows,
-                                         "note": "33.5 MB of recurrent weights + the rows' state per launch / HIP-event time per launch, measured beside the GEMM and search kernels of the other engines"}
+                                         "note": ("16.8 MB of int8 recurrent weights (counted once: the two row groups' second read comes from the L2s) + the rows' state per launch / HIP-event time per launch, "
+                                                  "measured beside the search kernels of the batches before" if i8 else
+                                                  "33.5 MB of recurrent weights + the rows' state per launch / HIP-event time per launch, measured beside the GEMM and search kernels of the other engines")}
         res.update({
             "stage_ms_per_step": {k: v / K for k, v in stage.items() if k.endswith("_ms")},
             "decoder_counters_last_step": dstats,
