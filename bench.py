@@ -920,6 +920,9 @@ def measure(wl, args, cx, steps, warmup):
             roofline["critical_path"] = {"kernel": lstm_name, "stream_busy_frac_of_step": kernels[lstm_name]["share_ms"] / (1e3 * elapsed / K), "bound": "hbm",
                                          "achieved": lg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lg / HBM_PEAK_GBS, "us_per_launch": 1e3 * lstm_avg_ms,
                                          "rows_per_launch": rows,
+                                         # the other queues of the pipeline by the same clock (HIP events between stage marks): with three engines the
+                                         # GEMM engine's chain (features, layers 1-3, x-projection) is as busy as the recurrence's
+                                         "queues_busy_frac_of_step": {k_: stage.get(k_ + "_ms", 0.0) / K / (1e3 * elapsed / K) for k_ in ("features", "dense_in", "lstm", "dense_out", "decoder_next")},
                                          "note": ("16.8 MB of int8 recurrent weights (counted once: the two row groups' second read comes from the L2s) + the rows' state per launch / HIP-event time per launch, "
                                                   "measured beside the search kernels of the batches before" if i8 else
                                                   "33.5 MB of recurrent weights + the rows' state per launch / HIP-event time per launch, measured beside the GEMM and search kernels of the other engines")}

@@ -120,6 +120,7 @@ def test_rows_whose_h_outgrows_x_take_the_joint_scale(tmp_path):
         assert float(np.abs(he - hw).max()) <= 4e-6, (t, float(np.abs(he - hw).max()))
         c, h = cw, he
     assert n_slow > T * B // 2 and out["slow_rows"] == n_slow, (n_slow, out["slow_rows"])
+    assert m.slowRows() == n_slow                    # (STTX_DebugSlowRows: the model's running count, every engine form)
 
 
 def test_a_chunk_of_steps_and_the_state_carried_between_calls(tmp_path):
