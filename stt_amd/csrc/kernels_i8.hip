@@ -15,6 +15,9 @@
 //     the assumption: a workgroup whose units hold a larger |h| flags the row; the consuming step then computes that row again from the
 //     f32 x_t and h_(t-1) at the true joint scale (the slow path below: plain int8 dot products over K = 2H for the row).
 //   * the cross-wave reduction of the int32 partial sums uses LDS atomics (order does not matter for integers).
+//   * a launch covers a 16-unit slice per blockIdx.x and a ROW GROUP per blockIdx.y (launch_lstm_i8_step: 64 rows per workgroup by default,
+//     so 128 rows are two workgroups per slice, one on every compute unit): flags, maxima and the slow path are per row, so every
+//     dealing of the rows gives the same bits.
 // Layouts: recurrent weights int8 packed per (workgroup, k-step of 64, gate tile, lane) -- 16 bytes per lane and MFMA, the same
 // fragment rule as the f16 form with twice the k per instruction; h_(t-1) int8 in B-fragment order [H/64][NT][64 lanes][16].
 #include <hip/hip_runtime.h>
