@@ -781,7 +781,10 @@ def measure(wl, args, cx, steps, warmup):
                    "audio": ("host (STTX_BatchSubmit: pageable int16 buffers, gathered into page-locked memory and copied to HBM inside the clock)" if (pipelined and host_audio)
                              else "device (int16 in HBM before the clock starts; `host_audio` = the same batches from host buffers)" if wl in ("batch", "bytes", "ragged") else "n/a"),
                    # two 64-utterance batches share one recurrence where the step is acoustic-bound (tunable `pair`; not the search-bound bytes setup)
-                   "rows_per_recurrent_step": (128 if (native.get_tuning("pair") and wl != "bytes" and (pipelined or wl == "ragged")) else 64)},
+                   "rows_per_recurrent_step": (128 if (native.get_tuning("pair") and wl != "bytes" and (pipelined or wl == "ragged")) else 64),
+                   # moves of the recurrence / output engine to fresh streams because a watched chunk's steps were picked up late (engine.cpp: am_replace_if_slow),
+                   # the whole process so far, and the last watched chunk's microseconds per step
+                   "queue_moves": native.get_tuning("am_moved"), "watched_step_us": native.get_tuning("am_step_us_x10") / 10.0},
         "verified": verified, "verified_against": verified_against, "verified_what": verified_what,
         "verify_counts": vcounts, "verify_mismatches": mismatches,
         # nothing reference-held pins the acoustic half (TensorFlow Lite is an un-vendored submodule, no model offline) nor
@@ -1030,7 +1033,7 @@ def main():
     if rank == 0 and wl == "batch" and world == 1 and not args.no_extras and not args.no_profile:
         # the other configs, same process, same build: short runs (a few seconds each), each with its own roofline
         sub = {}
-        for w, k, wu, kw in (("batch_i8", 12, 5, {}), ("ragged", 2, 1, {}), ("stream", 3, 1, {"utterances": 1000}), ("bytes", 8, 5, {}), ("peaky", 10, 2, {}), ("peaky_bytes", 6, 2, {})):   # (bytes: four batches in flight -- the warm-up covers every slot's first use)
+        for w, k, wu, kw in (("batch_i8", 12, 24, {}), ("ragged", 2, 1, {}), ("stream", 3, 1, {"utterances": 1000}), ("bytes", 8, 5, {}), ("peaky", 10, 2, {}), ("peaky_bytes", 6, 2, {})):   # (bytes: four batches in flight -- the warm-up covers every slot's first use; batch_i8: a second model of the process -- the warm-up covers the moves of its engines' queues, if the placement watch makes any: config.queue_moves)
             a2 = argparse.Namespace(**vars(args))
             a2.utterances = kw.get("utterances", 0)
             try:

@@ -256,9 +256,9 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::ve
   sl.wide.reserve(ctc_rows_ws_bytes(p, Bg, max_chunk));
   // the acoustic model as three engines (engine.h) when other groups are in flight beside this one; a lone group (blocking call,
   // latency matters) keeps everything on `stream`: its own GEMMs would only slow its own recurrence (6.5 vs 5.9 ms)
-  // (the int8 path stays on ONE acoustic stream: its GEMMs run at twice the f16 forms' operand rate and, as co-tenants, stretch the int8
-  // recurrent step from 18 to 50 us -- measured 7.1 ms per batch with three engines against 4.4 with one)
+  // (the int8 path takes the same form: tunable am_i8_pipe; 0 = one acoustic stream, 3.8 ms per batch wherever the engines' queues sit)
   const bool piped = pipelined && (!m->i8 || tune().am_i8_pipe != 0) && m->am_pipe_init();
+  if (piped) m->am_replace_if_slow();   // (a bad placement of the engines' hardware queues shows in the pipeline's own timing: engine.cpp)
   for (int k = 0; k < n_chunks; ++k) {
     hipEvent_t ev = m->ev_chunk[k % 2];  // an event may be re-recorded once the wait on it has been enqueued
     if (piped) {

@@ -211,6 +211,52 @@ bool ModelState::am_pipe_init() {
   return true;
 }
 
+// Which hardware queues the recurrence's and the output engine's streams land on decides whether the three engines work at all: the same
+// process, the same kernels, one idle stream created at another moment -- 3.0 or 6.5 ms per batch (int8 form; the f16 form 3.08 or 6.1:
+// profiles/r05_queue_placement.json).  In a bad placement every recurrent step (a fresh dispatch behind the one before it, 250 per batch)
+// is picked up tens of microseconds late, as if its queue were served in turns with another one.  HIP offers no say in the placement -- a
+// stream takes the process's next hardware queue -- but the symptom is unmistakable in the pipeline's own timing: a chunk's recurrence,
+// bracketed by two events on its stream, takes 17 - 23 us per step when the queue is served at once and 36 - 46 when it is not.  So the
+// engine watches one chunk at a time (no synchronisation: the events are read when they have long been reached) and, after two slow
+// readings in a row, moves the recurrence and the output engine to fresh streams -- created BEFORE the old ones are destroyed, so that they
+// take other hardware queues -- at most `am_moves` times per model.  A pipeline that is slow for another reason pays a few stream
+// synchronisations and stays where it was last.
+void ModelState::am_watch_begin(int T) {
+  if (tune().am_moves <= 0 || watch_armed || T < 32 || watch_moves > tune().am_moves) return;
+  if (!ev_watch[0]) for (auto& e : ev_watch) HIP_CHECK(hipEventCreate(&e));
+  HIP_CHECK(hipEventRecord(ev_watch[0], stream_l));
+  watch_steps = -T;                                    // (negative: begun, not ended)
+}
+void ModelState::am_watch_end() {
+  if (watch_steps >= 0 || watch_armed) return;
+  HIP_CHECK(hipEventRecord(ev_watch[1], stream_l));
+  watch_steps = -watch_steps;
+  watch_armed = true;
+}
+void ModelState::am_replace_if_slow() {
+  if (!watch_armed || hipEventQuery(ev_watch[1]) != hipSuccess) { (void)hipGetLastError(); return; }
+  watch_armed = false;
+  float ms = 0.0f;
+  if (hipEventElapsedTime(&ms, ev_watch[0], ev_watch[1]) != hipSuccess) { (void)hipGetLastError(); return; }
+  const float us = 1e3f * ms / (float)std::max(1, watch_steps);
+  const float hh = (float)g.n_hidden / 2048.0f;
+  const float limit = tune().am_slow_us > 0 ? (float)tune().am_slow_us : 31.0f * std::max(1.0f, hh * hh);   // (the bench's model: 17 - 23 us per step as run when served at once)
+  tune().am_step_us_x10 = (int)(us * 10.0f);
+  watch_slow = us > limit ? watch_slow + 1 : 0;
+  if (watch_slow < 2 || watch_moves >= tune().am_moves) return;
+  watch_slow = 0;
+  ++watch_moves;
+  __atomic_fetch_add(&tune().am_moved, 1, __ATOMIC_RELAXED);
+  hipStream_t nl = nullptr, no = nullptr;
+  int lo = 0, hi = 0;
+  HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  HIP_CHECK(hipStreamCreateWithPriority(&nl, hipStreamNonBlocking, hi));
+  HIP_CHECK(hipStreamCreateWithFlags(&no, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamSynchronize(stream_l)); HIP_CHECK(hipStreamSynchronize(stream_o));   // (rare: nothing of the old queues is left in flight)
+  (void)hipStreamDestroy(stream_l); (void)hipStreamDestroy(stream_o);
+  stream_l = nl; stream_o = no;
+}
+
 static int dense_lds_floor() {  // bytes; > 80 KiB = one GEMM workgroup per CU while the recurrence runs beside it
   const int kb = tune().dense_lds_kb;
   return kb <= 0 ? 0 : kb * 1024;
@@ -285,6 +331,7 @@ void ModelState::run_acoustic_chunk_piped_i8(const float* d_feats, const int* d_
       launch_lstm_i8_step(l, NT, stream_l, tune().lstm_i8_rows);
     }
   };
+  am_watch_begin(T);
   if (tune().lstm_graph) {
     LstmGraphKey key;
     memset(&key, 0, sizeof(key));
@@ -293,6 +340,7 @@ void ModelState::run_acoustic_chunk_piped_i8(const float* d_feats, const int* d_
     key.hp1 = (const void*)((uintptr_t)am_hq1.p ^ (uintptr_t)d_nframes);
     run_lstm_graph(key, steps);
   } else steps();
+  am_watch_end();
   stt_prof_mark_on(this, -1, 5, stream_l);
   HIP_CHECK(hipEventRecord(ev_x_free[slot], stream_l));
   HIP_CHECK(hipEventRecord(ev_h_ready[slot], stream_l));
@@ -416,6 +464,7 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
       launch_lstm_step(l, NT, stream_l);
     }
   };
+  am_watch_begin(T);
   if (tune().lstm_graph) {
     LstmGraphKey key;
     memset(&key, 0, sizeof(key));  // (padding bytes take part in the comparison)
@@ -423,6 +472,7 @@ void ModelState::run_acoustic_chunk_piped(const float* d_feats, const int* d_nfr
     key.T = T; key.par = t0 & 1; key.B = B; key.NT = NT; key.passes = l.passes; key.prio = l.prio; key.H = H; key.first = tune().lstm_form * 16 + tune().lstm_prefetch;  // (what else selects the kernel instance)
     run_lstm_graph(key, steps);
   } else steps();
+  am_watch_end();
   stt_prof_mark_on(this, -1, 5, stream_l);
   HIP_CHECK(hipEventRecord(ev_x_free[slot], stream_l));
   HIP_CHECK(hipEventRecord(ev_h_ready[slot], stream_l));

@@ -315,6 +315,15 @@ struct ModelState {
                                            // what the one-stream paths (streaming API, blocking calls) use on `stream`
   hipEvent_t ev_x_ready[kAmRing] = {}, ev_x_free[kAmRing] = {}, ev_h_ready[kAmRing] = {}, ev_h_free[kAmRing] = {};
   unsigned long long am_seq = 0;  // chunks sent through the pipe so far (slot = am_seq % kAmRing)
+  // Placement watch (engine.cpp: am_watch_begin / am_watch_end / am_replace_if_slow): one chunk's recurrence at a time is bracketed by two
+  // timing events; a pipeline whose steps are picked up late -- a bad placement of the engines' hardware queues -- moves the recurrence and the
+  // output engine to fresh streams the next time a group is enqueued.
+  hipEvent_t ev_watch[2] = {};
+  bool watch_armed = false;
+  int watch_steps = 0, watch_slow = 0, watch_moves = 0;
+  void am_watch_begin(int T);
+  void am_watch_end();
+  void am_replace_if_slow();
   // The recurrence of a chunk is T dependent launches whose arguments only depend on (ring slot, T, parity of t0, batch): the
   // second time a combination comes up it is captured into a hipGraph and replayed from then on -- one graph launch instead
   // of 16-48 kernel launches of host time (enqueueing a 64 x 5 s batch: ~300 launches, 1.5 ms on a quiet host, 2.5-5 ms on a

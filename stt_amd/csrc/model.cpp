@@ -108,6 +108,7 @@ ModelState::~ModelState() {
   for (auto& kv : hop_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   if (stream_h2d) (void)hipStreamDestroy(stream_h2d);
   for (auto& st : stage_) if (st.copied) (void)hipEventDestroy(st.copied);
+  for (auto& e : ev_watch) if (e) (void)hipEventDestroy(e);
   if (stream_l) (void)hipStreamDestroy(stream_l);
   if (stream_o) (void)hipStreamDestroy(stream_o);
   for (int i = 0; i < kAmRing; ++i)

@@ -30,8 +30,12 @@
   X(lstm_cotenant, 0, "STTX_TestLstmSteps only: this many x-projection GEMMs (6144 x 8192 x 2048, form dense_solo) run beside the steps") \
   X(lstm_stamps, 0, "STTX_TestLstmSteps only: in-kernel REFCLK stamps, summary on stderr")                                         \
   X(am_i8, -1, "acoustic model in the released models' own arithmetic (TFLite's hybrid int8 FULLY_CONNECTED: int8 activations per row, int32 sums): -1 = when the file is a dynamic-range quantised .tflite, 0 = never (int8 weights are de-quantised to f16), 1 = always (float weights are quantised at load as the converter does); read when a model is loaded") \
+  X(am_moves, 6, "three-engine form: how often a model may move its recurrence and output engine to fresh streams when a chunk's steps are picked up late twice in a row (0 = never watch)") \
+  X(am_slow_us, 0, "three-engine form: microseconds per recurrent step above which a chunk counts as slow (0 = 31 us x max(1, (n_hidden / 2048)^2))") \
+  X(am_moved, 0, "counter, not a knob: moves of the engines to fresh streams so far (all models)") \
+  X(am_step_us_x10, 0, "counter, not a knob: the last watched chunk's microseconds per recurrent step, times ten") \
   X(lstm_i8_rows, 64, "int8 recurrent step: rows per workgroup (16 / 32 / 64 / 128); a step of more rows runs that many row groups per 16-unit slice") \
-  X(am_i8_pipe, 0, "int8 path: batches in flight through three acoustic engines like the f16 path (1) instead of one acoustic stream (0, measured best: the int8 GEMMs as co-tenants stretch the int8 recurrent step from 18 to 50 us)") \
+  X(am_i8_pipe, 1, "int8 path: batches in flight through three acoustic engines like the f16 path (1: 3.0 - 3.2 ms per batch once the engines' queues sit well -- the placement watch, am_moves, sees to that) or on one acoustic stream (0: 3.8 ms wherever the queues sit)") \
   X(lstm_upw, 16, "hidden units per recurrent workgroup (16 or 8); read when a model is loaded")                                   \
   X(copy_kernel, 1, "small tables / result blocks through a copy kernel and mapped page-locked memory (0: copy engine)")           \
   X(search_lds_kb, 160, "LDS budget of the search kernel's layout (96..160)")                                                      \
