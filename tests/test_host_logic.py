@@ -199,3 +199,48 @@ def test_bench_checks_fail_the_run_on_a_forged_mismatch():
     assert bench.exit_code(dict(line, verify_counts={"unexplained": 1})) == 3
     assert bench.exit_code(dict(line, workloads={"stream": {"verified": False}})) == 3
     assert bench.exit_code(dict(line, workloads={"bytes": {"error": "RuntimeError('x')"}})) == 3
+
+
+def test_bench_final_line_stays_short_enough_for_the_driver():
+    """Round 5's line grew to 40 KB and the driver recorded `parsed: null`.  The LAST stdout line is compact_line(res): always JSON, always
+    under bench.FINAL_LINE_LIMIT, always with the contract's keys, `roofline` and `cpu_baseline` -- whatever the checks found (here: round 5's
+    own full result with 64 forged mismatch records of two 100-character transcripts in every line and sub-line)."""
+    import json
+    import bench
+    res = json.load(open(os.path.join(ROOT, "profiles", "r05_c_bench_line.json")))
+    mm = [{"id": [i, 0, i], "against": "reference", "got": "g" * 100, "want": "w" * 100, "got_confidence": -1.0 * i, "want_confidence": -2.0 * i,
+           "boundary_tie_steps": 3, "equals_the_restatement": True, "reference_reproduced_by_the_reference_order_restatement": True,
+           "explained_by_a_boundary_tie": True} for i in range(64)]
+    res["verify_mismatches"] = mm
+    res["verified_what"] = "x" * 5000
+    for r in res["workloads"].values():
+        r["verify_mismatches"] = list(mm)
+        r["verified_what"] = "y" * 5000
+    res["workloads"]["broken"] = {"error": "RuntimeError(%r)" % ("z" * 4000)}
+    assert len(json.dumps(res)) > 100000
+    line = json.dumps(bench.compact_line(res))
+    assert len(line) < bench.FINAL_LINE_LIMIT < 8192
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "verified", "verify_counts", "p50_utterance_latency_ms", "roofline", "cpu_baseline", "workloads"):
+        assert k in back, k
+    assert back["value"] == round(res["value"], 6) and back["ms_per_step"] == round(res["ms_per_step"], 6)
+    assert isinstance(back["config"]["workload"], str) and "model" not in back["config"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms"):
+        assert k in back["roofline"], k
+    assert back["roofline"]["bound"] in ("hbm", "mfma") and abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-6
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in back["cpu_baseline"], k
+    assert back["cpu_baseline"]["kind"] in ("reference", "port") and "value" in back["cpu_baseline"]["end_to_end"]
+    for w in ("batch_i8", "ragged", "stream", "bytes", "peaky", "peaky_bytes"):
+        for k in ("value", "ms_per_step", "verified", "verified_against", "unexplained", "roofline_frac"):
+            assert k in back["workloads"][w], (w, k)
+    assert "error" in back["workloads"]["broken"]
+    # what exit_code() reads survives the cut: a failed check is still visible in the short line
+    assert back["verify_counts"]["unexplained"] == res["verify_counts"]["unexplained"]
+    # a much smaller limit still yields valid JSON with the headline
+    tiny = bench.compact_line(res, limit=3500)
+    assert len(json.dumps(tiny)) <= 3500 and tiny["value"] == back["value"] and "roofline" in tiny and "cpu_baseline" in tiny
+    # and main() prints it LAST, after the detail
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('print("bench_detail: " + detail)') < src.index("print(json.dumps(compact_line(res)")
