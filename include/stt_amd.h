@@ -206,6 +206,8 @@ typedef struct STTX_ModelInfo {
   float relu_clip;
   unsigned int alphabet_bytes;
   int is_tflite;
+  int hybrid_int8;                 /* 1: the file's six matrices are symmetric int8 and the model will run TFLite's hybrid arithmetic (STTX_GetAcousticMode 1) */
+  int asymmetric_quantize_inputs;  /* 1: a FULLY_CONNECTED asks for asymmetric input quantisation: not restated, the weights are de-quantised (f16 path) */
 } STTX_ModelInfo;
 STTX_EXPORT int STTX_InspectModel(const char* aModelBuffer, unsigned int aBufferSize, STTX_ModelInfo* aInfo);
 /* aIndex 0..11: layer_1/weights, layer_1/bias, layer_2/weights, layer_2/bias, layer_3/weights, layer_3/bias, lstm/kernel,

@@ -34,7 +34,10 @@ def quantize_weights(w_in_out, per_channel=False):
     w = np.ascontiguousarray(np.asarray(w_in_out, dtype=F32).T)
     amax = np.abs(w).max(axis=1) if per_channel else np.array([np.abs(w).max()])
     scale = (np.maximum(amax, 1e-30) / 127.0).astype(F32)
-    q = np.clip(np.rint(w / (scale[:, None] if per_channel else scale[0])), -127, 127).astype(np.int8)
+    # the converter's quantize_weights pass goes through the same tensor_utils::SymmetricQuantizeFloats as the activations: round(w * (127 / range))
+    inv = (F32(127.0) / np.maximum(amax, 1e-30).astype(F32)).astype(F32)
+    t = (w * (inv[:, None] if per_channel else inv[0])).astype(F32)
+    q = np.clip(np.sign(t) * np.floor(np.abs(t).astype(np.float64) + 0.5), -127, 127).astype(np.int8)
     return q, scale
 
 
@@ -77,10 +80,27 @@ def _tanh(x):
     return np.tanh(np.asarray(x, dtype=np.float64)).astype(F32)
 
 
-class HybridModel:
-    """The exported graph (stt_amd/tflitefile.py mirrors export.py's) with every FULLY_CONNECTED as the hybrid kernel."""
+def _sigmoid_f32(x):
+    """The float form of TFLite's reference LOGISTIC, `1.f / (1.f + std::exp(-x))` (reference/logistic.h), with whatever float32 exp the host's
+    numpy has (a SIMD approximation, 1-3 ulp off the correctly rounded value -- like any libm's or Eigen's): the SECOND checker."""
+    x = np.asarray(x, dtype=F32)
+    return (F32(1) / (F32(1) + np.exp(-x, dtype=F32))).astype(F32)
 
-    def __init__(self, weights, per_channel=False, relu_clip=am_ref.RELU_CLIP):
+
+def _tanh_f32(x):
+    return np.tanh(np.asarray(x, dtype=F32), dtype=F32)
+
+
+class HybridModel:
+    """The exported graph (stt_amd/tflitefile.py mirrors export.py's) with every FULLY_CONNECTED as the hybrid kernel.
+    activations: "cr" = LOGISTIC / TANH correctly rounded (float64 evaluation, one rounding: what the engine's int8 path computes, so the
+    two agree to the last bits); "f32" = evaluated in float32 as a TFLite build would (1-3 ulp from "cr"; which ulp is build-specific).
+    The engine is stated against BOTH: bit-level against "cr", and within the tolerance tests/test_gpu_hybrid.py writes against "f32" --
+    that second figure is the honest size of "which float exp did your TFLite link" (round-5 advisor)."""
+
+    def __init__(self, weights, per_channel=False, relu_clip=am_ref.RELU_CLIP, activations="cr"):
+        assert activations in ("cr", "f32")
+        self.sig, self.tanh = (_sigmoid, _tanh) if activations == "cr" else (_sigmoid_f32, _tanh_f32)
         self.q = {}
         for k in ("layer_1/weights", "layer_2/weights", "layer_3/weights", "lstm/kernel", "layer_5/weights", "layer_6/weights"):
             w = np.asarray(weights[k], dtype=F32)
@@ -121,8 +141,8 @@ class HybridModel:
         for t in range(T):
             z = self._fc(np.concatenate([l3[:, t], h], axis=1), "lstm/kernel", self.b["lstm/bias"])     # concat([x_t, h]) . kernel + bias
             i, j, f, o = np.split(z, 4, axis=1)                                                          # gate order i, j, f, o (deepspeech_model.py:144-168)
-            c = (_sigmoid(f) * c + _sigmoid(i) * _tanh(j)).astype(F32)
-            h = (_sigmoid(o) * _tanh(c)).astype(F32)
+            c = (self.sig(f) * c + self.sig(i) * self.tanh(j)).astype(F32)
+            h = (self.sig(o) * self.tanh(c)).astype(F32)
             hs[:, t] = h
         l5 = self._dense(hs.reshape(B * T, self.H), "layer_5")
         logits = self._fc(l5, "layer_6/weights", self.b["layer_6/bias"])
@@ -131,8 +151,8 @@ class HybridModel:
         return (e / e.sum(axis=1, keepdims=True)).astype(F32).reshape(B, T, -1)
 
 
-def utterance_probs_batch(audios, weights, per_channel=False, spec=None):
+def utterance_probs_batch(audios, weights, per_channel=False, spec=None, activations="cr"):
     """Equal-length int16 utterances -> probs [B][T][C] through the hybrid kernels (features as oracle/am_ref.py)."""
     spec = spec or am_ref.MfccSpec()
     win = np.stack([am_ref.context_windows(spec.frames_fast(np.asarray(a, dtype=np.int16))) for a in audios])
-    return HybridModel(weights, per_channel).forward_batch(win)
+    return HybridModel(weights, per_channel, activations=activations).forward_batch(win)

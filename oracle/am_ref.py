@@ -91,7 +91,12 @@ class MfccSpec:
         x[:len(self.window)] *= self.window
         spec = np.fft.rfft(x)
         power = (spec.real * spec.real + spec.imag * spec.imag).astype(np.float32)  # spectrogram output tensor is float
-        amp = np.sqrt(power.astype(np.float64))
+        return self.from_power(power)
+
+    def from_power(self, power_f32):
+        """The Mfcc op proper (mfcc.cc: sqrt of the squared-magnitude spectrogram, mel filterbank, log, DCT): n_bins float32 -> n_coef float32.
+        This is the entry upstream TensorFlow's own unit test drives (core/kernels/mfcc_test.cc; tests/test_oracle_am.py holds its vector)."""
+        amp = np.sqrt(np.asarray(power_f32, dtype=np.float32).astype(np.float64))
         mel = np.zeros(self.n_mel, dtype=np.float64)
         for b in range(self.start_index, self.end_index + 1):  # mfcc_mel_filterbank.cc Compute()
             w = amp[b] * self.weights[b]

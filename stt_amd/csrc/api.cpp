@@ -1578,7 +1578,8 @@ int STTX_InspectModel(const char* aModelBuffer, unsigned int aBufferSize, STTX_M
   if (rc != STT_ERR_OK) { std::cerr << err << std::endl; return rc; }
   const Geometry& g = v.g;
   *aInfo = STTX_ModelInfo{g.n_input, g.n_context, g.n_hidden, g.n_classes, g.n_steps, g.sample_rate, g.win_len, g.win_step, g.beam_width,
-                          g.relu_clip, (unsigned)v.alphabet_bytes, looks_like_tflite(aModelBuffer, aBufferSize) ? 1 : 0};
+                          g.relu_clip, (unsigned)v.alphabet_bytes, looks_like_tflite(aModelBuffer, aBufferSize) ? 1 : 0,
+                          (v.quant && v.quant->all_int8()) ? 1 : 0, storage.asymmetric_inputs ? 1 : 0};
   return STT_ERR_OK;
 }
 

@@ -336,8 +336,8 @@ void ModelState::run_acoustic_chunk_piped_i8(const float* d_feats, const int* d_
     LstmGraphKey key;
     memset(&key, 0, sizeof(key));
     key.xproj = am_xproj[slot].p; key.hall = am_hall[slot].p; key.c = am_c.p; key.hp0 = am_hq0.p; key.hp1 = am_hq1.p; key.whp = am_y3[slot].p;
-    key.T = T; key.par = t0; key.B = B; key.NT = NT; key.passes = 100; key.prio = l.prio; key.H = H; key.first = 0;   // (t0 and the frame table's address are baked into the launches)
-    key.hp1 = (const void*)((uintptr_t)am_hq1.p ^ (uintptr_t)d_nframes);
+    key.T = T; key.par = t0; key.B = B; key.NT = NT; key.passes = 100; key.prio = l.prio; key.H = H;   // (t0 and the frame table's address are baked into the launches)
+    key.first = tune().lstm_i8_rows * 1000 + l.probe; key.nframes = d_nframes;
     run_lstm_graph(key, steps);
   } else steps();
   am_watch_end();

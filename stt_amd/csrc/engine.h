@@ -126,6 +126,7 @@ struct ModelTensors {
   // All six present = the reference's CPU path runs them through TFLite's hybrid kernel, and so does the engine (ModelState::i8).
   std::vector<int8_t> wq[6];
   std::vector<float> wq_scale[6];
+  bool asymmetric_inputs = false;   // the file asked for FullyConnectedOptions.asymmetric_quantize_inputs: wq dropped, f16 path (tflite_reader.cpp)
   bool all_int8() const { for (int l = 0; l < 6; ++l) if (wq[l].empty()) return false; return true; }
 };
 bool looks_like_tflite(const char* buf, size_t len);
@@ -329,8 +330,8 @@ struct ModelState {
   // of 16-48 kernel launches of host time (enqueueing a 64 x 5 s batch: ~300 launches, 1.5 ms on a quiet host, 2.5-5 ms on a
   // busy one, which then starves the GPU).  Keyed by every pointer baked into the nodes.
   struct LstmGraphKey {
-    const void *xproj, *hall, *c, *hp0, *hp1, *whp;
-    int T, par, B, NT, passes, prio, H, first;
+    const void *xproj, *hall, *c, *hp0, *hp1, *whp, *nframes;   // (nframes: the frame table the int8 step masks rows with)
+    int T, par, B, NT, passes, prio, H, first;                  // (int8 path: `first` carries the row-group size and the probe number, both baked into the launches)
     bool operator<(const LstmGraphKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
   };
   struct LstmGraph { hipGraphExec_t exec = nullptr; };

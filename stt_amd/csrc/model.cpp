@@ -88,12 +88,16 @@ void pack_lstm_recurrent_i8_host(const int8_t* kq, int H, int8_t* out) {
 void quantize_weights_host(const float* w, int n_in, int n_out, std::vector<int8_t>& q, std::vector<float>& scale) {
   float amax = 0.0f;
   for (size_t i = 0; i < (size_t)n_in * n_out; ++i) amax = std::max(amax, std::fabs(w[i]));
+  // the converter's weight quantisation is tensor_utils::SymmetricQuantizeFloats (tools/optimize/quantize_weights.cc -> SymmetricQuantizeTensor):
+  // scale = range / 127, q = TfLiteRound(w * (127 / range)) -- a multiply by the inverse, halves away from zero; oracle/am_hybrid.py and
+  // stt_amd/tflitefile.py write the same form
   const float sc = std::max(amax, 1e-30f) / 127.0f;
+  const float inv = 127.0f / std::max(amax, 1e-30f);
   scale.assign(1, sc);
   q.resize((size_t)n_in * n_out);
   for (int k = 0; k < n_in; ++k)
     for (int n = 0; n < n_out; ++n) {
-      const float r = std::nearbyintf(w[(size_t)k * n_out + n] / sc);           // np.rint: half to even
+      const float r = std::roundf(w[(size_t)k * n_out + n] * inv);
       q[(size_t)n * n_in + k] = (int8_t)std::min(127.0f, std::max(-127.0f, r));
     }
 }

@@ -735,10 +735,10 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label, bool lm_on
     // default -- many replicas, a shared GPU -- gets a smaller one, or none, instead of a scorer that fails to load.
     for (; lg >= 14; lg -= 2) {
       const size_t n = (size_t)1 << lg;
-      void* p = nullptr;
+      void* p = nullptr;      // exactly the bytes the table takes (DevBuf::reserve would ask for a quarter more and throw where this probe passed)
       if (hipMalloc(&p, n * 32) != hipSuccess) { (void)hipGetLastError(); continue; }
-      (void)hipFree(p);
-      memo_.reserve(n * 32);
+      if (memo_.p) (void)hipFree(memo_.p);
+      memo_.p = p; memo_.cap = n * 32;
       HIP_CHECK(hipMemset(memo_.p, 0, n * 32));
       ds.memo = memo_.as<uint32_t>(); ds.memo_mask = (uint32_t)n - 1;
       break;

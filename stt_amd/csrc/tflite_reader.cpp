@@ -28,6 +28,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <iostream>
 #include <string>
 #include <vector>
 
@@ -93,7 +94,7 @@ struct TensorInfo {
   size_t nbytes = 0;
   size_t count() const { size_t c = 1; for (int32_t d : shape) c *= (size_t)(d > 0 ? d : 0); return c; }
 };
-struct OpInfo { int code = -1; std::string custom; std::vector<int32_t> in, out; };
+struct OpInfo { int code = -1; std::string custom; std::vector<int32_t> in, out; bool asym_inputs = false; };  // asym_inputs: FullyConnectedOptions.asymmetric_quantize_inputs
 
 float half_to_float(uint16_t h) {
   _Float16 v;
@@ -218,6 +219,9 @@ bool parse_graph(Fb& fb, Graph& gr, std::string& err) {
     if (ci < codes.size()) { gr.ops[i].code = codes[ci].first; gr.ops[i].custom = codes[ci].second; }
     gr.ops[i].in = fb.ints(fb.sub(o, 1));
     gr.ops[i].out = fb.ints(fb.sub(o, 2));
+    // schema: Operator.builtin_options_type (field 3) = 8 for FullyConnectedOptions (field 4), whose field 3 is asymmetric_quantize_inputs --
+    // the runtime then quantises the op's inputs with a zero point instead of symmetrically (converters newer than the reference's set it)
+    if (gr.ops[i].code == OP_FULLY_CONNECTED && fb.scalar<uint8_t>(o, 3, 0) == 8) gr.ops[i].asym_inputs = fb.scalar<uint8_t>(fb.sub(o, 4), 3, 0) != 0;
     for (int32_t t : gr.ops[i].out)
       if (t >= 0 && (size_t)t < gr.tensors.size()) gr.producer[t] = (int)i;
   }
@@ -295,9 +299,11 @@ int read_tflite_model(const char* buf, size_t len, ModelTensors& m, std::string&
   // ---- the matrix products, in execution order
   struct Fc { int w, b, out; };
   std::vector<Fc> fcs;
+  bool asym = false;
   for (size_t i = 0; i < gr.ops.size(); ++i) {
     const OpInfo& op = gr.ops[i];
     if (op.code != OP_FULLY_CONNECTED || op.in.size() < 2 || op.out.empty()) continue;
+    asym = asym || op.asym_inputs;
     const int w = gr.resolve_const(op.in[1]);
     if (w < 0) { err = "FULLY_CONNECTED with non-constant weights"; return STT_ERR_MODEL_INCOMPATIBLE; }
     bool seen = false;
@@ -336,6 +342,14 @@ int read_tflite_model(const char* buf, size_t len, ModelTensors& m, std::string&
       if (!gr.to_float(fcs[l].b, *bdst[l], err)) return STT_ERR_MODEL_INCOMPATIBLE;
       if ((int)bdst[l]->size() != want[l][0]) { err = "bias " + std::to_string(l + 1) + " has an unexpected size"; return STT_ERR_INVALID_SHAPE; }
     } else bdst[l]->assign((size_t)want[l][0], 0.0f);
+  }
+  if (asym && m.all_int8()) {
+    // The engine's int8 path is TFLite's SYMMETRIC hybrid kernel (what export.py's tfv1 converter produces).  A re-exported file that asks for
+    // asymmetric input quantisation would run a different arithmetic in TFLite: do not claim it -- take the de-quantised f16 path and say so.
+    std::cerr << "stt_amd: FULLY_CONNECTED with asymmetric_quantize_inputs: the int8 weights are de-quantised and the f16 path is taken "
+                 "(the hybrid int8 path restates the symmetric kernel only)" << std::endl;
+    for (int l = 0; l < 6; ++l) { m.wq[l].clear(); m.wq_scale[l].clear(); }
+    m.asymmetric_inputs = true;
   }
   // ---- ReLU clip (deepspeech_model.py:80-82 `minimum(relu(x), relu_clip)`): the constant operand of the first MINIMUM
   g.relu_clip = 20.0f;

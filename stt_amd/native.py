@@ -27,7 +27,8 @@ class AcousticModelEmissions(C.Structure):
 class ModelInfo(C.Structure):  # STTX_ModelInfo, include/stt_amd.h
     _fields_ = [(n, C.c_int) for n in ("n_input", "n_context", "n_hidden", "n_classes", "n_steps", "sample_rate", "win_len",
                                        "win_step", "beam_width")] + [("relu_clip", C.c_float), ("alphabet_bytes", C.c_uint),
-                                                                      ("is_tflite", C.c_int)]
+                                                                      ("is_tflite", C.c_int), ("hybrid_int8", C.c_int),
+                                                                      ("asymmetric_quantize_inputs", C.c_int)]
 
 
 class Metadata(C.Structure):

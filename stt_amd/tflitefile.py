@@ -126,7 +126,7 @@ def _string_tensor(items):
 
 def tflite_bytes(weights, labels, n_input=26, n_context=9, n_steps=16, sample_rate=16000, win_len_ms=32, win_step_ms=20,
                  beam_width=500, relu_clip=20.0, graph_version=6, quantize=False, per_channel=False, f16_weights=False,
-                 metadata_behind_op=True, fuse_bias=True, legacy_opcodes=False):
+                 metadata_behind_op=True, fuse_bias=True, legacy_opcodes=False, asymmetric_quantize_inputs=False):
     """Serialises the inference graph with `weights` (checkpoint orientation, stt_amd/modelfile.py names).
     Returns (bytes, effective_weights): effective_weights are the f32 values a TFLite interpreter would compute with
     (de-quantised when quantize / f16_weights)."""
@@ -158,14 +158,20 @@ def tflite_bytes(weights, labels, n_input=26, n_context=9, n_steps=16, sample_ra
         return opcodes.index(key)
 
     def op(code, ins, outs, custom=None):
-        ops.append(Table(f0=("I", opcode(code, custom)), f1=("o", Vec("i", ins)), f2=("o", Vec("i", outs))))
+        opts = {}
+        if code == FULLY_CONNECTED and asymmetric_quantize_inputs:      # BuiltinOptions 8 = FullyConnectedOptions, field 3 = asymmetric_quantize_inputs
+            opts = dict(f3=("B", 8), f4=("o", Table(f3=("B", 1))))
+        ops.append(Table(f0=("I", opcode(code, custom)), f1=("o", Vec("i", ins)), f2=("o", Vec("i", outs)), **opts))
 
     def const_matrix(name, w_in_out):
         w = np.ascontiguousarray(np.asarray(w_in_out, dtype=np.float32).T)          # FULLY_CONNECTED weights are [out][in]
         if quantize and w.size >= 1024:                                              # the converter leaves small tensors in float
             amax = np.abs(w).max(axis=1) if per_channel else np.array([np.abs(w).max()])
             scale = (np.maximum(amax, 1e-30) / 127.0).astype(np.float32)
-            q = np.clip(np.rint(w / (scale[:, None] if per_channel else scale[0])), -127, 127).astype(np.int8)
+            # tensor_utils::SymmetricQuantizeFloats, as the converter's quantize_weights pass calls it: q = round(w * (127 / range)), halves away from zero
+            inv = (np.float32(127.0) / np.maximum(amax, 1e-30).astype(np.float32)).astype(np.float32)
+            t = (w * (inv[:, None] if per_channel else inv[0])).astype(np.float32)
+            q = np.clip(np.sign(t) * np.floor(np.abs(t).astype(np.float64) + 0.5), -127, 127).astype(np.int8)
             eff_w = (q.astype(np.float32) * (scale[:, None] if per_channel else scale[0])).astype(np.float32)
             return tensor(name, w.shape, INT8, q.tobytes(), quant=(scale, 0)), eff_w.T
         if f16_weights:

@@ -97,3 +97,41 @@ def test_engine_against_the_hybrid_int8_path(tmp_path, ref, port, english, fix, 
     if head == 1.0:
         assert a_err <= ABS_TOL[mode], line
     assert same >= MIN_EQUAL[mode][head], line
+
+
+# The SECOND checker (round-5 advisor): the same restatement with LOGISTIC / TANH evaluated in float32 as a TFLite build would (numpy's float32
+# exp / tanh: 1-3 ulp from the correctly rounded value the engine and the first checker compute).  TFLite itself is not in the tree, so which
+# float exp the reference's CPU path links is unknowable here; this is the SIZE of that unknown at the bench's shape: the quantised recurrence
+# turns a last-bit difference of one activation into a different int8 somewhere in the next row now and then.  Stated: rms |d ln p| <=
+# 1e-3 x head, max |d ln p| <= 2.5e-2 x head -- the same order as the f16 path's tolerance against the first checker, i.e. "which exp" costs
+# about what "f16 instead of int8 activations" costs; transcripts at a random-init head are a coin toss per frame either way.
+F32_RMS_TOL, F32_MAX_TOL = 1e-3, 2.5e-2
+F32_MIN_EQUAL = {1.0: 24, 32.0: 60}
+
+
+@pytest.mark.parametrize("head", [1.0, 32.0], ids=["random-init head", "head x 32 (peaky outputs)"])
+def test_int8_path_against_the_float32_activation_variant(tmp_path, ref, english, fix, head):
+    from oracle import am_hybrid
+    B = 64
+    w = synth.synth_weights(0, n_hidden=2048)
+    w["layer_6/weights"] = (w["layer_6/weights"] * head).astype(np.float32)
+    model = _model(tmp_path, w, "qf%d" % int(head), "int8")
+    model.enableExternalScorer(os.path.join(fix, "pruned_lm.scorer"))
+    audio = list(synth.synth_audio_batch(B, 80000, seed=4242))
+    got = np.stack(model.acousticProbs(audio))
+    want = am_hybrid.utterance_probs_batch(audio, w, activations="f32")
+    d = np.log(got) - np.log(want)
+    l_err, rms, a_err = float(np.abs(d).max()), float(np.sqrt(np.mean(d ** 2))), float(np.abs(got - want).max())
+    texts = model.sttBatch(audio)
+    A = ref.Alphabet(os.path.join(fix, "alphabet.txt"))
+    S = ref.Scorer(os.path.join(fix, "pruned_lm.scorer"), A)
+    res = ref.decode_batch(want.astype(np.float64), [250] * B, A, 500, os.cpu_count() or 1, S)
+    same = sum(1 for x, (_, tok) in zip(texts, res) if x == A.decode(tok).decode("utf-8", "replace"))
+    line = {"engine_path": "int8", "checker": "hybrid restatement with float32 LOGISTIC / TANH (numpy)", "head_scale": head, "max_abs_dp": a_err, "max_abs_dlnp": l_err,
+            "rms_dlnp": rms, "transcripts_equal": same, "of": B}
+    print("hybrid-int8 tolerance, second checker:", json.dumps(line))
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "hybrid_tolerance_int8_f32act_head%d.json" % int(head)), "w") as f:
+        json.dump(line, f)
+    assert rms <= F32_RMS_TOL * head and l_err <= F32_MAX_TOL * head, line
+    assert same >= F32_MIN_EQUAL[head], line

@@ -89,7 +89,7 @@ def test_dense_layers_bit_equal_and_the_cell_within_its_bound(tmp_path, per_chan
     p = (e / e.sum(axis=1, keepdims=True)).reshape(T, B, -1).transpose(1, 0, 2)
     assert float(np.abs(out["probs"] - p).max()) <= 1e-6
     if B > 1:
-        assert out["slow_rows"] == 0 or True       # (rows with small windows may take it; counted in the next test)
+        assert out["slow_rows"] >= 0                # (rows with small windows may take the joint-scale path; the next test counts them against the restatement)
 
 
 def test_rows_whose_h_outgrows_x_take_the_joint_scale(tmp_path):

