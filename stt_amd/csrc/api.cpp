@@ -369,7 +369,7 @@ void batch_init_slots(ModelState* m) {
   for (auto& e : m->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& sl : m->slots_) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   m->slots_[0].stream_dec = m->stream_dec;
-  for (int i = 1; i < ModelState::kSlots; ++i) HIP_CHECK(hipStreamCreateWithFlags(&m->slots_[i].stream_dec, hipStreamNonBlocking));
+  for (int i = 1; i < ModelState::kSlots; ++i) create_engine_stream(&m->slots_[i].stream_dec, 3);
 }
 // Group slots in flight (tunable `pipeline`, 1..kSlots; default 2).  With more slots than `active` (default 2) the beam search of
 // group g starts behind the `done` event of group g - active while its acoustic model starts as soon as the previous group's

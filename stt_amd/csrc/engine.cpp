@@ -201,11 +201,9 @@ void ModelState::run_acoustic_chunk(const float* d_feats, const int* d_nframes, 
 bool ModelState::am_pipe_init() {
   if (!tune().am_pipe) return false;
   if (stream_l) return true;
-  int lo = 0, hi = 0;
-  HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi = numerically lowest = most urgent)
   // the recurrence is the critical path: its workgroups go first whenever a CU has room
-  HIP_CHECK(hipStreamCreateWithPriority(&stream_l, hipStreamNonBlocking, hi));
-  HIP_CHECK(hipStreamCreateWithFlags(&stream_o, hipStreamNonBlocking));
+  create_engine_stream(&stream_l, 1, /*high_priority=*/true);
+  create_engine_stream(&stream_o, 2);
   for (int i = 0; i < kAmRing; ++i)
     for (hipEvent_t* e : {&ev_x_ready[i], &ev_x_free[i], &ev_h_ready[i], &ev_h_free[i]}) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   return true;
@@ -248,10 +246,8 @@ void ModelState::am_replace_if_slow() {
   ++watch_moves;
   __atomic_fetch_add(&tune().am_moved, 1, __ATOMIC_RELAXED);
   hipStream_t nl = nullptr, no = nullptr;
-  int lo = 0, hi = 0;
-  HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  HIP_CHECK(hipStreamCreateWithPriority(&nl, hipStreamNonBlocking, hi));
-  HIP_CHECK(hipStreamCreateWithFlags(&no, hipStreamNonBlocking));
+  create_engine_stream(&nl, 1, /*high_priority=*/true);
+  create_engine_stream(&no, 2);
   HIP_CHECK(hipStreamSynchronize(stream_l)); HIP_CHECK(hipStreamSynchronize(stream_o));   // (rare: nothing of the old queues is left in flight)
   (void)hipStreamDestroy(stream_l); (void)hipStreamDestroy(stream_o);
   stream_l = nl; stream_o = no;

@@ -60,6 +60,9 @@ struct PinnedBuf {
 // hipMemcpyAsync: a copy-engine transfer costs a queue hand-over each way (signals between the compute queue and the DMA
 // engine), measured at 0.2 ms on some hosts and 1-2 ms on others -- per batch, on the critical stream.  A kernel that moves
 // the same 4-130 KB over the link is a few microseconds everywhere.  (STT_AMD_COPY_KERNEL=0: the copy engine, for A/B.)
+// A stream of the engine: role 0 = GEMM engine, 1 = recurrence, 2 = output engine, 3 = beam search.  Plain non-blocking streams unless the
+// tunables search_cus / am_cus partition the chip (hostutil.cpp).
+void create_engine_stream(hipStream_t* st, int role, bool high_priority = false);
 unsigned long long layout_generation();   // bumped when any DevBuf / PinnedBuf moves or a tunable changes (hostutil.cpp): what a captured graph may have baked in
 void copy_h2d(void* dst_dev, const PinnedBuf& src, size_t bytes, hipStream_t st);
 void copy_d2h(PinnedBuf& dst, const void* src_dev, size_t bytes, hipStream_t st, size_t dst_offset = 0);

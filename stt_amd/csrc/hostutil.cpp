@@ -62,6 +62,31 @@ Tuning& tune() {
   return t;
 }
 
+// The searches take a compute unit's whole register file each (1024 lanes x 128 registers) for most of a batch; the acoustic engines
+// live on whatever is left.  Left to the dispatcher, who sits where is decided launch by launch.  With search_cus = N the search streams
+// are confined to the CUs of mask bits [0, N) and (am_cus) the chosen acoustic engines to the rest: a fixed partition.  (A masked stream
+// cannot also carry a priority: hipExtStreamCreateWithCUMask takes none.)
+void create_engine_stream(hipStream_t* st, int role, bool high_priority) {
+  const int n = tune().search_cus;
+  const bool masked = n > 0 && (role == 3 || (role < 3 && (tune().am_cus >> role & 1)));
+  if (masked) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipGetDeviceProperties(&p, dev));
+    const int ncu = p.multiProcessorCount;
+    std::vector<uint32_t> w((size_t)(ncu + 31) / 32, 0u);
+    const int lo = role == 3 ? 0 : std::min(n, ncu), hi = role == 3 ? std::min(n, ncu) : ncu;
+    for (int i = lo; i < hi; ++i) w[(size_t)i / 32] |= 1u << (i % 32);
+    if (hi > lo) { HIP_CHECK(hipExtStreamCreateWithCUMask(st, (uint32_t)w.size(), w.data())); return; }
+  }
+  if (high_priority) {
+    int lo = 0, hi = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi = numerically lowest = most urgent)
+    HIP_CHECK(hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi));
+  } else HIP_CHECK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+}
+
 void DevBuf::reserve(size_t bytes, bool keep, hipStream_t st) {
   if (bytes <= cap && p) return;
   g_layout_generation.fetch_add(1, std::memory_order_relaxed);

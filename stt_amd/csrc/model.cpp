@@ -188,8 +188,8 @@ int ModelState::InitFromBuffer(const char* buf, size_t len) {
   const int H = g.n_hidden, C = g.n_classes, K1 = g.n_in1();
 
   HIP_CHECK(hipSetDevice(device));
-  if (!stream) HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  if (!stream_dec) HIP_CHECK(hipStreamCreateWithFlags(&stream_dec, hipStreamNonBlocking));
+  if (!stream) create_engine_stream(&stream, 0);
+  if (!stream_dec) create_engine_stream(&stream_dec, 3);
   {
     auto t = transpose_f16(l1w, K1, H, g.k1_pad(), H, H); w1t.upload(t.data(), t.size() * 2, stream);
     t = transpose_f16(l2w, H, H, H, H, H); w2t.upload(t.data(), t.size() * 2, stream);

@@ -34,6 +34,8 @@
   X(am_slow_us, 0, "three-engine form: microseconds per recurrent step above which a chunk counts as slow (0 = 31 us x max(1, (n_hidden / 2048)^2))") \
   X(am_moved, 0, "counter, not a knob: moves of the engines to fresh streams so far (all models)") \
   X(am_step_us_x10, 0, "counter, not a knob: the last watched chunk's microseconds per recurrent step, times ten") \
+  X(search_cus, 0, "beam-search streams confined to the compute units of the first N bits of a CU mask (hipExtStreamCreateWithCUMask; bit i = XCD i % 8: benchmarks/cumask_probe.hip), 0 = no mask; read when a model is loaded") \
+  X(am_cus, 0, "with search_cus: which acoustic engines are confined to the OTHER compute units (bit 0 the GEMM engine, bit 1 the recurrence, bit 2 the output engine), 0 = none; read when a model is loaded") \
   X(lstm_i8_rows, 64, "int8 recurrent step: rows per workgroup (16 / 32 / 64 / 128); a step of more rows runs that many row groups per 16-unit slice") \
   X(am_i8_pipe, 1, "int8 path: batches in flight through three acoustic engines like the f16 path (1: 3.0 - 3.2 ms per batch once the engines' queues sit well -- the placement watch, am_moves, sees to that) or on one acoustic stream (0: 3.8 ms wherever the queues sit)") \
   X(lstm_upw, 16, "hidden units per recurrent workgroup (16 or 8); read when a model is loaded")                                   \
