@@ -1049,6 +1049,7 @@ def main():
     ap.add_argument("--host-audio", action="store_true", help="experiment: batch / bytes time STTX_BatchSubmit (host buffers, copy inside the clock) as the run's timed path")
     ap.add_argument("--no-pipeline", action="store_true", help="batch / bytes: one blocking call per step instead of several batches in flight")
     args = ap.parse_args()
+    os.environ["STT_AMD_TEST_HOOKS"] = "0"      # the measured library is the SHIPPED one (stt_amd/lib/libstt.so), never the tests' hooks build; before stt_amd is imported
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` means N: re-launch as N ranks, one per GPU, through the launcher the driver uses.  A box with fewer

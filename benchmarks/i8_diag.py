@@ -5,6 +5,8 @@
   3. the 128-row recurrent step alone: microseconds per step, and with parts switched off (tunable lstm_probe)."""
 import json
 import os
+
+os.environ.setdefault("STT_AMD_TEST_HOOKS", "1")   # a probe of single kernels: needs libstt_test.so (include/stt_amd_test.h)
 import sys
 import tempfile
 

@@ -3,6 +3,8 @@ same batches -- milliseconds per batch and how many rows took the recurrent step
 it (a float container quantised at load, torch in the process, a second model alive), one at a time."""
 import json
 import os
+
+os.environ.setdefault("STT_AMD_TEST_HOOKS", "1")   # a probe of single kernels: needs libstt_test.so (include/stt_amd_test.h)
 import sys
 import tempfile
 import time

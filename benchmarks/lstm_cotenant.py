@@ -3,6 +3,8 @@
 (tunable lstm_cotenant), in-kernel REFCLK stamps on.  What does a GEMM workgroup on the same CU cost a step, and where?"""
 import json
 import os
+
+os.environ.setdefault("STT_AMD_TEST_HOOKS", "1")   # a probe of single kernels: needs libstt_test.so (include/stt_amd_test.h)
 import sys
 import tempfile
 

@@ -4,6 +4,8 @@
 step's time goes.  Prints one JSON line per variant: microseconds per step."""
 import json
 import os
+
+os.environ.setdefault("STT_AMD_TEST_HOOKS", "1")   # a probe of single kernels: needs libstt_test.so (include/stt_amd_test.h)
 import sys
 import tempfile
 

@@ -3,6 +3,8 @@
 and with timing probe 4 (every wave settles its tile from its own partial sums: no LDS parking, no barrier; wrong results)."""
 import json
 import os
+
+os.environ.setdefault("STT_AMD_TEST_HOOKS", "1")   # a probe of single kernels: needs libstt_test.so (include/stt_amd_test.h)
 import sys
 import tempfile
 

@@ -33,6 +33,16 @@ run "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0" DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 run "ROC_SYSTEM_SCOPE_SIGNAL=0" ROC_SYSTEM_SCOPE_SIGNAL=0
 run "GPU_MAX_HW_QUEUES=4" GPU_MAX_HW_QUEUES=4
 run "eager recurrence (lstm_graph=0)" STT_AMD_TUNING=lstm_graph=0
+elif [ "$2" = i8 ]; then
+# the int8 path's recurrence: row groups, chunk lengths, searches side by side (run with workload batch_i8)
+run "defaults" X=1
+run "lstm_i8_rows=128 (one row group)" STT_AMD_TUNING=lstm_i8_rows=128
+run "lstm_i8_rows=32" STT_AMD_TUNING=lstm_i8_rows=32
+run "search on 128 CUs" STT_AMD_TUNING=search_cus=128
+run "pchunk=32" STT_AMD_TUNING=pchunk=32
+run "pchunk=64" STT_AMD_TUNING=pchunk=64
+run "active=2" STT_AMD_TUNING=active=2
+run "pipeline=3" STT_AMD_TUNING=pipeline=3
 else
 # a fixed partition of the chip (hipExtStreamCreateWithCUMask; benchmarks/cumask_probe.hip says where the bits land)
 run "defaults" X=1

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--set", default="")
     ap.add_argument("--scorer", default="synthetic", choices=["synthetic", "fixture"])
+    ap.add_argument("--emissions", default="model", choices=["model", "peaky"], help="peaky: bench.py's `peaky` workload (trained-like emissions of vocab.pruned.txt sentences; use --scorer fixture)")
     a = ap.parse_args()
     from stt_amd import native, synth
     native.lib()
@@ -37,6 +38,17 @@ def main():
         base = synth.synth_audio(n + 977 * a.streams, seed=11)
         audio = [base[977 * u:977 * u + n] for u in range(a.streams)]
         probs = np.stack(model.acousticProbs(audio))
+        if a.emissions == "peaky":      # (the recipe of bench.py's peaky workload)
+            vocab = open(os.path.join(bench.FIX, "vocab.pruned.txt")).read().split()
+            rng = np.random.RandomState(7)
+            em = []
+            for i in range(a.streams):
+                sent = ""
+                while len(sent) < 48:
+                    sent += (" " if sent else "") + str(rng.choice(vocab))
+                lab = [0 if ch == " " else (27 if ch == "'" else ord(ch) - ord("a") + 1) for ch in sent[:56]]
+                em.append(synth.peaky_emissions(lab, 250, 29, 28, seed=int(rng.randint(1 << 30)), noise=0.02))
+            probs = np.stack(em).astype(np.float32)
         T = probs.shape[1]
         for rep in range(a.reps):
             dec = model.createDecoder(a.streams, bench.BEAM)

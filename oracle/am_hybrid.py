@@ -146,9 +146,20 @@ class HybridModel:
             hs[:, t] = h
         l5 = self._dense(hs.reshape(B * T, self.H), "layer_5")
         logits = self._fc(l5, "layer_6/weights", self.b["layer_6/bias"])
-        logits = logits - logits.max(axis=1, keepdims=True)
-        e = np.exp(logits.astype(F32))
-        return (e / e.sum(axis=1, keepdims=True)).astype(F32).reshape(B, T, -1)
+        return self.softmax(logits).reshape(B, T, -1)
+
+    def softmax(self, logits):
+        """SOFTMAX of the float logits.  "cr": like LOGISTIC / TANH, the correctly rounded float of the real function at each of its two steps --
+        e = float(exp(l - max)) evaluated in float64, p = float(e / sum(e)) with the sum and the quotient in float64 (one rounding); the engine's
+        int8 path computes exactly this (kernels_am.hip: softmax_kernel, `exact`).  "f32": TFLite's reference float kernel as written --
+        float exp, a float sum, one float division per class -- with numpy's float32 exp."""
+        logits = np.asarray(logits, dtype=F32)
+        z = (logits - logits.max(axis=1, keepdims=True)).astype(F32)
+        if self.sig is _sigmoid:
+            e = np.exp(z.astype(np.float64)).astype(F32).astype(np.float64)
+            return (e / e.sum(axis=1, keepdims=True)).astype(F32)
+        e = np.exp(z, dtype=F32)
+        return (e / e.sum(axis=1, keepdims=True, dtype=F32)).astype(F32)
 
 
 def utterance_probs_batch(audios, weights, per_channel=False, spec=None, activations="cr"):

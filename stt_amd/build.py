@@ -12,6 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libstt.so")
+# The same objects plus the test hooks of include/stt_amd_test.h (STTX_Test*, STTX_Debug*, the timing-probe kernels): what tests/ load.  The
+# shipped libstt.so carries none of them.  Only the sources below know about STT_TEST_HOOKS and are compiled twice.
+LIB_TEST = os.path.join(HERE, "lib", "libstt_test.so")
+HOOK_SOURCES = ["kernels_am.hip", "kernels_i8.hip", "api.cpp", "fleet.cpp"]
 SOURCES = ["kernels_am.hip", "kernels_i8.hip", "ctc.hip", "hostutil.cpp", "scorer_dev.cpp", "model.cpp", "tflite_reader.cpp", "engine.cpp", "api.cpp", "fleet.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "hip", "-Wno-unused-result"]
 # ctc.hip: the search kernels run 1024 threads per workgroup (128 registers per lane) through one very long timestep loop.  Machine-level
@@ -29,30 +33,35 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers += [os.path.join(HERE, "..", "include", f) for f in ("coqui-stt.h", "stt_amd.h")]
+    headers += [os.path.join(HERE, "..", "include", f) for f in ("coqui-stt.h", "stt_amd.h", "stt_amd_test.h")]
     hdr_mtime = max(os.path.getmtime(h) for h in headers)
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
         if force or _newer(s, o) or hdr_mtime > os.path.getmtime(o):
-            jobs.append((s, o))
+            jobs.append((s, o, []))
+        if src in HOOK_SOURCES:
+            oh = os.path.join(OBJ, src.rsplit(".", 1)[0] + "_hooks.o")
+            if force or _newer(s, oh) or hdr_mtime > os.path.getmtime(oh):
+                jobs.append((s, oh, ["-DSTT_TEST_HOOKS"]))
 
     def cc(job):
-        s, o = job
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
+        s, o, defs = job
+        cmd = [hipcc] + FLAGS + defs + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
-    objs = [os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o") for src in SOURCES]
-    if jobs or not os.path.exists(LIB) or _newer(os.path.join(CSRC, "libstt.map"), LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread", "-Wl,--version-script=" + os.path.join(CSRC, "libstt.map")]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+    for lib, suffix in ((LIB, {}), (LIB_TEST, {src: "_hooks" for src in HOOK_SOURCES})):
+        objs = [os.path.join(OBJ, src.rsplit(".", 1)[0] + suffix.get(src, "") + ".o") for src in SOURCES]
+        if jobs or not os.path.exists(lib) or _newer(os.path.join(CSRC, "libstt.map"), lib):
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl", "-lpthread", "-Wl,--version-script=" + os.path.join(CSRC, "libstt.map")]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
     build_tools(force=force, verbose=verbose)
     return LIB
 

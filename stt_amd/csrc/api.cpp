@@ -9,9 +9,14 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "../../include/stt_amd.h"
+#ifdef STT_TEST_HOOKS
+#include "../../include/stt_amd_test.h"   // libstt_test.so only (stt_amd/build.py)
+#endif
 #include "engine.h"
 #include "scorer_host.h"
 #include "tuning.h"
@@ -554,11 +559,68 @@ std::vector<std::vector<Output>> batch_collect(ModelState* m, int ticket) {
   }
   return out;
 }
+// A few host threads that stay around for STTX_BatchSubmit's gather (round 5 spawned three std::threads per submit): run(n, f) calls f(k)
+// for k = 0 .. n-1, k = 0 on the caller's thread, and returns when all are done.  One submit at a time per process is the common case; a
+// second model's submit that arrives meanwhile simply gathers on its own thread.
+class GatherPool {
+ public:
+  static GatherPool& get() { static GatherPool* p = new GatherPool(3); return *p; }   // (never destroyed: no join at process exit)
+  void run(unsigned n, const std::function<void(unsigned)>& f) {
+    std::unique_lock<std::mutex> busy(busy_, std::try_to_lock);
+    if (!busy.owns_lock() || n <= 1) { for (unsigned k = 0; k < n; ++k) f(k); return; }
+    {
+      std::lock_guard<std::mutex> g(m_);
+      job_ = &f; next_ = 1; n_ = n; left_ = n - 1; ++gen_;
+    }
+    cv_.notify_all();
+    f(0);
+    for (;;) {   // the caller takes what the workers have not started yet, then waits for those that have
+      unsigned k;
+      { std::lock_guard<std::mutex> g(m_); if (next_ >= n_) break; k = next_++; }
+      f(k);
+      std::lock_guard<std::mutex> g(m_);
+      --left_;
+    }
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [&] { return left_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  explicit GatherPool(unsigned workers) {
+    for (unsigned i = 0; i < workers; ++i) std::thread([this] { work(); }).detach();
+  }
+  void work() {
+    unsigned long long seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> g(m_);
+      cv_.wait(g, [&] { return gen_ != seen && job_ && next_ < n_; });
+      seen = gen_;
+      while (job_ && next_ < n_) {
+        const unsigned k = next_++;
+        const std::function<void(unsigned)>* f = job_;
+        g.unlock();
+        (*f)(k);
+        g.lock();
+        if (--left_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::mutex busy_, m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(unsigned)>* job_ = nullptr;
+  unsigned next_ = 0, n_ = 0, left_ = 0;
+  unsigned long long gen_ = 0;
+};
+
 // STTX_BatchSubmit: host buffers -> one page-locked block [B][stride] -> HBM on the copy queue -> batch_submit() gated by the copy's event.
 // The host pays one pass over the samples (the gather into page-locked memory: the ABI hands over ordinary pageable buffers, which no
 // DMA engine may read in place); the transfer itself overlaps whatever the GPU is doing for the batches before this one.
 int batch_submit_host(ModelState* m, const short* const* bufs, const unsigned* sizes, unsigned B) {
   if (B == 0 || B > 64) throw std::runtime_error("STTX_BatchSubmit takes 1..64 utterances (one batch) per call");
+  if (!bufs || !sizes) throw std::runtime_error("STTX_BatchSubmit: NULL buffer / size array");
+  for (unsigned i = 0; i < B; ++i)
+    if (sizes[i] && !bufs[i]) throw std::runtime_error("STTX_BatchSubmit: utterance " + std::to_string(i) + " has " + std::to_string(sizes[i]) + " samples and a NULL buffer");
   HIP_CHECK(hipSetDevice(m->device));
   if (!m->stream_h2d) HIP_CHECK(hipStreamCreateWithFlags(&m->stream_h2d, hipStreamNonBlocking));
   ModelState::HostStage& hs = m->stage_[m->stage_seq_ % ModelState::kStage];
@@ -579,11 +641,8 @@ int batch_submit_host(ModelState* m, const short* const* bufs, const unsigned* s
   // 10 MB per 64 x 5 s batch: one thread moves it in ~1 ms, which is a third of what the GPU needs for the batch and sits between a
   // collect and the enqueue of the next group; four threads share it (below ~1 MB the threads cost more than they save)
   if (bytes >= (1u << 20) && B >= 8) {
-    constexpr unsigned NTH = 4;
-    std::thread th[NTH - 1];
-    for (unsigned k = 1; k < NTH; ++k) th[k - 1] = std::thread(gather, B * k / NTH, B * (k + 1) / NTH);
-    gather(0, B / NTH);
-    for (auto& t : th) t.join();
+    constexpr unsigned NPART = 8;    // (more parts than threads: whoever is free takes the next one)
+    GatherPool::get().run(NPART, [&](unsigned k) { gather(B * k / NPART, B * (k + 1) / NPART); });
   } else gather(0, B);
   HIP_CHECK(hipMemcpyAsync(hs.dev.p, hs.pin.p, bytes, hipMemcpyHostToDevice, m->stream_h2d));
   HIP_CHECK(hipEventRecord(hs.copied, m->stream_h2d));
@@ -1005,9 +1064,11 @@ Metadata** STTX_BatchCollectWithMetadata(ModelState* aCtx, int aTicket, unsigned
   return res;
 }
 
+#ifdef STT_TEST_HOOKS
 int STTX_DebugBatchProbs(ModelState* aCtx, int aTicket, float* aProbs, unsigned int aMaxFrames, unsigned int* aNumFrames) {
   return guarded([&]() { batch_probs(aCtx, aTicket, aProbs, aMaxFrames, aNumFrames); return (int)STT_ERR_OK; }, STT_ERR_FAIL_RUN_SESS);
 }
+#endif  // STT_TEST_HOOKS
 int STTX_SetTuning(const char* aName, int aValue) { return tuning_set(aName, aValue) == 0 ? STT_ERR_OK : STT_ERR_INVALID_SHAPE; }
 int STTX_GetTuning(const char* aName, int* aValue) { return tuning_get(aName, aValue) == 0 ? STT_ERR_OK : STT_ERR_INVALID_SHAPE; }
 void STTX_ConfigureRuntime(void) {
@@ -1315,6 +1376,7 @@ int STTX_DecoderErrorBits(const STTX_Decoder* d, int* aBits) {
 void STTX_DecoderFree(STTX_Decoder* d) { delete d; }
 
 // ---- kernel-level hooks
+#ifdef STT_TEST_HOOKS
 int STTX_TestDense(int M, int N, int K, const float* aX, const float* aW, const float* aBias, float aClip, int aEpilogue, float* aY) {
   return guarded([&]() {
     if (N % 128 || K % 64) return (int)STT_ERR_INVALID_SHAPE;
@@ -1341,11 +1403,13 @@ int STTX_TestDense(int M, int N, int K, const float* aX, const float* aW, const 
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_RUN_SESS);
 }
+#endif  // STT_TEST_HOOKS
 
 // TFLite's hybrid FULLY_CONNECTED on the int8 MFMA path (kernels.h: launch_quantize_rows + launch_dense_hybrid_i8), as a test hook:
 // x f32 [M][K], wq int8 [N][K], wscale [n_scales = 1 or N], bias [N] -> y f32 [M][N] (and, if asked for, the quantised rows and their
 // scales); aReps timed repetitions of quantisation + product (HIP events) -> *aElapsedMs per repetition.
 int STTX_GetAcousticMode(const ModelState* m) { return m && m->i8 ? 1 : 0; }
+#ifdef STT_TEST_HOOKS
 int STTX_DebugSlowRows(ModelState* m, unsigned int* aRows) {
   return guarded([&]() {
     if (!m || !aRows) return (int)STT_ERR_INVALID_SHAPE;
@@ -1356,7 +1420,9 @@ int STTX_DebugSlowRows(ModelState* m, unsigned int* aRows) {
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_RUN_SESS);
 }
+#endif  // STT_TEST_HOOKS
 
+#ifdef STT_TEST_HOOKS
 int STTX_TestHybridChain(ModelState* m, const float* aWindows, unsigned int aB, unsigned int aT, const float* aC, const float* aH, float* aL3, int* aAccX, float* aHAll,
                          float* aLogits, float* aProbs, float* aNewC, float* aNewH, unsigned int* aSlowRows, float* aLstmMs) {
   return guarded([&]() {
@@ -1393,7 +1459,9 @@ int STTX_TestHybridChain(ModelState* m, const float* aWindows, unsigned int aB, 
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_RUN_SESS);
 }
+#endif  // STT_TEST_HOOKS
 
+#ifdef STT_TEST_HOOKS
 int STTX_TestDenseHybrid(const float* aX, unsigned int aM, unsigned int aK, const signed char* aWq, const float* aWScale, unsigned int aNScales, const float* aBias,
                            unsigned int aN, float* aY, signed char* aQ, float* aRowScale, unsigned int aReps, float* aElapsedMs, int aEpi, float aClip) {
   return guarded([&]() {
@@ -1427,6 +1495,8 @@ int STTX_TestDenseHybrid(const float* aX, unsigned int aM, unsigned int aK, cons
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_RUN_SESS);
 }
+#endif  // STT_TEST_HOOKS
+#ifdef STT_TEST_HOOKS
 int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, unsigned int aPeriod, int aGraph, const float* aXproj, float* aC, float* aH,
                        unsigned short* aHAll, float* aElapsedMs) {
   return guarded([&]() {
@@ -1556,7 +1626,9 @@ int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, 
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_RUN_SESS);
 }
+#endif  // STT_TEST_HOOKS
 
+#ifdef STT_TEST_HOOKS
 int STTX_TestMath(int aOp, const float* aA, const float* aB, float* aOut, unsigned int aCount) {
   return guarded([&]() {
     HIP_CHECK(hipSetDevice(g_device));
@@ -1570,6 +1642,7 @@ int STTX_TestMath(int aOp, const float* aA, const float* aB, float* aOut, unsign
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_RUN_SESS);
 }
+#endif  // STT_TEST_HOOKS
 int STTX_InspectModel(const char* aModelBuffer, unsigned int aBufferSize, STTX_ModelInfo* aInfo) {
   if (!aModelBuffer || !aInfo) return STT_ERR_FAIL_CREATE_MODEL;
   ModelTensors storage; ModelView v; std::string err;
@@ -1597,12 +1670,15 @@ int STTX_ReadModelTensor(const char* aModelBuffer, unsigned int aBufferSize, int
   return STT_ERR_OK;
 }
 
+#ifdef STT_TEST_HOOKS
 int STTX_DebugLimitArena(int aFrames) { g_debug_arena_frames = aFrames; return STT_ERR_OK; }
+#endif  // STT_TEST_HOOKS
 
 // Host only: walk label sequences through the dictionary tables a scorer package parses into (the repacked automaton, or -- tunable
 // dict_tree_mb -- its unfolding into a tree).  aLabels holds aNumSeq sequences of aLen labels each (label ids, -1 = end of sequence);
 // aOut[seq * aLen + k] = -1 once a label had no arc, else bit 0 = "a word may end after label k" (the state has a space arc) and bit 1 =
 // "the tables are the tree".  What a test compares between the two forms: the language and the word ends are the same.
+#ifdef STT_TEST_HOOKS
 int STTX_TestDictionaryWalk(const char* aScorer, unsigned int aScorerBytes, int aSpaceLabel, const int* aLabels, unsigned int aNumSeq, unsigned int aLen, int* aOut) {
   return guarded([&]() {
     std::vector<char> copy((size_t)aScorerBytes + 16, 0);
@@ -1632,7 +1708,9 @@ int STTX_TestDictionaryWalk(const char* aScorer, unsigned int aScorerBytes, int 
     return (int)STT_ERR_OK;
   }, STT_ERR_SCORER_INVALID_TRIE);
 }
+#endif  // STT_TEST_HOOKS
 
+#ifdef STT_TEST_HOOKS
 int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* const* aWords, unsigned int aNumWords, int aBos, int aMode, float* aProbs, int* aLens) {
   return guarded([&]() {
     if (aMode == 0 || aMode == 3) {  // host: parse + hashed index (3: + the code-point blocks) + FullScore chain, no GPU
@@ -1680,6 +1758,7 @@ int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* const* aWord
     return (int)STT_ERR_OK;
   }, STT_ERR_FAIL_RUN_SESS);
 }
+#endif  // STT_TEST_HOOKS
 
 int STTX_PackLstmRecurrent(const float* aKernel, int aHidden, unsigned short* aOut) {
   if (aHidden % 128) return STT_ERR_INVALID_SHAPE;

@@ -106,7 +106,7 @@ static void acoustic_rows_i8(ModelState& m, const float* d_x1, int B, int T, flo
   launch_quantize_rows(act_b, qx, qs, M, H, st);
   launch_dense_hybrid_i8(qx, qs, m.w6q.as<signed char>(), m.s6.as<float>(), m.sn[5], m.b6q.as<float>(), m.ws_logits.p, M, CP, H, st, DENSE_EPI_I8_F32);
   SoftmaxArgs s{};
-  s.logits = m.ws_logits.as<float>(); s.probs = d_probs_out; s.M = M; s.C = C; s.ldl = CP; s.batch = B; s.t_max = probs_t_max;
+  s.logits = m.ws_logits.as<float>(); s.probs = d_probs_out; s.M = M; s.C = C; s.ldl = CP; s.batch = B; s.t_max = probs_t_max; s.exact = 1;
   launch_softmax(s, st);
 }
 
@@ -353,7 +353,7 @@ void ModelState::run_acoustic_chunk_piped_i8(const float* d_feats, const int* d_
   launch_quantize_rows(ws_o.as<float>(), qo, qos, M, H, stream_o);
   launch_dense_hybrid_i8(qo, qos, w6q.as<signed char>(), s6.as<float>(), sn[5], b6q.as<float>(), am_logits.p, M, CP, H, stream_o, DENSE_EPI_I8_F32);
   SoftmaxArgs sm{};
-  sm.logits = am_logits.as<float>(); sm.probs = probs_out; sm.M = M; sm.C = C; sm.ldl = CP; sm.batch = B; sm.t_max = t_max;
+  sm.logits = am_logits.as<float>(); sm.probs = probs_out; sm.M = M; sm.C = C; sm.ldl = CP; sm.batch = B; sm.t_max = t_max; sm.exact = 1;
   launch_softmax(sm, stream_o);
   stt_prof_mark_on(this, -1, 6, stream_o);
   HIP_CHECK(hipEventRecord(done, stream_o));

@@ -17,6 +17,9 @@
 #include <thread>
 
 #include "../../include/stt_amd.h"
+#ifdef STT_TEST_HOOKS
+#include "../../include/stt_amd_test.h"
+#endif
 #include "engine.h"
 
 namespace {
@@ -249,6 +252,7 @@ char** STTX_FleetSpeechToTextBatch(STTX_Fleet* f, const short* const* aBuffers, 
   return out;
 }
 
+#ifdef STT_TEST_HOOKS
 // Test hooks.  (1) Pack / pad / concatenate / unpack exactly as the two all-gathers do, on the host: aTexts[i] is the transcript of
 // utterance i, decoded by shard aShardOf[i] of aShards; returns the strings in the caller's order (STTX_FreeStrings) or NULL.
 char** STTX_TestFleetRecords(const char* const* aTexts, const unsigned int* aShardOf, unsigned int aCount, unsigned int aShards) {
@@ -267,6 +271,7 @@ char** STTX_TestFleetRecords(const char* const* aTexts, const unsigned int* aSha
 }
 // (2) The next STTX_FleetSpeechToTextBatch call fails on shard aShard before decoding (-1: off): the call must return NULL, not hang.
 int STTX_DebugFleetFailShard(STTX_Fleet* f, int aShard) { f->fail_shard = aShard; return STT_ERR_OK; }
+#endif  // STT_TEST_HOOKS
 
 void STTX_FleetFree(STTX_Fleet* f) { delete f; }
 

@@ -131,6 +131,7 @@ struct SoftmaxArgs {
   const float* logits;  // [M][ldl]
   float* probs;         // [B][t_max][C]
   int M, C, ldl, batch, t_max;
+  int exact;            // int8 path: every probability the correctly rounded float of exp(l - max) / sum (float64 evaluation, one rounding each)
 };
 
 // dst/src: device-addressable (HBM or mapped page-locked host memory); any size, any alignment

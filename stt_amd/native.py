@@ -8,7 +8,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libstt.so")
+PRODUCT_LIB_PATH = os.path.join(_HERE, "lib", "libstt.so")          # coqui-stt.h + stt_amd.h: what a binding loads
+TEST_LIB_PATH = os.path.join(_HERE, "lib", "libstt_test.so")        # the same objects + the hooks of include/stt_amd_test.h
+# tests/conftest.py and the benchmarks/ probes set STT_AMD_TEST_HOOKS=1; bench.py, __graft_entry__.smoke() and the `stt` client run the product
+TEST_HOOKS = os.environ.get("STT_AMD_TEST_HOOKS", "0") not in ("", "0")
+LIB_PATH = TEST_LIB_PATH if TEST_HOOKS else PRODUCT_LIB_PATH
 
 
 class TokenMetadata(C.Structure):
@@ -47,13 +51,20 @@ COQUI_STT_H = [
     "STT_ErrorCodeToErrorMessage",
 ]
 STT_AMD_H = [
-    "STTX_SetDevice", "STTX_GetDeviceCount", "STTX_SpeechToTextBatch", "STTX_SpeechToTextBatchWithMetadata",
-    "STTX_SpeechToTextBatchDevice", "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmit", "STTX_BatchSubmitDevice", "STTX_BatchCollect", "STTX_BatchCollectWithMetadata", "STTX_BatchCollectScored", "STTX_DebugBatchProbs", "STTX_SetTuning", "STTX_GetTuning", "STTX_ConfigureRuntime", "STTX_TestLstmSteps", "STTX_TestDenseHybrid", "STTX_GetAcousticMode", "STTX_DebugSlowRows", "STTX_TestHybridChain", "STTX_FeedAudioContentBatch", "STTX_FeedAudioContentBatchEx", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch", "STTX_DecodeStreamsBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling",
-    "STTX_GetStageTimes", "STTX_GetDecoderStats", "STTX_GetDecoderPhaseCycles", "STTX_GetDecoderStamps", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk",
-    "STTX_GetGeometry", "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam",
-    "STTX_DecoderStats", "STTX_DecoderErrorBits", "STTX_DecoderSetProfiling", "STTX_DecoderGetProfile", "STTX_DecoderFree", "STTX_TestDense", "STTX_TestMath", "STTX_PackLstmRecurrent",
-    "STTX_InspectModel", "STTX_ReadModelTensor", "STTX_TestLm", "STTX_TestDictionaryWalk", "STTX_DebugLimitArena", "STTX_FleetCreate", "STTX_FleetSize",
-    "STTX_FleetEnableExternalScorer", "STTX_FleetSetBeamWidth", "STTX_FleetSpeechToTextBatch", "STTX_FleetFree", "STTX_ShardUtterances", "STTX_TestFleetRecords", "STTX_DebugFleetFailShard",
+    "STTX_SetDevice", "STTX_GetDeviceCount", "STTX_SpeechToTextBatch", "STTX_SpeechToTextBatchWithMetadata", "STTX_SpeechToTextBatchDevice",
+    "STTX_BatchPipelineDepth", "STTX_BatchPipelineDepthFor", "STTX_BatchSubmit", "STTX_BatchSubmitDevice", "STTX_BatchCollect",
+    "STTX_BatchCollectWithMetadata", "STTX_BatchCollectScored", "STTX_SetTuning", "STTX_GetTuning", "STTX_ConfigureRuntime", "STTX_GetAcousticMode",
+    "STTX_FeedAudioContentBatch", "STTX_FeedAudioContentBatchEx", "STTX_IntermediateDecodeBatch", "STTX_FinishStreamBatch",
+    "STTX_DecodeStreamsBatch", "STTX_FreeStrings", "STTX_FreeMetadataArray", "STTX_SetProfiling", "STTX_GetStageTimes", "STTX_GetDecoderStats",
+    "STTX_GetDecoderPhaseCycles", "STTX_GetDecoderStamps", "STTX_ComputeMfcc", "STTX_AcousticProbs", "STTX_InferChunk", "STTX_GetGeometry",
+    "STTX_DecoderCreate", "STTX_DecoderNext", "STTX_DecoderDecode", "STTX_DecoderBeam", "STTX_DecoderStats", "STTX_DecoderErrorBits",
+    "STTX_DecoderSetProfiling", "STTX_DecoderGetProfile", "STTX_DecoderFree", "STTX_PackLstmRecurrent", "STTX_InspectModel", "STTX_ReadModelTensor",
+    "STTX_FleetCreate", "STTX_FleetSize", "STTX_FleetEnableExternalScorer", "STTX_FleetSetBeamWidth", "STTX_FleetSpeechToTextBatch",
+    "STTX_FleetFree", "STTX_ShardUtterances",
+]
+STT_AMD_TEST_H = [      # include/stt_amd_test.h: libstt_test.so only
+    "STTX_DebugBatchProbs", "STTX_TestLstmSteps", "STTX_TestDenseHybrid", "STTX_DebugSlowRows", "STTX_TestHybridChain", "STTX_TestDense",
+    "STTX_TestMath", "STTX_TestLm", "STTX_TestDictionaryWalk", "STTX_DebugLimitArena", "STTX_TestFleetRecords", "STTX_DebugFleetFailShard",
 ]
 
 _lib = None
@@ -166,6 +177,8 @@ def lib():
         "STTX_DebugFleetFailShard": (ci, [vp, ci]),
     }
     for name, (res, args) in sig.items():
+        if name in STT_AMD_TEST_H and not TEST_HOOKS:
+            continue                      # (the shipped library does not have them; a caller that needs one gets ctypes' AttributeError)
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
     _lib = L

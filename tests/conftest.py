@@ -7,6 +7,7 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("STT_AMD_TEST_HOOKS", "1")      # before stt_amd.native is imported: the tests load libstt_test.so (libstt.so + include/stt_amd_test.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 FIX = os.path.join(ROOT, "tests", "golden", "fixtures")

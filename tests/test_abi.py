@@ -24,15 +24,29 @@ def _declared(header):
     return sorted(set(re.findall(r"STTX?_EXPORT\s+[\w\s\*]*?\b(STTX?_[A-Za-z]+)\s*\(", src)))
 
 
+def _exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {l.split()[-1] for l in out.splitlines() if l.strip()}
+
+
 def test_exports_every_declared_symbol(native):
-    out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
-    a, b = _declared("coqui-stt.h"), _declared("stt_amd.h")
+    """libstt.so (what ships) exports coqui-stt.h + stt_amd.h and NOTHING else -- no test hook, no probe kernel; libstt_test.so (what the
+    tests load) the same plus include/stt_amd_test.h."""
+    a, b, t = _declared("coqui-stt.h"), _declared("stt_amd.h"), _declared("stt_amd_test.h")
     assert len(a) == 29, a            # reference coqui-stt.h:136-504 exports 29 functions
     assert sorted(a) == sorted(native.COQUI_STT_H)
     assert sorted(b) == sorted(native.STT_AMD_H)
-    missing = [s for s in a + b if s not in exported]
-    assert not missing, missing
+    assert sorted(t) == sorted(native.STT_AMD_TEST_H) and all(re.match(r"STTX_(Test|Debug)", n) for n in t)
+    assert not [n for n in b if re.match(r"STTX_(Test|Debug)", n)]
+    prod = _exported(native.PRODUCT_LIB_PATH)
+    assert {s for s in prod if s.startswith(("STT_", "STTX_"))} == set(a + b)
+    assert {s for s in _exported(native.TEST_LIB_PATH) if s.startswith(("STT_", "STTX_"))} == set(a + b + t)
+    # the shipped library carries no timing-probe kernels either (they are -DSTT_TEST_HOOKS instantiations: wrong results by design)
+    blob = open(native.PRODUCT_LIB_PATH, "rb").read()
+    assert b"lstm_probe4" not in blob and b"lstm_probe8" not in blob and b"lstm_i8_probe" not in blob      # (mangled kernel names; "lstm_probe" alone is a tunable's name)
+    assert b"lstm_probe8" in open(native.TEST_LIB_PATH, "rb").read()
+    # the tests run on the hooks build, everything else on the product
+    assert native.TEST_HOOKS and native.LIB_PATH == native.TEST_LIB_PATH
 
 
 def test_error_messages_and_version(native):

@@ -195,3 +195,41 @@ def test_host_audio_submit_equals_the_device_path(model, pair):
             assert texts == got[k][0] and list(conf) == list(got[k][1])
     finally:
         native.set_tuning("pair", 1)
+
+
+def test_host_audio_submit_refuses_null_buffers_and_serves_large_batches(model, tmp_path):
+    """STTX_BatchSubmit: a NULL buffer with a non-zero sample count is an error code (round 5 dereferenced it), a NULL buffer of length 0 is an
+    empty utterance; batches above 1 MB go through the persistent gather pool (eight parts on the caller's thread + three workers) --
+    several in a row, from two threads at once (the second gathers on its own thread), all equal to a blocking call."""
+    import ctypes
+    import threading
+    L = native.lib()
+    a = synth.synth_audio(8000, seed=1)
+    bufs = (ctypes.c_void_p * 2)(a.ctypes.data, None)
+    sizes = (ctypes.c_uint * 2)(len(a), 100)
+    assert L.STTX_BatchSubmit(model._impl, ctypes.cast(bufs, ctypes.POINTER(ctypes.c_void_p)), sizes, 2) < 0
+    assert L.STTX_BatchSubmit(model._impl, None, sizes, 2) < 0
+    sizes[1] = 0
+    t = L.STTX_BatchSubmit(model._impl, ctypes.cast(bufs, ctypes.POINTER(ctypes.c_void_p)), sizes, 2)
+    assert t > 0
+    texts, _ = model.collectBatchScored(t)
+    assert texts == model.sttBatch([a, a[:0]])
+    big = [synth.synth_audio(40000 + 997 * i, seed=900 + i) for i in range(16)]        # 1.4 MB: the pooled gather
+    want = model.sttBatch(big)
+    for _ in range(3):
+        assert model.collectBatchScored(model.submitBatch([x.copy() for x in big]))[0] == want
+    # the pool under two callers: a second model's submit while the first gathers
+    from stt_amd import Model
+    path = str(tmp_path / "small2.sttw")
+    modelfile.write_model(path, synth.synth_weights(11, n_hidden=256), synth.ENGLISH_LABELS, beam_width=64)
+    other = Model(path)
+    if other is not None:
+        out = {}
+
+        def run(m, key):
+            out[key] = [m.collectBatchScored(m.submitBatch([x.copy() for x in big]))[0] for _ in range(4)]
+        th = [threading.Thread(target=run, args=(model, "a")), threading.Thread(target=run, args=(other, "b"))]
+        [t_.start() for t_ in th]
+        [t_.join() for t_ in th]
+        assert all(r == want for r in out["a"])
+        assert all(r == want for r in out["b"])

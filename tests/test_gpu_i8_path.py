@@ -85,9 +85,8 @@ def test_dense_layers_bit_equal_and_the_cell_within_its_bound(tmp_path, per_chan
     l5 = hm._dense(out["h_all"].reshape(T * B, H), "layer_5")
     logits = hm._fc(l5, "layer_6/weights", hm.b["layer_6/bias"])
     assert np.array_equal(out["logits"].reshape(T * B, -1), logits), float(np.abs(out["logits"].reshape(T * B, -1) - logits).max())
-    e = np.exp((logits - logits.max(axis=1, keepdims=True)).astype(np.float32))
-    p = (e / e.sum(axis=1, keepdims=True)).reshape(T, B, -1).transpose(1, 0, 2)
-    assert float(np.abs(out["probs"] - p).max()) <= 1e-6
+    p = hm.softmax(logits).reshape(T, B, -1).transpose(1, 0, 2)
+    assert np.array_equal(out["probs"], p), float(np.abs(out["probs"] - p).max())      # the correctly rounded softmax, on both sides: bit equal
     if B > 1:
         assert out["slow_rows"] >= 0                # (rows with small windows may take the joint-scale path; the next test counts them against the restatement)
 
