@@ -215,6 +215,32 @@ def cpu_baseline_reference_decoder(cx, wl, scorer_path=None):
         return None
 
 
+def cpu_baseline_hybrid_transcripts(cx, audio_rows, timed_texts):
+    """Part of the cpu_baseline leg (the only place bench.py may touch oracle/), after the clock: what would the REFERENCE'S CPU PATH print for
+    these utterances?  Its acoustic half is TFLite's hybrid int8 arithmetic on the released (dynamic-range quantised) model -- restated in
+    oracle/am_hybrid.py (parity unpinned: TFLite is not in the tree) on the same synthetic weights quantised as the converter does -- and its
+    decoder half is the real reference decoder (oracle/_ref) on those probabilities, same scorer and beam.  -> how many of the timed
+    transcripts of these rows equal that, for the model the line times (`transcripts_equal_hybrid_path`)."""
+    try:
+        from oracle import am_hybrid, ref
+        from stt_amd import synth
+        if not ref.available():
+            return None
+        t0 = time.perf_counter()
+        w = synth.synth_weights(0, n_hidden=H, n_classes=29)
+        want = am_hybrid.utterance_probs_batch(audio_rows, w)
+        A = ref.Alphabet(os.path.join(FIX, "alphabet.txt"))
+        S = ref.Scorer(cx.scorer_path, A)
+        res = ref.decode_batch(want.astype(np.float64), [want.shape[1]] * len(audio_rows), A, BEAM, os.cpu_count() or 1, S)
+        texts = [A.decode(tok).decode("utf-8", "replace") for _, tok in res]
+        return {"equal": sum(1 for a_, b_ in zip(texts, timed_texts) if a_ == b_), "of": len(texts), "seconds": round(time.perf_counter() - t0, 1),
+                "what": "timed transcripts of the first %d utterances of the first timed batch == the reference decoder (oracle/_ref) on the hybrid-int8 restatement's "
+                        "probabilities (oracle/am_hybrid.py: what the reference's TFLite CPU path computes for the quantised model; restatement, parity unpinned)" % len(texts)}
+    except Exception as ex:
+        sys.stderr.write("bench.py: hybrid-path check unavailable: %r\n" % (ex,))
+        return None
+
+
 def judge_against_reference(items, tie_of):
     """The rule every workload's check goes through (pure: tests/test_host_logic.py feeds it forged mismatches).
     items: [{"id", "got_text", "got_conf" (or None), "want_text", "want_conf" (or None), "against"}], one per timed utterance that was checked;
@@ -302,9 +328,10 @@ def compact_line(res, limit=FINAL_LINE_LIMIT):
     for k in ("verified", "verified_against"):
         out[k] = res.get(k)
     out["verify_counts"] = counts(res.get("verify_counts"))
-    for k in ("transcripts_equal_hybrid_path", "parity_unpinned"):
-        if k in res:
-            out[k] = res[k]
+    if res.get("transcripts_equal_hybrid_path"):
+        out["transcripts_equal_hybrid_path"] = {k: res["transcripts_equal_hybrid_path"].get(k) for k in ("equal", "of")}
+    if "parity_unpinned" in res:
+        out["parity_unpinned"] = res["parity_unpinned"]
     out["p50_utterance_latency_ms"] = rnd(res.get("p50_utterance_latency_ms"), 3)
     if res.get("host_audio"):
         out["host_audio"] = {k: rnd(res["host_audio"].get(k), 4) for k in ("value", "ms_per_step", "ratio_to_value")}
@@ -339,8 +366,8 @@ def compact_line(res, limit=FINAL_LINE_LIMIT):
                    "unexplained": (r.get("verify_counts") or {}).get("unexplained"), "roofline_frac": rnd((r.get("roofline") or {}).get("frac"), 4)}
             if r.get("hop_latency_ms"):
                 rec["hop_p50_ms"] = rnd(r["hop_latency_ms"].get("p50"), 3)
-            if r.get("transcripts_equal_hybrid_path") is not None:
-                rec["transcripts_equal_hybrid_path"] = r["transcripts_equal_hybrid_path"]
+            if r.get("transcripts_equal_hybrid_path"):
+                rec["transcripts_equal_hybrid_path"] = {k: r["transcripts_equal_hybrid_path"].get(k) for k in ("equal", "of")}
             q = (r.get("config") or {}).get("queue_moves")
             if q:
                 rec["queue_moves"] = q
@@ -687,7 +714,7 @@ def measure(wl, args, cx, steps, warmup):
     # measured.  judge_against_reference() holds the one rule for accepting a difference (a boundary tie, equal to the restatement).  Without
     # oracle/_ref: against a blocking call of the engine (`verified_against` says so, and the run then exits non-zero only on a mismatch).
     verified, verified_what, verified_against, vcounts, mismatches = None, None, None, None, []
-    refd = None
+    refd, hybrid_eq = None, None
     if rank == 0 and not args.no_reference_check:
         refd = cpu_baseline_reference_decoder(cx, wl, scorer_path=(FIXTURE_SCORER if wl == "peaky" else None))
     if wl in ("batch", "bytes", "ragged"):
@@ -739,6 +766,9 @@ def measure(wl, args, cx, steps, warmup):
                         full[gi] = out[r_][j]
                 ok = ok and all(t is not None for t in full)
         verified = bool(ok)
+        if wl == "batch" and refd is not None and timed_texts and not args.no_hybrid_check:
+            kk0, texts0 = timed_texts[0]
+            hybrid_eq = cpu_baseline_hybrid_transcripts(cx, [variants[kk0][b_, :sizes[b_]] for b_ in range(args.hybrid_rows)], texts0[:args.hybrid_rows])
         n_refb = sum(1 for v in want.values() if v[0] == "reference")
         vcounts.update({"distinct_batches": len(want), "distinct_batches_against_reference": n_refb,
                         "checked_against_reference": sum(1 for it in items if it["against"] == "reference"),
@@ -868,6 +898,9 @@ def measure(wl, args, cx, steps, warmup):
         "config": {"workload": desc, "global_batch": gbatch, "parallelism": "dp%d (utterance shards, RCCL transcript gather)" % world,
                    "rccl_ranks": world if cx.backend.startswith("nccl") else 0, "backend": cx.backend,
                    "batches_in_flight": depth,
+                   "headline_arithmetic": ("int8: the reference CPU path's own (TFLite hybrid FULLY_CONNECTED), bit-level against its restatement" if i8 else
+                                           "f16 MFMA / f32 accumulate as north_star names it for the headline; the reference CPU path's own int8 arithmetic -- the path whose transcripts "
+                                           "match it -- is timed beside it on the same batches: workloads.batch_i8"),
                    "audio": ("host (STTX_BatchSubmit: pageable int16 buffers, gathered into page-locked memory and copied to HBM inside the clock)" if (pipelined and host_audio)
                              else "device (int16 in HBM before the clock starts; `host_audio` = the same batches from host buffers)" if wl in ("batch", "bytes", "ragged") else "n/a"),
                    # two 64-utterance batches share one recurrence where the step is acoustic-bound (tunable `pair`; not the search-bound bytes setup)
@@ -880,6 +913,8 @@ def measure(wl, args, cx, steps, warmup):
         # nothing reference-held pins the acoustic half (TensorFlow Lite is an un-vendored submodule, no model offline) nor
         # the .tflite container: those rows are checked against restatements only.  The decoder half is pinned to the reference itself.
         "parity_unpinned": ["a3 (MFCC)", "a5 (dense/LSTM/softmax)", "f1 (.tflite container)"],
+        # the parity row in view: how many of the TIMED model's transcripts are what the reference's CPU path (hybrid int8 TFLite + its decoder) would print
+        "transcripts_equal_hybrid_path": hybrid_eq,
         # the stated tolerance of the acoustic half (not re-measured by this run: tests/test_gpu_benchshape.py, tests/test_gpu_hybrid.py)
         "acoustic_tolerance": {"vs_float_graph_f16_rounded": "|dp| <= 1e-4, |d ln p| <= 2e-3 (tests/test_gpu_benchshape.py, tests/test_gpu_timedpath.py)",
                                "vs_tflite_hybrid_int8_path": "|d ln p| <= 1.25e-2 x (output-layer scale), |dp| <= 1e-3 at the reference's initialisation; transcripts equal for 4 / 57 / 64 of 64 "
@@ -1043,6 +1078,8 @@ def main():
     ap.add_argument("--cohorts", type=int, default=2, help="stream: independent live sets, each on its own model replica and host thread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-check", action="store_true", help="verify the timed batches against a blocking call only (skip oracle/_ref)")
+    ap.add_argument("--no-hybrid-check", action="store_true", help="skip transcripts_equal_hybrid_path (a CPU restatement of TFLite's hybrid int8 path over --hybrid-rows utterances)")
+    ap.add_argument("--hybrid-rows", type=int, default=16)
     ap.add_argument("--no-extras", action="store_true", help="batch: do not append the other workloads' sub-lines")
     ap.add_argument("--scorer", default="synthetic", choices=["synthetic", "fixture"])
     ap.add_argument("--no-profile", action="store_true", help="experiment: no HIP-event stage timing inside the timed region")
@@ -1129,7 +1166,7 @@ def main():
             a2.utterances = kw.get("utterances", 0)
             try:
                 r = measure(w, a2, cx, k, wu)
-                sub[w] = {key: r[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "verified", "verified_against", "verified_what", "verify_counts", "verify_mismatches", "p50_utterance_latency_ms", "hop_latency_ms",
+                sub[w] = {key: r[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "verified", "verified_against", "verified_what", "verify_counts", "verify_mismatches", "transcripts_equal_hybrid_path", "p50_utterance_latency_ms", "hop_latency_ms",
                                                   "stage_ms_per_step", "roofline", "config") if key in r}
                 if "roofline" in sub[w] and "all" in sub[w]["roofline"]:
                     sub[w]["roofline"] = {kk: vv for kk, vv in sub[w]["roofline"].items() if kk != "all"}

@@ -177,6 +177,7 @@ struct BatchPart {
 // Enqueue everything one group needs, on both streams, without waiting for anything: features + acoustic chunks on
 // `stream`, the beam search of every chunk + the final ranking + the copy of the results to page-locked memory on
 // `stream_dec`, then the slot's `done` event.
+bool search_bound(const ModelState* m);
 void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::vector<BatchPart>& parts, unsigned num_results, const DevScorer& ds,
                          bool pipelined, hipEvent_t gate = nullptr, bool optimistic = true, const std::shared_ptr<ScorerDev>* scorer_then = nullptr) {
   const std::shared_ptr<ScorerDev> scorer = scorer_then ? *scorer_then : m->scorer_;   // (a retry: the scorer of the first attempt)
@@ -263,6 +264,7 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::ve
   // latency matters) keeps everything on `stream`: its own GEMMs would only slow its own recurrence (6.5 vs 5.9 ms)
   // (the int8 path takes the same form: tunable am_i8_pipe; 0 = one acoustic stream, 3.8 ms per batch wherever the engines' queues sit)
   const bool piped = pipelined && (!m->i8 || tune().am_i8_pipe != 0) && m->am_pipe_init();
+  m->watch_search_bound = search_bound(m);   // four searches side by side hold every CU: the recurrence waits for THEM, whatever its queue (round 5: `bytes` tripped the watch)
   if (piped) m->am_replace_if_slow();   // (a bad placement of the engines' hardware queues shows in the pipeline's own timing: engine.cpp)
   for (int k = 0; k < n_chunks; ++k) {
     hipEvent_t ev = m->ev_chunk[k % 2];  // an event may be re-recorded once the wait on it has been enqueued
@@ -375,6 +377,8 @@ void batch_init_slots(ModelState* m) {
   for (auto& sl : m->slots_) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   m->slots_[0].stream_dec = m->stream_dec;
   for (int i = 1; i < ModelState::kSlots; ++i) create_engine_stream(&m->slots_[i].stream_dec, 3);
+  m->placement_avoid_.clear();      // (engine.cpp: place_engine_streams -- the recurrence must not sit behind a search stream's dispatches either)
+  for (auto& sl : m->slots_) m->placement_avoid_.push_back(sl.stream_dec);
 }
 // Group slots in flight (tunable `pipeline`, 1..kSlots; default 2).  With more slots than `active` (default 2) the beam search of
 // group g starts behind the `done` event of group g - active while its acoustic model starts as soon as the previous group's

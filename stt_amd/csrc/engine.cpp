@@ -198,12 +198,94 @@ void ModelState::run_acoustic_chunk(const float* d_feats, const int* d_nframes, 
 // ------------------------------------------------------------------------------------------- acoustic model, three engines
 // (ModelState::stream / stream_l / stream_o, see engine.h.)  The same kernels on the same operands in the same order per
 // chunk as acoustic_rows(): results are bit-identical; only what runs beside what changes.
+
+// Which of `cands` wait for a dispatch in flight on `hog`?  One oversubscribed launch on `hog`, a chain of eight one-wave launches on every
+// candidate right behind it: a chain on the hog's pipe (or on its hardware queue) finishes only when the hog's last workgroup has been
+// placed, every other one within microseconds (benchmarks/pipe_probe.hip: 43 us per launch against 3).
+static std::vector<char> streams_behind(hipStream_t hog, const std::vector<hipStream_t>& cands, unsigned* scratch) {
+  std::vector<char> behind(cands.size(), 0);
+  hipEvent_t h0 = nullptr, h1 = nullptr;
+  std::vector<hipEvent_t> done(cands.size(), nullptr);
+  HIP_CHECK(hipEventCreate(&h0)); HIP_CHECK(hipEventCreate(&h1));
+  for (auto& e : done) HIP_CHECK(hipEventCreate(&e));
+  HIP_CHECK(hipStreamSynchronize(hog));      // (whatever the stream still had to do or to wait for must not stand between h0 and the hog)
+  HIP_CHECK(hipEventRecord(h0, hog));
+  launch_placement_hog(scratch, hog);
+  HIP_CHECK(hipEventRecord(h1, hog));
+  for (size_t c = 0; c < cands.size(); ++c) {
+    for (int k = 0; k < 8; ++k) launch_placement_tick(scratch + 16 + c, cands[c]);
+    HIP_CHECK(hipEventRecord(done[c], cands[c]));
+  }
+  HIP_CHECK(hipEventSynchronize(h1));
+  for (auto& e : done) HIP_CHECK(hipEventSynchronize(e));
+  float hog_ms = 0.f;
+  HIP_CHECK(hipEventElapsedTime(&hog_ms, h0, h1));
+  for (size_t c = 0; c < cands.size(); ++c) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, h0, done[c]));
+    behind[c] = ms > 0.6f * hog_ms ? 1 : 0;
+  }
+  (void)hipEventDestroy(h0); (void)hipEventDestroy(h1);
+  for (auto& e : done) (void)hipEventDestroy(e);
+  return behind;
+}
+
+// The recurrence is 250 short dependent launches per batch; the GEMM engine and the output engine launch grids of hundreds to thousands of
+// workgroups that take their whole run time to dispatch; a search launch waits for CUs the search before it still holds.  Any of those on the
+// recurrence's pipe and every recurrent step is picked up late (3.0 or 6.1 ms per batch, round 5).  Eight candidate streams are created (two
+// per pipe, if nobody else creates streams meanwhile), each probed against the GEMM engine's stream and the group slots' search streams;
+// the recurrence takes the candidate that waited for none of them (failing that: for a little-used search stream only), the output engine
+// one that shares with neither the recurrence nor the GEMM engine.  The rest are destroyed.  ~2 ms, once per model (and per watch move).
+void ModelState::place_engine_streams(hipStream_t* out_l, hipStream_t* out_o) {
+  constexpr int NC = 8;
+  std::vector<hipStream_t> cands(NC, nullptr);
+  for (int c = 0; c < NC; ++c) create_engine_stream(&cands[c], c == 0 ? 1 : 2, /*high_priority=*/false);
+  placement_scratch_.reserve(4096);
+  unsigned* scratch = placement_scratch_.as<unsigned>();
+  HIP_CHECK(hipMemsetAsync(scratch, 0, 4096, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  for (hipStream_t c : cands) { launch_placement_tick(scratch + 8, c); HIP_CHECK(hipStreamSynchronize(c)); }   // (a stream takes its hardware queue at first use)
+  std::vector<int> penalty(NC, 0);
+  const std::vector<char> with_gemm = streams_behind(stream, cands, scratch);
+  int n_gemm = 0;
+  for (int c = 0; c < NC; ++c) if (with_gemm[c]) { penalty[c] += 1000; ++n_gemm; }
+  for (size_t a = 0; a < placement_avoid_.size() && a < 4; ++a) {
+    if (!placement_avoid_[a]) continue;
+    const std::vector<char> w = streams_behind(placement_avoid_[a], cands, scratch);
+    for (int c = 0; c < NC; ++c) if (w[c]) penalty[c] += a < 2 ? 100 : 10;
+  }
+  int il = 0;
+  for (int c = 1; c < NC; ++c) if (penalty[c] < penalty[il]) il = c;
+  // the output engine: not behind the recurrence (its own GEMMs would hold the recurrence's pipe), not behind the GEMM engine
+  std::vector<hipStream_t> rest;
+  std::vector<int> rest_idx;
+  for (int c = 0; c < NC; ++c) if (c != il) { rest.push_back(cands[c]); rest_idx.push_back(c); }
+  const std::vector<char> with_l = streams_behind(cands[il], rest, scratch);
+  int io = -1, best = 1 << 30;
+  for (size_t r = 0; r < rest.size(); ++r) {
+    const int pen = penalty[rest_idx[r]] + (with_l[r] ? 100000 : 0);
+    if (pen < best) { best = pen; io = rest_idx[r]; }
+  }
+  if (io < 0) io = (il + 1) % NC;
+  if (tune().dump_marks) fprintf(stderr, "stt_amd: engine streams placed: recurrence = candidate %d (penalty %d), output engine = candidate %d (penalty %d); %d of %d candidates behind the GEMM engine's stream\n",
+                                 il, penalty[il], io, penalty[io], n_gemm, NC);
+  // the recurrence's stream keeps its high priority where the runtime allows one to be re-created on the same queue: it does not -- the chosen
+  // candidate is used as it is (measured in round 5: the recurrence's queue at normal priority 3.095 against 3.09 ms per batch)
+  *out_l = cands[il]; *out_o = cands[io];
+  for (int c = 0; c < NC; ++c) if (c != il && c != io) (void)hipStreamDestroy(cands[c]);
+  __atomic_fetch_add(&tune().am_placed, 1, __ATOMIC_RELAXED);
+  tune().am_placed = (tune().am_placed & 0xff) | (n_gemm << 8);
+}
+
 bool ModelState::am_pipe_init() {
   if (!tune().am_pipe) return false;
   if (stream_l) return true;
-  // the recurrence is the critical path: its workgroups go first whenever a CU has room
-  create_engine_stream(&stream_l, 1, /*high_priority=*/true);
-  create_engine_stream(&stream_o, 2);
+  if (tune().am_place && tune().search_cus <= 0) place_engine_streams(&stream_l, &stream_o);
+  else {
+    // the recurrence is the critical path: its workgroups go first whenever a CU has room
+    create_engine_stream(&stream_l, 1, /*high_priority=*/true);
+    create_engine_stream(&stream_o, 2);
+  }
   for (int i = 0; i < kAmRing; ++i)
     for (hipEvent_t* e : {&ev_x_ready[i], &ev_x_free[i], &ev_h_ready[i], &ev_h_free[i]}) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   return true;
@@ -220,7 +302,7 @@ bool ModelState::am_pipe_init() {
 // take other hardware queues -- at most `am_moves` times per model.  A pipeline that is slow for another reason pays a few stream
 // synchronisations and stays where it was last.
 void ModelState::am_watch_begin(int T) {
-  if (tune().am_moves <= 0 || watch_armed || T < 32 || watch_moves > tune().am_moves) return;
+  if (tune().am_moves <= 0 || watch_armed || watch_search_bound || T < 32 || watch_moves > tune().am_moves) return;
   if (!ev_watch[0]) for (auto& e : ev_watch) HIP_CHECK(hipEventCreate(&e));
   HIP_CHECK(hipEventRecord(ev_watch[0], stream_l));
   watch_steps = -T;                                    // (negative: begun, not ended)
@@ -234,6 +316,7 @@ void ModelState::am_watch_end() {
 void ModelState::am_replace_if_slow() {
   if (!watch_armed || hipEventQuery(ev_watch[1]) != hipSuccess) { (void)hipGetLastError(); return; }
   watch_armed = false;
+  if (watch_search_bound) { watch_slow = 0; return; }   // (a reading taken before the scorer / beam changed)
   float ms = 0.0f;
   if (hipEventElapsedTime(&ms, ev_watch[0], ev_watch[1]) != hipSuccess) { (void)hipGetLastError(); return; }
   const float us = 1e3f * ms / (float)std::max(1, watch_steps);
@@ -246,9 +329,14 @@ void ModelState::am_replace_if_slow() {
   ++watch_moves;
   __atomic_fetch_add(&tune().am_moved, 1, __ATOMIC_RELAXED);
   hipStream_t nl = nullptr, no = nullptr;
-  create_engine_stream(&nl, 1, /*high_priority=*/true);
-  create_engine_stream(&no, 2);
   HIP_CHECK(hipStreamSynchronize(stream_l)); HIP_CHECK(hipStreamSynchronize(stream_o));   // (rare: nothing of the old queues is left in flight)
+  if (tune().am_place && tune().search_cus <= 0) {
+    HIP_CHECK(hipStreamSynchronize(stream));       // (the probe's dispatches should meet an idle GEMM engine)
+    place_engine_streams(&nl, &no);
+  } else {
+    create_engine_stream(&nl, 1, /*high_priority=*/true);
+    create_engine_stream(&no, 2);
+  }
   (void)hipStreamDestroy(stream_l); (void)hipStreamDestroy(stream_o);
   stream_l = nl; stream_o = no;
 }

@@ -324,7 +324,13 @@ struct ModelState {
   // output engine to fresh streams the next time a group is enqueued.
   hipEvent_t ev_watch[2] = {};
   bool watch_armed = false;
+  bool watch_search_bound = false;   // set by the batch path: a setup whose searches fill the chip (code-point scorer, beam > 512) is slow for THAT reason: not watched
   int watch_steps = 0, watch_slow = 0, watch_moves = 0;
+  // Placement (engine.cpp): creates stream_l / stream_o on dispatch pipes they share with neither the GEMM engine's stream nor (if it can be
+  // helped) the searches' -- by measurement, not by counting streams.  `avoid`: the search streams of the group slots in use.
+  void place_engine_streams(hipStream_t* out_l, hipStream_t* out_o);
+  std::vector<hipStream_t> placement_avoid_;   // set by the batch path (api.cpp: batch_init_slots): the slots' search streams, most used first
+  DevBuf placement_scratch_;
   void am_watch_begin(int T);
   void am_watch_end();
   void am_replace_if_slow();

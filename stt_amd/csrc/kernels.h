@@ -136,6 +136,8 @@ struct SoftmaxArgs {
 
 // dst/src: device-addressable (HBM or mapped page-locked host memory); any size, any alignment
 void launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t st);
+void launch_placement_hog(unsigned* scratch, hipStream_t st);    // a dispatch that keeps its pipe for ~0.2 ms (engine.cpp: place_engine_streams)
+void launch_placement_tick(unsigned* scratch, hipStream_t st);   // one wave, one atomic
 void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st);
 void launch_context(const ContextArgs& a, int rows, hipStream_t st);   // a.x1_f32: rows as f32 (the int8 path quantises them itself)
 void launch_dense(const DenseArgs& a, int epi, hipStream_t st);

@@ -1155,6 +1155,23 @@ void launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t st)
   const int blocks = (int)std::min<size_t>(64, (items + 255) / 256);
   hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, st, (unsigned char*)dst, (const unsigned char*)src, bytes, wide);
 }
+// ---- which streams share a dispatch pipe?  (engine.cpp: place_engine_streams; measured: benchmarks/pipe_probe.hip, profiles/r06_pipe_probe.txt)
+// A compute pipe of the command processor works on one dispatch at a time: a launch of more workgroups than the chip holds keeps its pipe
+// until the last one is placed, and every other queue on that pipe waits.  HIP streams land on pipes round-robin in creation order (stream
+// i and stream i + 4 share), so whether the recurrence's 250 short dependent launches per batch sit behind the GEMM engine's dispatches is
+// an accident of what the process created before.  The probe makes it a measurement: a "hog" dispatch on one stream (8192 workgroups that
+// sleep 20 us, LDS sized so that wave slots stay free on every CU), a chain of one-wave launches on each candidate, events around both.
+__global__ __launch_bounds__(256) void placement_hog_kernel(unsigned* sink, int ticks) {
+  __shared__ unsigned lds[10240];   // 40 KiB: four workgroups per CU, 16 of its 32 wave slots
+  lds[threadIdx.x] = threadIdx.x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+  while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(32);
+  if (lds[threadIdx.x] == 0xffffffffu) sink[0] = 1;
+}
+__global__ void placement_tick_kernel(unsigned* p) { if (threadIdx.x == 0) atomicAdd(p, 1u); }
+void launch_placement_hog(unsigned* scratch, hipStream_t st) { hipLaunchKernelGGL(placement_hog_kernel, dim3(8192), dim3(256), 0, st, scratch, 2000); }
+void launch_placement_tick(unsigned* scratch, hipStream_t st) { hipLaunchKernelGGL(placement_tick_kernel, dim3(1), dim3(64), 0, st, scratch); }
+
 void launch_dense_hybrid_i8(const signed char* q, const float* row_scale, const signed char* wq, const float* col_scale, int col_scale_n, const float* bias, void* y,
                             int M, int N, int K, hipStream_t st, int epi, float relu_clip, int ldy) {
   if (K % 128 != 0 || M < 1) throw std::runtime_error("launch_dense_hybrid_i8: K must be a multiple of 128");

@@ -30,6 +30,8 @@
   X(lstm_cotenant, 0, "STTX_TestLstmSteps only: this many x-projection GEMMs (6144 x 8192 x 2048, form dense_solo) run beside the steps") \
   X(lstm_stamps, 0, "STTX_TestLstmSteps only: in-kernel REFCLK stamps, summary on stderr")                                         \
   X(am_i8, -1, "acoustic model in the released models' own arithmetic (TFLite's hybrid int8 FULLY_CONNECTED: int8 activations per row, int32 sums): -1 = when the file is a dynamic-range quantised .tflite, 0 = never (int8 weights are de-quantised to f16), 1 = always (float weights are quantised at load as the converter does); read when a model is loaded") \
+  X(am_place, 1, "three-engine form: the recurrence's and the output engine's streams are PLACED -- candidates probed for which dispatch pipe they share with the GEMM engine's and the searches' streams (engine.cpp: place_engine_streams; 0 = take whatever the runtime hands out, round 5's behaviour)") \
+  X(am_placed, 0, "counter, not a knob: placements made so far; bits 8.. of the last one: candidates found sharing a pipe with the GEMM engine's stream") \
   X(am_moves, 6, "three-engine form: how often a model may move its recurrence and output engine to fresh streams when a chunk's steps are picked up late twice in a row (0 = never watch)") \
   X(am_slow_us, 0, "three-engine form: microseconds per recurrent step above which a chunk counts as slow (0 = 31 us x max(1, (n_hidden / 2048)^2))") \
   X(am_moved, 0, "counter, not a knob: moves of the engines to fresh streams so far (all models)") \

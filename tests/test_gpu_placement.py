@@ -1,0 +1,37 @@
+"""The batch pipeline must not care what else the process created before the model (round-5 verdict, weak 7: one idle hipStream doubled the
+batch time of both paths).  K = 0 .. 8 idle streams created before the model x {f16, int8 path}, each point in a FRESH process
+(benchmarks/queue_placement.py: hardware queues are handed out per process), 12 warm-up + 24 timed pipelined batches of 64 x 5 s at the
+bench's geometry: the steady-state time per batch of every K stays within 15 % of K = 0's.  Needs a MI355X."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import OUT, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _point(k, mode, extra=()):
+    env = dict(os.environ, STT_AMD_TEST_HOOKS="0")       # the shipped library
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "queue_placement.py"), "--idle", str(k), "--mode", mode, *extra],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("mode", ["f16", "int8"])
+def test_batch_time_does_not_depend_on_streams_created_before_the_model(mode):
+    pts = [_point(k, mode) for k in range(9)]
+    base = pts[0]["ms_per_batch"]
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "queue_placement_%s.json" % mode), "w") as f:
+        json.dump({"what": "benchmarks/queue_placement.py, one fresh process per point, am_place = 1 (default), am_moves = 6 (default)", "points": pts}, f, indent=1)
+    print("queue placement, %s:" % mode, [(p["idle_streams_before_the_model"], p["ms_per_batch"], p["watch_moves"]) for p in pts])
+    assert all(p["transcripts_repeat"] for p in pts)
+    assert all(p["placements"] >= 1 for p in pts)
+    worst = max(p["ms_per_batch"] for p in pts)
+    assert worst <= 1.15 * base, (base, [(p["idle_streams_before_the_model"], p["ms_per_batch"]) for p in pts])
+    assert base < 4.0, base                      # (and K = 0 itself is a good placement: 3.0 - 3.2 ms on the bench's box)
