@@ -377,6 +377,14 @@ void batch_init_slots(ModelState* m) {
   for (auto& sl : m->slots_) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   m->slots_[0].stream_dec = m->stream_dec;
   for (int i = 1; i < ModelState::kSlots; ++i) create_engine_stream(&m->slots_[i].stream_dec, 3);
+  if (tune().am_pipe && tune().am_place && tune().search_cus <= 0 && !m->stream_l) {
+    // every stream of the batch pipeline on a dispatch pipe chosen for its role (engine.cpp: place_batch_streams)
+    hipStream_t ss[ModelState::kSlots];
+    for (int i = 0; i < ModelState::kSlots; ++i) ss[i] = m->slots_[i].stream_dec;
+    m->place_batch_streams(ss, ModelState::kSlots);
+    for (int i = 0; i < ModelState::kSlots; ++i) m->slots_[i].stream_dec = ss[i];
+    m->stream_dec = ss[0];           // (slot 0's stream is the model's: ~ModelState destroys it)
+  }
   m->placement_avoid_.clear();      // (engine.cpp: place_engine_streams -- the recurrence must not sit behind a search stream's dispatches either)
   for (auto& sl : m->slots_) m->placement_avoid_.push_back(sl.stream_dec);
 }

@@ -277,10 +277,80 @@ void ModelState::place_engine_streams(hipStream_t* out_l, hipStream_t* out_o) {
   tune().am_placed = (tune().am_placed & 0xff) | (n_gemm << 8);
 }
 
+// The whole batch pipeline at once, before its first group is enqueued (api.cpp: batch_init_slots; nothing in flight): sixteen candidate
+// streams are sorted into pipe classes by probing (which candidates wait behind the GEMM engine's stream; then, for each class not yet seen,
+// which wait behind its first member), and every role gets a class of its own where there are enough: the recurrence one, the output
+// engine one, ALL group slots' search streams a third (searches run one or two at a time and only ever wait for CUs, never for each other's
+// dispatch) -- so that no search stream can sit on the recurrence's pipe either (the first cut probed the existing search streams and found,
+// with eight idle streams created before the model, every pipe already taken by one of them: 6.3 ms per batch again).
+void ModelState::place_batch_streams(hipStream_t* slot_streams, int n_slots) {
+  constexpr int NC = 16;
+  std::vector<hipStream_t> cands(NC, nullptr);
+  for (int c = 0; c < NC; ++c) create_engine_stream(&cands[c], 2, false);
+  placement_scratch_.reserve(4096);
+  unsigned* scratch = placement_scratch_.as<unsigned>();
+  HIP_CHECK(hipMemsetAsync(scratch, 0, 4096, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  for (hipStream_t c : cands) { launch_placement_tick(scratch + 8, c); HIP_CHECK(hipStreamSynchronize(c)); }   // (a stream takes its hardware queue at first use)
+  std::vector<int> cls(NC, -1);
+  {
+    const std::vector<char> g = streams_behind(stream, cands, scratch);
+    for (int c = 0; c < NC; ++c) if (g[c]) cls[c] = 0;                       // class 0: the GEMM engine's pipe (or queue)
+  }
+  int n_cls = 1;
+  for (int c = 0; c < NC && n_cls < 8; ++c) {
+    if (cls[c] >= 0) continue;
+    std::vector<hipStream_t> open; std::vector<int> open_idx;
+    for (int d = c + 1; d < NC; ++d) if (cls[d] < 0) { open.push_back(cands[d]); open_idx.push_back(d); }
+    cls[c] = n_cls;
+    if (!open.empty()) {
+      const std::vector<char> b = streams_behind(cands[c], open, scratch);
+      for (size_t r = 0; r < open.size(); ++r) if (b[r]) cls[open_idx[r]] = n_cls;
+    }
+    ++n_cls;
+  }
+  std::vector<std::vector<int>> members(n_cls);
+  for (int c = 0; c < NC; ++c) members[cls[c]].push_back(c);
+  std::vector<int> free_cls;                                                    // classes other than the GEMM engine's, largest first
+  for (int k = 1; k < n_cls; ++k) if (!members[k].empty()) free_cls.push_back(k);
+  std::stable_sort(free_cls.begin(), free_cls.end(), [&](int a, int b) { return members[a].size() > members[b].size(); });
+  std::vector<char> used(NC, 0);
+  auto take = [&](int k) -> hipStream_t {
+    for (int c : members[k]) if (!used[c]) { used[c] = 1; return cands[c]; }
+    return nullptr;
+  };
+  // searches get the largest class (they need n_slots streams), the recurrence the next, the output engine the third (or shares the searches')
+  const int ks = free_cls.size() > 0 ? free_cls[0] : 0, kr = free_cls.size() > 1 ? free_cls[1] : ks, ko = free_cls.size() > 2 ? free_cls[2] : ks;
+  hipStream_t nl = take(kr), no = take(ko);
+  if (!nl || !no) {   // (cannot happen with sixteen candidates unless the runtime hands out one queue for all of them: keep what exists)
+    for (hipStream_t c : cands) if (c != nl && c != no) (void)hipStreamDestroy(c);
+    if (nl) (void)hipStreamDestroy(nl);
+    if (no) (void)hipStreamDestroy(no);
+    return;
+  }
+  stream_l = nl; stream_o = no;
+  for (int i = 0; i < n_slots; ++i) {
+    hipStream_t st = take(ks);
+    if (!st && ko != ks) st = take(ko);
+    if (!st) continue;                            // (this slot keeps the stream it has)
+    if (slot_streams[i]) { HIP_CHECK(hipStreamSynchronize(slot_streams[i])); (void)hipStreamDestroy(slot_streams[i]); }
+    slot_streams[i] = st;
+  }
+  for (int c = 0; c < NC; ++c) if (!used[c]) (void)hipStreamDestroy(cands[c]);
+  if (tune().dump_marks) {
+    fprintf(stderr, "stt_amd: batch streams placed: %d pipe classes among %d candidates (sizes", n_cls, NC);
+    for (int k = 0; k < n_cls; ++k) fprintf(stderr, " %zu", members[k].size());
+    fprintf(stderr, "; class 0 = behind the GEMM engine); searches class %d, recurrence class %d, output engine class %d\n", ks, kr, ko);
+  }
+  __atomic_fetch_add(&tune().am_placed, 1, __ATOMIC_RELAXED);
+  tune().am_placed = (tune().am_placed & 0xff) | ((int)members[0].size() << 8) | (n_cls << 16);
+}
+
 bool ModelState::am_pipe_init() {
   if (!tune().am_pipe) return false;
-  if (stream_l) return true;
-  if (tune().am_place && tune().search_cus <= 0) place_engine_streams(&stream_l, &stream_o);
+  if (ev_x_ready[0]) return true;
+  if (stream_l) {}     // (placed with the group slots' search streams: place_batch_streams)
+  else if (tune().am_place && tune().search_cus <= 0) place_engine_streams(&stream_l, &stream_o);
   else {
     // the recurrence is the critical path: its workgroups go first whenever a CU has room
     create_engine_stream(&stream_l, 1, /*high_priority=*/true);

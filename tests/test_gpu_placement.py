@@ -1,5 +1,5 @@
 """The batch pipeline must not care what else the process created before the model (round-5 verdict, weak 7: one idle hipStream doubled the
-batch time of both paths).  K = 0 .. 8 idle streams created before the model x {f16, int8 path}, each point in a FRESH process
+batch time of both paths).  K = 0 .. 8 and 13 idle streams (13: more streams than the 16 hardware queues the engine asks the runtime for) created before the model x {f16, int8 path}, each point in a FRESH process
 (benchmarks/queue_placement.py: hardware queues are handed out per process), 12 warm-up + 24 timed pipelined batches of 64 x 5 s at the
 bench's geometry: the steady-state time per batch of every K stays within 15 % of K = 0's.  Needs a MI355X."""
 import json
@@ -24,7 +24,7 @@ def _point(k, mode, extra=()):
 
 @pytest.mark.parametrize("mode", ["f16", "int8"])
 def test_batch_time_does_not_depend_on_streams_created_before_the_model(mode):
-    pts = [_point(k, mode) for k in range(9)]
+    pts = [_point(k, mode) for k in (0, 1, 2, 3, 4, 5, 6, 7, 8, 13)]
     base = pts[0]["ms_per_batch"]
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, "queue_placement_%s.json" % mode), "w") as f:
