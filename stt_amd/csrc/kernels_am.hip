@@ -1160,7 +1160,7 @@ void launch_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t st)
 // until the last one is placed, and every other queue on that pipe waits.  HIP streams land on pipes round-robin in creation order (stream
 // i and stream i + 4 share), so whether the recurrence's 250 short dependent launches per batch sit behind the GEMM engine's dispatches is
 // an accident of what the process created before.  The probe makes it a measurement: a "hog" dispatch on one stream (8192 workgroups that
-// sleep 20 us, LDS sized so that wave slots stay free on every CU), a chain of one-wave launches on each candidate, events around both.
+// sleep 200 us, LDS sized so that wave slots stay free on every CU), two one-wave launches on each candidate, events around both.
 __global__ __launch_bounds__(256) void placement_hog_kernel(unsigned* sink, int ticks) {
   __shared__ unsigned lds[10240];   // 40 KiB: four workgroups per CU, 16 of its 32 wave slots
   lds[threadIdx.x] = threadIdx.x;
@@ -1169,7 +1169,9 @@ __global__ __launch_bounds__(256) void placement_hog_kernel(unsigned* sink, int 
   if (lds[threadIdx.x] == 0xffffffffu) sink[0] = 1;
 }
 __global__ void placement_tick_kernel(unsigned* p) { if (threadIdx.x == 0) atomicAdd(p, 1u); }
-void launch_placement_hog(unsigned* scratch, hipStream_t st) { hipLaunchKernelGGL(placement_hog_kernel, dim3(8192), dim3(256), 0, st, scratch, 2000); }
+// (8192 workgroups, 1024 resident at a time, 200 us each: the dispatch holds its pipe for ~1.6 ms -- several times what the host needs to issue
+// the candidates' chains behind it, so "finished before the hog's dispatch ended" separates the pipes cleanly)
+void launch_placement_hog(unsigned* scratch, hipStream_t st) { hipLaunchKernelGGL(placement_hog_kernel, dim3(8192), dim3(256), 0, st, scratch, 20000); }
 void launch_placement_tick(unsigned* scratch, hipStream_t st) { hipLaunchKernelGGL(placement_tick_kernel, dim3(1), dim3(64), 0, st, scratch); }
 
 void launch_dense_hybrid_i8(const signed char* q, const float* row_scale, const signed char* wq, const float* col_scale, int col_scale_n, const float* bias, void* y,
