@@ -42,9 +42,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NFFT>
 __global__ __launch_bounds__(NFFT / 2) void mfcc_kernel(MfccArgs a) {
   constexpr int HALF = NFFT / 2, NBIN = HALF + 1;  // threads = butterflies per stage; spectrum bins
-  __shared__ double2 buf[2][NFFT];
-  __shared__ double amp[NBIN];
-  __shared__ double lmel[40];
+  // (dynamic LDS: a 2048-point transform -- 32 ms windows at 44.1 / 48 kHz -- takes 2 x 32 KiB of ping-pong + the spectrum: past the 64 KiB a
+  // static declaration may have; launch_mfcc asks for it)
+  extern __shared__ __attribute__((aligned(16))) unsigned char mfcc_smem[];
+  double2 (*buf)[NFFT] = reinterpret_cast<double2 (*)[NFFT]>(mfcc_smem);          // [2][NFFT]
+  double* amp = reinterpret_cast<double*>(mfcc_smem + 2 * NFFT * sizeof(double2));  // [NBIN]
+  double* lmel = amp + NBIN + 1;                                                    // [40]
   const int frame = blockIdx.x;
   const int b = frame / a.t_max;
   const int f = frame - b * a.t_max;
@@ -1216,12 +1219,20 @@ void launch_dense_hybrid_i8(const signed char* q, const float* row_scale, const 
     default: hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_I8_F32>), dim3(8 * per_xcd), dim3(512), smem, st, b); break;
   }
 }
+template <int NFFT>
+static void launch_mfcc_inst(const MfccArgs& a, int n_frames_total, hipStream_t st) {
+  const size_t smem = (size_t)2 * NFFT * sizeof(double2) + (size_t)(NFFT / 2 + 2 + 40) * sizeof(double);
+  static std::once_flag once;
+  std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_kernel<NFFT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); });
+  hipLaunchKernelGGL(mfcc_kernel<NFFT>, dim3(n_frames_total), dim3(NFFT / 2), smem, st, a);
+}
 void launch_mfcc(const MfccArgs& a, int n_frames_total, hipStream_t st) {
   switch (a.fft_len) {
-    case 128: hipLaunchKernelGGL(mfcc_kernel<128>, dim3(n_frames_total), dim3(64), 0, st, a); break;
-    case 256: hipLaunchKernelGGL(mfcc_kernel<256>, dim3(n_frames_total), dim3(128), 0, st, a); break;
-    case 512: hipLaunchKernelGGL(mfcc_kernel<512>, dim3(n_frames_total), dim3(256), 0, st, a); break;
-    case 1024: hipLaunchKernelGGL(mfcc_kernel<1024>, dim3(n_frames_total), dim3(512), 0, st, a); break;
+    case 128: launch_mfcc_inst<128>(a, n_frames_total, st); break;
+    case 256: launch_mfcc_inst<256>(a, n_frames_total, st); break;
+    case 512: launch_mfcc_inst<512>(a, n_frames_total, st); break;
+    case 1024: launch_mfcc_inst<1024>(a, n_frames_total, st); break;
+    case 2048: launch_mfcc_inst<2048>(a, n_frames_total, st); break;      // 32 ms at 44.1 / 48 kHz (1411 / 1536 samples): 1024 threads
     default: throw std::runtime_error("launch_mfcc: unsupported FFT length");
   }
 }

@@ -153,10 +153,11 @@ int parse_model_file(const char* buf, size_t len, ModelTensors& tfl, ModelView& 
     for (int i = 0; i < 12; ++i) { v.t[i] = f; v.count[i] = cnt[i]; f += cnt[i]; }
   }
   const int H = g.n_hidden, C = g.n_classes;
-  // The feature kernel takes FFT lengths of 128 .. 1024 (TF's AudioSpectrogram: fft_length = NextPowerOfTwo(window), util/feeding.py:51-73
-  // -> spectrogram.cc): windows of 65 .. 1024 samples -- 32 ms at 8, 16, 22.05 or 32 kHz; longer ones (44.1 / 48 kHz) are refused
-  // rather than silently framed differently.  The DCT has 40 mel inputs, so at most 40 coefficients exist.
-  if (H % 128 != 0 || H < 128 || C < 2 || C > STT_MAX_CLASSES || g.win_len > 1024 || g.win_len <= 64 || g.win_step < 1 || g.sample_rate < 1000 || g.n_input > 40 || g.n_input < 1 ||
+  // The feature kernel takes FFT lengths of 128 .. 2048 (TF's AudioSpectrogram: fft_length = NextPowerOfTwo(window), util/feeding.py:51-73
+  // -> spectrogram.cc): windows of 65 .. 2048 samples -- 32 ms at 8, 16, 22.05, 32, 44.1 or 48 kHz (tflitemodelstate.cc:287-307 takes any
+  // window; one workgroup holds at most 1024 butterflies, so windows beyond 2048 samples are refused rather than silently framed
+  // differently).  The DCT has 40 mel inputs, so at most 40 coefficients exist.
+  if (H % 128 != 0 || H < 128 || C < 2 || C > STT_MAX_CLASSES || g.win_len > 2048 || g.win_len <= 64 || g.win_step < 1 || g.sample_rate < 1000 || g.n_input > 40 || g.n_input < 1 ||
       g.n_steps < 1 || g.n_context < 0 || g.beam_width < 1) {
     err = "model geometry outside what the engine supports";
     return STT_ERR_INVALID_SHAPE;

@@ -133,7 +133,7 @@ def test_config3_many_streams_batched_equal_one_by_one(model):
         streams[0].intermediateDecode()                                    # destroyed by the batch finish
 
 
-@pytest.mark.parametrize("sr,win,step", [(8000, 256, 160), (22050, 705, 441)])
+@pytest.mark.parametrize("sr,win,step", [(8000, 256, 160), (22050, 705, 441), (44100, 1411, 882), (48000, 1536, 960)])
 def test_other_sample_rates_take_the_reference_fft_length(tmp_path, sr, win, step):
     """util/config.py:306-325: a model trained on 8 kHz audio has 256-sample windows every 160 samples; TF's AudioSpectrogram then
     runs a 256-point FFT (129 bins), a 22.05 kHz one a 1024-point FFT.  Round 2 refused such models; the reference runs them.

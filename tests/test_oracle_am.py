@@ -45,7 +45,7 @@ def test_layer_stack_against_torch_lstmcell():
     assert np.abs(c.numpy()[0] - c_ref).max() < 1e-9 and np.abs(h.numpy()[0] - h_ref).max() < 1e-9
 
 
-@pytest.mark.parametrize("sr,win,step", [(16000, 512, 320), (8000, 256, 160), (22050, 705, 441)])
+@pytest.mark.parametrize("sr,win,step", [(16000, 512, 320), (8000, 256, 160), (22050, 705, 441), (48000, 1536, 960)])
 def test_power_spectrum_and_frame_count_against_scipy_fft(sr, win, step):
     """The feature restatement at the reference's geometries (util/config.py:306-325: 32 ms windows every 20 ms of whatever the
     sample rate is; TF AudioSpectrogram: fft_length = NextPowerOfTwo(window) -> 512, 256, 1024 points) against scipy's FFT and a
