@@ -55,6 +55,40 @@ __global__ __launch_bounds__(256) void persistent_probe(Bar* b, uint4* h, unsign
   if (acc.x == 0x12345678u) sink[blockIdx.x] = acc.y + acc.z + acc.w;
 }
 
+// Round 6 (the round-5 verdict's item 2c): the same skeleton with what an INT8 recurrence would move -- h as int8 (128 rows x 2048 = 256 KB,
+// a 64-row group 128 KB, 32 rows 64 KB) -- published with write-through (sc1) stores and fetched with eight 16-byte sc1 loads in flight per
+// lane (the guide's hand-off recipe: no L1 to invalidate, 62 - 122 GB/s per workgroup instead of the 25 a plain loop got in round 3).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void persistent_probe_i8(Bar* b, uint4* h, unsigned steps, unsigned h_bytes, unsigned long long* sink) {
+  unsigned phase = 0;
+  const unsigned n_wg = gridDim.x, per_xcc = n_wg / 8;
+  uint4 acc = {0, 0, 0, 0};
+  const unsigned n16 = h_bytes / 16, mine = n16 / n_wg;
+  for (unsigned t = 0; t < steps; ++t) {
+    for (unsigned i = threadIdx.x; i < mine; i += 256) {
+      const u32x4 v = {t, i, blockIdx.x, acc.x};
+      uint4* dst = &h[(size_t)(t & 1) * n16 + blockIdx.x * mine + i];
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(v) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    grid_barrier(b, n_wg, phase, per_xcc);
+    const uint4* src = h + (size_t)(t & 1) * n16;
+    for (unsigned i0 = threadIdx.x; i0 < n16; i0 += 256 * 8) {
+      u32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const unsigned i = i0 + 256u * k;
+        const uint4* q = src + (i < n16 ? i : 0);
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[k]) : "v"(q) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { acc.x ^= v[k].x; acc.y += v[k].y; acc.z ^= v[k].z; acc.w += v[k].w; }
+    }
+  }
+  if (acc.x == 0x12345678u) sink[blockIdx.x] = acc.y + acc.z + acc.w;
+}
+
 __global__ void trivial(unsigned long long* sink) { if (threadIdx.x == 1025) sink[0] = 1; }
 
 int main() {
@@ -77,6 +111,20 @@ int main() {
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         printf("{\"probe\": \"persistent step skeleton\", \"workgroups\": %d, \"h_exchange_bytes\": %u, \"us_per_step\": %.3f}\n", n_wg, with_h ? hb : 0u, 1e3 * ms / steps);
       }
+    }
+  }
+  for (int n_wg : {128, 256}) {
+    for (unsigned hb : {65536u, 131072u, 262144u}) {
+      CHECK(hipMemset(b, 0, sizeof(Bar)));
+      hipLaunchKernelGGL(persistent_probe_i8, dim3(n_wg), dim3(256), 0, 0, b, h, 10u, hb, sink);
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipMemset(b, 0, sizeof(Bar)));
+      CHECK(hipEventRecord(e0));
+      hipLaunchKernelGGL(persistent_probe_i8, dim3(n_wg), dim3(256), 0, 0, b, h, steps, hb, sink);
+      CHECK(hipEventRecord(e1));
+      CHECK(hipDeviceSynchronize());
+      float ms2; CHECK(hipEventElapsedTime(&ms2, e0, e1));
+      printf("{\"probe\": \"persistent step skeleton, int8 h: sc1 stores, 8 x 16 B sc1 loads in flight per lane\", \"workgroups\": %d, \"h_exchange_bytes\": %u, \"us_per_step\": %.3f}\n", n_wg, hb, 1e3 * ms2 / steps);
     }
   }
   // the alternative: a kernel boundary (dependent launches of a trivial 128-workgroup kernel on one stream)
