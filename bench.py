@@ -631,7 +631,11 @@ def measure(wl, args, cx, steps, warmup):
     hop_lat.clear()
     extra.clear()
     profiled = wl in ("batch", "bytes", "ragged") and not args.no_profile
-    model.setProfiling(profiled)
+    # Inside the clock only the events the roofline needs -- around the dominant kernel's launches, on its own stream (STTX_SetProfiling 3) --
+    # when batches are in flight: every HIP event is a barrier packet on its queue and the full set of stage marks costs the pipeline ~3 %
+    # (profiles/NOTES.md round 5).  The other engines' busy times come from an untimed repeat of the same K batches with every mark on.
+    live_marks_only = bool(profiled and pipelined and not args.all_marks)
+    model.setProfiling(3 if live_marks_only else profiled)
     stage, step_s, timed_texts, timed_conf, timed_all = {}, [], [], [], []
     depth = model.pipelineDepth() if pipelined else 1
     host_submit_s = 0.0
@@ -667,11 +671,20 @@ def measure(wl, args, cx, steps, warmup):
         torch.cuda.synchronize()
         return time.perf_counter() - t_begin
 
-    device_resident = None
+    device_resident, stage_all_marks = None, None
     if pipelined:
         elapsed = timed_pipeline(host_audio, True)
         if profiled:
             stage = dict(model.stageTimes())                      # (summed over the K batches when the pipeline drained)
+        if live_marks_only:
+            model.setProfiling(1)
+            e_all = timed_pipeline(host_audio, None)               # untimed for the line: the same K batches, every stage mark on
+            st_all = dict(model.stageTimes())
+            for k_ in ("features_ms", "dense_in_ms", "dense_out_ms", "decoder_next_ms", "decoder_decode_ms"):
+                stage[k_] = st_all[k_]
+            stage_all_marks = {"ms_per_step": 1e3 * e_all / steps, "lstm_ms_per_step": st_all["lstm_ms"] / steps,
+                               "what": "untimed repeat of the same K batches with every stage mark on (STTX_SetProfiling 1): the source of the other engines' busy times; "
+                                       "lstm_ms / lstm_launches / the roofline come from the timed region (marks on the recurrence's stream only)"}
         if not host_audio and wl == "batch" and not i8 and not args.no_profile:
             # beside it, not instead of it: the same K batches from host buffers, copy inside the clock
             model.setProfiling(False)
@@ -928,6 +941,8 @@ def measure(wl, args, cx, steps, warmup):
         res["host_audio"] = device_resident
         if not device_resident["transcripts_and_confidences_equal_the_timed_run"]:
             res["verified"] = False
+    if stage_all_marks is not None:
+        res["stage_table_run"] = stage_all_marks
     if pipelined:
         res["host_enqueue_ms_per_step"] = 1e3 * host_submit_s / K     # host time inside STTX_BatchSubmit (the gather into page-locked memory included)
     if wl == "stream":
@@ -1082,6 +1097,7 @@ def main():
     ap.add_argument("--hybrid-rows", type=int, default=16)
     ap.add_argument("--no-extras", action="store_true", help="batch: do not append the other workloads' sub-lines")
     ap.add_argument("--scorer", default="synthetic", choices=["synthetic", "fixture"])
+    ap.add_argument("--all-marks", action="store_true", help="experiment: every stage mark inside the timed region (rounds 1-5; costs the pipeline ~3 %)")
     ap.add_argument("--no-profile", action="store_true", help="experiment: no HIP-event stage timing inside the timed region")
     ap.add_argument("--host-audio", action="store_true", help="experiment: batch / bytes time STTX_BatchSubmit (host buffers, copy inside the clock) as the run's timed path")
     ap.add_argument("--no-pipeline", action="store_true", help="batch / bytes: one blocking call per step instead of several batches in flight")

@@ -33,6 +33,17 @@ run "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0" DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 run "ROC_SYSTEM_SCOPE_SIGNAL=0" ROC_SYSTEM_SCOPE_SIGNAL=0
 run "GPU_MAX_HW_QUEUES=4" GPU_MAX_HW_QUEUES=4
 run "eager recurrence (lstm_graph=0)" STT_AMD_TUNING=lstm_graph=0
+elif [ "$2" = chunks ]; then
+# with the engines' streams placed (no more 3.0-or-6.1 lottery between runs): chunk lengths and row groups, both paths
+run "defaults" X=1
+run "defaults (again)" X=1
+run "pchunk=32" STT_AMD_TUNING=pchunk=32
+run "pchunk=64" STT_AMD_TUNING=pchunk=64
+run "pchunk=96" STT_AMD_TUNING=pchunk=96
+run "pchunk0=32" STT_AMD_TUNING=pchunk0=32
+run "pchunk0=48,pchunk=64" STT_AMD_TUNING=pchunk0=48,pchunk=64
+run "lstm_i8_rows=128" STT_AMD_TUNING=lstm_i8_rows=128
+run "active=2" STT_AMD_TUNING=active=2
 elif [ "$2" = i8 ]; then
 # the int8 path's recurrence: row groups, chunk lengths, searches side by side (run with workload batch_i8)
 run "defaults" X=1

@@ -136,7 +136,9 @@ STTX_EXPORT char** STTX_DecodeStreamsBatch(StreamingState* const* aStreams, cons
  * aMs receives up to aCap floats: [0] features, [1] dense layers 1-3 + x-projection, [2] LSTM recurrence,
  * [3] layers 5-6 + softmax, [4] decoder next, [5] decoder decode + D2H, [6] LSTM launches, [7] timesteps.
  * aEnable: 0 = off, 1 = stage events + decoder counters, 2 = also the search kernel's per-phase shader-cycle
- * counters (STTX_GetDecoderPhaseCycles; they cost a few percent of the search kernel, so not inside timed runs). */
+ * counters (STTX_GetDecoderPhaseCycles; they cost a few percent of the search kernel, so not inside timed runs), 3 = ONLY the events
+ * around the recurrence's launches on its own stream ([2], [6], [7] are filled): the one live measurement a timed run needs for its
+ * roofline -- every event is a barrier packet on its queue, and all of them together cost the batch pipeline ~3 %. */
 STTX_EXPORT int STTX_SetProfiling(ModelState* aCtx, int aEnable);
 STTX_EXPORT int STTX_GetStageTimes(ModelState* aCtx, float* aMs, int aCap);
 /* Decoder counters accumulated over the last batch call: steps, candidates, lm queries, lm memory probes. */

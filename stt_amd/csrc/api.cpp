@@ -36,7 +36,7 @@ std::unordered_map<ModelState*, int> g_models;
 Prof& prof_of(ModelState* m) { return m->prof_; }
 void mark_on(ModelState* m, int id, int which, hipStream_t st) {
   Prof& p = prof_of(m);
-  if (!p.on) return;
+  if (!p.on || (p.only >= 0 && which != p.only)) return;
   if (p.used == p.pool.size()) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); p.pool.push_back(e); }
   hipEvent_t e = p.pool[p.used++];
   HIP_CHECK(hipEventRecord(e, st));
@@ -292,7 +292,7 @@ void batch_enqueue_group(ModelState* m, ModelState::GroupSlot& sl, const std::ve
   launch_ctc_decode(p, ds, m->dev_alphabet, sl.dec.table.as<DecStream>(), Bg, o, sl.stream_dec);
   copy_d2h(sl.h_out, sl.out.p, sl.out_layout.bytes, sl.stream_dec);  // all results, one block
   mark_on(m, -1, which, sl.stream_dec);
-  sl.prof_enqueued = prof_of(m).on; sl.prof_stamp_bytes = 0;
+  sl.prof_enqueued = prof_of(m).on && prof_of(m).only < 0; sl.prof_stamp_bytes = 0;   // (level 3: no counter block behind the results either)
   if (sl.prof_enqueued) {  // the search counters ride behind the results (no extra synchronisation when they are read)
     const size_t tb = sizeof(DecStream) * (size_t)Bg, sb = p.stamps ? (size_t)Bg * 64 * 8 : 0;
     sl.h_prof.reserve(tb + sb);
@@ -345,6 +345,7 @@ void batch_collect_group(ModelState* m, ModelState::GroupSlot& sl, std::vector<s
       dst.push_back(std::move(ou));
     }
   }
+  if (pr.on && pr.only >= 0) { pr.ms[6] += (float)sl.t_max; pr.ms[7] += (float)sl.t_max * sl.Bg; }   // (level 3: the launch and timestep counts still)
   if (pr.on && sl.prof_enqueued) {  // (only what was enqueued with profiling on carries a profiling block)
     pr.ms[6] += (float)sl.t_max; pr.ms[7] += (float)sl.t_max * sl.Bg;
     const DecStream* tb = sl.h_prof.as<DecStream>();
@@ -1140,7 +1141,7 @@ void STTX_FreeMetadataArray(Metadata** aMetadata, unsigned int aCount) {
 }
 int STTX_SetProfiling(ModelState* aCtx, int aEnable) {
   Prof& p = prof_of(aCtx);
-  p.on = aEnable != 0; p.phase_cycles = aEnable >= 2;
+  p.on = aEnable != 0; p.phase_cycles = aEnable == 2; p.only = aEnable == 3 ? 5 : -1;
   return STT_ERR_OK;
 }
 int STTX_GetStageTimes(ModelState* aCtx, float* aMs, int aCap) {

@@ -181,6 +181,7 @@ struct Output {
 struct Prof {
   bool on = false;
   bool phase_cycles = false;  // level 2: also the search kernel's per-phase cycle counters
+  int only = -1;              // level 3: marks of ONE mark list only (5 = the recurrence's stream: what bench.py's roofline needs live); -1 = all of them
   std::vector<hipEvent_t> pool;
   size_t used = 0;
   std::vector<std::pair<int, hipEvent_t>> marks[7];  // [0] = acoustic stream, [1 + s] = the search stream of group slot s, [5], [6] = recurrence / output-layer streams

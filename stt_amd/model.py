@@ -257,7 +257,8 @@ class Model(object):
         return (c, h, hall, ms.value) if timing else (c, h, hall)
 
     def setProfiling(self, level):
-        """0/False = off, 1/True = stage events + decoder counters, 2 = also the search kernel's phase cycle counters."""
+        """0/False = off, 1/True = stage events + decoder counters, 2 = also the search kernel's phase cycle counters, 3 = only the events around
+        the recurrence's launches (lstm_ms, lstm_launches, timesteps)."""
         native.lib().STTX_SetProfiling(self._impl, int(level))
 
     def stageTimes(self):
