@@ -321,12 +321,20 @@ __global__ __launch_bounds__(W8 ? 512 : T * T * 64, W8 ? 4 : 1) void dense_kerne
 // 128-square eight-wave form's, and each operand byte staged feeds 1.33x the flops.  One K-tile of prefetch then covers the
 // landing latency by itself (alone: 0.94 PF/s against 0.74; beside the recurrent step 0.62 against 0.51).  110 registers: two
 // waves per SIMD fit beside the 128-row step's 288.  Same k order per output element as every other form: bit-identical results.
-template <int EPI>
+// NS = 4 (round 6, tunable dense_solo = 4): the same tile and the same 96 KiB as FOUR stages of 24 KiB -- K-tiles of 32 (rows of 64 bytes), three
+// of them in flight behind a counted s_waitcnt and a raw s_barrier.  With one workgroup per CU nobody covers a K-tile's DMA round trip but
+// the K-tiles before it: one tile of prefetch made a 64-deep K-tile cost max(1.1 k cycles of MFMA, the round trip) + a barrier -- ~2.6 k cycles
+// measured alone.  Bank layout of a 64-byte row: slot s of row r holds K-chunk s ^ (((r >> 3) & 1) << 1) -- for the 16-lane groups a
+// ds_read_b128 is serviced in ({0-3, 12-15, 20-27}, ...: rows 0-3 and 12-15 at chunk c together with rows 4-11 at chunk c + 1) the sixteen
+// 16-byte slots of a 256-byte bank line are then all different (checked by enumeration).  Same k order per output element: bit-identical.
+template <int EPI, int NS = 2>
 __global__ __launch_bounds__(512, 2) void dense_wide_kernel(DenseArgs a) {
   constexpr int BM = 128, BN = 256, NTHR = 512, MJ = 4;
-  constexpr int TILE_W = BN * GT_BK * 2, TILE_X = BM * GT_BK * 2, STAGE_BYTES = TILE_W + TILE_X;  // 32 + 16 KiB
-  constexpr int RPI = NTHR / 8;                   // 64 rows staged per DMA instruction of the whole workgroup
-  constexpr int ITW = BN / RPI, ITX = BM / RPI;   // 4 + 2 DMA instructions per thread and stage
+  constexpr int BK = NS == 4 ? 32 : GT_BK;        // K-tile depth in 2-byte units; a row of a staged tile is BK * 2 bytes
+  constexpr int RB = BK * 2, CPR = RB / 16;       // row bytes, 16-byte chunks per row
+  constexpr int TILE_W = BN * RB, TILE_X = BM * RB, STAGE_BYTES = TILE_W + TILE_X;  // 32 + 16 KiB (NS = 4: 16 + 8)
+  constexpr int RPI = NTHR / CPR;                 // rows staged per DMA instruction of the whole workgroup (64; NS = 4: 128)
+  constexpr int ITW = BN / RPI, ITX = BM / RPI;   // 4 + 2 DMA instructions per thread and stage (NS = 4: 2 + 1)
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[];  // [stage][W | X]
   lds_u8* const lds = (lds_u8*)lds_raw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -361,8 +369,8 @@ __global__ __launch_bounds__(512, 2) void dense_wide_kernel(DenseArgs a) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < MJ; ++j) acc[i][j] = (acc_t){0, 0, 0, 0};
-  const int srow = tid >> 3;
-  const int schunk = (tid & 7) ^ (srow & 7);
+  const int srow = tid / CPR;
+  const int schunk = NS == 4 ? ((tid & 3) ^ (((srow >> 3) & 1) << 1)) : ((tid & 7) ^ (srow & 7));   // (RPI is a multiple of 16: it changes neither swizzle)
   const _Float16* wsrc[ITW];
   const _Float16* xsrc[ITX];
 #pragma unroll
@@ -388,23 +396,36 @@ __global__ __launch_bounds__(512, 2) void dense_wide_kernel(DenseArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rw = wn * 64 + i * 16 + frow;
-    offw[i] = (unsigned)rw * 128u + (unsigned)((fq ^ (rw & 7)) << 4);
+    offw[i] = NS == 4 ? (unsigned)rw * 64u + (unsigned)((fq ^ (((rw >> 3) & 1) << 1)) << 4) : (unsigned)rw * 128u + (unsigned)((fq ^ (rw & 7)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
     const int rx = wm * 64 + j * 16 + frow;
-    offx[j] = (unsigned)rx * 128u + (unsigned)((fq ^ (rx & 7)) << 4);
+    offx[j] = NS == 4 ? (unsigned)rx * 64u + (unsigned)((fq ^ (((rx >> 3) & 1) << 1)) << 4) : (unsigned)rx * 128u + (unsigned)((fq ^ (rx & 7)) << 4);
   }
-  const int nk = K / GT_BK;
+  const int nk = K / BK;
   STAGE_W(0, 0);
-  __syncthreads();  // (waits for the DMA: vmcnt(0) + barrier)
+  if (NS == 4) {
+    if (nk > 1) STAGE_W(1, BK);
+    if (nk > 2) STAGE_W(2, 2 * BK);
+  } else __syncthreads();  // (waits for the DMA: vmcnt(0) + barrier)
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) STAGE_W(cur ^ 1, (kt + 1) * GT_BK);
+    if (NS == 4) {
+      // tile kt has landed once at most the DMA instructions of the tiles issued after it (kt + 1, kt + 2) are outstanding (loads retire in
+      // order); behind the barrier every wave's part of tile kt is there and every wave is done reading tile kt - 1, whose stage takes kt + 3
+      const int after = nk - 1 - kt;
+      if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (ITW + ITX)) : "memory");
+      else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ITW + ITX) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 3 < nk) STAGE_W((cur + 3) & 3, (kt + 3) * BK);
+    } else if (kt + 1 < nk) STAGE_W(cur ^ 1, (kt + 1) * BK);
     const lds_u8* const bw = lds + cur * STAGE_BYTES;
     const lds_u8* const bx = bw + TILE_W;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < RB / 64; ++ks) {
       f16x8 fa[4], fb[MJ];
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const __attribute__((address_space(3))) f16x8*>(bw + (offw[i] ^ (unsigned)(ks << 6)));
@@ -418,8 +439,13 @@ __global__ __launch_bounds__(512, 2) void dense_wide_kernel(DenseArgs a) {
           else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     }
-    __syncthreads();  // tile kt+1 has landed; every wave is done reading tile kt
-    cur ^= 1;
+    if (NS == 4) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of tile kt are complete before it reaches the next barrier
+      cur = (cur + 1) & 3;
+    } else {
+      __syncthreads();  // tile kt+1 has landed; every wave is done reading tile kt
+      cur ^= 1;
+    }
   }
 #undef STAGE_W
   if constexpr (I8) {
@@ -1213,6 +1239,20 @@ void launch_dense_hybrid_i8(const signed char* q, const float* row_scale, const 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_I8_RELU_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_I8_RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   });
+  if (tune().dense_solo >= 4) {   // four stages of 24 KiB (K-tiles of 64 int8)
+    static std::once_flag once4[16];
+    std::call_once(once4[dev & 15], [&]() {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_I8_F32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_I8_RELU_F32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_I8_RAW, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    });
+    switch (epi) {
+      case DENSE_EPI_I8_RELU_F32: hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_I8_RELU_F32, 4>), dim3(8 * per_xcd), dim3(512), smem, st, b); break;
+      case DENSE_EPI_I8_RAW: hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_I8_RAW, 4>), dim3(8 * per_xcd), dim3(512), smem, st, b); break;
+      default: hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_I8_F32, 4>), dim3(8 * per_xcd), dim3(512), smem, st, b); break;
+    }
+    return;
+  }
   switch (epi) {
     case DENSE_EPI_I8_RELU_F32: hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_I8_RELU_F32>), dim3(8 * per_xcd), dim3(512), smem, st, b); break;
     case DENSE_EPI_I8_RAW: hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_I8_RAW>), dim3(8 * per_xcd), dim3(512), smem, st, b); break;
@@ -1282,6 +1322,16 @@ void launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_RELU_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_BIAS_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     });
+    if (a.solo >= 4 && a.K % 32 == 0) {   // four stages of 24 KiB
+      static std::once_flag once4[16];
+      std::call_once(once4[dev & 15], [&]() {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_RELU_F16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wide_kernel<DENSE_EPI_BIAS_F32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      });
+      if (epi == DENSE_EPI_RELU_F16) hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_RELU_F16, 4>), dim3(8 * per_xcd), dim3(512), smem, st, b);
+      else hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_BIAS_F32, 4>), dim3(8 * per_xcd), dim3(512), smem, st, b);
+      return;
+    }
     if (epi == DENSE_EPI_RELU_F16) hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_RELU_F16>), dim3(8 * per_xcd), dim3(512), smem, st, b);
     else hipLaunchKernelGGL((dense_wide_kernel<DENSE_EPI_BIAS_F32>), dim3(8 * per_xcd), dim3(512), smem, st, b);
     return;

@@ -17,7 +17,7 @@
   X(pchunk, 48, "batches in flight: frames of the later time-chunks")                                                              \
   X(am_pipe, 1, "acoustic model of the batch path as three engines (0: one stream)")                                               \
   X(dense_lds_kb, 82, "LDS floor of the two-stage GEMM form when it runs beside the recurrence (one workgroup per CU)")            \
-  X(dense_solo, 3, "GEMM form beside the recurrence: 3 = 128x256 eight-wave, 2 = 128-square three-stage eight-wave, 1 = four-wave, 0 = padded") \
+  X(dense_solo, 3, "GEMM form beside the recurrence: 4 = 128x256 eight-wave in four stages of K = 32 (three K-tiles in flight), 3 = 128x256 eight-wave, 2 = 128-square three-stage eight-wave, 1 = four-wave, 0 = padded") \
   X(dense_solo_test, -1, "STTX_TestDense: force DenseArgs::solo (-1 = off)")                                                       \
   X(dense_tile, 0, "force the GEMM tile side (128 / 256; 0 = by shape)")                                                           \
   X(dense_big_min, 480, "256-square tiles from this many tiles on")                                                                \

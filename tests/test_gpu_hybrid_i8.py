@@ -30,8 +30,17 @@ def _run(x, wq, wscale, bias, reps=0, epi=0, clip=0.0):
     return y, q, rs, float(ms.value)
 
 
+@pytest.fixture(params=[3, 4], ids=["two stages of K = 128", "four stages of K = 64"])
+def wide_form(request):
+    """Both staging forms of the 128 x 256 tile (tunable dense_solo; kernels_am.hip: dense_wide_kernel<EPI, NS>): integer sums, same bits."""
+    from stt_amd import native
+    native.set_tuning("dense_solo", request.param)
+    yield request.param
+    native.set_tuning("dense_solo", 3)
+
+
 @pytest.mark.parametrize("per_channel", [False, True])
-def test_hybrid_fully_connected_is_bit_equal_to_the_restatement(per_channel):
+def test_hybrid_fully_connected_is_bit_equal_to_the_restatement(per_channel, wide_form):
     rng = np.random.default_rng(21)
     M, K, N = 300, 2048, 512                      # (M not a multiple of the 128-row tile)
     x = (rng.standard_normal((M, K)) * rng.uniform(0.01, 6.0, size=(M, 1))).astype(np.float32)
@@ -51,7 +60,7 @@ def test_hybrid_fully_connected_is_bit_equal_to_the_restatement(per_channel):
     assert np.array_equal(y, want), float(np.abs(y - want).max())
 
 
-def test_hybrid_gemm_at_the_bench_shape():
+def test_hybrid_gemm_at_the_bench_shape(wide_form):
     """The x-projection of one 48-frame chunk of 128 rows (M = 6144, K = 2048, N = 8192), int32 sums beyond 2^24 included (the
     int -> float conversion rounds like the reference's); timed, and written beside the f16 form's figure for DESIGN.md 7.1."""
     rng = np.random.default_rng(22)
@@ -71,7 +80,8 @@ def test_hybrid_gemm_at_the_bench_shape():
     out = {"M": M, "K": K, "N": N, "ms_quantise_plus_product": ms, "int8_TOP_s": 2.0 * M * K * N / (ms * 1e-3) / 1e12,
            "note": "row quantisation + 128 x 256 tile on v_mfma_i32_16x16x64_i8, alone on the chip; the f16 form of the same product: benchmarks / DESIGN.md 8.3 (0.94 PF/s alone)"}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "hybrid_i8_gemm.json"), "w"))
+    out["dense_solo"] = wide_form
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "hybrid_i8_gemm_form%d.json" % wide_form), "w"))
 
 
 @pytest.mark.parametrize("M", [16, 5, 40])

@@ -94,7 +94,7 @@ def test_dense_forms_beside_the_recurrence_are_bit_identical(M, N, K, epi):
     outs = []
     try:
         native.set_tuning("dense_tile", 128)
-        for solo in (0, 1, 2, 3):                       # 3: the 128 x 256 eight-wave tile (where N allows; else the same as 2)
+        for solo in (0, 1, 2, 3, 4):                    # 3: the 128 x 256 eight-wave tile (where N allows; else the same as 2); 4: the same in four stages of K = 32
             native.set_tuning("dense_solo_test", solo)
             y = np.zeros((M, N), dtype=np.float32)
             assert native.lib().STTX_TestDense(M, N, K, x.ctypes.data, w.ctypes.data, bias.ctypes.data, 20.0, epi, y.ctypes.data) == 0
