@@ -1732,7 +1732,7 @@ int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* const* aWord
       HostScorer hs;
       const int rc = parse_scorer(reinterpret_cast<const uint8_t*>(copy.data()), aLmBytes, -1, true, hs);
       if (rc != STT_ERR_OK) return rc;
-      if (!hs.lmi_ok) return (int)STT_ERR_SCORER_INVALID_LM;
+      if (!hs.lmi_ok && !(hs.probing && aMode == 0)) return (int)STT_ERR_SCORER_INVALID_LM;   // (a probing binary has no index: its own tables answer)
       KState st[2] = {};
       int cur = 0;
       if (aBos) { st[0].length = 1; st[0].words[0] = hs.bos_index; st[0].backoff[0] = hs.bos_backoff; }
@@ -1749,7 +1749,8 @@ int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* const* aWord
           else return (int)STT_ERR_INVALID_SHAPE;
           aProbs[i] = hs.full_score_blocks(st[cur], cp, st[cur ^ 1], nl, wi);
         } else
-        aProbs[i] = hs.full_score_indexed(st[cur], aWords[i], strlen(aWords[i]), st[cur ^ 1], nl, wi);
+        aProbs[i] = hs.probing ? hs.full_score_probing(st[cur], aWords[i], strlen(aWords[i]), st[cur ^ 1], nl, wi)
+                               : hs.full_score_indexed(st[cur], aWords[i], strlen(aWords[i]), st[cur ^ 1], nl, wi);
         aLens[i] = nl;
         cur ^= 1;
       }

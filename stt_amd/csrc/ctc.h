@@ -68,6 +68,16 @@ struct DevScorer {
   uint8_t prob_bits, backoff_bits;
   uint32_t bos_index;
   float bos_backoff;
+  // KenLM PROBING / REST_PROBING binaries (model types 0, 1: kenlm/lm/search_hashed.hh): `unigram` = Weights[count + 1] of p_wstride bytes
+  // ({prob, backoff[, rest]}; the sign bit of the STORED prob is "independent left", Prob() sets it), one open-addressing table per middle
+  // order of p_estride-byte entries {uint64 key, Weights} and one of 12-byte entries {key, prob} for the longest order; key = the chained
+  // CombineWordHash of the n-gram's word indices, newest first; bucket = key % buckets, linear probing, key 0 = empty.
+  int probing;
+  int p_wstride, p_estride;
+  const uint8_t* p_mid[STT_KENLM_MAX_ORDER - 2];
+  uint64_t p_mid_buckets[STT_KENLM_MAX_ORDER - 2];
+  const uint8_t* p_lon;
+  uint64_t p_lon_buckets;
   // dictionary FST, repacked: state s -> arcs [state_pos[s], state_pos[s+1]); arc = {ilabel, child state} where
   // child state = Start() if the arc's target is final (path_trie.cpp:79-87), else the target
   int fst_start;

@@ -232,10 +232,73 @@ __device__ __forceinline__ uint32_t vocab_slot(const DevScorer& s, uint64_t h, D
   }
 }
 
+// HashedSearch (kenlm/lm/search_hashed.hh:26-29,107-125): the node of an n-gram is the chained hash of its word indices; a middle / longest
+// record is found by linear probing from key % buckets (util/probing_hash_table.hh: DivMod), an empty bucket has key 0.
+__device__ __forceinline__ uint64_t combine_word_hash(uint64_t current, uint32_t next) {
+  return (current * 8978948897894561157ULL) ^ ((uint64_t)(1 + next) * 17894857484156487943ULL);
+}
+__device__ __forceinline__ const uint8_t* probing_find(const uint8_t* table, uint64_t buckets, int stride, uint64_t key, unsigned& probes) {
+  uint64_t i = key % buckets;
+  for (uint64_t n = 0; n < buckets; ++n) {   // (a well-formed table always holds an empty bucket: Size() takes entries + 1 at least)
+    const uint8_t* e = table + i * (uint64_t)stride;
+    const uint64_t got = ld64u(e);
+    ++probes;
+    if (got == key) return e;
+    if (got == 0) return nullptr;
+    if (++i == buckets) i = 0;
+  }
+  return nullptr;
+}
+// GenericModel<HashedSearch<...>, ProbingVocabulary>::FullScore: the same ScoreExceptBackoff / ResumeScore (model.cc:285-338) as the trie form
+// below, with HashedSearch's lookups.  (Rest costs of REST_PROBING models are never read: FullScore's prob is what the scorer uses.)
+__device__ float kenlm_full_score_probing(const DevScorer& s, const KState& in, uint32_t new_word, KState& out, unsigned& probes, int* ngram_length) {
+  const uint8_t* u = s.unigram + (uint64_t)s.p_wstride * new_word;
+  const uint32_t praw = ld32u(u);
+  float prob = __uint_as_float(praw | 0x80000000u);
+  out.backoff[0] = __uint_as_float(ld32u(u + 4));
+  ++probes;
+  bool independent_left = (praw & 0x80000000u) != 0;
+  uint64_t node = (uint64_t)new_word;
+  int nl = 1;
+  int out_len = has_extension(out.backoff[0]) ? 1 : 0;
+  out.words[0] = new_word;
+  bool go = in.length != 0;
+#pragma unroll
+  for (int om2 = 0; om2 < STT_KENLM_MAX_ORDER - 1; ++om2) {
+    if (om2 + 1 < STT_KENLM_MAX_ORDER - 1) { out.words[om2 + 1] = in.words[om2]; out.backoff[om2 + 1] = 0.0f; }
+    if (go) {
+      if (om2 == in.length || independent_left) go = false;
+      else if (om2 == s.order - 2) {
+        go = false;
+        const uint8_t* e = probing_find(s.p_lon, s.p_lon_buckets, 12, combine_word_hash(node, in.words[om2]), probes);
+        if (e) { prob = __uint_as_float(ld32u(e + 8)); nl = s.order; }
+      } else if (om2 < STT_KENLM_MAX_ORDER - 2) {
+        node = combine_word_hash(node, in.words[om2]);
+        const uint8_t* e = probing_find(s.p_mid[om2], s.p_mid_buckets[om2], s.p_estride, node, probes);
+        if (!e) go = false;     // (LookupMiddle sets independent_left; nothing reads it after a miss)
+        else {
+          const uint32_t pr = ld32u(e + 8);
+          const float b = __uint_as_float(ld32u(e + 12));
+          independent_left = (pr & 0x80000000u) != 0;
+          out.backoff[om2 + 1] = b; prob = __uint_as_float(pr | 0x80000000u); nl = om2 + 2;
+          if (has_extension(b)) out_len = nl;
+        }
+      }
+    }
+  }
+  if (ngram_length) *ngram_length = nl;
+  out.length = out_len;
+#pragma unroll
+  for (int i = 0; i < STT_KENLM_MAX_ORDER - 1; ++i)
+    if (i >= nl - 1 && i < in.length) prob = __fadd_rn(prob, in.backoff[i]);
+  return prob;
+}
+
 // GenericModel::FullScore (model.cc:170-176) = ScoreExceptBackoff (:285-310) + ResumeScore (:312-338).
 // Written with compile-time indices only (fully unrolled over KENLM_MAX_ORDER) so that both states stay in registers.
 __device__ __forceinline__ float kenlm_full_score(const DevScorer& s, const KState& in, uint32_t new_word, KState& out, unsigned& probes,
                                                   const DevVocabSlot* uni = nullptr, int* ngram_length = nullptr) {
+  if (s.probing) return kenlm_full_score_probing(s, in, new_word, out, probes, ngram_length);
   KNode node;
   float prob;
   if (uni) {  // unigram record copied into the vocabulary slot at load time

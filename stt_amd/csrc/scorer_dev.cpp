@@ -386,12 +386,72 @@ float HostScorer::full_score_blocks(const KState& in, uint32_t cp, KState& out, 
 
 // SortedVocabulary::Index (lm/vocab.hh:72-83): binary search over the sorted hashes (host side)
 uint32_t HostScorer::vocab_index(uint64_t h) const {
+  if (probing) {   // ProbingVocabulary::Index (lm/vocab.hh:162-165): 12-byte entries {hash, index}, linear probing from hash % buckets, hash 0 = empty
+    uint64_t i = h % p_vocab_buckets;
+    for (uint64_t n = 0; n < p_vocab_buckets; ++n) {
+      const uint64_t got = rd64(buf + p_vocab_tab_off + 12 * i);
+      if (got == h) return rd32(buf + p_vocab_tab_off + 12 * i + 8);
+      if (got == 0) return 0;
+      if (++i == p_vocab_buckets) i = 0;
+    }
+    return 0;
+  }
   uint64_t lo = 0, hi = vocab_n;
   while (lo < hi) {
     const uint64_t m2 = lo + (hi - lo) / 2, v = rd64(buf + vocab_off + 8 * m2);
     if (v < h) lo = m2 + 1; else if (v > h) hi = m2; else return (uint32_t)(m2 + 1);
   }
   return 0;
+}
+
+// GenericModel<HashedSearch<Value>, ProbingVocabulary>::FullScore (lm/model.cc:170-176,285-338; lm/search_hashed.hh:26-29,93-125) on the host.
+float HostScorer::full_score_probing(const KState& in, const char* word, size_t word_len, KState& out, int& ngram_length, uint32_t& word_index) const {
+  auto find = [&](uint64_t tab_off, uint64_t buckets, int stride, uint64_t key) -> const uint8_t* {
+    uint64_t i = key % buckets;
+    for (uint64_t n = 0; n < buckets; ++n) {
+      const uint8_t* e = buf + tab_off + i * (uint64_t)stride;
+      const uint64_t got = rd64(e);
+      if (got == key) return e;
+      if (got == 0) return nullptr;
+      if (++i == buckets) i = 0;
+    }
+    return nullptr;
+  };
+  auto combine = [](uint64_t cur, uint32_t next) { return (cur * 8978948897894561157ULL) ^ ((uint64_t)(1 + next) * 17894857484156487943ULL); };
+  auto has_ext = [](float b) { uint32_t u; memcpy(&u, &b, 4); return u != 0x80000000u; };
+  auto neg = [](uint32_t raw) { raw |= 0x80000000u; float f; memcpy(&f, &raw, 4); return f; };
+  const uint32_t wi = vocab_index(murmur64a(word, word_len, 0));
+  word_index = wi;
+  const uint8_t* u = buf + unigram_off + (uint64_t)p_wstride * wi;
+  const uint32_t praw = rd32(u);
+  float prob = neg(praw);
+  out = KState{};
+  out.backoff[0] = rdf(u + 4);
+  bool independent_left = (praw & 0x80000000u) != 0;
+  uint64_t node = wi;
+  int nl = 1, out_len = has_ext(out.backoff[0]) ? 1 : 0;
+  out.words[0] = wi;
+  for (int i = 0; i + 1 < STT_KENLM_MAX_ORDER - 1 && i < in.length; ++i) out.words[i + 1] = in.words[i];   // CopyRemainingHistory (entries past length unused)
+  for (int om2 = 0; om2 < in.length && om2 < STT_KENLM_MAX_ORDER - 1; ++om2) {
+    if (independent_left) break;
+    if (om2 == order - 2) {
+      const uint8_t* e = find(p_lon_off, p_lon_buckets, 12, combine(node, in.words[om2]));
+      if (e) { prob = rdf(e + 8); nl = order; }
+      break;
+    }
+    node = combine(node, in.words[om2]);
+    const uint8_t* e = find(p_mid_off[om2], p_mid_buckets[om2], p_estride, node);
+    if (!e) break;
+    const uint32_t pr = rd32(e + 8);
+    const float b = rdf(e + 12);
+    independent_left = (pr & 0x80000000u) != 0;
+    out.backoff[om2 + 1] = b; prob = neg(pr); nl = om2 + 2;
+    if (has_ext(b)) out_len = nl;
+  }
+  ngram_length = nl;
+  out.length = out_len;
+  for (int i = nl - 1; i < in.length; ++i) prob += in.backoff[i];
+  return prob;
 }
 
 // FullScore through the index, on the host: what the search kernel's LM waves do with four lanes per query.
@@ -424,7 +484,12 @@ int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, 
   const int ord = fp[0];
   const int model_type = (int)rd32(fp + 8);
   if (ord < 2 || ord > STT_KENLM_MAX_ORDER) return STT_ERR_SCORER_INVALID_LM;
-  if (model_type < 2 || model_type > 5) return STT_ERR_SCORER_INVALID_LM;
+  if (model_type < 0 || model_type > 5) return STT_ERR_SCORER_INVALID_LM;
+  // PROBING (0: lm/model_type.hh:9): hash tables instead of the bit-packed trie.  REST_PROBING (1) has the same tables with a third float per
+  // record (the strides below cover it), but no such binary can be built here to check it against KenLM (build_binary -r wants the lower-order
+  // models): refused rather than claimed.
+  if (model_type == 1) return STT_ERR_SCORER_INVALID_LM;
+  const bool probing = model_type <= 1;
   const bool quant = (model_type == 3 || model_type == 5), array = (model_type == 4 || model_type == 5);
   uint64_t* counts = hs.counts;
   if (len < 108 + 8 * (size_t)ord) return STT_ERR_SCORER_INVALID_LM;
@@ -433,11 +498,40 @@ int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, 
 
   uint64_t off = align8(108 + 8 * (uint64_t)ord);
   if (off + 8 > len) return STT_ERR_SCORER_INVALID_LM;
-  const uint64_t vocab_n = rd64(buf + off);
+  if (probing) {
+    // GenericModel<HashedSearch<Value>, ProbingVocabulary>::SetupMemory (lm/model.cc:27-35): vocabulary, unigrams, one table per middle order,
+    // the longest order's table, back to back.  Table sizes: util/probing_hash_table.hh:108-111 with the file's own probing_multiplier.
+    const float mult = rdf(fp + 4);
+    if (!(mult > 1.0f) || mult > 1024.0f) return STT_ERR_SCORER_INVALID_LM;
+    auto buckets_of = [&](uint64_t entries) { return std::max<uint64_t>(entries + 1, (uint64_t)(mult * (float)entries)); };
+    hs.probing = true;
+    hs.p_wstride = model_type == 1 ? 12 : 8;      // RestWeights {prob, backoff, rest} / ProbBackoff
+    hs.p_estride = 8 + hs.p_wstride;              // {uint64 key, Weights}: 16 bytes, or 20 (#pragma pack(4), lm/value.hh:118-126)
+    if (rd32(buf + off) != 0) return STT_ERR_SCORER_INVALID_LM;   // kProbingVocabularyVersion (lm/vocab.cc:257)
+    hs.p_vocab_buckets = buckets_of(counts[0]);
+    hs.p_vocab_tab_off = off + 8;                 // ALIGN8(sizeof(ProbingVocabularyHeader {version, bound}))
+    off += 8 + 12 * hs.p_vocab_buckets;           // ProbingVocabularyEntry {uint64 key, WordIndex value}, #pragma pack(4)
+    hs.unigram_off = off;
+    off += (counts[0] + 1) * (uint64_t)hs.p_wstride;
+    for (int i = 0; i < ord - 2; ++i) {
+      hs.p_mid_off[i] = off; hs.p_mid_buckets[i] = buckets_of(counts[i + 1]);
+      off += hs.p_mid_buckets[i] * (uint64_t)hs.p_estride;
+      if (off > len) return STT_ERR_SCORER_INVALID_LM;
+    }
+    hs.p_lon_off = off; hs.p_lon_buckets = buckets_of(counts[ord - 1]);
+    off += hs.p_lon_buckets * 12;                 // ProbEntry {uint64 key, Prob}, #pragma pack(4) (lm/search_hashed.hh:31-42)
+    if (off > len) return STT_ERR_SCORER_INVALID_LM;
+    hs.buf = buf; hs.order = ord; hs.model_type = model_type; hs.quant = false;
+    hs.vocab_n = counts[0] ? counts[0] - 1 : 0; hs.vocab_off = 0; hs.lm_end = off;
+    hs.alpha = 0.0; hs.beta = 0.0; hs.utf8 = false; hs.fst_start = 0;
+  }
+  const uint64_t vocab_n = probing ? hs.vocab_n : rd64(buf + off);
   const uint64_t vocab_off = off + 8;
   if (vocab_n > counts[0]) return STT_ERR_SCORER_INVALID_LM;
-  off += 8 + 8 * counts[0];
+  if (!probing) off += 8 + 8 * counts[0];
   uint8_t prob_bits = 0, backoff_bits = 0;
+  uint64_t unigram_off = hs.unigram_off, lm_end = hs.lm_end;
+  if (!probing) {
   if (quant) {
     if (off + 8 > len) return STT_ERR_SCORER_INVALID_LM;
     prob_bits = buf[off + 1]; backoff_bits = buf[off + 2];
@@ -447,7 +541,7 @@ int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, 
     hs.qprob_off[ord - 2] = t; t += 4ULL << prob_bits;
     off = t;
   }
-  const uint64_t unigram_off = off;
+  unigram_off = off;
   off += (counts[0] + 2) * 16;
   if (off > len) return STT_ERR_SCORER_INVALID_LM;
   uint8_t cfg_bhiksha = 0;
@@ -478,11 +572,12 @@ int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, 
   lon.base_off = off; lon.word_bits = required_bits(counts[0]); lon.total_bits = (uint8_t)(lon.word_bits + longest_bits);
   lon.entries = counts[ord - 1];
   off += ((1 + counts[ord - 1]) * lon.total_bits + 7) / 8 + 8;
-  const uint64_t lm_end = off;  // GetEndOfSearchOffset, lm/model.cc:265-267
+  lm_end = off;  // GetEndOfSearchOffset, lm/model.cc:265-267
   if (lm_end > len) return STT_ERR_SCORER_INVALID_LM;
   hs.buf = buf; hs.order = ord; hs.model_type = model_type; hs.quant = quant; hs.prob_bits = prob_bits; hs.backoff_bits = backoff_bits;
   hs.vocab_n = vocab_n; hs.vocab_off = vocab_off; hs.unigram_off = unigram_off; hs.lm_end = lm_end;
   hs.alpha = 0.0; hs.beta = 0.0; hs.utf8 = false; hs.fst_start = 0;
+  }   // (!probing: the trie's layout)
 
   if (!lm_only) {
     if (len <= lm_end) return STT_ERR_SCORER_NO_TRIE;
@@ -606,7 +701,21 @@ int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, 
   while ((uint64_t)vt_n < 2 * vocab_n + 2) vt_n <<= 1;
   hs.vtab.assign(vt_n, DevVocabSlot{0, 0, 0, 0.f, 0.f, 0, 0});
   hs.uni_ok = ord >= 2 && counts[1] < 0xFFFFFFFFull;
-  if (vocab_off + 8 * vocab_n > len) return STT_ERR_SCORER_INVALID_LM;
+  if (!probing && vocab_off + 8 * vocab_n > len) return STT_ERR_SCORER_INVALID_LM;
+  if (probing) {
+    // the engine's own table over ProbingVocabulary's: every occupied bucket {hash, index}; the unigram copies stay unused (uni_ok false: the
+    // probing FullScore reads the Weights array itself)
+    hs.uni_ok = false;
+    for (uint64_t b = 0; b < hs.p_vocab_buckets; ++b) {
+      const uint64_t h = rd64(buf + hs.p_vocab_tab_off + 12 * b);
+      if (!h) continue;
+      const uint32_t wi = rd32(buf + hs.p_vocab_tab_off + 12 * b + 8);
+      if (wi == 0 || wi >= counts[0]) return STT_ERR_SCORER_INVALID_LM;
+      uint32_t slot = (uint32_t)h & (vt_n - 1);
+      while (hs.vtab[slot].used) slot = (slot + 1) & (vt_n - 1);
+      hs.vtab[slot] = DevVocabSlot{h, wi, 1, 0.f, 0.f, 0, 0};
+    }
+  } else
   for (uint64_t i = 0; i < vocab_n; ++i) {
     const uint64_t h = rd64(buf + vocab_off + 8 * i);
     uint32_t slot = (uint32_t)h & (vt_n - 1);
@@ -637,16 +746,18 @@ int parse_scorer(const uint8_t* buf, size_t len, int space_label, bool lm_only, 
   if (hs.hints.empty()) hs.hints.push_back(0);
   // <s> index and backoff (lm/model.cc:115-124)
   hs.bos_index = hs.vocab_index(murmur64a("<s>", 3, 0));
-  hs.bos_backoff = rdf(buf + unigram_off + 16 * (uint64_t)hs.bos_index + 4);
+  hs.bos_backoff = probing ? rdf(buf + unigram_off + (uint64_t)hs.p_wstride * hs.bos_index + 4) : rdf(buf + unigram_off + 16 * (uint64_t)hs.bos_index + 4);
   // The index is read by the word-mode search step with label bitmaps (ctc.hip: ctc_masked_ok), by the code-point step on a miss of its
   // FullScore memo (tunable cp_index) and by the LM test hooks; order-6 models and word dictionaries without bitmaps never touch it: do
   // not build what cannot be used.
-  const bool index_usable = lm_only || (ord <= 5 && hs.uni_ok && (hs.utf8 ? tune().cp_index != 0 : hs.fst_bitmap_ok));
+  // (a probing model's tables hold hashes of contexts, not word indices: the n-grams cannot be enumerated, so neither the index nor the
+  // code-point tables exist for it -- every query is a FullScore through the file's own hash tables)
+  const bool index_usable = !probing && (lm_only || (ord <= 5 && hs.uni_ok && (hs.utf8 ? tune().cp_index != 0 : hs.fst_bitmap_ok)));
   try { hs.lmi_ok = index_usable && build_lm_index(hs); }
   catch (const std::bad_alloc&) { hs.lmi_ok = false; }  // no memory for the table: the scorer still loads (trie walk), as it does in the reference
   if (!hs.lmi_ok) { hs.lmi.clear(); hs.lmi.shrink_to_fit(); hs.lmi_buckets = 0; }
-  if (hs.utf8 && !lm_only && tune().unit_bounds != 0) build_unit_bounds(hs);
-  if ((hs.utf8 || lm_only) && tune().cp_blocks != 0) (void)build_cp_blocks(hs);
+  if (!probing && hs.utf8 && !lm_only && tune().unit_bounds != 0) build_unit_bounds(hs);
+  if (!probing && (hs.utf8 || lm_only) && tune().cp_blocks != 0) (void)build_cp_blocks(hs);
   return STT_ERR_OK;
 }
 
@@ -715,6 +826,11 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label, bool lm_on
   ds.prob_bits = hs.prob_bits; ds.backoff_bits = hs.backoff_bits;
   ds.prob_mask = (1u << hs.prob_bits) - 1; ds.backoff_mask = (1u << hs.backoff_bits) - 1;
   ds.bos_index = hs.bos_index; ds.bos_backoff = hs.bos_backoff;
+  ds.probing = hs.probing ? 1 : 0; ds.p_wstride = hs.p_wstride; ds.p_estride = hs.p_estride;
+  if (hs.probing) {
+    for (int i = 0; i < ord - 2; ++i) { ds.p_mid[i] = d + hs.p_mid_off[i]; ds.p_mid_buckets[i] = hs.p_mid_buckets[i]; }
+    ds.p_lon = d + hs.p_lon_off; ds.p_lon_buckets = hs.p_lon_buckets;
+  }
   ds.fst_start = hs.fst_start; ds.fst_tree = hs.fst_tree ? 1 : 0;
   if (!lm_only) {
     ds.fst_state_pos = fst_pos_.as<uint32_t>(); ds.fst_arcs = fst_arcs_.as<uint2>(); ds.fst_has_space = fst_space_.as<uint8_t>();

@@ -27,6 +27,12 @@ struct HostScorer {
   HostBitPacked mid[STT_KENLM_MAX_ORDER - 2], lon;
   uint32_t bos_index = 0;
   float bos_backoff = 0.0f;
+  // PROBING / REST_PROBING binaries (model types 0, 1): byte offsets of the open-addressing tables and their bucket counts
+  bool probing = false;
+  int p_wstride = 0, p_estride = 0;
+  uint64_t p_vocab_tab_off = 0, p_vocab_buckets = 0;
+  uint64_t p_mid_off[STT_KENLM_MAX_ORDER - 2] = {}, p_mid_buckets[STT_KENLM_MAX_ORDER - 2] = {};
+  uint64_t p_lon_off = 0, p_lon_buckets = 0;
   // dictionary (ctc.h: DevScorer::fst_*)
   int fst_start = 0;
   uint64_t n_states = 0;
@@ -74,6 +80,8 @@ struct HostScorer {
   uint32_t vocab_index(uint64_t murmur_hash) const;
   // GenericModel::FullScore through the index (the arithmetic of the search kernel's LM waves, on the host)
   float full_score_indexed(const KState& in, const char* word, size_t word_len, KState& out, int& ngram_length, uint32_t& word_index) const;
+  // ... and through a PROBING / REST_PROBING binary's own hash tables (the arithmetic of ctc.hip: kenlm_full_score_probing, on the host)
+  float full_score_probing(const KState& in, const char* word, size_t word_len, KState& out, int& ngram_length, uint32_t& word_index) const;
 };
 
 // STT_ERR_* code.  lm_only: a bare KenLM binary without the 'TRIE' trailer (test hook).
