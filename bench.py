@@ -1097,6 +1097,7 @@ def main():
     ap.add_argument("--hybrid-rows", type=int, default=16)
     ap.add_argument("--no-extras", action="store_true", help="batch: do not append the other workloads' sub-lines")
     ap.add_argument("--scorer", default="synthetic", choices=["synthetic", "fixture"])
+    ap.add_argument("--idle-streams", type=int, default=0, help="experiment: create this many HIP streams (each used once) before any model: shifts which dispatch pipes the engine's streams land on")
     ap.add_argument("--all-marks", action="store_true", help="experiment: every stage mark inside the timed region (rounds 1-5; costs the pipeline ~3 %)")
     ap.add_argument("--no-profile", action="store_true", help="experiment: no HIP-event stage timing inside the timed region")
     ap.add_argument("--host-audio", action="store_true", help="experiment: batch / bytes time STTX_BatchSubmit (host buffers, copy inside the clock) as the run's timed path")
@@ -1153,6 +1154,13 @@ def main():
 
     from stt_amd import native, synth
     native.lib().STTX_SetDevice(local_rank)
+    if args.idle_streams > 0:
+        scratch = torch.zeros(64, dtype=torch.int16, device=dev)
+        cx.idle = [torch.cuda.Stream(device=dev) for _ in range(args.idle_streams)]
+        for st_ in cx.idle:
+            with torch.cuda.stream(st_):
+                scratch.zero_()
+        torch.cuda.synchronize()
     wl = args.workload
     cx.bytes_model = None
     cx.i8_model = None

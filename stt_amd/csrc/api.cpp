@@ -1574,6 +1574,7 @@ int STTX_TestLstmSteps(ModelState* m, unsigned int aBatch, unsigned int aSteps, 
       launch_lstm_step(w, NT, m->stream);
       HIP_CHECK(hipStreamSynchronize(m->stream));
       hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+      std::lock_guard<std::recursive_mutex> capturing(hip_capture_mutex());
       HIP_CHECK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
       try { steps(); } catch (...) { (void)hipStreamEndCapture(m->stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
       HIP_CHECK(hipStreamEndCapture(m->stream, &graph));

@@ -539,6 +539,7 @@ void ModelState::run_lstm_graph(const LstmGraphKey& key, const std::function<voi
     }
     LstmGraph gr;
     hipGraph_t graph = nullptr;
+    std::lock_guard<std::recursive_mutex> capturing(hip_capture_mutex());   // (no other thread's device-wide synchronisation or free meanwhile)
     HIP_CHECK(hipStreamBeginCapture(stream_l, hipStreamCaptureModeRelaxed));
     try { steps(); }
     catch (...) { (void)hipStreamEndCapture(stream_l, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }  // never leave the stream capturing
@@ -1139,6 +1140,7 @@ bool streams_process(const std::vector<StreamingState*>& ss, bool flush_partial,
           const unsigned long long gen0 = layout_generation();
           ModelState::HopGraph gr;
           hipGraph_t graph = nullptr;
+          std::lock_guard<std::recursive_mutex> capturing(hip_capture_mutex());   // (two cohorts on two threads: the other one may be growing a buffer right now)
           HIP_CHECK(hipStreamBeginCapture(m.stream, hipStreamCaptureModeRelaxed));
           try { enqueue(); }
           catch (...) { (void)hipStreamEndCapture(m.stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }

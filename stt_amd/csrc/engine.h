@@ -31,6 +31,11 @@
       throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " + __FILE__ + ":" + std::to_string(__LINE__)); \
   } while (0)
 
+// One lock for what may not overlap in a process: a stream capture on one thread and a device-wide synchronisation / free on another
+// (HIP answers the latter with "operation not permitted when stream is capturing" and invalidates the capture -- found in round 6 with two
+// streaming cohorts on two threads: one captured a hop while the other grew a buffer).  Held around every capture and inside the buffers' reserve().
+std::recursive_mutex& hip_capture_mutex();
+
 // Growable device allocation (never shrinks); the engine keeps its workspaces resident in HBM.
 struct DevBuf {
   void* p = nullptr;
@@ -38,7 +43,7 @@ struct DevBuf {
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p) { std::lock_guard<std::recursive_mutex> no_capture(hip_capture_mutex()); (void)hipFree(p); } }
   void reserve(size_t bytes, bool keep = false, hipStream_t st = nullptr);
   void upload(const void* src, size_t bytes, hipStream_t st = nullptr);
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -51,7 +56,7 @@ struct PinnedBuf {
   PinnedBuf() = default;
   PinnedBuf(const PinnedBuf&) = delete;
   PinnedBuf& operator=(const PinnedBuf&) = delete;
-  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  ~PinnedBuf() { if (p) { std::lock_guard<std::recursive_mutex> no_capture(hip_capture_mutex()); (void)hipHostFree(p); } }
   void reserve(size_t bytes);
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
   void* dev() const;  // the same bytes as the GPU addresses them (kernels read / write page-locked host memory over the link)

@@ -87,8 +87,11 @@ void create_engine_stream(hipStream_t* st, int role, bool high_priority) {
   } else HIP_CHECK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
 }
 
+std::recursive_mutex& hip_capture_mutex() { static std::recursive_mutex* m = new std::recursive_mutex; return *m; }
+
 void DevBuf::reserve(size_t bytes, bool keep, hipStream_t st) {
   if (bytes <= cap && p) return;
+  std::lock_guard<std::recursive_mutex> no_capture(hip_capture_mutex());   // (hipDeviceSynchronize / hipFree below; a reserve INSIDE a capture is the capturing thread's own: recursive)
   g_layout_generation.fetch_add(1, std::memory_order_relaxed);
   size_t ncap = bytes + bytes / 4 + 256;
   void* np = nullptr;
@@ -108,6 +111,7 @@ void DevBuf::reserve(size_t bytes, bool keep, hipStream_t st) {
 }
 void PinnedBuf::reserve(size_t bytes) {
   if (bytes <= cap && p) return;
+  std::lock_guard<std::recursive_mutex> no_capture(hip_capture_mutex());
   g_layout_generation.fetch_add(1, std::memory_order_relaxed);
   if (p) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipHostFree(p)); }  // (a copy kernel may still be moving the old block)
   p = nullptr;
