@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--moves", type=int, default=6)
     ap.add_argument("--batches", type=int, default=24)
     ap.add_argument("--hidden", type=int, default=2048)
+    ap.add_argument("--bytes", action="store_true", help="a search-bound setup instead: byte-output model (256 classes), pruned_lm.bytes.scorer, beam 1024, four searches side by side")
     a = ap.parse_args()
     from stt_amd import Model, modelfile, native, synth
     from test_gpu_async import _DeviceArray
@@ -45,13 +46,13 @@ def main():
     native.set_tuning("am_place", a.place)
     native.set_tuning("am_moves", a.moves)
     native.set_tuning("am_i8", 1 if a.mode == "int8" else 0)
-    w = synth.synth_weights(0, n_hidden=a.hidden)
+    w = synth.synth_weights(0, n_hidden=a.hidden, n_classes=256 if a.bytes else 29)
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "m.sttw")
-        modelfile.write_model(path, w, synth.ENGLISH_LABELS, beam_width=500)
+        modelfile.write_model(path, w, [bytes([i + 1]) for i in range(255)] if a.bytes else synth.ENGLISH_LABELS, beam_width=1024 if a.bytes else 500)
         m = Model(path)
     assert m.acousticMode() == (1 if a.mode == "int8" else 0)
-    m.enableExternalScorer(os.path.join(ROOT, "tests", "golden", "fixtures", "pruned_lm.scorer"))
+    m.enableExternalScorer(os.path.join(ROOT, "tests", "golden", "fixtures", "pruned_lm.bytes.scorer" if a.bytes else "pruned_lm.scorer"))
     B, N = 64, 80000
     dev = [_DeviceArray(synth.synth_audio_batch(B, N, seed=100003 + v)) for v in range(4)]
     depth = m.pipelineDepth()

@@ -372,17 +372,36 @@ void sync_everything(ModelState* m) {  // failure path: nothing of a call may st
   sync_acoustic_streams(m, false);
   for (auto& sl : m->slots_) if (sl.stream_dec) (void)hipStreamSynchronize(sl.stream_dec);
 }
+bool search_bound(const ModelState* m);
 void batch_init_slots(ModelState* m) {
-  if (m->ev_chunk[0]) return;
+  const bool place = tune().am_pipe && tune().am_place && tune().search_cus <= 0;
+  if (m->ev_chunk[0]) {
+    // placed for the other kind of setup (the scorer or the beam width changed since): place again, with nothing in flight
+    if (place && m->placed_search_bound_ >= 0 && m->placed_search_bound_ != (int)search_bound(m) && !m->async_any()) {
+      sync_everything(m);
+      if (m->stream_l) { (void)hipStreamDestroy(m->stream_l); m->stream_l = nullptr; }
+      if (m->stream_o) { (void)hipStreamDestroy(m->stream_o); m->stream_o = nullptr; }
+      hipStream_t ss[ModelState::kSlots];
+      for (int i = 0; i < ModelState::kSlots; ++i) ss[i] = m->slots_[i].stream_dec;
+      m->place_batch_streams(ss, ModelState::kSlots, search_bound(m));
+      for (int i = 0; i < ModelState::kSlots; ++i) m->slots_[i].stream_dec = ss[i];
+      m->stream_dec = ss[0];
+      m->placed_search_bound_ = (int)search_bound(m);
+      m->placement_avoid_.clear();
+      for (auto& sl : m->slots_) m->placement_avoid_.push_back(sl.stream_dec);
+    }
+    return;
+  }
   for (auto& e : m->ev_chunk) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& sl : m->slots_) HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   m->slots_[0].stream_dec = m->stream_dec;
   for (int i = 1; i < ModelState::kSlots; ++i) create_engine_stream(&m->slots_[i].stream_dec, 3);
-  if (tune().am_pipe && tune().am_place && tune().search_cus <= 0 && !m->stream_l) {
+  if (place && !m->stream_l) {
     // every stream of the batch pipeline on a dispatch pipe chosen for its role (engine.cpp: place_batch_streams)
     hipStream_t ss[ModelState::kSlots];
     for (int i = 0; i < ModelState::kSlots; ++i) ss[i] = m->slots_[i].stream_dec;
-    m->place_batch_streams(ss, ModelState::kSlots);
+    m->place_batch_streams(ss, ModelState::kSlots, search_bound(m));
+    m->placed_search_bound_ = (int)search_bound(m);
     for (int i = 0; i < ModelState::kSlots; ++i) m->slots_[i].stream_dec = ss[i];
     m->stream_dec = ss[0];           // (slot 0's stream is the model's: ~ModelState destroys it)
   }

@@ -1984,15 +1984,28 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
       uint32_t ts_new, pend;
       uint64_t nkey;
       {
-        L.score[nxt][r] = L.ev_ext[x]; L.pb[nxt][r] = L.ev_blank[x]; L.pnb[nxt][r] = L.ev_self[x];
-        L.ch[nxt][r] = L.ch[cur][x]; L.node[nxt][r] = L.node[cur][x]; L.fst[nxt][r] = L.fst[cur][x];
-        if (MASKED) { L.a0[nxt][r] = L.a0[cur][x]; L.sm[nxt][r] = L.sm[cur][x]; }
-        else if (L.a0.p0) { L.a0[nxt][r] = L.a0[cur][x]; L.an[nxt][r] = L.an[cur][x]; }
+        // every field READ first, then every field written: the compiler cannot prove that a store to [nxt][r] leaves a later load of
+        // [cur][x] alone (same address space, run-time indices), so "a = b; c = d; ..." became twenty dependent LDS round trips (3.0 k cycles of the
+        // write phase on the waves that copy live entries, round 6 stamps); with the loads in flight together it is one.
+        const float v_score = L.ev_ext[x], v_pb = L.ev_blank[x], v_pnb = L.ev_self[x];
+        const uint32_t v_ch = L.ch[cur][x], v_node = L.node[cur][x], v_bnd = L.bnd[cur][x];
+        const int v_fst = L.fst[cur][x];
+        uint32_t v_a0 = 0, v_sm = 0, v_pqe = 0, v_run = 0; uint16_t v_an = 0; uint64_t v_wlo = 0, v_whi = 0; float v_pqs = 0.0f;
+        const bool arcs_plain = !MASKED && L.a0.p0 != nullptr, words = MODE == 1 && L.pqe.p0 != nullptr;
+        if (MASKED) { v_a0 = L.a0[cur][x]; v_sm = L.sm[cur][x]; }
+        else if (arcs_plain) { v_a0 = L.a0[cur][x]; v_an = L.an[cur][x]; }
         nkey = L.key[cur][x];
-        L.bnd[nxt][r] = L.bnd[cur][x];
-        if (MODE == 1 && L.pqe.p0) { L.wlo[nxt][r] = L.wlo[cur][x]; L.whi[nxt][r] = L.whi[cur][x]; L.pqe[nxt][r] = L.pqe[cur][x]; L.pqs[nxt][r] = L.pqs[cur][x]; }
-        if (MODE == 2) L.run[nxt][r] = L.run[cur][x];
+        if (words) { v_wlo = L.wlo[cur][x]; v_whi = L.whi[cur][x]; v_pqe = L.pqe[cur][x]; v_pqs = L.pqs[cur][x]; }
+        if (MODE == 2) v_run = L.run[cur][x];
         pend = L.ev_exti[x]; ts_new = L.ts[cur][x];
+        __builtin_amdgcn_sched_barrier(0);
+        L.score[nxt][r] = v_score; L.pb[nxt][r] = v_pb; L.pnb[nxt][r] = v_pnb;
+        L.ch[nxt][r] = v_ch; L.node[nxt][r] = v_node; L.fst[nxt][r] = v_fst;
+        if (MASKED) { L.a0[nxt][r] = v_a0; L.sm[nxt][r] = v_sm; }
+        else if (arcs_plain) { L.a0[nxt][r] = v_a0; L.an[nxt][r] = v_an; }
+        L.bnd[nxt][r] = v_bnd;
+        if (words) { L.wlo[nxt][r] = v_wlo; L.whi[nxt][r] = v_whi; L.pqe[nxt][r] = v_pqe; L.pqs[nxt][r] = v_pqs; }
+        if (MODE == 2) L.run[nxt][r] = v_run;
       }
       finish_entry(r, nkey, pend, ts_new);
     }
@@ -2001,46 +2014,54 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
       uint32_t ts_new, pend;
       uint64_t nkey;
       {
+        // loads first, in two waves of independent reads (the candidate's record; then everything of its parent), stores last -- see the copy
+        // loop above: written as a sequence of "dst = src" statements every load waited for the store before it
         const uint32_t slot = lds_add((LDS_AS uint32_t*)&sc[SC_PAN], 1u);   // (first: its round trip overlaps the reads below)
         const int cx = (int)x - n;
         const uint32_t pi = CAND_PI(cx);
+        const float lpv = CAND_LOGP(cx);
+        const int cf = ((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst()[cx];
         const int i = (int)(pi & 0xFFFFu);
         const uint32_t c = CLS_AT((pi >> 16) & 0x7FFFu);
-        const float lpv = CAND_LOGP(cx);
+        const bool words = MODE == 1 && L.pqe.p0 != nullptr;
         const uint32_t pnode = L.node[cur][i];
-        L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
-        const int cf = ((uint32_t)cx < L.mcap) ? L.lc_fst[cx] : S.c_fst()[cx];
-        L.ch[nxt][r] = c; L.fst[nxt][r] = cf;
-        if (MASKED) {  // (a0 / sm of the child's dictionary state: written at the end by the thread that ranked this entry)
-        } else if (SC_ON && L.a0.p0) {  // arc range of the child's dictionary state; top bit: a word may end here (space arc)
-          const uint32_t f0 = s.fst_state_pos[cf], f1 = s.fst_state_pos[cf + 1];
-          const uint32_t sp = MODE == 1 ? (uint32_t)s.fst_has_space[cf] : 0u;
-          L.a0[nxt][r] = f0; L.an[nxt][r] = (uint16_t)((f1 - f0) | (sp << 15));
+        const uint64_t pkey = L.key[cur][i];
+        const uint32_t pbnd = L.bnd[cur][i];
+        const uint32_t pts = L.ts[cur][i];
+        uint32_t ppqe = STT_NONE, prun = 0, pch = 0;
+        uint64_t lo = 0, hi = 0;
+        if (words) { ppqe = L.pqe[cur][i]; lo = L.wlo[cur][i]; hi = L.whi[cur][i]; }
+        if (MODE == 2) { prun = L.run[cur][i]; pch = L.ch[cur][i]; }
+        const uint8_t one = (words && lab1) ? lab1[c] : (uint8_t)0;
+        uint32_t f0 = 0, f1 = 0, sp = 0;
+        const bool arcs_plain = !MASKED && SC_ON && L.a0.p0 != nullptr;
+        if (arcs_plain) {  // arc range of the child's dictionary state; top bit: a word may end here (space arc)
+          f0 = s.fst_state_pos[cf]; f1 = s.fst_state_pos[cf + 1];
+          sp = MODE == 1 ? (uint32_t)s.fst_has_space[cf] : 0u;
         }
-        nkey = child_key(L.key[cur][i], c, p.key_mask);
-        uint32_t b = L.bnd[cur][i];
-        if (MODE == 1 && (int)c == al.space_id) b = L.pqe.p0 ? L.pqe[cur][i] : S.pq()[pnode];  // the boundary entry scored in P3 (or earlier)
+        __builtin_amdgcn_sched_barrier(0);
+        L.score[nxt][r] = lpv; L.pb[nxt][r] = NEG; L.pnb[nxt][r] = lpv;
+        L.ch[nxt][r] = c; L.fst[nxt][r] = cf;
+        if (arcs_plain) { L.a0[nxt][r] = f0; L.an[nxt][r] = (uint16_t)((f1 - f0) | (sp << 15)); }   // (bitmap form: a0 / sm are written at the end by the thread that ranked this entry)
+        nkey = child_key(pkey, c, p.key_mask);
+        uint32_t b = pbnd;
+        if (MODE == 1 && (int)c == al.space_id) b = L.pqe.p0 ? ppqe : S.pq()[pnode];  // the boundary entry scored in P3 (or earlier)
         L.bnd[nxt][r] = b;
-        if (MODE == 1 && L.pqe.p0) {
-          uint64_t lo = 0, hi = 0;
-          if ((int)c != al.space_id) {
-            lo = L.wlo[cur][i]; hi = L.whi[cur][i];
-            const uint8_t one = lab1 ? lab1[c] : (uint8_t)0;
-            if (one) word_push(lo, hi, one);
-            else { const int b0 = c ? al.label_off[c - 1] : 0, b1 = al.label_off[c]; for (int bb = b0; bb < b1; ++bb) word_push(lo, hi, al.label_bytes[bb]); }
-          }
+        if (words) {
+          if ((int)c == al.space_id) { lo = 0; hi = 0; }
+          else if (one) word_push(lo, hi, one);
+          else { const int b0 = c ? al.label_off[c - 1] : 0, b1 = al.label_off[c]; for (int bb = b0; bb < b1; ++bb) word_push(lo, hi, al.label_bytes[bb]); }
           L.wlo[nxt][r] = lo; L.whi[nxt][r] = hi; L.pqe[nxt][r] = STT_NONE;
         }
         if (slot < S.pa_cap()) { store_node(S.pa(), slot, pnode, c); S.pq()[slot] = STT_NONE; L.node[nxt][r] = slot; }
         else { L.node[nxt][r] = 0; lds_or(&sc[SC_ERR], 1); }
         if (MODE == 2) {  // utf8 cache: the child's run, and its boundary entry (a new one when it completes a code point)
           const uint8_t byte = (uint8_t)(c + 1);
-          const uint32_t prun = L.run[cur][i];
           uint32_t unit = 0, nb = STT_NONE;
           unsigned probes6 = 0;
           if (al.byte_labels) {
             L.run[nxt][r] = utf8_child_run(prun, byte);
-            if (b != STT_NONE && utf8_step_clean(prun, L.ch[cur][i] == STT_ROOT_CH, byte, unit)) {
+            if (b != STT_NONE && utf8_step_clean(prun, pch == STT_ROOT_CH, byte, unit)) {
               if (pi >> 31) {
                 if (slot < S.pa_cap()) {
                   lm_word_query_cached<false, true>(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], slot, b, true, (uint64_t)unit, 0ULL, nb, probes6);
@@ -2051,7 +2072,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
           } else L.run[nxt][r] = 0;  // not a UTF8Alphabet: every prefix takes the generic walk (nb stays STT_NONE)
           L.bnd[nxt][r] = nb;
         }
-        pend = (NEG < lpv) ? L.ts[cur][i] : 0xFFFFFFFEu;  // :246-251 with log_prob_nb_cur == -inf
+        pend = (NEG < lpv) ? pts : 0xFFFFFFFEu;  // :246-251 with log_prob_nb_cur == -inf
         ts_new = STT_ROOT_CH;                              // timesteps == nullptr
       }
       finish_entry(r, nkey, pend, ts_new);

@@ -283,7 +283,10 @@ void ModelState::place_engine_streams(hipStream_t* out_l, hipStream_t* out_o) {
 // engine one, ALL group slots' search streams a third (searches run one or two at a time and only ever wait for CUs, never for each other's
 // dispatch) -- so that no search stream can sit on the recurrence's pipe either (the first cut probed the existing search streams and found,
 // with eight idle streams created before the model, every pipe already taken by one of them: 6.3 ms per batch again).
-void ModelState::place_batch_streams(hipStream_t* slot_streams, int n_slots) {
+// spread_searches (a search-bound setup -- code-point scorer, beam > 512: four searches side by side, each waiting for its own chunk events):
+// the group slots' search streams take FOUR DIFFERENT classes instead of one.  Four event-gated queues on one pipe run a batch in 71 ms
+// instead of 47 (`bytes`, round 6): a queue whose head packet waits for an event holds up the queues behind it on that pipe.
+void ModelState::place_batch_streams(hipStream_t* slot_streams, int n_slots, bool spread_searches) {
   constexpr int NC = 16;
   std::vector<hipStream_t> cands(NC, nullptr);
   for (int c = 0; c < NC; ++c) create_engine_stream(&cands[c], 2, false);
@@ -330,8 +333,14 @@ void ModelState::place_batch_streams(hipStream_t* slot_streams, int n_slots) {
   }
   stream_l = nl; stream_o = no;
   for (int i = 0; i < n_slots; ++i) {
-    hipStream_t st = take(ks);
-    if (!st && ko != ks) st = take(ko);
+    hipStream_t st = nullptr;
+    if (spread_searches) {
+      const int order[4] = {ks, ko, kr, 0};
+      for (int k = 0; k < 4 && !st; ++k) st = take(order[(i + k) & 3]);
+    } else {
+      st = take(ks);
+      if (!st && ko != ks) st = take(ko);
+    }
     if (!st) continue;                            // (this slot keeps the stream it has)
     if (slot_streams[i]) { HIP_CHECK(hipStreamSynchronize(slot_streams[i])); (void)hipStreamDestroy(slot_streams[i]); }
     slot_streams[i] = st;

@@ -335,7 +335,8 @@ struct ModelState {
   // Placement (engine.cpp): creates stream_l / stream_o on dispatch pipes they share with neither the GEMM engine's stream nor (if it can be
   // helped) the searches' -- by measurement, not by counting streams.  `avoid`: the search streams of the group slots in use.
   void place_engine_streams(hipStream_t* out_l, hipStream_t* out_o);
-  void place_batch_streams(hipStream_t* slot_streams, int n_slots);   // recurrence, output engine AND the group slots' search streams, each role a pipe class of its own
+  void place_batch_streams(hipStream_t* slot_streams, int n_slots, bool spread_searches);
+  int placed_search_bound_ = -1;    // the kind of setup the streams were placed for (-1: not placed)   // recurrence, output engine AND the group slots' search streams, each role a pipe class of its own
   std::vector<hipStream_t> placement_avoid_;   // set by the batch path (api.cpp: batch_init_slots): the slots' search streams, most used first
   DevBuf placement_scratch_;
   void am_watch_begin(int T);

@@ -35,3 +35,17 @@ def test_batch_time_does_not_depend_on_streams_created_before_the_model(mode):
     worst = max(p["ms_per_batch"] for p in pts)
     assert worst <= 1.15 * base, (base, [(p["idle_streams_before_the_model"], p["ms_per_batch"]) for p in pts])
     assert base < 4.0, base                      # (and K = 0 itself is a good placement: 3.0 - 3.2 ms on the bench's box)
+
+
+def test_a_search_bound_setup_keeps_its_searches_on_different_pipes():
+    """Code-point scorer / beam 1024: four searches side by side, each waiting for its own chunk events.  Round 6's first placement put all four
+    search streams on ONE pipe class (fine for the two alternating searches of the headline setup): 71 ms per batch instead of 47 on the bytes
+    workload.  Search-bound setups spread them over four classes (engine.cpp: place_batch_streams, spread_searches): placed must not be slower
+    than unplaced."""
+    extra = ("--bytes", "--hidden", "512", "--batches", "8")
+    placed = _point(0, "f16", extra)
+    raw = _point(0, "f16", extra + ("--place", "0", "--moves", "0"))
+    print("search-bound placement:", placed["ms_per_batch"], "placed,", raw["ms_per_batch"], "unplaced")
+    assert placed["transcripts_repeat"] and raw["transcripts_repeat"]
+    assert placed["placements"] >= 1
+    assert placed["ms_per_batch"] <= 1.15 * raw["ms_per_batch"], (placed, raw)
