@@ -887,7 +887,7 @@ struct Lds {
   LDS_AS uint16_t *cls, *pos;
   LDS_AS uint8_t* lab1;                       // [C] the byte of every single-byte label (0 otherwise)
   LDS_AS uint32_t *hist, *cumb;
-  LDS_AS uint16_t* lmw;                      // the LM wave's list of prefixes to score this step
+  LDS_AS uint16_t* lmw; uint32_t lmw_cap;    // the LM waves' lists of prefixes to score (bitmap step: one list of lmw_cap entries per beam buffer, see ctc_step)
   LDS_AS uint64_t* exp_tab; LDS_AS double* log_tab;  // sttmath.h tables (32 x u64, 32 x f64)
   LDS_AS uint8_t* own; uint32_t own_cap;     // expand: per-wave table item -> owning lane (aliases skey/sseg/cumb, idle in that phase)
   LDS_AS uint64_t* skey; LDS_AS uint32_t *ssrc, *sseg;
@@ -900,7 +900,7 @@ struct Lds {
 };
 // phase cycle counters (s_memtime is a scalar memory operation with a wait: only on request, DecParams::phase_cycles)
 #define TICK(k) do { if (p.phase_cycles && tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); L.acc[4 + (k)] += now_ - tick_; tick_ = now_; } } while (0)
-enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_NA, SC_NI, SC_ICUR, SC_FILL, SC_DONE, SC_NS, SC_THB, SC_COUNT = 24 };
+enum { SC_M = 0, SC_CUTLEN, SC_LMQ, SC_PROBES, SC_ERR, SC_KMIN, SC_KMAX, SC_BT, SC_BTH, SC_BTCUM, SC_PAN, SC_TAN, SC_BEN, SC_NQ, SC_NA, SC_NI, SC_ICUR, SC_FILL, SC_DONE, SC_NS, SC_THB, SC_LMD, SC_NLM0, SC_NLM1, SC_COUNT = 24 };
 #define NEG_HI 0xFF7FFFFFu  // high word of the selection key of score == -NUM_FLT_INF
 
 
@@ -942,7 +942,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
   offs[k++] = take(sn * 8); offs[k++] = take(sn * 4); offs[k++] = take((NBUCKET + 1) * 4);
   const uint32_t own_cap = (uint32_t)((o - o_own) / NWAVES) & ~3u;
   offs[k++] = take(64 * 4);
-  offs[k++] = take(cap * 2);                                       // lmw
+  offs[k++] = take(arcs ? cap * 4 : cap * 2);                      // lmw (narrow beams: one list of cap entries per beam buffer)
   offs[k++] = take(32 * 8); offs[k++] = take(32 * 8);              // exp / log tables
   offs[k++] = take(12 * 8);
   offs[k++] = take(64 * 8);                                        // stm
@@ -985,7 +985,7 @@ __host__ __device__ __attribute__((always_inline)) inline Lds lds_carve(int C, L
     l->skey = (LDS_AS uint64_t*)(base + offs[k++]); l->sseg = (LDS_AS uint32_t*)(base + offs[k++]); l->cumb = (LDS_AS uint32_t*)(base + offs[k++]);
     l->own = (LDS_AS uint8_t*)(base + o_own); l->own_cap = own_cap;
     l->wtot = (LDS_AS uint32_t*)(base + offs[k++]);
-    l->lmw = (LDS_AS uint16_t*)(base + offs[k++]);
+    l->lmw = (LDS_AS uint16_t*)(base + offs[k++]); l->lmw_cap = cap;
     l->exp_tab = (LDS_AS uint64_t*)(base + offs[k++]); l->log_tab = (LDS_AS double*)(base + offs[k++]);
     l->acc = (LDS_AS unsigned long long*)(base + offs[k++]);
     l->stm = (LDS_AS unsigned long long*)(base + offs[k++]);
@@ -1229,6 +1229,12 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
   // divergent-looking exit the structurizer may send lanes round the loop without the lane the operation relies on
   n = __builtin_amdgcn_readfirstlane(n); cur = __builtin_amdgcn_readfirstlane(cur);
   unsigned long long tick_ = p.phase_cycles ? __builtin_readcyclecounter() : 0ull;
+  // Bitmap step: the LM waves -- the youngest waves of the workgroup, last in issue arbitration -- run at their query priority from the first
+  // instruction of the step (round 6: they arrived last at the end of the score phase in half of the steps).  Reset after their queries.
+  if (MASKED && n > NWAVES && p.lm_prio >= 3) {
+    const int nlm0 = n > 256 ? (p.n_lm_waves == 4 ? 4 : (p.n_lm_waves == 1 ? 1 : 2)) : 1;   // (= nlm below)
+    if (wave >= NWAVES - nlm0) __builtin_amdgcn_s_setprio(3);
+  }
   float pre = 0.0f;
   // (consumed in P3; bitmap form: by wave 8 -- waves 0..7 have a merge per thread there, wave 0 was the last to arrive with this on top)
   const int prep_c = MODE_T == 4 ? tid - 512 : tid;
@@ -1246,6 +1252,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
   // (bitmap step: every thread clears the events of its own prefix in the pre-pass below -- no barrier in between)
   if (!MASKED) for (int i = tid; i < n; i += NTHREADS) { L.ev_self[i] = absent(); L.ev_blank[i] = absent(); L.ev_ext[i] = absent(); L.ev_exti[i] = 0; }
   L.hist[tid] = 0;
+  if (MASKED && tid == 0) sc[SC_NLM0 + (cur ^ 1)] = 0;   // (the LM list of the beam this step will write: see the LM waves below)
   if (tid == 0) { sc[SC_M] = 0; sc[SC_LMQ] = 0; sc[SC_PROBES] = 0; sc[SC_KMIN] = -1; sc[SC_KMAX] = 0; sc[SC_NQ] = 0; sc[SC_NA] = 0; sc[SC_NS] = 0; sc[SC_THB] = 0; }
   const bool sort_classes = (p.cutoff_prob < 1.0) || (p.cutoff_top_n < C);
   int cutoff_len = WIDE ? wh.cutoff_len : C;
@@ -1332,10 +1339,29 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
     // (the chain of dependent reads was the critical path of the phase when the phase ended at a barrier: issue it first)
     if (p.lm_prio >= 3) __builtin_amdgcn_s_setprio(3); else if (p.lm_prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.lm_prio == 1) __builtin_amdgcn_s_setprio(1);
     const unsigned long long lmw_t0 = p.phase_cycles ? __builtin_readcyclecounter() : 0ull;
-    const int ksp = POS_OF(al.space_id);
     const int lw = wave - nw_exp;
-    LDS_AS uint16_t* list = L.lmw + lw * (512 / (nlm > 0 ? nlm : 1));
     unsigned lmq = 0;
+    if (MASKED) {
+      // Bitmap step, the EAGER list (round 6): every prefix whose word may end and that has no score yet was put on the list of its beam
+      // buffer when that beam was written (write phase below; the first step of a launch: the kernel's prologue) -- whether or not its
+      // space extension survives this step's cut-off (the entry is a cache of what the reference would compute when it needs it; on the
+      // bench's emissions it is the same 13.0 queries per step).  The LM waves no longer scan the beam first: 3.4 k of their 9 k cycles.
+      const uint32_t n_list = (uint32_t)__builtin_amdgcn_readfirstlane(sc[SC_NLM0 + cur]);
+      const LDS_AS uint16_t* list = L.lmw + (uint32_t)cur * L.lmw_cap;
+      const uint32_t per = (n_list + (uint32_t)nlm - 1u) / (uint32_t)nlm;
+      const uint32_t q0 = (uint32_t)lw * per, q1 = q0 + per < n_list ? q0 + per : n_list;
+      for (uint32_t q = q0 + (uint32_t)lane; q < q1; q += 64) {
+        const int i = (int)list[q];
+        if (L.pqe[cur][i] == STT_NONE && L.bnd[cur][i] != STT_NONE && L.score[cur][i] != NEG) {
+          uint32_t ne;
+          const double raw = lm_word_query_cached<MASKED>(s, al, S, lab1, (LDS_AS uint32_t*)&sc[SC_BEN], L.node[cur][i], L.bnd[cur][i], true, L.wlo[cur][i], L.whi[cur][i], ne, probes);
+          L.pqe[cur][i] = ne; L.pqs[cur][i] = (float)__dmul_rn(raw, s.alpha);
+          ++lmq;
+        }
+      }
+    } else {
+    const int ksp = POS_OF(al.space_id);
+    LDS_AS uint16_t* list = L.lmw + lw * (512 / (nlm > 0 ? nlm : 1));
     if (ksp != 0xFFFF) {
       const float lpsp = LP_AT(ksp, al.space_id);
       uint32_t n_need = 0;
@@ -1365,6 +1391,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
         L.pqe[cur][i] = ne; L.pqs[cur][i] = (float)__dmul_rn(raw, s.alpha);
         ++lmq;
       }
+    }
     }
     if (lmq) lds_add(&sc[SC_LMQ], (int)lmq);
     if (p.phase_cycles && lane == 0 && wave == NWAVES - 1) L.acc[4 + 7] += __builtin_readcyclecounter() - lmw_t0;  // phase slot 7: the (last) LM wave's own time
@@ -1627,6 +1654,12 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
     // queries, and what the later phases need from them -- the scores of this step's "prefix + space" extensions -- is only read
     // in the key phase, after the next real barrier (score_ext below); an LM wave goes straight to that barrier when it is done.
     if (!lmw_) { signal_count(&sc[SC_DONE]); (void)wait_count(&sc[SC_DONE], n_cons, &sc[SC_ERR], p.wait_spins); }
+    else {
+      // (no barrier after the score phase, see there: an LM wave publishes its scores through a counter, and its threads take elements of
+      // the key phase like everybody's -- for that it needs the candidate list complete itself)
+      signal_count(&sc[SC_LMD]);
+      (void)wait_count(&sc[SC_DONE], n_cons, &sc[SC_ERR], p.wait_spins);
+    }
   } else __syncthreads();
   if (p.stamps && lane == 0) L.stm[16 + wave] += __builtin_readcyclecounter() - arrive_;
   if (!MASKED && p.stamps && tid == 0) {
@@ -1777,7 +1810,11 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
   }
   if (probes) lds_add(&sc[SC_PROBES], (int)probes);
   if (MASKED && p.stamps && lane == 0) L.stm[32 + wave] += __builtin_readcyclecounter() - tick_;   // profiling level 2: arrival at the end of the score phase (wave 0: since its last TICK)
-  __syncthreads();
+  // Bitmap step with LM waves: NO barrier between the score phase and the key phase (round 6: the LM waves were the last to arrive in half of
+  // the steps, 7.5 k cycles after the first wave).  What the key phase needs from them -- pqe / pqs of this step's "prefix + space"
+  // extensions -- is waited for through their counter; everything else the key phase reads was complete when the items were (SC_DONE).
+  if (MASKED && lm_wave) (void)wait_count(&sc[SC_LMD], (uint32_t)nlm, &sc[SC_ERR], p.wait_spins);
+  else __syncthreads();
   TICK(3);
   STEP_FENCE();
 
@@ -2006,6 +2043,8 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
         L.bnd[nxt][r] = v_bnd;
         if (words) { L.wlo[nxt][r] = v_wlo; L.whi[nxt][r] = v_whi; L.pqe[nxt][r] = v_pqe; L.pqs[nxt][r] = v_pqs; }
         if (MODE == 2) L.run[nxt][r] = v_run;
+        // (bitmap step: a word may end here and nobody has scored it yet -> the LM list of the new beam)
+        if (MASKED && ((v_sm >> (uint32_t)al.space_id) & 1u) != 0 && v_pqe == STT_NONE) L.lmw[(uint32_t)nxt * L.lmw_cap + (uint32_t)lds_add(&sc[SC_NLM0 + nxt], 1)] = (uint16_t)r;
       }
       finish_entry(r, nkey, pend, ts_new);
     }
@@ -2078,7 +2117,10 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
       finish_entry(r, nkey, pend, ts_new);
     }
     P6_STAMP(2);
-    if (MASKED && r_rec != 0xFFFFFFFFu) { L.a0[nxt][r_rec] = rec_new.x; L.sm[nxt][r_rec] = rec_new.y; }
+    if (MASKED && r_rec != 0xFFFFFFFFu) {
+      L.a0[nxt][r_rec] = rec_new.x; L.sm[nxt][r_rec] = rec_new.y;
+      if (((rec_new.y >> (uint32_t)al.space_id) & 1u) != 0) L.lmw[(uint32_t)nxt * L.lmw_cap + (uint32_t)lds_add(&sc[SC_NLM0 + nxt], 1)] = (uint16_t)r_rec;   // (a new prefix has no score yet)
+    }
     __builtin_amdgcn_s_waitcnt(0);
     P6_STAMP(3);
 #undef P6_STAMP
@@ -2090,7 +2132,7 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
 #undef CLS_AT
 #undef LP_AT
   if (tid == 0) {
-    if (MASKED) { sc[SC_NI] = 0; sc[SC_ICUR] = 0; sc[SC_FILL] = 0; sc[SC_DONE] = 0; }  // the next step's pre-pass starts without a barrier of its own
+    if (MASKED) { sc[SC_NI] = 0; sc[SC_ICUR] = 0; sc[SC_FILL] = 0; sc[SC_DONE] = 0; sc[SC_LMD] = 0; }  // the next step's pre-pass starts without a barrier of its own
     L.acc[0] += 1; L.acc[1] += (unsigned long long)m; L.acc[2] += (unsigned long long)sc[SC_LMQ]; L.acc[3] += (unsigned long long)(unsigned)sc[SC_PROBES];
   }
   abs_t++;
@@ -2159,7 +2201,7 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(NextArgs) {
   for (uint32_t h = tid; h < HTN; h += NTHREADS) L.ht_key[h] = 0;
   if (L.bloom) for (uint32_t h = tid; h < BLOOM_WORDS; h += NTHREADS) L.bloom[h] = 0;
   if (tid < 32) { L.exp_tab[tid] = sttm::kExp2Tab[tid]; L.log_tab[tid] = sttm::kLogfTab[tid >> 1][tid & 1]; }
-  if (tid == 0) { L.sc[SC_NI] = 0; L.sc[SC_ICUR] = 0; L.sc[SC_FILL] = 0; L.sc[SC_DONE] = 0; L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
+  if (tid == 0) { L.sc[SC_NI] = 0; L.sc[SC_ICUR] = 0; L.sc[SC_FILL] = 0; L.sc[SC_DONE] = 0; L.sc[SC_LMD] = 0; L.sc[SC_NLM0] = 0; L.sc[SC_NLM1] = 0; L.sc[SC_ERR] = 0; L.sc[SC_PAN] = (int)G.pa_n; L.sc[SC_TAN] = (int)G.ta_n; L.sc[SC_BEN] = (int)G.be_n; }
   if (tid < 12) L.acc[tid] = 0;
   if (tid < 64) L.stm[tid] = 0;
   __syncthreads();  // the math tables must be in place before the first row is prepared
@@ -2192,6 +2234,9 @@ __global__ __launch_bounds__(NTHREADS) void ctc_next_kernel(NextArgs) {
     }
   }
   for (int i = tid; i < n; i += NTHREADS) ht_insert(L, L.key[0][i], i);
+  if (MASKED)   // the LM list of the beam as loaded (ctc_step: the eager list)
+    for (int i = tid; i < n; i += NTHREADS)
+      if (((L.sm[0][i] >> (uint32_t)al.space_id) & 1u) != 0 && L.pqe[0][i] == STT_NONE) L.lmw[lds_add(&L.sc[SC_NLM0], 1)] = (uint16_t)i;
   __syncthreads();
   for (int t = 0; t < nfr; ++t)
     ctc_step<MODE, WIDE>(ka, gq, L, cur, n, start_expanding, abs_t, t & 1, t + 1 < nfr ? row + (size_t)(t + 1) * p.C : nullptr, t);
