@@ -104,6 +104,13 @@ struct DevScorer {
   const float* cp_ub;
   float cp_ub_max;
   int cp_ub_on;   // cp_ub_max is valid
+  // utf8 mode, bigram blocks (scorer_host.h: HostScorer::cpt / cpb_tab / cpb_rec; tunable cp_blocks): FullScore of a code point u after
+  // context word w1 through ONE table entry per (w1, u >> 6) -- shared by the 64 sibling code points a prefix's children complete -- and the
+  // unigram record cpt[u]; a stored bigram continues in the hashed index from its slot.  null = not built.
+  const uint32_t* cpt;       // [65536] x {word index, prob, backoff, flags (1 = in the vocabulary, 2 = no longer n-gram ends with it)}
+  const uint32_t* cpb_tab;   // [cpb_mask + 1] x {w1 (0xFFFFFFFF = free), block, offset, count, present (u64), indep (u64)}
+  const uint32_t* cpb_rec;   // x {prob, backoff, slot of the bigram in the hashed index}
+  uint32_t cpb_mask;
   // hot words (murmur hashes of the words)
   int n_hot;
   const uint64_t* hot_hash;

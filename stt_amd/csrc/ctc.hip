@@ -694,6 +694,72 @@ __device__ __forceinline__ void lm_memo_store(const DevScorer& s, const LmMemoKe
   m[0] = a; m[1] = b;
 }
 
+// The code point a unit's packed bytes spell (first byte lowest), if they are its shortest UTF-8 form of one to three bytes -- the form under
+// which the vocabulary knows it (scorer_dev.cpp: build_cp_blocks keys cpt by that form); anything else: false.
+__device__ __forceinline__ bool utf8_unit_code_point(uint32_t u, uint32_t& cp) {
+  const uint32_t b0 = u & 0xFFu, b1 = (u >> 8) & 0xFFu, b2 = (u >> 16) & 0xFFu;
+  if (u < 0x80u) { cp = u; return u != 0u; }
+  if (u < 0x10000u) { cp = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu); return (b0 & 0xE0u) == 0xC0u && (b1 & 0xC0u) == 0x80u && cp >= 0x80u; }
+  if (u < 0x1000000u) {
+    cp = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
+    return (b0 & 0xF0u) == 0xE0u && (b1 & 0xC0u) == 0x80u && (b2 & 0xC0u) == 0x80u && cp >= 0x800u && !(cp >= 0xD800u && cp < 0xE000u);
+  }
+  return false;
+}
+// GenericModel::FullScore of code point `cp` (a word of the model: cpt flags bit 0) from state `in` through the bigram blocks: HostScorer::
+// full_score_blocks (scorer_dev.cpp) on the device.  Order 2 is ONE table entry for (in.words[0], cp >> 6) -- the same entry for the 64 sibling
+// code points a prefix's children complete, whose unigram records are one contiguous 1 KB of cpt -- and a bit of its presence map; a stored
+// bigram (rare: 5 % of the bench's queries) continues in the hashed index from the slot its record names.  `unit` = the code point's bytes
+// (hashed only on that path).  Same floats as the index and the trie walk (tests/test_cp_blocks.py, tests/test_gpu_lm.py).
+__device__ __forceinline__ float lm_full_score_blocks(const DevScorer& s, const KState& in, uint32_t cp, uint32_t unit, const u32x4& ct, KState& out, unsigned& probes) {
+  const uint32_t wi = ct.x;
+  const float uprob = __uint_as_float(ct.y), uback = __uint_as_float(ct.z);
+  const bool uindep = (ct.w & 2u) != 0;
+  LmiLevel lv[LMI_MAX_HIST];
+#pragma unroll
+  for (int q = 0; q < LMI_MAX_HIST; ++q) { lv[q].found = 0; lv[q].prob = 0.0f; lv[q].backoff = 0.0f; lv[q].indep = 0; }
+  if (!uindep && in.length > 0 && s.order >= 2) {
+    const uint32_t w1 = in.words[0], block = cp >> 6;
+    const GLB_AS u32x4* tab = (const GLB_AS u32x4*)s.cpb_tab;
+    uint32_t hsl = cpb_hash(w1, block) & s.cpb_mask;
+    u32x4 e0, e1;
+    bool have = false;
+    for (;;) {
+      e0 = tab[(size_t)hsl * 2]; e1 = tab[(size_t)hsl * 2 + 1];
+      ++probes;
+      if (e0.x == 0xFFFFFFFFu) break;
+      if (e0.x == w1 && e0.y == block) { have = true; break; }
+      hsl = (hsl + 1u) & s.cpb_mask;
+    }
+    const uint64_t present = (uint64_t)e1.x | ((uint64_t)e1.y << 32), indep = (uint64_t)e1.z | ((uint64_t)e1.w << 32);
+    const uint64_t bit = 1ull << (cp & 63u);
+    if (have && (present & bit) != 0ull) {
+      const GLB_AS uint32_t* r = (const GLB_AS uint32_t*)s.cpb_rec + (size_t)(e0.z + (uint32_t)__popcll(present & (bit - 1ull))) * 3;
+      const uint32_t r0 = r[0], r1 = r[1], r2 = r[2];
+      ++probes;
+      lv[0].found = 1; lv[0].prob = __uint_as_float(r0); lv[0].backoff = __uint_as_float(r1); lv[0].indep = (indep & bit) != 0ull ? 1 : 0;
+      // orders >= 3: the hashed index, from the bigram's slot on (lm_full_score_indexed's chain, entered at its second level)
+      const uint32_t nb = unit < 0x100u ? 1u : (unit < 0x10000u ? 2u : 3u);
+      uint64_t key = lmi_step(murmur_packed((uint64_t)unit, 0ull, (int)nb), w1);
+      uint32_t parent = r2;
+      bool going = !lv[0].indep;
+#pragma unroll
+      for (int hi = 1; hi < 4; ++hi) {
+        if (going && hi < s.order - 1 && hi < in.length) {
+          key = lmi_step(key, in.words[hi]);
+          LmiEntry e;
+          const uint32_t slot = lmi_probe(s.lmi, s.lmi_buckets, lmi_bucket(key, s.lmi_buckets), hi + 2, in.words[hi], parent, e);
+          probes += 1;
+          if (slot == LMI_NOT_FOUND) going = false;
+          else { lv[hi].found = 1; lv[hi].prob = e.prob; lv[hi].backoff = e.backoff; lv[hi].indep = (e.wl & LMI_INDEP_BIT) ? 1 : 0; parent = slot; if (lv[hi].indep) going = false; }
+        } else going = false;
+      }
+    }
+  }
+  int nl;
+  return lmi_combine(s.order, in, wi, uprob, uback, uindep, lv, out, nl);
+}
+
 // IDX: FullScore through the hashed n-gram index (the scorer must have one: orders <= 5), else the trie walk
 // the trie walk as a real call: the cold side of the code-point step's FullScore (a scorer without the index), kept out of its registers
 __device__ __noinline__ float kenlm_full_score_call(const DevScorer& s, const KState* in, uint32_t wi, KState* out, unsigned* probes, const DevVocabSlot* uni) {
@@ -709,17 +775,33 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
   // The word's bytes come from the beam state (have_word) or from a walk back to the previous boundary; words longer than
   // 16 bytes take the generic label-array path.
   if (!have_word) word_walk(al, S, lab1, node, lo, hi, probes);
-  uint64_t h;
-  if ((lo & hi) != ~0ULL) h = murmur_packed(lo, hi, word_nbytes(lo, hi));
-  else h = murmur_path_word(al, S, node, probes);   // a word of more than 16 bytes
+  // Code-point step with bigram blocks (DevScorer::cpt): a unit that is one code point of the model's vocabulary needs no hash of its bytes,
+  // no vocabulary probe and no memo -- its unigram record is cpt[code point] (the 64 siblings scored by neighbouring lanes read one KB).
+  bool via_blocks = false;
+  u32x4 ct = {0u, 0u, 0u, 0u};
+  uint32_t cp = 0;
+  if constexpr (RT_IDX) {
+    if (s.cpt != nullptr && have_word && hi == 0ULL && lo < 0x1000000ULL && utf8_unit_code_point((uint32_t)lo, cp)) {
+      ct = ((const GLB_AS u32x4*)s.cpt)[cp];
+      ++probes;
+      via_blocks = (ct.w & 1u) != 0;
+    }
+  }
+  uint64_t h = 0;
+  if (!via_blocks || s.n_hot != 0) {   // (the blocks' path hashes the unit only for hot words -- and where a stored bigram continues in the index)
+    if ((lo & hi) != ~0ULL) h = murmur_packed(lo, hi, word_nbytes(lo, hi));
+    else h = murmur_path_word(al, S, node, probes);   // a word of more than 16 bytes
+  }
   const BEntry ep = load_be(S, e_prev);  // issued before the vocabulary probe: the two reads are independent
   ++probes;
   BEntry en;
   float prob;
   bool word_oov;
   // a caller that only wants the value (no new entry, so no out-state) asks the FullScore cache first
-  const bool use_memo = !IDX && be_n == nullptr && s.memo != nullptr && ep.st.length <= 4;
+  const bool use_memo = !IDX && !via_blocks && be_n == nullptr && s.memo != nullptr && ep.st.length <= 4;
   LmMemoKey mk;
+  if (via_blocks) { prob = lm_full_score_blocks(s, ep.st, cp, (uint32_t)lo, ct, en.st, probes); word_oov = false; }
+  else {
   if (use_memo) {
     const uint32_t u3 = (have_word && hi == 0 && (lo >> 24) == 0 && ((uint32_t)lo >> 16) != 0 && (((uint32_t)lo >> 4) & 0xFu) == 0xEu) ? (uint32_t)lo : 0u;   // three bytes, the first 1110xxxx
     mk = lm_memo_key(s, ep.st.words[0], ep.st.words[1], ep.st.words[2], ep.st.words[3], (uint32_t)ep.st.length, h, u3);
@@ -733,6 +815,7 @@ __device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al
     else prob = kenlm_full_score(s, ep.st, wi, en.st, probes, (wi != 0 && s.uni_in_vtab) ? &vs : nullptr);
     word_oov = wi == 0;
     if (use_memo) lm_memo_store(s, mk, prob, word_oov);
+  }
   }
   en.oov_hist = (uint16_t)((ep.oov_hist << 1) | (word_oov ? 1u : 0u));
   const bool oov = (en.oov_hist & ((1u << s.order) - 1u)) != 0;  // this word + the order-1 before it
@@ -1771,9 +1854,15 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
       }
       if (tid < n && !((L.ev_exti[tid] >> 31) && !is_absent(L.ev_ext[tid]))) { my_score = merge_live<WIDE>(p, L, W, cur, tid); merged = true; }
     } else {
+      // (a candidate's record is read one trip ahead: beyond the first `mcap` it sits in the stream's HBM workspace, and the read was the
+      // first of three dependent round trips of a trip -- record, boundary entry + unigram record, bigram block)
+      uint32_t pi_nx = 0; float lp_nx = 0.0f;
+      if (tid < m) { pi_nx = CAND_PI(tid); lp_nx = CAND_LOGP(tid); }
       for (int x = tid; x < m + n; x += NTHREADS) {
         uint32_t pi; float lp0;
-        if (x < m) { pi = CAND_PI(x); if (!(pi >> 31)) continue; lp0 = CAND_LOGP(x); }
+        const uint32_t pi_c = pi_nx; const float lp_c = lp_nx;
+        if (x + NTHREADS < m) { pi_nx = CAND_PI(x + NTHREADS); lp_nx = CAND_LOGP(x + NTHREADS); }
+        if (x < m) { pi = pi_c; if (!(pi >> 31)) continue; lp0 = lp_c; }
         else { const int j = x - m; pi = L.ev_exti[j]; if (!(pi >> 31) || is_absent(L.ev_ext[j])) continue; lp0 = L.ev_ext[j]; }
         const int i = (int)(pi & 0xFFFFu);
         const uint32_t first = (x < m) ? CLS_AT((pi >> 16) & 0x7FFFu) : L.ch[cur][x - m];  // utf8 mode scores the *new* prefix

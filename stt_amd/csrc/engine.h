@@ -107,7 +107,7 @@ class ScorerDev {
 
  private:
   int Parse(const uint8_t* buf, size_t len, int space_label, bool lm_only);
-  DevBuf blob_, fst_pos_, fst_arcs_, fst_space_, fst_rec_, vtab_, hint_, lmi_, memo_, cp_ub_;
+  DevBuf blob_, fst_pos_, fst_arcs_, fst_space_, fst_rec_, vtab_, hint_, lmi_, memo_, cp_ub_, cpt_, cpb_tab_, cpb_rec_;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -49,6 +49,13 @@ LMI_HD bool lmi_is(uint32_t wl, uint32_t word, int level) {
   return (wl & ~LMI_INDEP_BIT) == ((word & LMI_WORD_MASK) | ((uint32_t)level << LMI_LEVEL_SHIFT));
 }
 
+// slot hash of the bigram blocks' table (scorer_host.h: cpb_tab; key = context word, block of 64 consecutive code points)
+LMI_HD uint32_t cpb_hash(uint32_t w1, uint32_t block) {
+  uint64_t a = ((uint64_t)w1 << 32 | block) * 0x9E3779B97F4A7C15ULL;
+  a ^= a >> 29;
+  return (uint32_t)(a * 0xD6E8FEB86659FD93ULL >> 32);
+}
+
 // What one trie level contributes to FullScore: found = the n-gram of that order exists (and every shorter one did).
 struct LmiLevel { int found; float prob, backoff; int indep; };
 

@@ -267,11 +267,6 @@ static size_t utf8_of(uint32_t cp, unsigned char* u) {   // U+0001 .. U+FFFF (su
   if (cp < 0x800) { u[0] = (unsigned char)(0xC0 | (cp >> 6)); u[1] = (unsigned char)(0x80 | (cp & 0x3F)); return 2; }
   u[0] = (unsigned char)(0xE0 | (cp >> 12)); u[1] = (unsigned char)(0x80 | ((cp >> 6) & 0x3F)); u[2] = (unsigned char)(0x80 | (cp & 0x3F)); return 3;
 }
-static inline uint32_t cpb_hash(uint32_t w1, uint32_t block) {
-  uint64_t a = ((uint64_t)w1 << 32 | block) * 0x9E3779B97F4A7C15ULL;
-  a ^= a >> 29;
-  return (uint32_t)(a * 0xD6E8FEB86659FD93ULL >> 32);
-}
 
 // The bigram blocks of scorer_host.h.  Needs the hashed index (the records carry their slots: orders >= 3 continue there).
 static bool build_cp_blocks(HostScorer& hs) {
@@ -316,7 +311,7 @@ static bool build_cp_blocks(HostScorer& hs) {
   size_t n_ent = 0;
   for (size_t i = 0; i < tups.size(); ++i) if (i == 0 || tups[i].w1 != tups[i - 1].w1 || (tups[i].cp >> 6) != (tups[i - 1].cp >> 6)) ++n_ent;
   uint32_t cap = 16;
-  while ((uint64_t)cap < 2 * (uint64_t)n_ent + 2) cap <<= 1;
+  while ((uint64_t)cap < 4 * (uint64_t)n_ent + 2) cap <<= 1;   // (load <= 1/4: most lookups are for a (context, block) the model has no bigram in -- an unsuccessful search, 1.4 probes at this load, 2.5 at 1/2)
   if (tups.size() >= 0xFFFFFFF0ull) return false;
   hs.cpb_tab.assign(cap, HostScorer::CpbEntry{0xFFFFFFFFu, 0u, 0u, 0u, 0ull, 0ull});
   hs.cpb_mask = cap - 1;
@@ -843,6 +838,15 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label, bool lm_on
   if (!hs.cp_ub.empty()) {
     ds.cp_ub_max = hs.cp_ub_max; ds.cp_ub_on = 1;
     if (tune().unit_bounds >= 2) { cp_ub_.upload(hs.cp_ub.data(), hs.cp_ub.size() * 4); ds.cp_ub = cp_ub_.as<float>(); }
+  }
+  if (hs.cpb_ok && hs.lmi_ok && hs.utf8 && !lm_only) {   // bigram blocks of the code-point step (ctc.hip: lm_full_score_blocks)
+    static_assert(sizeof(HostScorer::CptEntry) == 16 && sizeof(HostScorer::CpbEntry) == 32 && sizeof(HostScorer::CpbRec) == 12, "device layout of the bigram blocks");
+    try {
+      cpt_.upload(hs.cpt.data(), hs.cpt.size() * sizeof(HostScorer::CptEntry));
+      cpb_tab_.upload(hs.cpb_tab.data(), hs.cpb_tab.size() * sizeof(HostScorer::CpbEntry));
+      cpb_rec_.upload(hs.cpb_rec.empty() ? (const void*)hs.cpt.data() : (const void*)hs.cpb_rec.data(), std::max<size_t>(12, hs.cpb_rec.size() * sizeof(HostScorer::CpbRec)));
+      ds.cpt = cpt_.as<uint32_t>(); ds.cpb_tab = cpb_tab_.as<uint32_t>(); ds.cpb_rec = cpb_rec_.as<uint32_t>(); ds.cpb_mask = hs.cpb_mask;
+    } catch (const std::exception&) { ds.cpt = nullptr; ds.cpb_tab = nullptr; ds.cpb_rec = nullptr; (void)hipGetLastError(); }   // no HBM for them: memo + index
   }
   const bool memo_on = tune().lm_memo != 0;  // (0: measure without)
   if (hs.utf8 && ord <= 5 && !lm_only && memo_on) {  // FullScore cache of the code-point search (ctc.h: DevScorer::memo)

@@ -56,7 +56,7 @@
   X(lm_memo, 1, "code-point scorer: FullScore memo table (0 off, 1 = 2^24 entries of 32 B -- measured on the code-point bench scorer: 2^18 66.4 ms per batch, 2^22 54.1, 2^24 49.3 --, 10..26 = log2 of the entry count); read when a scorer is loaded")                                                                         \
   X(unit_bounds, 1, "code-point scorer: upper bounds of the LM score (candidates that cannot reach the beam skip FullScore): 1 = the largest over all units, 2 = also a table by code point; read when a scorer is loaded") \
   X(dict_tree_mb, 2048, "dictionary unfolded into a tree (no arc reads in the search): byte cap in MiB, 0 = keep the automaton")           \
-  X(cp_blocks, 0, "code-point scorer: also build the bigram blocks (context x 64 consecutive code points -> one table entry + one slice); host side only so far (STTX_TestLm mode 3); read when a scorer is loaded")   \
+  X(cp_blocks, 1, "code-point scorer: bigram blocks (context x 64 consecutive code points -> one table entry + one slice of records; unigram records by code point): a FullScore of a unit that is one code point of the vocabulary goes through them -- no hash of its bytes, no vocabulary probe, no memo (round 6: the bytes workload 50.1 -> 45.6 ms per batch, the LM phase on flat emissions 1.36 M -> 0.87 M cycles per stream-timestep); 0 = memo + index only; read when a scorer is loaded")   \
   X(cp_index, 1, "code-point scorer: a FullScore that misses the memo goes through the hashed n-gram index (one bucket read per order) instead of the trie walk (an interpolation search per order); read when a scorer is loaded")   \
   X(lm_index_mb, 4096, "hashed n-gram index: byte cap in MiB (larger models take the trie walk)")                                  \
   X(arena_shrink, 1, "test hook: divides the optimistic arena sizes of a batch group (forces the overflow -> decode-again path)")        \

@@ -25,7 +25,7 @@ def _both(lm, words, bos):
     try:
         return native.lm_score(lm, words, bos, mode=3), native.lm_score(lm, words, bos, mode=0)
     finally:
-        native.set_tuning("cp_blocks", 0)
+        native.set_tuning("cp_blocks", 1)     # (the default since round 6)
 
 
 def test_blocks_equal_the_index_and_the_port_trie_walk(cp_lm, port):
@@ -81,5 +81,9 @@ def test_sibling_sweep_over_a_block(cp_lm, port):
 
 def test_blocks_need_the_tunable(cp_lm):
     lm, units = cp_lm
-    with pytest.raises(RuntimeError):
-        native.lm_score(lm, [str(units[0])], True, mode=3)               # cp_blocks = 0: not built
+    native.set_tuning("cp_blocks", 0)
+    try:
+        with pytest.raises(RuntimeError):
+            native.lm_score(lm, [str(units[0])], True, mode=3)           # cp_blocks = 0: not built
+    finally:
+        native.set_tuning("cp_blocks", 1)
