@@ -1799,6 +1799,14 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
   if (!WIDE && next_row) { if (MASKED) prep_row_at(p, L, buf ^ 1, prep_c, pre); else prep_row(p, L, buf ^ 1, next_row, pre); }
   bool merged = false;
   float my_score = NEG;
+  // bitmap form: log_p of a "prefix i + space" extension with the language-model score of prefix i added (:209-243) -- the score the
+  // LM waves (or, without them, the threads of the phase below) left in pqs
+  auto score_ext = [&](float lp0, int i) -> float {
+    float lms = 0.0f;
+    if (L.pqe[cur][i] != STT_NONE) lms = L.pqs[cur][i]; else lds_or(&sc[SC_ERR], 8);
+    const float lpv = __fadd_rn(lp0, lms);                  // log_p += score;
+    return (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
+  };
   if (SC_ON) {
     unsigned lmq = 0;
     if (MASKED) {  // no queue in this form; the LM waves (still in their queries, or waiting at the barrier below) have nothing to do here
@@ -1813,7 +1821,17 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
           ++lmq;
         }
       }
-      if (!lmw_ && tid < n && !((L.ev_exti[tid] >> 31) && !is_absent(L.ev_ext[tid]))) { my_score = merge_live<WIDE>(p, L, W, cur, tid); merged = true; }
+      if (lm_wave) {
+        // With LM waves: their scores are waited for HERE, through their counter -- since round 6 they work off a list made when the beam was
+        // written and are done ~3 k cycles before the items are, so the wait is free in most steps -- and every live prefix is merged in one
+        // go.  (Before, a prefix whose extension waited for a score was merged in the key phase: every wave holding one ran the merge twice.)
+        (void)wait_count(&sc[SC_LMD], (uint32_t)nlm, &sc[SC_ERR], p.wait_spins);
+        if (!lmw_ && tid < n) {
+          const uint32_t xi = L.ev_exti[tid];
+          if ((xi >> 31) && !is_absent(L.ev_ext[tid])) L.ev_ext[tid] = score_ext(L.ev_ext[tid], (int)(xi & 0xFFFFu));
+          my_score = merge_live<WIDE>(p, L, W, cur, tid); merged = true;
+        }
+      } else if (!lmw_ && tid < n && !((L.ev_exti[tid] >> 31) && !is_absent(L.ev_ext[tid]))) { my_score = merge_live<WIDE>(p, L, W, cur, tid); merged = true; }
     } else if (lm_queue) {
       const int nq = __builtin_amdgcn_readfirstlane(sc[SC_NQ]);
       for (int q = NTHREADS - 1 - tid; q < nq; q += NTHREADS) {
@@ -1900,10 +1918,9 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
   if (probes) lds_add(&sc[SC_PROBES], (int)probes);
   if (MASKED && p.stamps && lane == 0) L.stm[32 + wave] += __builtin_readcyclecounter() - tick_;   // profiling level 2: arrival at the end of the score phase (wave 0: since its last TICK)
   // Bitmap step with LM waves: NO barrier between the score phase and the key phase (round 6: the LM waves were the last to arrive in half of
-  // the steps, 7.5 k cycles after the first wave).  What the key phase needs from them -- pqe / pqs of this step's "prefix + space"
-  // extensions -- is waited for through their counter; everything else the key phase reads was complete when the items were (SC_DONE).
-  if (MASKED && lm_wave) (void)wait_count(&sc[SC_LMD], (uint32_t)nlm, &sc[SC_ERR], p.wait_spins);
-  else __syncthreads();
+  // the steps, 7.5 k cycles after the first wave).  What the merges and the key phase need from them -- pqe / pqs of this step's "prefix +
+  // space" extensions -- was waited for through their counter; everything else the key phase reads was complete when the items were (SC_DONE).
+  if (!(MASKED && lm_wave)) __syncthreads();   // (with LM waves: waited for above, before the merges)
   TICK(3);
   STEP_FENCE();
 
@@ -1917,14 +1934,6 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
   int total = n + m;
   uint64_t kreg0 = ~0ULL, kreg1 = ~0ULL;
   uint32_t hmin = 0xFFFFFFFFu, hmax = 0;
-  // bitmap form: log_p of a "prefix i + space" extension with the language-model score of prefix i added (:209-243) -- the score the
-  // LM waves (or, without them, the phase above) left in pqs
-  auto score_ext = [&](float lp0, int i) -> float {
-    float lms = 0.0f;
-    if (L.pqe[cur][i] != STT_NONE) lms = L.pqs[cur][i]; else lds_or(&sc[SC_ERR], 8);
-    const float lpv = __fadd_rn(lp0, lms);                  // log_p += score;
-    return (float)__dadd_rn((double)lpv, s.beta);           // log_p += ext_scorer_->beta;
-  };
   if (SC_UTF8) {
     // code-point step: the live prefix's key stays in a register; the new prefixes that can still reach the beam (log-probability at or
     // above theta) put {key, element} on ONE compact list in the stream's workspace -- with theta in force a few thousand of the ~60 k
