@@ -699,6 +699,42 @@ def measure(wl, args, cx, steps, warmup):
                                "transcripts_and_confidences_equal_the_timed_run": bool(same),
                                "what": "the same K batches through STTX_BatchSubmit: pageable host int16 buffers (coqui-stt.h:294-297), gathered into page-locked memory "
                                        "and copied to HBM on a queue of their own, everything inside the clock"}
+    elif wl in ("peaky", "peaky_bytes") and world == 1 and args.decoders_in_flight > 1:
+        # The decoder stage as the whole chip runs it: `--decoders-in-flight` decoders side by side, one host thread each (STTX_Decoder* calls
+        # release the GIL; every decoder has its own stream and result blocks).  One decoder of 64 streams is 64 workgroups -- a quarter of the
+        # chip -- and the CPU leg beside it runs the reference on every host core at once.  A step is still one decoder's 64 x 250 frames;
+        # p50 latency is per decoder, submit to transcripts.
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(k):
+            d = decoders[k]
+            tb = time.perf_counter()
+            d.next(em)
+            tc = time.perf_counter()
+            res_ = d.decode(1, 256)
+            td = time.perf_counter()
+            if wl == "peaky_bytes":
+                tx = [bytes(int(t) + 1 for t in r[0][1]).decode("utf-8", "replace") if r else "" for r in res_]
+            else:
+                tx = ["".join(" " if t == 0 else ("'" if t == 27 else chr(ord("a") + int(t) - 1)) for t in r[0][1]) if r else "" for r in res_]
+            return tx, [float(r[0][0]) if r else 0.0 for r in res_], tc - tb, td - tc, time.perf_counter() - tb
+
+        pool = ThreadPoolExecutor(args.decoders_in_flight)
+        list(pool.map(lambda _: None, range(args.decoders_in_flight)))      # threads exist before the clock starts
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = list(pool.map(one, range(warmup, warmup + steps)))
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        pool.shutdown()
+        for tx, cf, tn, tdd, lat in outs:
+            step_s.append(lat)
+            timed_texts.append((0, tx))
+            timed_conf.append(cf)
+            timed_all.append([tx])
+            extra["next_ms"] = extra.get("next_ms", 0.0) + 1e3 * tn
+            extra["decode_ms"] = extra.get("decode_ms", 0.0) + 1e3 * tdd
+        extra["decoders_in_flight"] = args.decoders_in_flight
     else:
         if dist is not None:
             dist.barrier()
@@ -959,11 +995,13 @@ def measure(wl, args, cx, steps, warmup):
                            "note": "host-timed whole hop, not a single kernel: launch-bound (about 45 kernels per hop)"}
     elif wl in ("peaky", "peaky_bytes"):
         ms = extra.get("next_ms", 0.0) / K      # DecoderState::next alone: H2D of 1.9 MB of emissions + the search launch, host-timed
-        res["stage_ms_per_step"] = {k_: v_ / K for k_, v_ in extra.items()}
+        dif = int(extra.pop("decoders_in_flight", 1))
+        res["stage_ms_per_step"] = {k_: v_ / K for k_, v_ in extra.items()}      # (per decoder, host-timed: with several in flight they overlap)
+        res["config"]["decoders_in_flight"] = dif
         by = BATCH * 250 * (C * 4 + 2 * beam * 40)
         res["roofline"] = {"kernel": "ctc_next_kernel (+ H2D of %.1f MB emissions)" % (BATCH * 250 * C * 4 / 1e6), "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "us_per_stream_timestep": 1e3 * ms / 250.0,
-                           "note": "host-timed STTX_DecoderNext of 64 streams x 250 frames (state slabs allocated before the clock)"}
+                           "note": "host-timed STTX_DecoderNext of 64 streams x 250 frames (state slabs allocated before the clock); %d decoder(s) in flight, one host thread each: ms_per_step is the whole job's, this is ONE launch of 64 workgroups" % dif}
     else:
         T = 250
         rows = res["config"]["rows_per_recurrent_step"]
@@ -1101,6 +1139,7 @@ def main():
     ap.add_argument("--all-marks", action="store_true", help="experiment: every stage mark inside the timed region (rounds 1-5; costs the pipeline ~3 %)")
     ap.add_argument("--no-profile", action="store_true", help="experiment: no HIP-event stage timing inside the timed region")
     ap.add_argument("--host-audio", action="store_true", help="experiment: batch / bytes time STTX_BatchSubmit (host buffers, copy inside the clock) as the run's timed path")
+    ap.add_argument("--decoders-in-flight", type=int, default=4, help="peaky / peaky_bytes: decoders driven side by side, one host thread each (a decoder is one workgroup per stream: 64 streams are a quarter of the chip); 1 = one after the other (rounds 1-5)")
     ap.add_argument("--no-pipeline", action="store_true", help="batch / bytes: one blocking call per step instead of several batches in flight")
     args = ap.parse_args()
     os.environ["STT_AMD_TEST_HOOKS"] = "0"      # the measured library is the SHIPPED one (stt_amd/lib/libstt.so), never the tests' hooks build; before stt_amd is imported

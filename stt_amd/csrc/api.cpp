@@ -1270,6 +1270,12 @@ struct STTX_Decoder {
   DecoderBatch db;
   DecParams p;
   DevBuf probs, fbegin, fcount, wide, stamps;
+  // A decoder runs on a stream and result blocks of its OWN: several decoders of one model may be driven side by side from several host
+  // threads (one decoder = one workgroup per stream: 64 streams are a quarter of the chip) -- round 6, bench.py's decoder-stage workloads.
+  hipStream_t st = nullptr;
+  DevBuf ws_out;
+  PinnedBuf h_out;
+  ~STTX_Decoder() { if (st) (void)hipStreamDestroy(st); }
   HotTables ht;
   int prof = 0;            // STTX_DecoderSetProfiling
   float search_ms = 0;     // HIP-event time of the search launches since profiling was switched on
@@ -1280,7 +1286,9 @@ int STTX_DecoderCreate(ModelState* m, unsigned int aNumStreams, unsigned int aBe
     HIP_CHECK(hipSetDevice(m->device));
     std::unique_ptr<STTX_Decoder> d(new STTX_Decoder());
     d->m = m; d->scorer = m->scorer_; d->hot = m->hot_words_;
+    create_engine_stream(&d->st, 3);
     m->decoder_create(d->db, (int)aNumStreams, (int)aBeamWidth, 256, d->scorer);  // arenas for 256 frames up front, like a stream's; longer inputs grow them (decoder_reserve)
+    HIP_CHECK(hipStreamSynchronize(m->stream));   // (the table was initialised on the model's stream; everything after runs on the decoder's own)
     d->p = DecParams{};
     d->p.C = m->g.n_classes; d->p.blank = d->p.C - 1; d->p.beam = (int)aBeamWidth; d->p.cutoff_top_n = (int)aCutoffTopN; d->p.cutoff_prob = aCutoffProb;
     *retval = d.release();
@@ -1294,21 +1302,21 @@ int STTX_DecoderNext(STTX_Decoder* d, const float* aProbs, unsigned int aStride,
     const int n = d->db.n_streams;
     std::vector<int> more(n), zeros(n, 0);
     for (int i = 0; i < n; ++i) more[i] = (int)aNumFrames[i];
-    m->decoder_reserve(d->db, more);
-    d->probs.upload(aProbs, (size_t)n * aStride * d->p.C * 4, m->stream);
-    d->fbegin.upload(zeros.data(), n * 4, m->stream);
-    d->fcount.upload(more.data(), n * 4, m->stream);
+    m->decoder_reserve(d->db, more, d->st);
+    d->probs.upload(aProbs, (size_t)n * aStride * d->p.C * 4, d->st);
+    d->fbegin.upload(zeros.data(), n * 4, d->st);
+    d->fcount.upload(more.data(), n * 4, d->st);
     d->p.t_max = (int)aStride;
     DevScorer ds = m->current_scorer(d->scorer, d->hot, d->ht);
     int max_frames = 1;
     for (int i = 0; i < n; ++i) max_frames = std::max(max_frames, more[i]);
     d->wide.reserve(ctc_rows_ws_bytes(d->p, n, max_frames));
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (d->prof) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); HIP_CHECK(hipEventRecord(e0, m->stream)); }
-    launch_ctc_next(d->p, ds, m->dev_alphabet, d->db.table.as<DecStream>(), n, d->probs.as<float>(), d->fbegin.as<int>(), d->fcount.as<int>(), m->stream,
+    if (d->prof) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); HIP_CHECK(hipEventRecord(e0, d->st)); }
+    launch_ctc_next(d->p, ds, m->dev_alphabet, d->db.table.as<DecStream>(), n, d->probs.as<float>(), d->fbegin.as<int>(), d->fcount.as<int>(), d->st,
                     max_frames, d->wide.p);
-    if (d->prof) HIP_CHECK(hipEventRecord(e1, m->stream));
-    HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (d->prof) HIP_CHECK(hipEventRecord(e1, d->st));
+    HIP_CHECK(hipStreamSynchronize(d->st));
     if (d->prof) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1)); d->search_ms += ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     HIP_CHECK(hipGetLastError());
     return (int)STT_ERR_OK;
@@ -1318,7 +1326,8 @@ int STTX_DecoderDecode(const STTX_Decoder* d, unsigned int aNumResults, unsigned
                        double* aConfidences, int* aNumResultsOut) {
   return guarded([&]() {
     HIP_CHECK(hipSetDevice(d->m->device));
-    auto outs = decode_streams(*d->m, d->db, d->scorer, d->hot, const_cast<STTX_Decoder*>(d)->ht, aNumResults, (int)aMaxLen);
+    STTX_Decoder* dm = const_cast<STTX_Decoder*>(d);   // (workspaces only)
+    auto outs = decode_table(*d->m, d->db.table.as<DecStream>(), d->db.n_streams, d->db.beam, d->db.C, d->scorer, d->hot, dm->ht, aNumResults, (int)aMaxLen, d->st, &dm->ws_out, &dm->h_out);
     for (size_t i = 0; i < outs.size(); ++i) {
       aNumResultsOut[i] = (int)outs[i].size();
       for (size_t r = 0; r < outs[i].size(); ++r) {

@@ -774,8 +774,9 @@ void ModelState::decoder_create(DecoderBatch& db, int n_streams, int beam, int e
 
 // Streaming use: make sure stream i can append `more_frames[i]` further timesteps.  Grows the whole slab
 // (copying the live state) when an arena would overflow; rare (capacity doubles).
-void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_frames) {
+void ModelState::decoder_reserve(DecoderBatch& db, const std::vector<int>& more_frames, hipStream_t st_in) {
   if (g_debug_arena_frames > 0) return;  // test hook: no growth
+  hipStream_t stream = st_in ? st_in : this->stream;   // (shadows the member on purpose: everything below runs on the caller's stream)
   HIP_CHECK(hipMemcpyAsync(db.host.data(), db.table.p, sizeof(DecStream) * db.n_streams, hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
   bool grow = false;
@@ -847,18 +848,22 @@ std::vector<std::vector<Output>> decode_streams(const ModelState& mc, const Deco
 }
 
 std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_table, int n, int beam, int C, std::shared_ptr<ScorerDev> sc,
-                                              const std::map<std::string, float>& hot, HotTables& ht, unsigned num_results, int max_len) {
+                                              const std::map<std::string, float>& hot, HotTables& ht, unsigned num_results, int max_len,
+                                              hipStream_t st, DevBuf* ws, PinnedBuf* ho) {
   const int nr = (int)std::max(1u, std::min<unsigned>(num_results, (unsigned)beam));
   const DecodeBlock blk = DecodeBlock::layout(n, nr, max_len);
-  m.ws_out.reserve(blk.bytes); m.h_out.reserve(blk.bytes);
-  const DecodeOut o = blk.view(m.ws_out.p, nr, max_len);
+  DevBuf& ws_out = ws ? *ws : m.ws_out;
+  PinnedBuf& h_out = ho ? *ho : m.h_out;
+  hipStream_t stream = st ? st : m.stream;
+  ws_out.reserve(blk.bytes); h_out.reserve(blk.bytes);
+  const DecodeOut o = blk.view(ws_out.p, nr, max_len);
   DecParams p{};
   p.C = C; p.blank = C - 1; p.beam = beam; p.cutoff_top_n = 40; p.cutoff_prob = 1.0; p.t_max = 0;
   DevScorer ds = m.current_scorer(sc, hot, ht);
-  launch_ctc_decode(p, ds, m.dev_alphabet, d_table, n, o, m.stream);
-  copy_d2h(m.h_out, m.ws_out.p, blk.bytes, m.stream);  // one block, page-locked destination
-  HIP_CHECK(hipStreamSynchronize(m.stream));
-  const DecodeOut h = blk.view(m.h_out.p, nr, max_len);
+  launch_ctc_decode(p, ds, m.dev_alphabet, d_table, n, o, stream);
+  copy_d2h(h_out, ws_out.p, blk.bytes, stream);  // one block, page-locked destination
+  HIP_CHECK(hipStreamSynchronize(stream));
+  const DecodeOut h = blk.view(h_out.p, nr, max_len);
   const uint32_t *tok = h.tokens, *ts = h.timesteps;
   const int *lens = h.lens, *nres = h.n_results;
   const double* conf = h.confidence;

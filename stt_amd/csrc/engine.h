@@ -386,7 +386,7 @@ struct ModelState {
   // decode_cache: lay out (and clear) the arrays of the incremental back-tracking -- streams that are decoded hop after hop
   void decoder_create(DecoderBatch& db, int n_streams, int beam, int expected_frames, std::shared_ptr<ScorerDev> sc, PinnedBuf* staging = nullptr,
                       bool optimistic = false, bool decode_cache = false);
-  void decoder_reserve(DecoderBatch& db, const std::vector<int>& more_frames);
+  void decoder_reserve(DecoderBatch& db, const std::vector<int>& more_frames, hipStream_t st = nullptr);   // (st: the stream the table is read back on; null = the model's)
 };
 
 
@@ -422,8 +422,11 @@ struct StreamingState {
 
 std::vector<std::vector<Output>> decode_streams(const ModelState& m, const DecoderBatch& db, std::shared_ptr<ScorerDev> sc,
                                                 const std::map<std::string, float>& hot, HotTables& ht, unsigned num_results, int max_len);
+// (st / ws / ho: the caller's own stream, device and page-locked result blocks -- a STTX_Decoder's, so that several decoders of one model can run
+// side by side from several host threads; null = the model's)
 std::vector<std::vector<Output>> decode_table(ModelState& m, const DecStream* d_table, int n, int beam, int C, std::shared_ptr<ScorerDev> sc,
-                                              const std::map<std::string, float>& hot, HotTables& ht, unsigned num_results, int max_len);
+                                              const std::map<std::string, float>& hot, HotTables& ht, unsigned num_results, int max_len,
+                                              hipStream_t st = nullptr, DevBuf* ws = nullptr, PinnedBuf* ho = nullptr);
 // Many streams of one model at once (same beam width, scorer and hot words; otherwise the callers fall back to one by one):
 // what STT_FeedAudioContent / STT_IntermediateDecode / flushBuffers do, with the ready windows of all streams pushed through
 // the acoustic model and the beam search as one batch.

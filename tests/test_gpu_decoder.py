@@ -154,6 +154,49 @@ def test_decoder_streams_are_independent_and_chunking_is_exact(models, port, eng
         assert a == b == c, i
 
 
+def test_decoders_of_one_model_on_several_host_threads(models, english, fix):
+    """Round 6: a STTX_Decoder runs on a stream and result blocks of its own, so several decoders of ONE model may be driven side by side from
+    several host threads (bench.py's decoder-stage workloads keep four in flight).  Eight decoders on four threads, fed in chunks with a
+    decode after every chunk: every result equals the same work done one decoder after the other."""
+    import threading
+    vocab = open(os.path.join(fix, "vocab.pruned.txt")).read().split()
+    rng = np.random.RandomState(91)
+    m = models[("word", True)]
+    jobs = []
+    for j in range(8):
+        rows = []
+        for i in range(6):
+            sent = " ".join(rng.choice(vocab, size=rng.randint(2, 6)))
+            lab = [0 if ch == " " else (27 if ch == "'" else ord(ch) - ord("a") + 1) for ch in sent]
+            rows.append(synth.peaky_emissions(lab, 120, 29, 28, seed=100 * j + i, noise=0.2)[:120])
+        jobs.append(np.stack(rows).astype(np.float32))
+
+    def run(batch):
+        d = m.createDecoder(len(batch), 100)
+        out = []
+        for k in range(0, batch.shape[1], 40):
+            d.next(batch[:, k:k + 40])
+            out.append([canon(r) for r in d.decode(3)])
+        return out
+
+    want = [run(b) for b in jobs]
+    got, errs = [None] * len(jobs), []
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                for j in range(t, len(jobs), 4):
+                    got[j] = run(jobs[j])
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    assert got == want
+
+
 def test_decoder_with_synthetic_order5_scorer(models, port, english, fix, tmp_path):
     """A scorer written by stt_amd/tools (synthetic order-5 quantised array trie, 3000 pseudo-words, words up to 15 letters):
     exercises every trie level, the Bhiksha hint table, the interpolation search and the 16-byte word registers."""
