@@ -180,7 +180,6 @@ struct DecParams {
   int lm_prio;     // bitmap step: s_setprio of the language-model waves while they run their queries (filled in by launch_ctc_next)
   int wait_spins;  // bitmap step: polls a counter wait may take before it gives up with error bit 0x10 (filled in by launch_ctc_next)
   unsigned long long key_mask;  // test hook (tunable debug_key_bits): path keys truncated, so that collisions happen and the guard (error bit 0x20) can be seen to fire; ~0 otherwise (filled in by launch_ctc_next)
-  int exp;         // bitmap step: A/B switches (tunable search_exp; filled in by launch_ctc_next)
   int n_lm_waves;  // bitmap step: waves of the workgroup that only run language-model queries (0 = by beam width; filled in by launch_ctc_next)
   // profiling level 2: [n_streams][64] shader cycles, summed over the steps.  Slots: [w] wave w reaches the end of the expand phase
   // (since the step began; wave 0: since its last phase tick), [16 + w] its wait there, [32 + w] (bitmap step) arrival at the end of

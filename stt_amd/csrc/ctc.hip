@@ -2563,7 +2563,7 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
                      const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st, int max_frames, void* wide_ws) {
   DecParams p = p_in;
   const bool wide = ctc_is_wide(p.beam, p.C, s.enabled && s.utf8);
-  p.wide_rows = nullptr; p.wide_stride = 0; p.wide_max_frames = 0; p.n_lm_waves = 0; p.item_cap = 0; p.exp = 0;
+  p.wide_rows = nullptr; p.wide_stride = 0; p.wide_max_frames = 0; p.n_lm_waves = 0; p.item_cap = 0;
   if (wide && (!wide_ws || max_frames <= 0 || p.C > STT_MAX_CLASSES)) { fprintf(stderr, "stt_amd: launch_ctc_next: wide alphabet without a row workspace\n"); abort(); }
   const int cb = cap_bucket(p.beam);
   if (wide || (ctc_sorts_classes(p) && wide_ws && max_frames > 0 && p.C <= WIDE_SORT_N)) {
@@ -2575,7 +2575,6 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
   p.wait_spins = tune().wait_spins > 0 ? tune().wait_spins : (1 << 22);
   p.key_mask = (tune().debug_key_bits >= 4 && tune().debug_key_bits < 63) ? ((1ULL << tune().debug_key_bits) - 1ULL) : ~0ULL;
   p.lm_prio = tune().lm_prio;
-  p.exp = tune().search_exp;
   const int mode = !s.enabled ? 0 : (s.utf8 ? 2 : ((!wide && ctc_masked_ok(p, s, al)) ? 4 : 1));
   const size_t lds = ctc_next_lds_bytes(p.beam, wide ? 0 : (mode == 4 ? 32 : p.C), s.enabled && s.utf8);   // (mode 4: the kernel carves its layout for 32 classes)
   p.lds_kb = lds_budget_kb_host();

@@ -47,7 +47,6 @@
   X(lm_prio, 3, "s_setprio of the search step's language-model waves during their queries (0..3)")                               \
   X(lm_waves, 0, "language-model waves of the search step (0 = by beam width)")                                                    \
   X(exp_waves, 0, "expand waves of the search step (0 = all the others)")                                                          \
-  X(search_exp, 0, "A/B switches of the word-mode search step (bit mask, DecParams::exp in ctc.h; every value gives the same beams)") \
   X(wait_spins, 0, "test hook: polls (of 256 cycles) an intra-workgroup counter wait of the search step may take before it gives up with error bit 0x10 (0 = 4 M, about half a second)") \
   X(debug_key_bits, 0, "test hook: path keys of the search truncated to this many bits (4..62; 0 = all 63): forces key collisions, which the guard must flag (error bit 0x20)") \
   X(item_table_cap, 0, "test hook: items per pass of the bitmap step's expand table (0 = what fits; small values force the several-pass path)") \
