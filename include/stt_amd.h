@@ -164,7 +164,11 @@ STTX_EXPORT int STTX_GetGeometry(const ModelState* aCtx, int* aOut10);
 
 /* ---- decoder on caller-supplied emissions ----------------------------------------------------- */
 typedef struct STTX_Decoder STTX_Decoder;
-/* aNumStreams independent DecoderStates sharing the model's alphabet, scorer and hot words (captured now). */
+/* aNumStreams independent DecoderStates sharing the model's alphabet, scorer and hot words (captured now).
+ * Threads: a decoder runs on a HIP stream and result blocks of its own, so DIFFERENT decoders of one model may be driven from different host
+ * threads at the same time (one decoder = one workgroup per stream: 64 streams are a quarter of an MI355X; bench.py's decoder-stage
+ * workloads keep four decoders in flight).  One decoder is used from one thread at a time, and no decoder call may overlap a call that
+ * changes the model (scorer, hot words, tunables) -- the reference's rule for a model, applied per decoder. */
 STTX_EXPORT int STTX_DecoderCreate(ModelState* aCtx, unsigned int aNumStreams, unsigned int aBeamWidth, double aCutoffProb,
                                   unsigned int aCutoffTopN, STTX_Decoder** retval);
 /* aProbs: [aNumStreams][aStride][n_classes] floats; stream i consumes its first aNumFrames[i] rows. */
