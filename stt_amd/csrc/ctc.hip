@@ -12,6 +12,8 @@
 //       workgroup prefix sum                                                    :150-207, path_trie.cpp:37-100
 //   P3  language-model scores of boundary extensions (trie walk in HBM); in word mode one KenLM FullScore from the
 //       cached state of the previous word boundary                            :209-243, scorer.cpp:308-396
+//       (bitmap step, round 6: the LM waves work off a list made when the beam was written and are waited for through a counter;
+//        code-point step: FullScore through the bigram blocks -- lm_full_score_blocks)
 //   P4  merge the <=3 events of every live prefix in the reference's visiting order :166-193,245-253
 //   P5  scores (iterate_to_vec); bucket histogram + prefix sum finds the beam_size-th key, kept keys are ranked inside
 //       their bucket segment (rank == position in the new beam)               path_trie.cpp:159-190, :263-274
