@@ -555,6 +555,7 @@ def measure(wl, args, cx, steps, warmup):
         desc = ("configs[4] decoder stage on peaky synthetic byte emissions (blank ~0.9, every byte of 19 three-byte code points held 2 frames, noise mass as "
                 "the word-mode peaky workload): 64 streams x 250 frames, 256 classes, beam_width=1024, scorer = " + scorer_desc)
         gbatch = world * BATCH
+        native.set_tuning("decoder_streams", max(1, min(4, args.decoders_in_flight)) if world == 1 else 1)
         decoders = [model.createDecoder(BATCH, beam) for _ in range(steps + warmup)]
     else:  # peaky
         vocab = open(os.path.join(FIX, "vocab.pruned.txt")).read().split()
@@ -574,6 +575,7 @@ def measure(wl, args, cx, steps, warmup):
         desc = ("configs[1] decoder stage on peaky synthetic emissions (blank ~0.9, labels held 2 frames, noise 0.02): 64 streams x 250 frames, "
                 "beam_width=500, scorer = " + scorer_desc)
         gbatch = world * BATCH
+        native.set_tuning("decoder_streams", max(1, min(4, args.decoders_in_flight)) if world == 1 else 1)      # (a pool of streams for the decoders: INTEGRATION.md)
         decoders = [model.createDecoder(BATCH, BEAM) for _ in range(steps + warmup)]    # state slabs: allocated before the clock starts
     step_no = [0]
     step_conf = []      # peaky workloads: the best transcript's confidence per stream, per step

@@ -165,9 +165,10 @@ STTX_EXPORT int STTX_GetGeometry(const ModelState* aCtx, int* aOut10);
 /* ---- decoder on caller-supplied emissions ----------------------------------------------------- */
 typedef struct STTX_Decoder STTX_Decoder;
 /* aNumStreams independent DecoderStates sharing the model's alphabet, scorer and hot words (captured now).
- * Threads: a decoder runs on a HIP stream and result blocks of its own, so DIFFERENT decoders of one model may be driven from different host
- * threads at the same time (one decoder = one workgroup per stream: 64 streams are a quarter of an MI355X; bench.py's decoder-stage
- * workloads keep four decoders in flight).  One decoder is used from one thread at a time, and no decoder call may overlap a call that
+ * Threads: a decoder has result blocks of its own and runs on one of the model's decoder streams (tunable decoder_streams: 1 = the model's own
+ * stream, the default; 2..4 = a pool dealt round-robin at creation), so DIFFERENT decoders of one model may be driven from different host
+ * threads at the same time -- side by side on the GPU with decoder_streams > 1 (one decoder = one workgroup per stream: 64 streams are a
+ * quarter of an MI355X; bench.py's decoder-stage workloads keep four decoders in flight).  One decoder is used from one thread at a time, and no decoder call may overlap a call that
  * changes the model (scorer, hot words, tunables) -- the reference's rule for a model, applied per decoder. */
 STTX_EXPORT int STTX_DecoderCreate(ModelState* aCtx, unsigned int aNumStreams, unsigned int aBeamWidth, double aCutoffProb,
                                   unsigned int aCutoffTopN, STTX_Decoder** retval);

@@ -1270,12 +1270,12 @@ struct STTX_Decoder {
   DecoderBatch db;
   DecParams p;
   DevBuf probs, fbegin, fcount, wide, stamps;
-  // A decoder runs on a stream and result blocks of its OWN: several decoders of one model may be driven side by side from several host
-  // threads (one decoder = one workgroup per stream: 64 streams are a quarter of the chip) -- round 6, bench.py's decoder-stage workloads.
-  hipStream_t st = nullptr;
+  // A decoder runs on one of the model's decoder streams (ModelState::decoder_stream: a pool of eight, dealt round-robin) and result blocks
+  // of its OWN: several decoders of one model may be driven side by side from several host threads (one decoder = one workgroup per
+  // stream: 64 streams are a quarter of the chip) -- round 6, bench.py's decoder-stage workloads.
+  hipStream_t st = nullptr;   // (the model's: not destroyed here)
   DevBuf ws_out;
   PinnedBuf h_out;
-  ~STTX_Decoder() { if (st) (void)hipStreamDestroy(st); }
   HotTables ht;
   int prof = 0;            // STTX_DecoderSetProfiling
   float search_ms = 0;     // HIP-event time of the search launches since profiling was switched on
@@ -1286,7 +1286,7 @@ int STTX_DecoderCreate(ModelState* m, unsigned int aNumStreams, unsigned int aBe
     HIP_CHECK(hipSetDevice(m->device));
     std::unique_ptr<STTX_Decoder> d(new STTX_Decoder());
     d->m = m; d->scorer = m->scorer_; d->hot = m->hot_words_;
-    create_engine_stream(&d->st, 3);
+    d->st = m->decoder_stream();
     m->decoder_create(d->db, (int)aNumStreams, (int)aBeamWidth, 256, d->scorer);  // arenas for 256 frames up front, like a stream's; longer inputs grow them (decoder_reserve)
     HIP_CHECK(hipStreamSynchronize(m->stream));   // (the table was initialised on the model's stream; everything after runs on the decoder's own)
     d->p = DecParams{};

@@ -841,6 +841,15 @@ void check_decoder_errors(const int* errors, int n) {
   }
 }
 
+hipStream_t ModelState::decoder_stream() {
+  const int n = std::min(tune().decoder_streams, (int)kDecoderStreams);
+  if (n <= 1) return stream;      // (the default: every decoder on the model's own stream, as in rounds 1 - 5)
+  std::lock_guard<std::mutex> lk(decoder_stream_mu_);
+  hipStream_t& s = decoder_streams_[decoder_stream_next_++ % (unsigned)n];
+  if (!s) create_engine_stream(&s, 3);
+  return s;
+}
+
 std::vector<std::vector<Output>> decode_streams(const ModelState& mc, const DecoderBatch& db, std::shared_ptr<ScorerDev> sc,
                                                 const std::map<std::string, float>& hot, HotTables& ht, unsigned num_results, int max_len) {
   ModelState& m = const_cast<ModelState&>(mc);  // workspaces only

@@ -204,6 +204,21 @@ struct ModelState {
   unsigned beam_width_ = 500;
   hipStream_t stream = nullptr;      // acoustic model, streaming path, decode
   hipStream_t stream_dec = nullptr;  // batch path: the beam search of chunk k runs here while `stream` computes chunk k+1
+  // Standalone decoders (STTX_Decoder): by default on the model's own stream; with the tunable decoder_streams = N (2 .. 4) on a POOL of N streams
+  // owned by the model, dealt round-robin at creation, so that decoders of one model can be driven side by side from several host threads (two
+  // on one stream simply take turns; one decoder is a quarter of the chip, so four is the useful number).  Opt-in, and not a stream per
+  // decoder, because of what tests/test_gpu_fuzz.py with STT_FUZZ_SEED=2 found in round 6: with four models alive and a stream per decoder
+  // (or a pool of 8, or of 4, per model) the process holds more streams than the runtime has hardware queues (GPU_MAX_HW_QUEUES = 16), the
+  // decoders' launches are kernels of changing instantiations and scratch sizes (the code-point step spills), and the run ends in a GPU
+  // memory fault or a corrupted beam (error bit 0x20) although every call is host-synchronous; with at most 16 streams in the process
+  // (pools of 1, 2, 4 with two models; one shared stream) it never does, and none of HSA_ENABLE_SCRATCH_ASYNC_RECLAIM=0 /
+  // HSA_NO_SCRATCH_RECLAIM=1 / AMD_OPT_FLUSH=0 changes it.  Suspected: scratch state of a hardware queue shared by several streams.  See
+  // INTEGRATION.md ("more streams than hardware queues").
+  static constexpr int kDecoderStreams = 4;
+  hipStream_t decoder_streams_[kDecoderStreams] = {};
+  unsigned decoder_stream_next_ = 0;
+  std::mutex decoder_stream_mu_;
+  hipStream_t decoder_stream();
   int device = 0;
 
   // weights in HBM (f16, transposed / packed; see kernels_am.hip header)

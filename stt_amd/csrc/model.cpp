@@ -107,6 +107,7 @@ ModelState::~ModelState() {
   for (StreamingState* s : stream_pool_) delete s;
   if (stream) (void)hipStreamDestroy(stream);
   if (stream_dec) (void)hipStreamDestroy(stream_dec);
+  for (hipStream_t s : decoder_streams_) if (s) (void)hipStreamDestroy(s);
   for (auto& e : ev_chunk) if (e) (void)hipEventDestroy(e);
   for (auto& kv : lstm_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   for (auto& kv : hop_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);

@@ -59,6 +59,8 @@
   X(cp_blocks, 1, "code-point scorer: bigram blocks (context x 64 consecutive code points -> one table entry + one slice of records; unigram records by code point): a FullScore of a unit that is one code point of the vocabulary goes through them -- no hash of its bytes, no vocabulary probe, no memo (round 6: the bytes workload 50.1 -> 45.6 ms per batch, the LM phase on flat emissions 1.36 M -> 0.87 M cycles per stream-timestep); 0 = memo + index only; read when a scorer is loaded")   \
   X(cp_index, 1, "code-point scorer: a FullScore that misses the memo goes through the hashed n-gram index (one bucket read per order) instead of the trie walk (an interpolation search per order); read when a scorer is loaded")   \
   X(lm_index_mb, 4096, "hashed n-gram index: byte cap in MiB (larger models take the trie walk)")                                  \
+  X(decoder_streams, 1, "standalone decoders (STTX_Decoder*): 1 = every decoder on the model's own stream; 2..4 = a pool of that many streams per model, dealt round-robin when a decoder is created, so that decoders can be driven side by side from several host threads (bench.py's decoder-stage workloads: 4); keep the process at or below GPU_MAX_HW_QUEUES streams -- engine.h, INTEGRATION.md") \
+  X(debug_poison, 0, "test hook: every new device buffer is filled with this byte pattern first (1 = 0xFF, 2 = 0xA5; 0 = left as the allocator returns it): a read of memory nobody wrote then yields absurd indices instead of whatever the previous owner left there") \
   X(arena_shrink, 1, "test hook: divides the optimistic arena sizes of a batch group (forces the overflow -> decode-again path)")        \
   X(hop_replays, 0, "counter, not a knob: streaming hops whose acoustic + search pass was replayed from a captured graph")                 \
   X(arena_retries, 0, "counter, not a knob: batch groups decoded again with full-size arenas after an overflow flag")                 \

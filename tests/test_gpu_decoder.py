@@ -181,6 +181,8 @@ def test_decoders_of_one_model_on_several_host_threads(models, english, fix):
 
     want = [run(b) for b in jobs]
     got, errs = [None] * len(jobs), []
+    from stt_amd import native
+    native.set_tuning("decoder_streams", 4)      # (a pool of four streams for this model's decoders; default 1: the model's own)
 
     def worker(t):
         try:
@@ -193,6 +195,7 @@ def test_decoders_of_one_model_on_several_host_threads(models, english, fix):
     ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
     [t.start() for t in ths]
     [t.join() for t in ths]
+    native.set_tuning("decoder_streams", 1)
     assert not errs, errs
     assert got == want
 

@@ -97,6 +97,8 @@ def _fuzz(rigs, port, fix, mode, lm):
             m.clearHotWords()
             for wd, boost in hot.items():
                 m.addHotWord(wd, boost)
+        if os.environ.get("STT_FUZZ_TRACE"):
+            print("CASE", tag, flush=True)      # (the last line before a GPU fault names the case)
         d = m.createDecoder(n_streams, beam, cp, ctn)
         cuts = sorted(set(int(x) for x in rng.randint(1, T + 1, size=int(rng.randint(0, 4))))) + [T]
         k0 = 0
