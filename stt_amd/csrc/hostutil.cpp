@@ -96,7 +96,10 @@ void DevBuf::reserve(size_t bytes, bool keep, hipStream_t st) {
   size_t ncap = bytes + bytes / 4 + 256;
   void* np = nullptr;
   HIP_CHECK(hipMalloc(&np, ncap));
-  if (tune().debug_poison) HIP_CHECK(hipMemset(np, tune().debug_poison == 2 ? 0xA5 : 0xFF, ncap));   // (test hook: see tuning.h)
+  if (tune().debug_poison) {   // (test hook: see tuning.h; the fill runs on the NULL stream, which the engine's non-blocking streams do not wait for: finish it here)
+    HIP_CHECK(hipMemset(np, tune().debug_poison == 2 ? 0xA5 : 0xFF, ncap));
+    HIP_CHECK(hipDeviceSynchronize());
+  }
   if (p) {
     if (keep) {
       HIP_CHECK(hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st));

@@ -115,3 +115,38 @@ def test_two_prefixes_with_one_path_key_are_flagged_not_merged(tmp_path, fix):
         d3.next(x)
         r3 = d3.decode(1)
         assert d3.stats()["error"] == 0 and r3[0][0][0] == good[0][0][0] and np.array_equal(r3[0][0][1], good[0][0][1])
+
+
+def test_results_do_not_depend_on_what_a_fresh_allocation_holds(tmp_path, fix):
+    """Tunable debug_poison: every new device buffer is filled with 0xFF before it is handed out (round 6: found while chasing a GPU memory
+    fault; the whole GPU suite passes under it).  The cut kept here: a model with word scorer and one with the code-point (bytes) scorer,
+    blocking call, batch call, stream, standalone decoder -- loaded and run with the fill on -- give what they give without it."""
+    from stt_amd import Model, native
+    audio = [synth.synth_audio(24000 + 1600 * i, seed=40 + i) for i in range(5)]
+    x = np.random.RandomState(1).rand(3, 30, 29).astype(np.float32)
+    x /= x.sum(2, keepdims=True)
+
+    def run():
+        w = synth.synth_weights(5, n_hidden=256)
+        w["layer_6/weights"] = (w["layer_6/weights"] * 6.0).astype(np.float32)
+        path = str(tmp_path / "m.sttw")
+        modelfile.write_model(path, w, synth.ENGLISH_LABELS, beam_width=100)
+        m = Model(path)
+        m.enableExternalScorer(os.path.join(fix, "pruned_lm.scorer"))
+        out = [m.stt(audio[0]), m.sttBatch(audio)]
+        s = m.createStream()
+        for k in range(0, len(audio[1]), 5120):
+            s.feedAudioContent(audio[1][k:k + 5120])
+        out.append(s.finishStream())
+        d = m.createDecoder(3, 100)
+        d.next(x)
+        out.append([[(float(c), list(map(int, t)), list(map(int, ts))) for c, t, ts in r] for r in d.decode(4)])
+        return out
+
+    want = run()
+    native.set_tuning("debug_poison", 1)
+    try:
+        got = run()
+    finally:
+        native.set_tuning("debug_poison", 0)
+    assert got == want
