@@ -119,8 +119,8 @@ def test_two_prefixes_with_one_path_key_are_flagged_not_merged(tmp_path, fix):
 
 def test_results_do_not_depend_on_what_a_fresh_allocation_holds(tmp_path, fix):
     """Tunable debug_poison: every new device buffer is filled with 0xFF before it is handed out (round 6: found while chasing a GPU memory
-    fault; the whole GPU suite passes under it).  The cut kept here: a model with word scorer and one with the code-point (bytes) scorer,
-    blocking call, batch call, stream, standalone decoder -- loaded and run with the fill on -- give what they give without it."""
+    fault; the whole GPU suite passes under it).  The cut kept here: a model with its scorer, loaded and run with the fill on -- blocking call, batch
+    call, stream, standalone decoder -- gives what it gives without it."""
     from stt_amd import Model, native
     audio = [synth.synth_audio(24000 + 1600 * i, seed=40 + i) for i in range(5)]
     x = np.random.RandomState(1).rand(3, 30, 29).astype(np.float32)
