@@ -212,8 +212,8 @@ struct ModelState {
   // decoders' launches are kernels of changing instantiations and scratch sizes (the code-point step spills), and the run ends in a GPU
   // memory fault or a corrupted beam (error bit 0x20) although every call is host-synchronous; with at most 16 streams in the process
   // (pools of 1, 2, 4 with two models; one shared stream) it never does, and none of HSA_ENABLE_SCRATCH_ASYNC_RECLAIM=0 /
-  // HSA_NO_SCRATCH_RECLAIM=1 / AMD_OPT_FLUSH=0 changes it.  Suspected: scratch state of a hardware queue shared by several streams.  See
-  // INTEGRATION.md ("more streams than hardware queues").
+  // HSA_NO_SCRATCH_RECLAIM=1 / AMD_OPT_FLUSH=0 changes it; a plain HIP program of that shape is clean (benchmarks/scratch_queue_probe.hip), and so
+  // is the fuzz beside 24 idle foreign streams with the decoders on the model's stream.  See INTEGRATION.md ("More streams than hardware queues").
   static constexpr int kDecoderStreams = 4;
   hipStream_t decoder_streams_[kDecoderStreams] = {};
   unsigned decoder_stream_next_ = 0;
