@@ -1790,11 +1790,20 @@ int STTX_TestLm(const char* aLm, unsigned int aLmBytes, const char* const* aWord
     const int rc = sc.LoadLmOnly(aLm, aLmBytes);
     if (rc != STT_ERR_OK) return rc;
     if (aMode == 2 && (!sc.dev.lmi || sc.dev.order > 5 || !sc.dev.uni_in_vtab)) return (int)STT_ERR_SCORER_INVALID_LM;
+    if (aMode == 4 && !sc.dev.cpt) return (int)STT_ERR_SCORER_INVALID_LM;   // (the bigram blocks on the DEVICE: tunable cp_blocks, a code-point model)
     std::vector<uint64_t> hs(aNumWords);
-    for (unsigned i = 0; i < aNumWords; ++i) hs[i] = stt_murmur64a(aWords[i], strlen(aWords[i]));
+    for (unsigned i = 0; i < aNumWords; ++i) {
+      hs[i] = stt_murmur64a(aWords[i], strlen(aWords[i]));
+      if (aMode == 4) {   // the unit's bytes, first byte lowest (three at most)
+        const size_t wl = strlen(aWords[i]);
+        if (wl == 0 || wl > 3) return (int)STT_ERR_INVALID_SHAPE;
+        hs[i] = 0;
+        for (size_t b = 0; b < wl; ++b) hs[i] |= (uint64_t)(unsigned char)aWords[i][b] << (8 * b);
+      }
+    }
     DevBuf dh, dp, dl;
     dh.upload(hs.data(), hs.size() * 8); dp.reserve((size_t)aNumWords * 4); dl.reserve((size_t)aNumWords * 4);
-    launch_test_lm(sc.dev, dh.as<uint64_t>(), (int)aNumWords, aBos, aMode == 2 ? 1 : 0, dp.as<float>(), dl.as<int>(), nullptr);
+    launch_test_lm(sc.dev, dh.as<uint64_t>(), (int)aNumWords, aBos, aMode == 4 ? 2 : (aMode == 2 ? 1 : 0), dp.as<float>(), dl.as<int>(), nullptr);
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(aProbs, dp.p, (size_t)aNumWords * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(aLens, dl.p, (size_t)aNumWords * 4, hipMemcpyDeviceToHost));

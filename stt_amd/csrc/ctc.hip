@@ -713,7 +713,8 @@ __device__ __forceinline__ bool utf8_unit_code_point(uint32_t u, uint32_t& cp) {
 // code points a prefix's children complete, whose unigram records are one contiguous 1 KB of cpt -- and a bit of its presence map; a stored
 // bigram (rare: 5 % of the bench's queries) continues in the hashed index from the slot its record names.  `unit` = the code point's bytes
 // (hashed only on that path).  Same floats as the index and the trie walk (tests/test_cp_blocks.py, tests/test_gpu_lm.py).
-__device__ __forceinline__ float lm_full_score_blocks(const DevScorer& s, const KState& in, uint32_t cp, uint32_t unit, const u32x4& ct, KState& out, unsigned& probes) {
+__device__ __forceinline__ float lm_full_score_blocks(const DevScorer& s, const KState& in, uint32_t cp, uint32_t unit, const u32x4& ct, KState& out, unsigned& probes,
+                                                      int* ngram_length = nullptr) {
   const uint32_t wi = ct.x;
   const float uprob = __uint_as_float(ct.y), uback = __uint_as_float(ct.z);
   const bool uindep = (ct.w & 2u) != 0;
@@ -759,7 +760,9 @@ __device__ __forceinline__ float lm_full_score_blocks(const DevScorer& s, const 
     }
   }
   int nl;
-  return lmi_combine(s.order, in, wi, uprob, uback, uindep, lv, out, nl);
+  const float r = lmi_combine(s.order, in, wi, uprob, uback, uindep, lv, out, nl);
+  if (ngram_length) *ngram_length = nl;
+  return r;
 }
 
 // IDX: FullScore through the hashed n-gram index (the scorer must have one: orders <= 5), else the trie walk
@@ -2637,7 +2640,14 @@ __global__ void test_lm_kernel(DevScorer s, const uint64_t* hashes, int n, int b
   unsigned probes = 0;
   for (int i = 0; i < n; ++i) {
     float prob; int nl = 0;
-    if (use_index) { DevVocabSlot vs; const uint32_t wi = vocab_slot(s, hashes[i], vs, probes); prob = lm_full_score_indexed(s, st[cur], hashes[i], wi, vs, st[cur ^ 1], probes, &nl); }
+    if (use_index == 2) {   // the bigram blocks: hashes[i] holds the unit's UTF-8 bytes, first byte lowest (a code point of the vocabulary; else prob = NaN)
+      const uint32_t unit = (uint32_t)hashes[i];
+      uint32_t cp = 0;
+      u32x4 ct = {0u, 0u, 0u, 0u};
+      if (s.cpt != nullptr && utf8_unit_code_point(unit, cp)) ct = ((const GLB_AS u32x4*)s.cpt)[cp];
+      if (ct.w & 1u) prob = lm_full_score_blocks(s, st[cur], cp, unit, ct, st[cur ^ 1], probes, &nl);
+      else { prob = __uint_as_float(0x7FC00000u); st[cur ^ 1] = st[cur]; }
+    } else if (use_index) { DevVocabSlot vs; const uint32_t wi = vocab_slot(s, hashes[i], vs, probes); prob = lm_full_score_indexed(s, st[cur], hashes[i], wi, vs, st[cur ^ 1], probes, &nl); }
     else { const uint32_t wi = vocab_index(s, hashes[i], probes); prob = kenlm_full_score(s, st[cur], wi, st[cur ^ 1], probes, nullptr, &nl); }
     if (threadIdx.x == 0) { probs[i] = prob; lens[i] = nl; }
     cur ^= 1;

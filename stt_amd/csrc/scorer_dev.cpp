@@ -839,7 +839,7 @@ int ScorerDev::Parse(const uint8_t* buf, size_t len, int space_label, bool lm_on
     ds.cp_ub_max = hs.cp_ub_max; ds.cp_ub_on = 1;
     if (tune().unit_bounds >= 2) { cp_ub_.upload(hs.cp_ub.data(), hs.cp_ub.size() * 4); ds.cp_ub = cp_ub_.as<float>(); }
   }
-  if (hs.cpb_ok && hs.lmi_ok && hs.utf8 && !lm_only) {   // bigram blocks of the code-point step (ctc.hip: lm_full_score_blocks)
+  if (hs.cpb_ok && hs.lmi_ok && (hs.utf8 || lm_only)) {   // bigram blocks of the code-point step (ctc.hip: lm_full_score_blocks; a bare LM: the test hook's)
     static_assert(sizeof(HostScorer::CptEntry) == 16 && sizeof(HostScorer::CpbEntry) == 32 && sizeof(HostScorer::CpbRec) == 12, "device layout of the bigram blocks");
     try {
       cpt_.upload(hs.cpt.data(), hs.cpt.size() * sizeof(HostScorer::CptEntry));

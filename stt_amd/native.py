@@ -196,7 +196,7 @@ def take_string(ptr):
 
 def lm_score(lm_bytes, words, bos=True, mode=0):
     """STTX_TestLm: KenLM FullScore over `words` -> (log10 probs f32, matched n-gram lengths).  mode 0 = hashed index on the
-    host (no GPU), 1 = device trie walk, 2 = device index lookup."""
+    host (no GPU), 1 = device trie walk, 2 = device index lookup, 3 = the code-point bigram blocks on the host, 4 = the same on the device."""
     import numpy as np
     ws = [w if isinstance(w, bytes) else w.encode() for w in words]
     arr = (C.c_char_p * len(ws))(*ws)
