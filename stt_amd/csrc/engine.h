@@ -208,12 +208,12 @@ struct ModelState {
   // owned by the model, dealt round-robin at creation, so that decoders of one model can be driven side by side from several host threads (two
   // on one stream simply take turns; one decoder is a quarter of the chip, so four is the useful number).  Opt-in, and not a stream per
   // decoder, because of what tests/test_gpu_fuzz.py with STT_FUZZ_SEED=2 found in round 6: with four models alive and a stream per decoder
-  // (or a pool of 8, or of 4, per model) the process holds more streams than the runtime has hardware queues (GPU_MAX_HW_QUEUES = 16), the
+  // (or a pool of 8, or of 4, per model) the decoders' launches hop across 16 or more streams, the
   // decoders' launches are kernels of changing instantiations and scratch sizes (the code-point step spills), and the run ends in a GPU
-  // memory fault or a corrupted beam (error bit 0x20) although every call is host-synchronous; with at most 16 streams in the process
-  // (pools of 1, 2, 4 with two models; one shared stream) it never does, and none of HSA_ENABLE_SCRATCH_ASYNC_RECLAIM=0 /
+  // memory fault or a corrupted beam (error bit 0x20) although every call is host-synchronous; with at most 8 decoder streams in the process
+  // (pools of 1, 2, 4 with two models; one shared stream) it never does, GPU_MAX_HW_QUEUES=32 changes nothing, and none of HSA_ENABLE_SCRATCH_ASYNC_RECLAIM=0 /
   // HSA_NO_SCRATCH_RECLAIM=1 / AMD_OPT_FLUSH=0 changes it; a plain HIP program of that shape is clean (benchmarks/scratch_queue_probe.hip), and so
-  // is the fuzz beside 24 idle foreign streams with the decoders on the model's stream.  See INTEGRATION.md ("More streams than hardware queues").
+  // is the fuzz beside 24 idle foreign streams with the decoders on the model's stream.  See INTEGRATION.md ("Decoders hopping across many streams").
   static constexpr int kDecoderStreams = 4;
   hipStream_t decoder_streams_[kDecoderStreams] = {};
   unsigned decoder_stream_next_ = 0;
