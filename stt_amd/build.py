@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "lib", "libstt.so")
 # The same objects plus the test hooks of include/stt_amd_test.h (STTX_Test*, STTX_Debug*, the timing-probe kernels): what tests/ load.  The
 # shipped libstt.so carries none of them.  Only the sources below know about STT_TEST_HOOKS and are compiled twice.
 LIB_TEST = os.path.join(HERE, "lib", "libstt_test.so")
-HOOK_SOURCES = ["kernels_am.hip", "kernels_i8.hip", "api.cpp", "fleet.cpp"]
+HOOK_SOURCES = ["kernels_am.hip", "kernels_i8.hip", "ctc.hip", "api.cpp", "fleet.cpp"]
 SOURCES = ["kernels_am.hip", "kernels_i8.hip", "ctc.hip", "hostutil.cpp", "scorer_dev.cpp", "model.cpp", "tflite_reader.cpp", "engine.cpp", "api.cpp", "fleet.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "hip", "-Wno-unused-result"]
 # ctc.hip: the search kernels run 1024 threads per workgroup (128 registers per lane) through one very long timestep loop.  Machine-level

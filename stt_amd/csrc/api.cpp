@@ -3,6 +3,7 @@
 // Function-by-function replacement of native_client/stt.cc:336-737, native_client/modelstate.cc:32-76 and
 // native_client/stt_errors.cc:4-19.  All recognition work is enqueued on the GPU; an unusable GPU runtime or a
 // missing kernel image surfaces as an error code / NULL, never as a silent CPU path.
+#include <unistd.h>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -1317,6 +1318,7 @@ int STTX_DecoderNext(STTX_Decoder* d, const float* aProbs, unsigned int aStride,
                     max_frames, d->wide.p);
     if (d->prof) HIP_CHECK(hipEventRecord(e1, d->st));
     HIP_CHECK(hipStreamSynchronize(d->st));
+    if (tune().debug_scribble & 32) usleep(2000);   // (experiment: time for the runtime's asynchronous scratch reclaim)
     if (d->prof) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, e0, e1)); d->search_ms += ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     HIP_CHECK(hipGetLastError());
     return (int)STT_ERR_OK;

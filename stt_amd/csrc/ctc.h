@@ -201,6 +201,7 @@ struct DecodeOut {
 // `max_frames` = upper bound of frame_count[]; `wide_ws` = ctc_rows_ws_bytes(...) bytes of device memory: required when
 // ctc_is_wide(p.beam, p.C); optional otherwise (with it, the per-row class sort of C > cutoff_top_n alphabets -- byte mode --
 // runs row-parallel ahead of the search instead of inside every sequential step).
+void launch_debug_scribble(hipStream_t st, int mode);   // test hook (tunable debug_scribble; ctc.hip)
 void launch_ctc_next(const DecParams& p, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
                      const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st,
                      int max_frames = 0, void* wide_ws = nullptr);

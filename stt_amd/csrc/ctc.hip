@@ -2564,6 +2564,54 @@ static void check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { fprintf(stderr, "stt_amd: %s: %s\n", what, hipGetErrorString(e)); throw std::runtime_error(std::string("kernel launch failed: ") + what); }
 }
+#ifdef STT_TEST_HOOKS
+// Test hook (libstt_test.so only; tunable debug_scribble, bit 0): dirty what a kernel does not own between launches -- the LDS of every compute unit, the
+// launch queue's scratch memory (2 KB per lane, more than any instantiation of the search kernel spills), a good part of the vector
+// registers.  512 workgroups of 1024 lanes: two passes over the chip's 256 compute units.
+template <bool SCRATCH, bool LDSREG>
+__global__ __launch_bounds__(1024) void debug_scribble_kernel(unsigned* sink, unsigned pattern, unsigned lds_words) {
+  extern __shared__ unsigned scribble_lds[];
+  unsigned acc = 0;
+  if constexpr (LDSREG) {
+    for (unsigned i = threadIdx.x; i < lds_words; i += 1024) scribble_lds[i] = pattern ^ (i * 2654435761u);
+    unsigned r[64];
+#pragma unroll
+    for (unsigned k = 0; k < 64; ++k) r[k] = pattern ^ (k * 0x9E3779B9u) ^ threadIdx.x;
+#pragma unroll
+    for (unsigned k = 0; k < 64; ++k) asm volatile("" : "+v"(r[k]));   // (all 64 live in registers at once)
+#pragma unroll
+    for (unsigned k = 0; k < 64; ++k) acc += r[k];
+    __syncthreads();
+    acc += scribble_lds[(threadIdx.x * 31u) % lds_words];
+  }
+  if constexpr (SCRATCH) {
+    volatile unsigned priv[512];
+    for (unsigned k = 0; k < 512; ++k) priv[k] = pattern + k * 0x01010101u;
+    for (unsigned k = 0; k < 512; k += 17) acc += priv[(k * 7 + threadIdx.x) & 511];
+  }
+  if (acc == 0x13572468u && sink) sink[0] = acc;   // (never true in practice: keeps the work alive)
+}
+// debug_scribble: bit 0 on; bit 2 no scratch; bit 3 no LDS / registers; bit 4 one workgroup instead of 512 (experiments: benchmarks/r06_scribble_fuzz.sh)
+void launch_debug_scribble(hipStream_t st, int mode_in) {
+  const int mode = mode_in ? mode_in : tune().debug_scribble;
+  const bool scratch = !(mode & 4), ldsreg = !(mode & 8);
+  const int lds = ldsreg ? 160 * 1024 : 0, grid = (mode & 16) ? 1 : 512;
+  static std::once_flag once;
+  std::call_once(once, [&]() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(debug_scribble_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(debug_scribble_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  static unsigned seq = 0;
+  const unsigned pat = 0xDEAD0000u + (++seq);
+  if (scratch && ldsreg) hipLaunchKernelGGL((debug_scribble_kernel<true, true>), dim3(grid), dim3(1024), lds, st, (unsigned*)nullptr, pat, (unsigned)(lds / 4));
+  else if (scratch) hipLaunchKernelGGL((debug_scribble_kernel<true, false>), dim3(grid), dim3(1024), 0, st, (unsigned*)nullptr, pat, 1u);
+  else if (ldsreg) hipLaunchKernelGGL((debug_scribble_kernel<false, true>), dim3(grid), dim3(1024), lds, st, (unsigned*)nullptr, pat, (unsigned)(lds / 4));
+  else hipLaunchKernelGGL((debug_scribble_kernel<false, false>), dim3(grid), dim3(1024), 0, st, (unsigned*)nullptr, pat, 1u);
+}
+#else
+void launch_debug_scribble(hipStream_t, int) {}   // (the shipped library carries no scribbler)
+#endif
+
 void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabet& al, DecStream* streams, int n_streams,
                      const float* probs, const int* frame_begin, const int* frame_count, hipStream_t st, int max_frames, void* wide_ws) {
   DecParams p = p_in;
@@ -2576,6 +2624,7 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
     hipLaunchKernelGGL(ctc_wide_rows_kernel, dim3(n_streams * max_frames), dim3(1024), 0, st, p, probs, frame_begin, frame_count);
     check_launch("ctc_wide_rows_kernel");
   }
+  if (tune().debug_scribble & 1) { launch_debug_scribble(st, 0); check_launch("debug_scribble_kernel"); }
   p.n_lm_waves = tune().lm_waves; p.item_cap = tune().item_table_cap;
   p.wait_spins = tune().wait_spins > 0 ? tune().wait_spins : (1 << 22);
   p.key_mask = (tune().debug_key_bits >= 4 && tune().debug_key_bits < 63) ? ((1ULL << tune().debug_key_bits) - 1ULL) : ~0ULL;

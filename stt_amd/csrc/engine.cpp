@@ -842,11 +842,14 @@ void check_decoder_errors(const int* errors, int n) {
 }
 
 hipStream_t ModelState::decoder_stream() {
-  const int n = std::min(tune().decoder_streams, (int)kDecoderStreams);
+  const int n = std::min(tune().decoder_streams, (tune().debug_scribble & 2) ? (int)kDecoderStreamsDebug : (int)kDecoderStreams);
   if (n <= 1) return stream;      // (the default: every decoder on the model's own stream, as in rounds 1 - 5)
   std::lock_guard<std::mutex> lk(decoder_stream_mu_);
   hipStream_t& s = decoder_streams_[decoder_stream_next_++ % (unsigned)n];
-  if (!s) create_engine_stream(&s, 3);
+  if (!s) {
+    create_engine_stream(&s, 3);
+    if (tune().debug_scribble & 64) { launch_debug_scribble(s, 1 | 8 | 16); HIP_CHECK(hipStreamSynchronize(s)); }   // (experiment: the queue's scratch sized once, when the stream is made)
+  }
   return s;
 }
 

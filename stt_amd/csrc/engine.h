@@ -208,14 +208,13 @@ struct ModelState {
   // owned by the model, dealt round-robin at creation, so that decoders of one model can be driven side by side from several host threads (two
   // on one stream simply take turns; one decoder is a quarter of the chip, so four is the useful number).  Opt-in, and not a stream per
   // decoder, because of what tests/test_gpu_fuzz.py with STT_FUZZ_SEED=2 found in round 6: with four models alive and a stream per decoder
-  // (or a pool of 8, or of 4, per model) the decoders' launches hop across 16 or more streams, the
-  // decoders' launches are kernels of changing instantiations and scratch sizes (the code-point step spills), and the run ends in a GPU
-  // memory fault or a corrupted beam (error bit 0x20) although every call is host-synchronous; with at most 8 decoder streams in the process
-  // (pools of 1, 2, 4 with two models; one shared stream) it never does, GPU_MAX_HW_QUEUES=32 changes nothing, and none of HSA_ENABLE_SCRATCH_ASYNC_RECLAIM=0 /
-  // HSA_NO_SCRATCH_RECLAIM=1 / AMD_OPT_FLUSH=0 changes it; a plain HIP program of that shape is clean (benchmarks/scratch_queue_probe.hip), and so
-  // is the fuzz beside 24 idle foreign streams with the decoders on the model's stream.  See INTEGRATION.md ("Decoders hopping across many streams").
-  static constexpr int kDecoderStreams = 4;
-  hipStream_t decoder_streams_[kDecoderStreams] = {};
+  // (or a pool of 8, or of 4, per model) the decoders' launches hop across 16 or more streams and the run ends in a GPU memory fault, a
+  // corrupted beam (error bit 0x20) or a hang although every call is host-synchronous.  Narrowed to the launch queues' SCRATCH memory
+  // (the code-point step spills 1.2 KB per lane; benchmarks/r06_scribble_fuzz.sh, profiles/NOTES.md): not a read of anything the kernels did
+  // not write (tunable debug_scribble), gone with GPU_MAX_HW_QUEUES=1 or with a one-workgroup scratch kernel before every search launch,
+  // untouched by the HSA_* reclaim switches.  See INTEGRATION.md ("Decoders hopping across many streams").
+  static constexpr int kDecoderStreams = 4, kDecoderStreamsDebug = 16;   // (debug_scribble bit 1: the faulting configuration, for experiments)
+  hipStream_t decoder_streams_[kDecoderStreamsDebug] = {};
   unsigned decoder_stream_next_ = 0;
   std::mutex decoder_stream_mu_;
   hipStream_t decoder_stream();

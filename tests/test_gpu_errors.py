@@ -150,3 +150,46 @@ def test_results_do_not_depend_on_what_a_fresh_allocation_holds(tmp_path, fix):
     finally:
         native.set_tuning("debug_poison", 0)
     assert got == want
+
+
+def test_search_results_do_not_depend_on_leftovers_in_lds_scratch_or_registers(tmp_path, fix, port):
+    """Tunable debug_scribble bit 0 (libstt_test.so): before EVERY search launch a kernel on the same stream overwrites the LDS of every compute
+    unit, 2 KB of scratch memory per lane (the code-point step spills 1.2 KB) and 64 vector registers with a changing pattern.  A search kernel that
+    read LDS, a spill slot or a register it had not written would then see garbage instead of what its own previous launch left there -- on one
+    stream such a bug can hide for ever.  Word-mode and code-point scorers, chunked input, three streams per launch; N-best lists equal to the
+    runs without the scribbler.  (Round 6: the extended fuzz passes under it too -- profiles/NOTES.md, "The fault of the extended fuzz".)"""
+    from stt_amd import Model, native
+    ulabels, _ = port.utf8_alphabet()
+    rng = np.random.RandomState(7)
+
+    def emissions(C, T):
+        x = rng.randn(3, T, C) * 1.5
+        e = np.exp(x - x.max(2, keepdims=True))
+        return (e / e.sum(2, keepdims=True)).astype(np.float32)
+
+    xw, xb = emissions(29, 40), emissions(256, 14)
+    models = []
+    for name, labels, scorer in (("w", synth.ENGLISH_LABELS, "pruned_lm.scorer"), ("b", ulabels, "pruned_lm.bytes.scorer")):
+        path = str(tmp_path / (name + ".sttw"))
+        modelfile.write_model(path, synth.synth_weights(3, n_hidden=128, n_classes=len(labels) + 1), labels, beam_width=100)
+        m = Model(path)
+        m.enableExternalScorer(os.path.join(fix, scorer))
+        models.append(m)
+
+    def run():
+        out = []
+        for m, x, beam, cut in ((models[0], xw, 100, (1.0, 40)), (models[0], xw, 300, (0.99, 300)), (models[1], xb, 64, (0.99, 300)), (models[1], xb, 200, (1.0, 40))):
+            d = m.createDecoder(3, beam, *cut)
+            for k in range(0, x.shape[1], 5):
+                d.next(x[:, k:k + 5])
+            out.append([[(float(c), list(map(int, t)), list(map(int, ts))) for c, t, ts in r] for r in d.decode(6)])
+            assert d.stats()["error"] == 0
+        return out
+
+    want = run()
+    native.set_tuning("debug_scribble", 1)
+    try:
+        got = run()
+    finally:
+        native.set_tuning("debug_scribble", 0)
+    assert got == want
