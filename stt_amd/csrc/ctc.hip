@@ -30,6 +30,19 @@
 #include <string>
 
 #include "ctc.h"
+// The code-point step's cold paths (lm_score: the generic label walk; the trie walk of a scorer without the hashed index) and its FullScore
+// wrapper used to be REAL calls: the compiler kept lm_word_query_cached<false, true>, lm_score and is_scoring_boundary out of line and
+// kenlm_full_score_call was __noinline__ on purpose ("kept out of the step's registers", round 4).  Measured at the end of round 6
+// (benchmarks/r06_nocalls_check.sh): the calling convention cost far more than it kept out -- ctc_next_kernel<2, ...> 122 spilled vector
+// registers and 1168 - 1184 B of scratch per lane with the calls, 21 and 480 B with everything inlined (<1, ...>: 53 / 176 B -> 7 - 14 / 32 - 60 B;
+// <4, ...>: 1 / 8 B -> none), the bytes workload 43.3 -> 38.2 ms per batch, bit-identical.  -DSTT_DEVICE_CALLS restores the calls.
+#ifdef STT_DEVICE_CALLS
+#define STT_CALLS_INLINE
+#define STT_CALLS_NOINLINE __noinline__
+#else
+#define STT_CALLS_INLINE __forceinline__
+#define STT_CALLS_NOINLINE __forceinline__
+#endif
 #include "lmindex.h"
 #include "tuning.h"
 #include "sttmath.h"
@@ -373,7 +386,7 @@ __device__ uint64_t hash_labels_reversed(const DevAlphabet& al, const uint32_t* 
 // The prefix to score is `first` (a virtual last label, or STT_ROOT_CH for none) on top of path-arena node `node`.
 // Returns log_cond_prob + hot_boost as a double; the caller multiplies by alpha and rounds to float exactly like the
 // reference's `float score = (get_log_cond_prob(...) + hot_boost) * alpha`.
-__device__ double lm_score(const DevScorer& s, const DevAlphabet& al, const uint2* pa, uint32_t node, uint32_t first, bool with_hot, unsigned& probes) {
+__device__ STT_CALLS_INLINE double lm_score(const DevScorer& s, const DevAlphabet& al, const uint2* pa, uint32_t node, uint32_t first, bool with_hot, unsigned& probes) {
   uint64_t hashes[STT_KENLM_MAX_ORDER];
   int n = 0;
   uint32_t cur = node;
@@ -436,7 +449,7 @@ __device__ double lm_score(const DevScorer& s, const DevAlphabet& al, const uint
 }
 
 // Scorer::is_scoring_boundary (scorer.cpp:272-299) for the prefix (`first` on top of `node`) and label `new_label`
-__device__ bool is_scoring_boundary(const DevScorer& s, const DevAlphabet& al, const uint2* pa, uint32_t node, uint32_t first, uint32_t new_label, unsigned& probes) {
+__device__ STT_CALLS_INLINE bool is_scoring_boundary(const DevScorer& s, const DevAlphabet& al, const uint2* pa, uint32_t node, uint32_t first, uint32_t new_label, unsigned& probes) {
   if (!s.utf8) return (int)new_label == al.space_id;
   uint32_t cur = node, pending = first;
   int dist = 0;
@@ -767,7 +780,7 @@ __device__ __forceinline__ float lm_full_score_blocks(const DevScorer& s, const 
 
 // IDX: FullScore through the hashed n-gram index (the scorer must have one: orders <= 5), else the trie walk
 // the trie walk as a real call: the cold side of the code-point step's FullScore (a scorer without the index), kept out of its registers
-__device__ __noinline__ float kenlm_full_score_call(const DevScorer& s, const KState* in, uint32_t wi, KState* out, unsigned* probes, const DevVocabSlot* uni) {
+__device__ STT_CALLS_NOINLINE float kenlm_full_score_call(const DevScorer& s, const KState* in, uint32_t wi, KState* out, unsigned* probes, const DevVocabSlot* uni) {
   unsigned pr = 0;
   const float r = kenlm_full_score(s, *in, wi, *out, pr, uni);
   *probes += pr;
@@ -775,7 +788,7 @@ __device__ __noinline__ float kenlm_full_score_call(const DevScorer& s, const KS
 }
 // RT_IDX (code-point step): the index if the scorer has one (decided per scorer at load time: a run-time test), else the trie walk
 template <bool IDX, bool RT_IDX = false>
-__device__ double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al, const GStream& S, const LDS_AS uint8_t* lab1, LDS_AS uint32_t* be_n, uint32_t node, uint32_t e_prev,
+__device__ STT_CALLS_INLINE double lm_word_query_cached(const DevScorer& s, const DevAlphabet& al, const GStream& S, const LDS_AS uint8_t* lab1, LDS_AS uint32_t* be_n, uint32_t node, uint32_t e_prev,
                                        bool have_word, uint64_t lo, uint64_t hi, uint32_t& out_entry, unsigned& probes) {
   // The word's bytes come from the beam state (have_word) or from a walk back to the previous boundary; words longer than
   // 16 bytes take the generic label-array path.
