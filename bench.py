@@ -1034,7 +1034,7 @@ def measure(wl, args, cx, steps, warmup):
         # counters are never collected inside a timed run).  Only valid for the batch workload's shapes.
         pmc, pmc_file = {}, None
         if wl == "batch":
-            for prof in (("r06_a_i8_pmc_traffic.json", "r05_c_i8_pmc_traffic.json", "r05_b_i8_pmc_traffic.json") if i8 else ("r06_h_pmc_traffic.json", "r06_a_pmc_traffic.json", "r05_c_pmc_traffic.json", "r05_b_pmc_traffic.json", "r04_n_pmc_traffic.json", "r03_l_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
+            for prof in (("r06_a_i8_pmc_traffic.json", "r05_c_i8_pmc_traffic.json", "r05_b_i8_pmc_traffic.json") if i8 else ("r06_k_pmc_traffic.json", "r06_h_pmc_traffic.json", "r06_a_pmc_traffic.json", "r05_c_pmc_traffic.json", "r05_b_pmc_traffic.json", "r04_n_pmc_traffic.json", "r03_l_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))["kernels"]
                     pmc_file = prof
