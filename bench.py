@@ -1237,6 +1237,12 @@ def main():
                     sub[w]["roofline"] = {kk: vv for kk, vv in sub[w]["roofline"].items() if kk != "all"}
             except Exception as ex:      # a failing side workload must not take the driver's line with it; it is reported, not hidden
                 sub[w] = {"error": repr(ex)}
+            if w == "batch_i8" and not os.environ.get("STT_BENCH_KEEP_MODELS"):
+                # the int8 model is not needed again: its ten streams (engines, searches) go back to the runtime, so that the later side workloads do
+                # not share hardware queues with them (sixteen per process: INTEGRATION.md)
+                cx.i8_model = None
+                import gc
+                gc.collect()
         res["workloads"] = sub
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and wl == "batch" and not args.no_profile:
