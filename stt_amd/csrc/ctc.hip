@@ -25,6 +25,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -2582,14 +2583,15 @@ static void check_launch(const char* what) {
 // launch queue's scratch memory (2 KB per lane, more than any instantiation of the search kernel spills), a good part of the vector
 // registers.  512 workgroups of 1024 lanes: two passes over the chip's 256 compute units.
 template <bool SCRATCH, bool LDSREG>
-__global__ __launch_bounds__(1024) void debug_scribble_kernel(unsigned* sink, unsigned pattern, unsigned lds_words) {
+__global__ __launch_bounds__(1024) void debug_scribble_kernel(unsigned* sink, unsigned pattern, unsigned lds_words, unsigned zero, unsigned w_lo, unsigned w_hi) {
   extern __shared__ unsigned scribble_lds[];
   unsigned acc = 0;
+  const unsigned keep = zero ? 0u : 0xFFFFFFFFu;   // (bit 7 of debug_scribble: everything is overwritten with ZEROS -- what fresh memory from the runtime holds)
   if constexpr (LDSREG) {
-    for (unsigned i = threadIdx.x; i < lds_words; i += 1024) scribble_lds[i] = pattern ^ (i * 2654435761u);
+    for (unsigned i = threadIdx.x; i < lds_words; i += 1024) scribble_lds[i] = (pattern ^ (i * 2654435761u)) & keep;
     unsigned r[64];
 #pragma unroll
-    for (unsigned k = 0; k < 64; ++k) r[k] = pattern ^ (k * 0x9E3779B9u) ^ threadIdx.x;
+    for (unsigned k = 0; k < 64; ++k) r[k] = (pattern ^ (k * 0x9E3779B9u) ^ threadIdx.x) & keep;
 #pragma unroll
     for (unsigned k = 0; k < 64; ++k) asm volatile("" : "+v"(r[k]));   // (all 64 live in registers at once)
 #pragma unroll
@@ -2599,7 +2601,7 @@ __global__ __launch_bounds__(1024) void debug_scribble_kernel(unsigned* sink, un
   }
   if constexpr (SCRATCH) {
     volatile unsigned priv[512];
-    for (unsigned k = 0; k < 512; ++k) priv[k] = pattern + k * 0x01010101u;
+    for (unsigned k = (w_lo < 512u ? w_lo : 512u); k < (w_hi < 512u ? w_hi : 512u); ++k) priv[k] = (pattern + k * 0x01010101u) & keep;   // (tunables debug_scribble_lo / _hi: only these words of every lane's scratch)
     for (unsigned k = 0; k < 512; k += 17) acc += priv[(k * 7 + threadIdx.x) & 511];
   }
   if (acc == 0x13572468u && sink) sink[0] = acc;   // (never true in practice: keeps the work alive)
@@ -2616,10 +2618,10 @@ void launch_debug_scribble(hipStream_t st, int mode_in) {
   });
   static unsigned seq = 0;
   const unsigned pat = 0xDEAD0000u + (++seq);
-  if (scratch && ldsreg) hipLaunchKernelGGL((debug_scribble_kernel<true, true>), dim3(grid), dim3(1024), lds, st, (unsigned*)nullptr, pat, (unsigned)(lds / 4));
-  else if (scratch) hipLaunchKernelGGL((debug_scribble_kernel<true, false>), dim3(grid), dim3(1024), 0, st, (unsigned*)nullptr, pat, 1u);
-  else if (ldsreg) hipLaunchKernelGGL((debug_scribble_kernel<false, true>), dim3(grid), dim3(1024), lds, st, (unsigned*)nullptr, pat, (unsigned)(lds / 4));
-  else hipLaunchKernelGGL((debug_scribble_kernel<false, false>), dim3(grid), dim3(1024), 0, st, (unsigned*)nullptr, pat, 1u);
+  if (scratch && ldsreg) hipLaunchKernelGGL((debug_scribble_kernel<true, true>), dim3(grid), dim3(1024), lds, st, (unsigned*)nullptr, pat, (unsigned)(lds / 4), (unsigned)((mode >> 7) & 1), (unsigned)tune().debug_scribble_lo, (unsigned)tune().debug_scribble_hi);
+  else if (scratch) hipLaunchKernelGGL((debug_scribble_kernel<true, false>), dim3(grid), dim3(1024), 0, st, (unsigned*)nullptr, pat, 1u, (unsigned)((mode >> 7) & 1), (unsigned)tune().debug_scribble_lo, (unsigned)tune().debug_scribble_hi);
+  else if (ldsreg) hipLaunchKernelGGL((debug_scribble_kernel<false, true>), dim3(grid), dim3(1024), lds, st, (unsigned*)nullptr, pat, (unsigned)(lds / 4), (unsigned)((mode >> 7) & 1), (unsigned)tune().debug_scribble_lo, (unsigned)tune().debug_scribble_hi);
+  else hipLaunchKernelGGL((debug_scribble_kernel<false, false>), dim3(grid), dim3(1024), 0, st, (unsigned*)nullptr, pat, 1u, (unsigned)((mode >> 7) & 1), (unsigned)tune().debug_scribble_lo, (unsigned)tune().debug_scribble_hi);
 }
 #else
 void launch_debug_scribble(hipStream_t, int) {}   // (the shipped library carries no scribbler)
@@ -2632,7 +2634,7 @@ void launch_ctc_next(const DecParams& p_in, const DevScorer& s, const DevAlphabe
   p.wide_rows = nullptr; p.wide_stride = 0; p.wide_max_frames = 0; p.n_lm_waves = 0; p.item_cap = 0;
   if (wide && (!wide_ws || max_frames <= 0 || p.C > STT_MAX_CLASSES)) { fprintf(stderr, "stt_amd: launch_ctc_next: wide alphabet without a row workspace\n"); abort(); }
   const int cb = cap_bucket(p.beam);
-  if (wide || (ctc_sorts_classes(p) && wide_ws && max_frames > 0 && p.C <= WIDE_SORT_N)) {
+  if (wide || (ctc_sorts_classes(p) && wide_ws && max_frames > 0 && p.C <= WIDE_SORT_N && !(tune().debug_scribble & 256))) {   // (debug_scribble bit 8: narrow alphabets sort their classes in the search kernel, no row records)
     p.wide_rows = (const unsigned char*)wide_ws; p.wide_stride = ctc_wide_row_bytes(p.C); p.wide_max_frames = max_frames;
     hipLaunchKernelGGL(ctc_wide_rows_kernel, dim3(n_streams * max_frames), dim3(1024), 0, st, p, probs, frame_begin, frame_count);
     check_launch("ctc_wide_rows_kernel");
