@@ -1406,6 +1406,16 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
   // and it is parked at -inf.  The surviving beam is the reference's, entry for entry (bytes goldens, bytes fuzz, test_gpu_configs).
   // (-inf = no such statement this step.  Hot words add to the score and are not in the bound: no pruning with them.)
   float thr = NEG;
+  // the same with the bound: log_p + (bound * alpha) + beta, rounded as the reference rounds the score itself (monotone in the bound)
+  auto lm_bound = [&](float lp0, float ub) -> float {
+    const float lpv = __fadd_rn(lp0, (float)__dmul_rn((double)ub, s.alpha));
+    return (float)__dadd_rn((double)lpv, s.beta);
+  };
+  if (!MASKED) __syncthreads();
+  // (AFTER the barrier: with class pruning, `pos[blank]` and `lp[position of blank]` are written by ONE thread of the loops above.  Until
+  // the end of round 6 this stood before the barrier -- a wave that ran ahead of the writer read last step's values or "cut off", waves
+  // disagreed about thr, and the `thr != NEG` block below holds two barriers: a wrong beam, a launch that never ends or a wild index, in
+  // one run of fifty of ONE fuzz case and in every run once something delayed the waves -- DESIGN.md 10.10, profiles/NOTES.md.)
   if (SC_UTF8 && full_beam && s.n_hot == 0 && s.alpha >= 0.0) {
     const int kb = POS_OF(p.blank);
     const float sw = L.score[cur][n - 1];
@@ -1414,12 +1424,6 @@ __device__ __forceinline__ void ctc_step(const CONST_AS NextArgs* ka, const CONS
       if (!(bw < min_cutoff)) thr = bw;
     }
   }
-  // the same with the bound: log_p + (bound * alpha) + beta, rounded as the reference rounds the score itself (monotone in the bound)
-  auto lm_bound = [&](float lp0, float ub) -> float {
-    const float lpv = __fadd_rn(lp0, (float)__dmul_rn((double)ub, s.alpha));
-    return (float)__dadd_rn((double)lpv, s.beta);
-  };
-  if (!MASKED) __syncthreads();
   TICK(0);
   STEP_FENCE();
 
