@@ -73,11 +73,29 @@ def test_fuzz_decoder_against_port(rigs, port, fix, mode, lm, step, item_cap):
         native.set_tuning("item_table_cap", 0)
 
 
-def _fuzz(rigs, port, fix, mode, lm):
+def test_code_point_step_with_class_pruning_when_waves_are_delayed(rigs, port, fix):
+    """Regression test of the race that round 6 chased as "the decoders' fault" (DESIGN.md 10.10): with a code-point scorer, a full beam and
+    class pruning (cut-off 0.99 / 300), the search step computed `thr` from pos[blank] / lp[position of blank] BEFORE the barrier that
+    publishes them; waves disagreed about thr and about the two barriers of the block that depends on it -- a wrong beam, a launch that never
+    ends or a GPU memory fault, in one default-configuration run in fifty of seed 2's case 17 and in EVERY run once something delayed the
+    waves.  The two configurations that made it certain: the decoders hopping across sixteen streams, and a 512-workgroup scratch-using
+    kernel in front of every search launch (test-library tunable debug_scribble, bits 1 and 0)."""
+    from stt_amd import native
+    for scribble, streams in ((2, 16), (1, 1)):
+        native.set_tuning("debug_scribble", scribble)
+        native.set_tuning("decoder_streams", streams)
+        try:
+            _fuzz(rigs, port, fix, "bytes", True, seed=2)
+        finally:
+            native.set_tuning("debug_scribble", 0)
+            native.set_tuning("decoder_streams", 1)
+
+
+def _fuzz(rigs, port, fix, mode, lm, seed=None):
     m, P, labels, space = rigs[(mode, lm)]
     C = len(labels) + 1
     vocab = open(os.path.join(fix, "vocab.pruned.txt")).read().split()
-    rng = np.random.RandomState({"word": 100, "bytes": 200}[mode] + int(lm) + 1000 * int(os.environ.get("STT_FUZZ_SEED", "0")))  # (other seeds: more cases)
+    rng = np.random.RandomState({"word": 100, "bytes": 200}[mode] + int(lm) + 1000 * int(os.environ.get("STT_FUZZ_SEED", "0") if seed is None else seed))  # (other seeds: more cases)
     beams = [1, 2, 3, 7, 16, 63, 64, 65, 100, 128, 129, 257, 500, 513] if mode == "word" else [1, 5, 64, 65, 200, 300]
     n_cases = 90 if mode == "word" else 30
     for case in range(n_cases):
