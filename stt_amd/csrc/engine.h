@@ -206,13 +206,9 @@ struct ModelState {
   hipStream_t stream_dec = nullptr;  // batch path: the beam search of chunk k runs here while `stream` computes chunk k+1
   // Standalone decoders (STTX_Decoder): by default on the model's own stream; with the tunable decoder_streams = N (2 .. 4) on a POOL of N streams
   // owned by the model, dealt round-robin at creation, so that decoders of one model can be driven side by side from several host threads (two
-  // on one stream simply take turns; one decoder is a quarter of the chip, so four is the useful number).  Opt-in, and not a stream per
-  // decoder, because of what tests/test_gpu_fuzz.py with STT_FUZZ_SEED=2 found in round 6: with four models alive and a stream per decoder
-  // (or a pool of 8, or of 4, per model) the decoders' launches hop across 16 or more streams and the run ends in a GPU memory fault, a
-  // corrupted beam (error bit 0x20) or a hang although every call is host-synchronous.  Narrowed to the launch queues' SCRATCH memory
-  // (the code-point step spills 1.2 KB per lane; benchmarks/r06_scribble_fuzz.sh, profiles/NOTES.md): not a read of anything the kernels did
-  // not write (tunable debug_scribble), gone with GPU_MAX_HW_QUEUES=1 or with a one-workgroup scratch kernel before every search launch,
-  // untouched by the HSA_* reclaim switches.  See INTEGRATION.md ("Decoders hopping across many streams").
+  // on one stream simply take turns; one decoder is a quarter of the chip, so four is the useful number).  Not a stream per decoder: a process
+  // should stay at or below the sixteen hardware queues the engine asks for (streams beyond that share queues).  (The GPU memory fault that the
+  // extended fuzz of round 6 ran into with sixteen decoder streams was a race in the code-point search step, fixed: DESIGN.md 10.10.)
   static constexpr int kDecoderStreams = 4, kDecoderStreamsDebug = 16;   // (debug_scribble bit 1: the faulting configuration, for experiments)
   hipStream_t decoder_streams_[kDecoderStreamsDebug] = {};
   unsigned decoder_stream_next_ = 0;

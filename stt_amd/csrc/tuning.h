@@ -61,7 +61,7 @@
   X(lm_index_mb, 4096, "hashed n-gram index: byte cap in MiB (larger models take the trie walk)")                                  \
   X(decoder_streams, 1, "standalone decoders (STTX_Decoder*): 1 = every decoder on the model's own stream; 2..4 = a pool of that many streams per model, dealt round-robin when a decoder is created, so that decoders can be driven side by side from several host threads (bench.py's decoder-stage workloads: 4); keep the process at or below GPU_MAX_HW_QUEUES streams -- engine.h, INTEGRATION.md") \
   X(debug_poison, 0, "test hook: every new device buffer is filled with this byte pattern first (1 = 0xFF, 2 = 0xA5; 0 = left as the allocator returns it): a read of memory nobody wrote then yields absurd indices instead of whatever the previous owner left there") \
-  X(debug_scribble, 0, "test hook: bit 0 = before every search launch a kernel on the same stream overwrites the LDS of every compute unit, the launch queue's scratch memory and the vector registers with a pattern (a read of LDS / scratch / a register the search kernel did not write then sees garbage instead of what its own previous launch left there); bit 1 = the decoder pool may hold 16 streams per model (decoder_streams up to 16: the configuration of the round-6 fault); bits 2 - 6: variants of the scribbler for benchmarks/r06_scribble_fuzz.sh (no scratch, no LDS / registers, one workgroup, a sleep after each decoder launch, once per stream); the scribbler exists in libstt_test.so only") \
+  X(debug_scribble, 0, "test hook: bit 0 = before every search launch a kernel on the same stream overwrites the LDS of every compute unit, the launch queue's scratch memory and the vector registers with a pattern (a read of LDS / scratch / a register the search kernel did not write then sees garbage instead of what its own previous launch left there); bit 1 = the decoder pool may hold 16 streams per model (decoder_streams up to 16: the configuration in which round 6's race in the code-point step showed every time -- DESIGN.md 10.10); bits 2 - 6: variants of the scribbler for benchmarks/r06_scribble_fuzz.sh (no scratch, no LDS / registers, one workgroup, a sleep after each decoder launch, once per stream); the scribbler exists in libstt_test.so only") \
   X(debug_scribble_lo, 0, "test hook: first 4-byte word of every lane's scratch memory the scribbler writes") \
   X(debug_scribble_hi, 512, "test hook: one past the last word the scribbler writes (bisection of a read of uninitialised scratch)") \
   X(arena_shrink, 1, "test hook: divides the optimistic arena sizes of a batch group (forces the overflow -> decode-again path)")        \
